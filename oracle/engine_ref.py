@@ -1,0 +1,121 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the inference
+engine state machine (engines/aot_engine.py:241-465,533-568,571-725 and
+engines/deaot_engine.py:20-56 of /root/reference/aot_plus) on top of
+``oracle.lstt_ref``.  Encoder / decoder are passed in as plain PyTorch modules
+(they are outside the hot path and run through PyTorch unchanged).
+
+Parity status: pinned against the imported reference (tests/golden + direct
+comparison in tests/test_oracle_vs_reference.py); see oracle/lstt_ref.py.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import lstt_ref as R
+
+
+class OracleDeAOTEngine:
+    """Single-engine (<= 10 objects) DeAOT + RMem inference engine on CPU, fp32."""
+
+    def __init__(self, model, long_term_mem_gap: int = 5):
+        self.model = model
+        self.cfg = model.cfg
+        self.long_term_mem_gap = long_term_mem_gap
+        self.sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        self.lstt = R.DeAOTOracle(self.sd, self.cfg.MODEL_LSTT_NUM)
+        self.trace = None
+        self.restart_engine()
+
+    def restart_engine(self):                                   # aot_engine.py:533-563
+        self.frame_step = 0
+        self.last_mem_step = -1
+        self.long_memories_indexes: List[int] = []
+        self.input_size_2d = None
+        self.enc_size_2d = None
+        self.enc_hw = None
+        self.pred_id_logits = None
+        self.lstt.clear_memory()
+        self.policy_log = []
+
+    def eval(self):
+        return self
+
+    def _decode(self, enc, emb, output_size):                   # aot_engine.py:438-465
+        logits = self.model.decode_id_logits(emb, enc)
+        # obj_nums is [max_obj] for every sub-engine (aot_engine.py:697), so the
+        # "remove unused identities" slice (:451-453) is empty.
+        self.pred_id_logits = logits
+        if output_size is not None:
+            logits = F.interpolate(logits, size=output_size, mode="bilinear",
+                                   align_corners=self.cfg.MODEL_ALIGN_CORNERS)
+        return logits
+
+    @torch.no_grad()
+    def add_reference_frame(self, img, mask, obj_nums=None, frame_step=-1):   # :241-325
+        if frame_step == -1:
+            frame_step = self.frame_step
+        enc = self.model.encode_image(img)
+        if self.input_size_2d is None:
+            self.input_size_2d = tuple(img.shape[2:])
+            self.enc_size_2d = tuple(enc[-1].shape[2:])
+            self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
+        h, w = self.enc_size_2d
+        id_emb = R.id_assign(mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM)
+        emb = enc[-1][0].permute(1, 2, 0).reshape(h * w, -1)    # bchw_2_lbc (utils/tensor.py:3-6)
+        out = self.lstt.forward(emb, h, w, curr_id_emb=id_emb, trace=self.trace)
+        self.last_mem_step = frame_step
+        self.lstt.init_memory()
+        self.long_memories_indexes.append(self.frame_step)
+        self._decode(enc, out, None)
+
+    @torch.no_grad()
+    def match_propogate_one_frame(self, img, mask=None, output_size=None):    # :398-436
+        self.frame_step += 1
+        enc = self.model.encode_image(img)
+        h, w = self.enc_size_2d
+        emb = enc[-1][0].permute(1, 2, 0).reshape(h * w, -1)
+        out = self.lstt.forward(emb, h, w, curr_id_emb=None, trace=self.trace)
+        self.last_lstt_out = out
+        return self._decode(enc, out, output_size)
+
+    @torch.no_grad()
+    def update_memory(self, curr_mask):                         # :327-369, :714-720
+        h, w = self.enc_size_2d
+        id_emb = R.id_assign(curr_mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM)
+        update_long = False
+        if (not self.cfg.NO_LONG_MEMORY) and \
+                self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            update_long = True
+            self.last_mem_step = self.frame_step
+        self.lstt.update_short_memories(id_emb, update_long)
+        if update_long:
+            self.long_memories_indexes.append(self.frame_step)
+            fg = R.foreground_proba(self.pred_id_logits, h, w)
+            log = {"frame": self.frame_step, "indexes_before": list(self.long_memories_indexes)}
+            self.lstt.restrict_long_memories(self.cfg.FORMER_MEM_LEN, self.cfg.LATTER_MEM_LEN,
+                                             self.long_memories_indexes, fg, log)
+            log["indexes_after"] = list(self.long_memories_indexes)
+            self.policy_log.append(log)
+
+
+def run_clip(engine, imgs, label0, out_hw=None):
+    """The evaluator's per-frame protocol (networks/managers/evaluator.py:384-441,
+    518-523): reference frame, then per frame match -> softmax -> argmax -> nearest
+    resize -> update_memory.  Returns list of int64 label maps [H0,W0] (frame 1..)."""
+    H, W = imgs[0].shape[2:]
+    if out_hw is None:
+        out_hw = (H, W)
+    engine.restart_engine()
+    engine.add_reference_frame(imgs[0], label0, obj_nums=[int(label0.max().item())], frame_step=0)
+    labels = []
+    for t in range(1, len(imgs)):
+        logit = engine.match_propogate_one_frame(imgs[t], output_size=out_hw)
+        prob = torch.softmax(logit, dim=1)
+        pred = torch.argmax(prob, dim=1, keepdim=True).float()
+        labels.append(pred[0, 0].long().cpu())
+        cur = F.interpolate(pred, size=engine.input_size_2d, mode="nearest")
+        engine.update_memory(cur)
+    return labels

@@ -1,0 +1,139 @@
+"""VOS model container: PyTorch encoder/decoder + parameter holders for the LSTT.
+
+``build_vos_model(name, cfg)`` mirrors the reference factory
+(/root/reference/aot_plus/networks/models/__init__.py:5-12).  The returned module has
+reference-identical ``state_dict()`` keys so reference
+checkpoints load by name, but the LSTT sub-modules are *parameter holders only*:
+their forward pass is executed by the HIP kernels in ``rmem_amd.csrc`` through
+``rmem_amd.lstt.DeAOTLSTT`` (the engine calls that, never ``nn.Module.forward``).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .nets import ResNet50Encoder, FPNHead
+
+
+class _DW(nn.Module):
+    """Holder for DWConv2d.conv (layers/basic.py:38-47): 5x5 depth-wise, no bias."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 5, padding=2, groups=c, bias=False)
+
+
+class _GP(nn.Module):
+    """Holder for GatedPropagation params (layers/attention.py:93-137)."""
+
+    def __init__(self, d_qk, d_vu, d_att, use_linear):
+        super().__init__()
+        e = d_vu * 2
+        if use_linear:
+            self.linear_QK = nn.Linear(d_qk, d_att)
+            self.linear_V1 = nn.Linear(d_vu // 2, e // 2)
+            self.linear_V2 = nn.Linear(d_vu // 2, e // 2)
+            self.linear_U1 = nn.Linear(d_vu // 2, e // 2)
+            self.linear_U2 = nn.Linear(d_vu // 2, e // 2)
+        self.dw_conv = _DW(e)
+        self.projection = nn.Linear(e, d_vu)
+
+
+class _LocalGP(nn.Module):
+    """Holder for LocalGatedPropagation params (layers/attention.py:220-287)."""
+
+    def __init__(self, d_vu, d_att, max_dis=7):
+        super().__init__()
+        e = d_vu * 2
+        win = 2 * max_dis + 1
+        self.relative_emb_k = nn.Conv2d(d_att, win * win, 1)
+        self.dw_conv = _DW(e)
+        self.projection = nn.Linear(e, d_vu)
+
+
+class _GPMLayer(nn.Module):
+    """Holder for GatedPropagationModule params (layers/transformer.py:1010-1082)."""
+
+    def __init__(self, d_model, layer_idx):
+        super().__init__()
+        d_att = d_model // 2
+        e = d_model * 2
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear_QV = nn.Linear(d_model, d_att + e)
+        self.linear_U = nn.Linear(d_model, e)
+        if layer_idx == 0:
+            self.linear_ID_V = nn.Linear(d_model, e)
+        else:
+            self.id_norm1 = nn.LayerNorm(d_model)
+            self.linear_ID_V = nn.Linear(d_model * 2, e)
+            self.linear_ID_U = nn.Linear(d_model, e)
+        self.long_term_attn = _GP(d_model, e, d_att, use_linear=False)
+        self.short_term_attn = _LocalGP(e, d_att)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.id_norm2 = nn.LayerNorm(d_model)
+        self.self_attn = _GP(e, e, d_att, use_linear=True)
+
+
+class _GN1D(nn.Module):
+    def __init__(self, c, groups):
+        super().__init__()
+        self.gn = nn.GroupNorm(groups, c)
+
+
+class _DualBranchGPM(nn.Module):
+    """Holder for DualBranchGPM params (layers/transformer.py:700-763)."""
+
+    def __init__(self, num_layers, d_model):
+        super().__init__()
+        self.layers = nn.ModuleList(_GPMLayer(d_model, i) for i in range(num_layers))
+        self.decoder_norms = nn.ModuleList([_GN1D(d_model * 2, 2)])
+
+
+class DeAOT(nn.Module):
+    """DeAOT + RMem model (models/deaot.py:10-69, models/aot.py:12-103)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        if cfg.MODEL_ENCODER != "resnet50":
+            raise NotImplementedError(cfg.MODEL_ENCODER)
+        if cfg.MODEL_ATT_HEADS != 1 or cfg.MODEL_SELF_HEADS != 1:
+            raise NotImplementedError("DeAOT hot path is built for 1 head (default_deaot.py:14-15)")
+        self.cfg = cfg
+        self.max_obj_num = cfg.MODEL_MAX_OBJ_NUM
+        d = cfg.MODEL_ENCODER_EMBEDDING_DIM
+        self.encoder = ResNet50Encoder()
+        self.encoder_projector = nn.Conv2d(cfg.MODEL_ENCODER_DIM[-1], d, 1)
+        self.LSTT = _DualBranchGPM(cfg.MODEL_LSTT_NUM, d)
+        self.decoder = FPNHead(d * 2, cfg.MODEL_MAX_OBJ_NUM + 1, hidden_dim=d,
+                               shortcut_dims=cfg.MODEL_ENCODER_DIM,
+                               align_corners=cfg.MODEL_ALIGN_CORNERS,
+                               decode_intermediate_input=False)
+        id_dim = cfg.MODEL_MAX_OBJ_NUM + (2 if cfg.MODEL_IGNORE_TOKEN else 1)
+        if cfg.MODEL_ALIGN_CORNERS:
+            self.patch_wise_id_bank = nn.Conv2d(id_dim, d, 17, stride=16, padding=8)
+        else:
+            self.patch_wise_id_bank = nn.Conv2d(id_dim, d, 16, stride=16, padding=0)
+        self.id_norm = nn.LayerNorm(d)
+        self.use_temporal_pe = cfg.USE_TEMPORAL_POSITIONAL_EMBEDDING
+        if not (self.use_temporal_pe and cfg.TEMPORAL_POSITIONAL_EMBEDDING_SLOT_4):
+            raise NotImplementedError("hot path is built for the 4-slot temporal PE (r50_deaotl.py:14-16)")
+        self.cur_pos_emb = nn.Parameter(torch.zeros(1, d // 2))
+        self.mem_pos_emb = nn.Parameter(torch.zeros(4, d // 2))
+
+    # -- pass-throughs to PyTorch (models/aot.py:116-134, deaot.py:57-63)
+    def encode_image(self, img):
+        xs = self.encoder(img)
+        xs[-1] = self.encoder_projector(xs[-1])
+        return xs
+
+    def decode_id_logits(self, lstt_emb_nc, shortcuts):
+        """lstt_emb_nc: [N, 2d] token-major tensor (the LSTT output)."""
+        n, _, h, w = shortcuts[-1].shape
+        emb = lstt_emb_nc.view(h, w, n, -1).permute(2, 3, 0, 1)
+        return self.decoder([shortcuts[-1], emb], shortcuts)
+
+
+def build_vos_model(name, cfg, **kwargs):
+    if name == "deaot":
+        return DeAOT(cfg, **kwargs)
+    raise NotImplementedError(name)

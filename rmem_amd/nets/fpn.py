@@ -1,0 +1,48 @@
+"""FPN segmentation head, key-compatible with the reference decoder
+(/root/reference/aot_plus/networks/decoders/fpn.py:7-68, layers/basic.py:60-70).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _ConvGN(nn.Module):
+    def __init__(self, cin, cout, k, groups=8):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=k // 2)
+        self.gn = nn.GroupNorm(groups, cout)
+
+    def forward(self, x):
+        return self.gn(self.conv(x))
+
+
+class FPNHead(nn.Module):
+    def __init__(self, in_dim, out_dim, hidden_dim=256,
+                 shortcut_dims=(256, 512, 1024, 1024), align_corners=True,
+                 decode_intermediate_input=False):
+        super().__init__()
+        self.align_corners = align_corners
+        self.decode_intermediate_input = decode_intermediate_input
+        h = hidden_dim
+        self.conv_in = _ConvGN(in_dim, h, 1)
+        self.conv_16x = _ConvGN(h, h, 3)
+        self.conv_8x = _ConvGN(h, h // 2, 3)
+        self.conv_4x = _ConvGN(h // 2, h // 2, 3)
+        self.adapter_16x = nn.Conv2d(shortcut_dims[-2], h, 1)
+        self.adapter_8x = nn.Conv2d(shortcut_dims[-3], h, 1)
+        self.adapter_4x = nn.Conv2d(shortcut_dims[-4], h // 2, 1)
+        self.conv_out = nn.Conv2d(h // 2, out_dim, 1)
+
+    def _up(self, x, like):
+        return F.interpolate(x, size=like.shape[-2:], mode="bilinear",
+                             align_corners=self.align_corners)
+
+    def forward(self, inputs, shortcuts):
+        x = torch.cat(inputs, dim=1) if self.decode_intermediate_input else inputs[-1]
+        x = F.relu(self.conv_in(x))
+        x = F.relu(self.conv_16x(self.adapter_16x(shortcuts[-2]) + x))
+        x = F.relu(self.conv_8x(self.adapter_8x(shortcuts[-3]) + self._up(x, shortcuts[-3])))
+        x = F.relu(self.conv_4x(self.adapter_4x(shortcuts[-4]) + self._up(x, shortcuts[-4])))
+        return self.conv_out(x)

@@ -1,0 +1,40 @@
+"""Seeded input generators shared by make_golden.py (reference side) and the tests
+(oracle / HIP side).  numpy RandomState streams are stable across platforms, so the
+fixtures only need to hold the reference's *outputs*."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+BLOCK_CASES = [  # (layer, T, h, w, ref_frame)
+    (0, 1, 5, 7, False), (1, 2, 5, 7, False), (1, 4, 8, 11, False),
+    (2, 5, 8, 11, False), (1, 8, 5, 7, False), (0, 1, 8, 11, True), (2, 1, 5, 7, True),
+    (1, 3, 9, 13, False),
+]
+
+
+def block_case_name(layer, T, h, w, ref_frame):
+    return f"block_l{layer}_T{T}_{h}x{w}{'_ref' if ref_frame else ''}"
+
+
+def block_inputs(layer, T, h, w, ref_frame):
+    rs = np.random.RandomState(1000 + 17 * layer + T * 3 + h + (500 if ref_frame else 0))
+    n = h * w
+    r = lambda *s: torch.from_numpy(rs.standard_normal(s).astype(np.float32))
+    d = dict(tgt=r(n, 256), tgt_id=None if layer == 0 else r(n, 256) * 0.7)
+    # key-like tensors get the scale the synthetic model produces (std ~1.9)
+    d.update(bank_K=r(T, n, 128) * 1.5, bank_V=r(T, n, 512) * 0.5, bank_IDV=r(T, n, 512) * 0.5,
+             short_K=r(n, 128) * 1.5, short_V=r(n, 512) * 0.5, short_IDV=r(n, 512) * 0.5,
+             id_emb=r(n, 256))
+    return d
+
+
+IDASSIGN_CASES = [(97, 129), (65, 81), (49, 33)]
+
+
+def idassign_label(H, W):
+    rs = np.random.RandomState(H * 7 + W)
+    coarse = torch.from_numpy(rs.randint(0, 11, (1, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
+    label = torch.nn.functional.interpolate(coarse, size=(H, W), mode="nearest")
+    label[:, :, 10:20, 5:25] = 255
+    return label

@@ -1,0 +1,176 @@
+"""Generate the golden fixtures in this directory by running the *reference*
+(/root/reference, imported on CPU through refharness.py) on seeded synthetic inputs
+with the name-keyed synthetic weights of ``rmem_amd.synth``.
+
+Run (build container only; the reference never travels):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures are data only (inputs + the reference's outputs):
+  manifest_r50_deaotl.json   state_dict keys / shapes
+  block_*.npz                one GatedPropagationModule.forward call (transformer.py:1091)
+  idassign_*.npz             one_hot_mask + assign_identity + get_id_emb
+  clip_small_*.json/.npz     engine state machine on small clips (indexes, EMA, visits, labels)
+  clip_480p.json/.npz        481x849 clip: per-frame label hashes + a few logits (fp16)
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import refharness as rh  # noqa: E402
+from rmem_amd.synth import synth_clip  # noqa: E402
+from inputs import (BLOCK_CASES, IDASSIGN_CASES, block_case_name, block_inputs,  # noqa: E402
+                    idassign_label)
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.to(torch.uint8).contiguous().numpy().tobytes()).hexdigest()
+
+
+def to2d(x_nc, h, w):
+    """[N,C] -> [1,C,h,w] (seq_to_2d, layers/basic.py:73-77)."""
+    return x_nc.view(h, w, 1, -1).permute(2, 3, 0, 1).contiguous()
+
+
+def gen_manifest(model):
+    man = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, "manifest_r50_deaotl.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+
+
+def gen_blocks(model):
+    """Direct calls of the reference block on seeded inputs (tests/golden/inputs.py)."""
+    temporal = torch.cat((model.cur_pos_emb, model.mem_pos_emb), dim=0)
+    for layer, T, h, w, ref_frame in BLOCK_CASES:
+        blk = model.LSTT.layers[layer]
+        blk.short_term_attn.qk_mask = None
+        blk.short_term_attn.local_mask = None
+        blk.short_term_attn.last_size_2d = None
+        i = block_inputs(layer, T, h, w, ref_frame)
+        tgt, tgt_id = i["tgt"], i["tgt_id"]
+        kw = dict(size_2d=(h, w), temporal_encoding=temporal, save_atten_weights=not ref_frame)
+        with torch.no_grad(), rh.quiet():
+            if ref_frame:
+                out = blk(tgt[:, None], None if tgt_id is None else tgt_id[:, None],
+                          None, None, curr_id_emb=i["id_emb"][:, None], **kw)
+            else:
+                out = blk(tgt[:, None], None if tgt_id is None else tgt_id[:, None],
+                          [i["bank_K"][:, :, None], i["bank_V"][:, :, None], None,
+                           i["bank_IDV"][:, :, None]],
+                          [to2d(i["short_K"], h, w), to2d(i["short_V"], h, w), None,
+                           to2d(i["short_IDV"], h, w)], **kw)
+        o_tgt, o_id, mems = out
+        curr, glob, loc = mems
+        d = dict(out_tgt=o_tgt[:, 0].numpy(), out_tgt_id=o_id[:, 0].numpy(),
+                 curr_K=curr[0][:, 0].numpy(), curr_V=curr[1][:, 0].numpy(),
+                 curr_z=np.zeros((0,), np.float32) if curr[3] is None else curr[3][:, 0].numpy())
+        if ref_frame:
+            d.update(glob_IDV=glob[3][0, :, 0].numpy())
+        else:
+            d.update(mass=blk.record_attn_weight.numpy())
+        np.savez_compressed(os.path.join(HERE, block_case_name(layer, T, h, w, ref_frame) + ".npz"), **d)
+
+
+def gen_idassign(model):
+    ref = rh.import_reference()
+    from utils.image import one_hot_mask            # reference util (import only)
+    eng = ref["aot_engine"].AOTEngine(model, 0, 5)
+    for (H, W) in IDASSIGN_CASES:
+        label = idassign_label(H, W)
+        eng.restart_engine()
+        eh, ew = (H - 1) // 16 + 1, (W - 1) // 16 + 1
+        eng.update_size((H, W), (eh, ew))
+        with torch.no_grad():
+            oh, ign = one_hot_mask(label, 10)
+            emb = eng.assign_identity(oh, ign)      # [N,1,256]
+        np.savez_compressed(os.path.join(HERE, f"idassign_{H}x{W}.npz"),
+                            id_emb=emb[:, 0].numpy(), eh=eh, ew=ew)
+
+
+def run_reference_clip(engine, imgs, label0, out_hw, capture_logits=()):
+    """Drives the reference engine with the evaluator's protocol
+    (managers/evaluator.py:384-441,518-523) and records state after every frame."""
+    sub = None
+    rec = dict(indexes=[], ema=[], visits=[], labels=[], hist=[], logits={}, mass0=[])
+    with torch.no_grad(), rh.quiet():
+        engine.restart_engine()
+        engine.add_reference_frame(imgs[0], label0.int(), obj_nums=[int(label0.max())], frame_step=0)
+        sub = engine.aot_engines[0]
+        lstt = sub.AOT.LSTT
+        for t in range(1, len(imgs)):
+            logit = engine.match_propogate_one_frame(imgs[t], output_size=out_hw)
+            prob = torch.softmax(logit, dim=1)
+            pred = torch.argmax(prob, dim=1, keepdim=True).float()
+            cur = F.interpolate(pred, size=engine.input_size_2d, mode="nearest")
+            engine.update_memory(cur)
+            rec["indexes"].append(list(sub.long_memories_indexes))
+            rec["ema"].append({int(k): float(v) for k, v in lstt.stored_attn_weight_dict.items()})
+            rec["visits"].append({int(k): int(v) for k, v in lstt.stored_frame_times.items()})
+            rec["labels"].append(pred[0, 0].to(torch.uint8))
+            rec["hist"].append(torch.bincount(pred.flatten().long(), minlength=11).tolist())
+            rec["mass0"].append(lstt.layers[0].record_attn_weight.sum(0).tolist())
+            if t in capture_logits:
+                rec["logits"][t] = sub.pred_id_logits.clone()
+    return rec
+
+
+def gen_clips():
+    small = [  # name, H, W, frames, gap, former, latter
+        ("k4_gap2", 97, 129, 16, 2, 1, 3),
+        ("k4_gap5", 97, 129, 24, 5, 1, 3),
+        ("k8_gap2", 81, 113, 28, 2, 1, 7),
+        ("k2_gap1", 81, 97, 10, 1, 1, 1),
+    ]
+    for name, H, W, frames, gap, former, latter in small:
+        cfg, model, engine = rh.build_reference("r50_deaotl", former, latter, gap)
+        imgs, lab = synth_clip(11, frames, H, W, 3)
+        rec = run_reference_clip(engine, imgs, lab, (H, W), capture_logits=(frames - 1,))
+        meta = dict(H=H, W=W, frames=frames, gap=gap, former=former, latter=latter, seed=11,
+                    indexes=rec["indexes"], ema=rec["ema"], visits=rec["visits"],
+                    hist=rec["hist"], mass0=rec["mass0"],
+                    label_sha=[sha(l) for l in rec["labels"]])
+        with open(os.path.join(HERE, f"clip_small_{name}.json"), "w") as f:
+            json.dump(meta, f)
+        np.savez_compressed(os.path.join(HERE, f"clip_small_{name}.npz"),
+                            labels=torch.stack(rec["labels"]).numpy(),
+                            last_logits=rec["logits"][frames - 1].numpy())
+        print("clip", name, "indexes", rec["indexes"][-1])
+
+    # full 480p geometry (481x849 -> 31x54), K=4, gap=2 so an eviction occurs at frame 8
+    cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 2)
+    H, W, frames = 481, 849, 10
+    imgs, lab = synth_clip(0, frames, H, W, 3)
+    rec = run_reference_clip(engine, imgs, lab, (480, 854), capture_logits=(1, 8, 9))
+    meta = dict(H=H, W=W, out_hw=[480, 854], frames=frames, gap=2, former=1, latter=3, seed=0,
+                indexes=rec["indexes"], ema=rec["ema"], visits=rec["visits"], hist=rec["hist"],
+                mass0=rec["mass0"], label_sha=[sha(l) for l in rec["labels"]])
+    with open(os.path.join(HERE, "clip_480p.json"), "w") as f:
+        json.dump(meta, f)
+    np.savez_compressed(os.path.join(HERE, "clip_480p.npz"),
+                        **{f"logits_{t}": v.numpy().astype(np.float16) for t, v in rec["logits"].items()},
+                        labels=torch.stack(rec["labels"]).numpy())
+    print("clip 480p indexes", rec["indexes"])
+
+
+def main():
+    torch.manual_seed(0)
+    cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
+    gen_manifest(model)
+    gen_blocks(model)
+    gen_idassign(model)
+    gen_clips()
+    os.system(f"du -sh {HERE}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,28 @@
+"""CPU, build container only: the oracle against the *imported* reference on a fresh
+seed (not a committed fixture).  Skipped where /root/reference does not exist."""
+import pytest
+import torch
+
+import refharness as rh
+
+pytestmark = pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+
+
+def test_oracle_matches_reference_clip():
+    from oracle.engine_ref import OracleDeAOTEngine, run_clip
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+    cfg, rmodel, rengine = rh.build_reference("r50_deaotl", 1, 2, gap=1)
+    mine = build_vos_model("deaot", get_config("r50_deaotl", 1, 2)).eval()
+    load_synthetic_weights(mine)
+    imgs, lab = synth_clip(5, 9, 113, 97, 3)
+    with torch.no_grad(), rh.quiet():
+        ref_labels = run_clip(rengine, imgs, lab.int())
+    ora = OracleDeAOTEngine(mine, long_term_mem_gap=1)
+    my_labels = run_clip(ora, imgs, lab)
+    assert rengine.aot_engines[0].long_memories_indexes == ora.long_memories_indexes
+    for a, b in zip(ref_labels, my_labels):
+        assert int((a != b).sum()) == 0
+    d = (rengine.aot_engines[0].pred_id_logits - ora.pred_id_logits).abs().max().item()
+    assert d < 1e-4
