@@ -1,0 +1,180 @@
+/* rmem_hip.h -- C ABI of librmem_hip.so: the MI355X (gfx950) kernels of the RMem /
+ * DeAOT hot path.
+ *
+ * The reference (Restricted-Memory/RMem) is pure PyTorch and has no FFI for this path
+ * (SURVEY.md section 8b); these entry points are what a binding of the reference's
+ * attention layers would call instead of their PyTorch bodies.  Every declaration
+ * cites the reference code it replaces (paths relative to /root/reference/aot_plus/).
+ *
+ * Conventions
+ *   - every pointer is a device (HBM) pointer unless marked "host";
+ *   - no hidden allocation, no synchronisation, no global mutable state: the caller
+ *     owns all buffers and workspaces; kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*), so calls are hipGraph-capturable;
+ *   - return value: 0 = enqueued, <0 = error (RMEM_ERR_*); no exceptions cross the ABI;
+ *   - "planes": an fp32 tensor carried as two bf16 tensors hi = bf16(x),
+ *     lo = bf16(x - hi) (rmem_bf16 = raw bf16 bits).  `nsplit` = 3 multiplies
+ *     hi*lo + lo*hi + hi*hi on the bf16 MFMA pipe (fp32-class accuracy), `nsplit` = 1
+ *     multiplies hi*hi only (plain bf16) and ignores the lo pointers;
+ *   - tokens are row-major over the feature map, p = y*w + x (layers/basic.py:73-77).
+ */
+#ifndef RMEM_HIP_H
+#define RMEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t rmem_bf16;
+
+#define RMEM_OK 0
+#define RMEM_ERR_INVALID (-1)
+#define RMEM_ERR_LAUNCH (-2)
+
+/* ABI version (bumped on any signature change). */
+int rmem_abi_version(void);
+
+/* ------------------------------------------------------------------ linear layers
+ * D = act(X . Y^T + bias) on the bf16 MFMA pipe.  X is [M][K], Y is [N][K] (both
+ * K-contiguous planes), D is [M][N].  Either operand may be continued along K by a
+ * second source (x2/y2) after k_split elements (concatenated inputs).  With
+ * bias_per_row the roles are swapped (X = weight, Y = activation) and D is the
+ * transposed output, which is how channel-major memories (V^T) are produced.
+ * Replaces the nn.Linear / 1x1-conv calls of GatedPropagationModule.forward
+ * (layers/transformer.py:1106-1123,1238-1244), GatedPropagation.forward
+ * (layers/attention.py:151-172,209) and relative_emb_k (layers/attention.py:314).
+ */
+typedef struct {
+  const rmem_bf16 *xh, *xl; int64_t ldx;   /* X planes, first K segment              */
+  const rmem_bf16 *xh2, *xl2; int64_t ldx2; /* second K segment (or NULL)             */
+  int32_t kx_split;                        /* elements of K served by the first X source */
+  const rmem_bf16 *yh, *yl; int64_t ldy;
+  const rmem_bf16 *yh2, *yl2; int64_t ldy2;
+  int32_t ky_split;
+  int32_t M, N, K;                         /* K, k*_split multiples of 64            */
+  const float *bias; int32_t bias_per_row; /* bias[N] (or bias[M] when per row), may be NULL */
+  int32_t act;                             /* 0 none, 1 SiLU (x*sigmoid(x), attention.py:89) */
+  float *d0; int64_t ldd0;                 /* fp32 out for columns [0, csplit)       */
+  float *d1; int64_t ldd1;                 /* fp32 out for columns [csplit, N)       */
+  int32_t csplit;                          /* = N when there is one destination       */
+  int32_t accumulate;                      /* D += result (fused residual add)       */
+  rmem_bf16 *pah, *pal; int64_t ldpa;      /* planes of the result (may be NULL)      */
+  rmem_bf16 *pbh, *pbl; int64_t ldpb;      /* planes of result + addvec[col] (may be NULL) */
+  const float *addvec;
+  int32_t nbatch;                          /* gridDim.z; strides below in elements    */
+  int64_t bsx, bsy, bsd, bsbias, bspa;
+  int32_t nsplit;                          /* 1 or 3                                   */
+  int32_t tile;                            /* 0 auto, 64 or 128                        */
+} rmem_linear_args;
+
+int rmem_linear(const rmem_linear_args *a, void *stream);
+
+/* ------------------------------------------------------------------ attention
+ * Memory-read attention of GatedPropagation.forward (layers/attention.py:174-206) in
+ * three launches over a materialised bf16 probability matrix:
+ *   rmem_attn_scores(pass=0)  running row max of S = scale*(Q.K^T + bias)   (plain bf16)
+ *   rmem_attn_scores(pass=1)  P = exp(S - max) -> planes, partial row sums   (nsplit)
+ *   rmem_attn_pv              partial O = P . V per key split                 (nsplit)
+ *   rmem_attn_combine         G = (sum_splits O) / rowsum * U, per-slot attention mass
+ *
+ * mode 0 ("bank", long-term / self): keys are T logical slots of the ring bank,
+ *   slot t lives at physical slot slot_map[t]; the temporal positional embedding
+ *   (layers/transformer.py:1140-1172) enters as bias[q][t] = (Q[q]+cur_pe).mem_pe[row(t)]
+ *   so the stored keys stay PE-free.
+ * mode 1 ("window", short-term): one slot (the previous frame); key k is visible to
+ *   query q iff |ky-qy| <= 7 and |kx-qx| <= 7 and it gets the relative bias
+ *   R[q][(ky-qy+7)*15 + (kx-qx+7)] (layers/attention.py:305-346: out-of-image keys are
+ *   the -1e8 entries, which softmax turns into exact zeros).
+ *
+ * Layouts: K planes [slot][Npad][128]; V^T planes [slot][ncols][Npad] (channel-major);
+ * Q planes [Npad][128]; P planes blocked [key/32][Npad][32]; Npad = N rounded up to 128.
+ */
+typedef struct {
+  int32_t mode;                            /* 0 bank, 1 window                         */
+  int32_t pass;                            /* 0 row max, 1 probabilities               */
+  const rmem_bf16 *kh, *kl; int64_t k_slot_stride;   /* K planes base, elements per slot */
+  const int32_t *slot_map;                 /* device [T] logical -> physical slot       */
+  int32_t T, N, Npad;
+  const rmem_bf16 *qh, *ql;                /* Q planes [Npad][128]                      */
+  float scale;                             /* 1/sqrt(d_att)                             */
+  const float *bias;                       /* mode 0: [N][T] or NULL                    */
+  const float *R; int32_t ldr; int32_t h, w;  /* mode 1                                 */
+  uint32_t *rowmax;                        /* [Npad] order-encoded running max (memset 0 before pass 0) */
+  rmem_bf16 *ph, *pl;                      /* pass 1: P planes                          */
+  float *lpart; int32_t nparts;            /* pass 1: [Npad][nparts] partial row sums, part = key/64 */
+  int32_t nsplit;                          /* pass 1 precision (pass 0 always runs plain bf16) */
+} rmem_scores_args;
+
+int rmem_attn_scores(const rmem_scores_args *a, void *stream);
+
+typedef struct {
+  int32_t mode;                            /* 0 bank, 1 window (banded k range)         */
+  const rmem_bf16 *ph, *pl;                /* P planes blocked [key/32][Npad][32]       */
+  const rmem_bf16 *vh, *vl; int64_t v_slot_stride;   /* V^T planes [slot][ncols][Npad]  */
+  const int32_t *slot_map; int32_t T, N, Npad;
+  int32_t ncols;                           /* 1024 (V | ID_V)                           */
+  int32_t h, w;                            /* mode 1                                    */
+  float *part;                             /* [ksplits][Npad][ncols] fp32               */
+  int32_t ksplits;
+  int32_t nsplit;
+} rmem_pv_args;
+
+int rmem_attn_pv(const rmem_pv_args *a, void *stream);
+
+typedef struct {
+  int32_t mode; int32_t T, N, Npad, ncols, h, w;
+  const float *part; int32_t ksplits;
+  const float *lpart; int32_t nparts;
+  const float *U; int64_t ldu;             /* gate [N][ncols] (attention.py:206)        */
+  float *G; int64_t ldg;                   /* out: gated aggregate [N][ncols] fp32      */
+  float *mass;                             /* out (may be NULL): [N][T] = record_attn_weight (transformer.py:1186-1192) */
+} rmem_combine_args;
+
+int rmem_attn_combine(const rmem_combine_args *a, void *stream);
+
+/* bias[q][t] = (Q[q] + cur_pe) . mem_pe[pe_row[t]]   (layers/transformer.py:1140-1172) */
+int rmem_pe_bias(const float *Q, int64_t ldq, const float *cur_pe, const float *mem_pe,
+                 const int32_t *pe_row_host, int32_t T, int32_t N, int32_t d, float *bias,
+                 void *stream);
+
+/* ------------------------------------------------------------------ pointwise / norms */
+/* LayerNorm over C=256 channels -> planes (+ optional fp32); nn.LayerNorm of
+ * layers/transformer.py:1104,1120,1223-1224 and models/deaot.py:41. */
+int rmem_layernorm_split(const float *x, int64_t ldx, const float *gamma, const float *beta,
+                         int32_t N, int32_t C, float eps, rmem_bf16 *oh, rmem_bf16 *ol,
+                         int64_t ldo, float *of32, int64_t ldof, void *stream);
+
+/* Depth-wise 5x5, pad 2, no bias, on token-major [h*w][C] (layers/basic.py:38-57);
+ * wt is [25][C] (tap-major).  Output planes. */
+int rmem_dwconv5x5_split(const float *g, int64_t ldg, const float *wt, int32_t h, int32_t w,
+                         int32_t C, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, void *stream);
+
+/* Final GroupNorm1D(2 groups) over [tgt | tgt_id] (layers/transformer.py:806-808,
+ * layers/basic.py:6-12): statistics over 256 channels x N tokens per group.
+ * ws: >= 4*ceil(N/64) doubles. */
+int rmem_groupnorm2(const float *tgt, const float *tgt_id, int32_t N, int32_t C,
+                    const float *gamma, const float *beta, float eps, double *ws,
+                    float *out, int64_t ldo, void *stream);
+
+/* ID assignment: label map -> one-hot(+ignore) -> Conv2d(k,stride,pad) -> LayerNorm_C
+ * (utils/image.py:69-74, engines/aot_engine.py:208-232, models/aot.py:67-74,
+ * models/deaot.py:65-69).  wt is [ncls][k][k][C]; gamma NULL skips the LayerNorm (AOT). */
+int rmem_id_assign(const uint8_t *label, int32_t H, int32_t W, const float *wt, const float *bias,
+                   int32_t ncls, int32_t ksize, int32_t stride, int32_t pad, int32_t eh, int32_t ew,
+                   int32_t C, const float *gamma, const float *beta, float eps,
+                   rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32, int64_t ldof,
+                   void *stream);
+
+/* RMem relevance: out[t] = sum_q mass[q][t] * fg[q]   (layers/transformer.py:900-904) */
+int rmem_attn_mass_reduce(const float *mass, int32_t N, int32_t T, const float *fg, float *out,
+                          void *stream);
+
+/* fp32 -> planes (weights at load time, fixtures in tests) */
+int rmem_split_planes(const float *x, int64_t n, rmem_bf16 *hi, rmem_bf16 *lo, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMEM_HIP_H */

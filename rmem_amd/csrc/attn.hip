@@ -1,0 +1,374 @@
+// attn.hip -- memory-read attention (long-term bank / windowed short-term / self) as
+// three MFMA launches over a materialised split-bf16 probability matrix.
+// See include/rmem_hip.h for the contract and DESIGN.md for the roofline accounting.
+#include "../../include/rmem_hip.h"
+#include "gemm_core.h"
+
+// Key-tile band [t_lo, t_hi) (units of 128 keys) visible to query tile `qtile`
+// (128 queries) under the 15x15 window: rows y(q_lo)-7 .. y(q_hi)+7.
+__host__ __device__ inline void band_tiles(int qtile, int N, int h, int w, int& t_lo, int& t_hi) {
+  const int q_lo = qtile * 128;
+  int q_hi = qtile * 128 + 127;
+  if (q_hi > N - 1) q_hi = N - 1;
+  int y_lo = q_lo / w - 7;
+  if (y_lo < 0) y_lo = 0;
+  int y_hi = q_hi / w + 7;
+  if (y_hi > h - 1) y_hi = h - 1;
+  t_lo = (y_lo * w) / 128;
+  t_hi = ((y_hi + 1) * w + 127) / 128;
+}
+
+// ------------------------------------------------------------------ scores (swapped: rows = keys)
+template <int NS, int PASS>
+__global__ __launch_bounds__(256) void scores_kernel(rmem_scores_args a) {
+  using Cfg = GemmCfg<128, 128, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int qtile = blockIdx.y;
+  const int tiles_per_slot = a.Npad / 128;
+  int t = 0, ktile;  // ktile: key tile inside the slot
+  if (a.mode == 0) {
+    t = blockIdx.x / tiles_per_slot;
+    ktile = blockIdx.x - t * tiles_per_slot;
+  } else {
+    int t_lo, t_hi;
+    band_tiles(qtile, a.N, a.h, a.w, t_lo, t_hi);
+    ktile = t_lo + blockIdx.x;
+    if (ktile >= t_hi) return;
+  }
+  const int phys = a.slot_map ? a.slot_map[t] : t;
+
+  RowMajorOperand lx, ly;
+  lx.hi = a.kh + (long)phys * a.k_slot_stride;
+  lx.lo = a.kl ? a.kl + (long)phys * a.k_slot_stride : nullptr;
+  lx.ld = 128;
+  lx.hi2 = lx.lo2 = nullptr;
+  lx.ld2 = 0;
+  lx.kt_split = 1 << 30;
+  lx.row0 = ktile * 128;
+  lx.rows = a.Npad;
+  ly.hi = a.qh;
+  ly.lo = a.ql;
+  ly.ld = 128;
+  ly.hi2 = ly.lo2 = nullptr;
+  ly.ld2 = 0;
+  ly.kt_split = 1 << 30;
+  ly.row0 = qtile * 128;
+  ly.rows = a.Npad;
+
+  GemmFrag<Cfg> f;
+  f.zero();
+  gemm_mainloop<Cfg>(f, lx, ly, 0, 2, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const float inv_w = a.mode == 1 ? 1.0f / (float)a.w : 0.f;
+  // key axis of P / lpart: logical slot-major
+  const long key_axis0 = (long)t * a.Npad + ktile * 128 + wr * 64;
+
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int q = qtile * 128 + frag_col<Cfg>(wc, tn, lane);
+    const bool qvalid = q < a.N;
+    float bias_q = 0.f;
+    int qy = 0, qx = 0;
+    const float* Rq = nullptr;
+    if (a.mode == 0) {
+      if (a.bias && qvalid) bias_q = a.bias[(long)q * a.T + t];
+    } else {
+      qy = fast_div(q, inv_w);
+      qx = q - qy * a.w;
+      Rq = a.R + (long)(qvalid ? q : 0) * a.ldr;
+    }
+    float mrow = 0.f;
+    if (PASS == 1) mrow = qvalid ? dec_ordered(a.rowmax[q]) : 0.f;
+    float mx = -3.0e38f, lsum = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tok = ktile * 128 + frag_row<Cfg>(wr, tm, r, lane);
+        bool valid = qvalid && tok < a.N;
+        float s;
+        if (a.mode == 0) {
+          s = a.scale * (f.acc[tm][tn][r] + bias_q);
+        } else {
+          const int ky = fast_div(tok, inv_w);
+          const int kx = tok - ky * a.w;
+          const int dy = ky - qy, dx = kx - qx;
+          valid = valid && dy >= -7 && dy <= 7 && dx >= -7 && dx <= 7;
+          const float rb = valid ? Rq[(dy + 7) * 15 + dx + 7] : 0.f;
+          s = a.scale * f.acc[tm][tn][r] + rb;
+        }
+        if (PASS == 0) {
+          if (valid) mx = fmaxf(mx, s);
+        } else {
+          const float p = valid ? expf(s - mrow) : 0.f;
+          pv[r] = p;
+          lsum += p;
+        }
+      }
+      if (PASS == 1) {
+        // P blocked [key/32][Npad][32]: this lane owns keys 8g + 4*(lane>>5) + {0..3}
+        const long kb = (key_axis0 + tm * 32) >> 5;
+        const long base = (kb * a.Npad + q) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16_t hi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_bf16(pv[4 * g + e], hi[e], lo[e]);
+          uint2 vh, vl;
+          vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+          vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+          *reinterpret_cast<uint2*>(a.ph + base + 8 * g) = vh;
+          if (a.pl) {
+            vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+            vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+            *reinterpret_cast<uint2*>(a.pl + base + 8 * g) = vl;
+          }
+        }
+      }
+    }
+    if (PASS == 0) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (lane < 32 && qvalid && mx > -2.9e38f) atomicMax(a.rowmax + q, enc_ordered(mx));
+    } else {
+      lsum += __shfl_xor(lsum, 32);
+      if (lane < 32) a.lpart[(long)q * a.nparts + (key_axis0 >> 6)] = lsum;
+    }
+  }
+}
+
+static int max_band_tiles(int N, int Npad, int h, int w) {
+  int mx = 0;
+  for (int qt = 0; qt < Npad / 128; ++qt) {
+    int lo, hi;
+    band_tiles(qt, N, h, w, lo, hi);
+    if (hi - lo > mx) mx = hi - lo;
+  }
+  return mx;
+}
+
+template <int NS, int PASS>
+static int launch_scores(const rmem_scores_args& a, hipStream_t s) {
+  using Cfg = GemmCfg<128, 128, NS>;
+  const int qtiles = a.Npad / 128;
+  const int ktiles = a.mode == 0 ? a.T * (a.Npad / 128) : max_band_tiles(a.N, a.Npad, a.h, a.w);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scores_kernel<NS, PASS>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((scores_kernel<NS, PASS>), dim3(ktiles, qtiles), dim3(256), Cfg::LDS_BYTES, s, a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_attn_scores(const rmem_scores_args* ap, void* stream) {
+  if (!ap) return RMEM_ERR_INVALID;
+  const rmem_scores_args& a = *ap;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0) return RMEM_ERR_INVALID;
+  if (!a.kh || !a.qh || !a.rowmax) return RMEM_ERR_INVALID;
+  if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
+  if (a.mode != 0 && a.mode != 1) return RMEM_ERR_INVALID;
+  if (a.pass == 0) return launch_scores<1, 0>(a, s);
+  if (a.pass != 1 || !a.ph || !a.lpart) return RMEM_ERR_INVALID;
+  if (a.nsplit == 3) {
+    if (!a.kl || !a.ql || !a.pl) return RMEM_ERR_INVALID;
+    return launch_scores<3, 1>(a, s);
+  }
+  if (a.nsplit == 1) return launch_scores<1, 1>(a, s);
+  return RMEM_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------ P . V
+struct PBlockedOperand {
+  const bf16_t* hi;
+  const bf16_t* lo;
+  long npad;
+  int row0;
+  __device__ __forceinline__ const u32x4_t* ptr(int plane, int kt, int r, int c) const {
+    const long kb = (long)kt * 2 + (c >> 2);
+    const bf16_t* b = plane ? lo : hi;
+    return reinterpret_cast<const u32x4_t*>(b + (kb * npad + row0 + r) * 32 + (c & 3) * 8);
+  }
+};
+
+struct VtOperand {
+  const bf16_t* hi;
+  const bf16_t* lo;
+  long slot_stride, ld;
+  const int* slot_map;
+  int tps;  // 64-key tiles per slot
+  int row0, rows;
+  __device__ __forceinline__ const u32x4_t* ptr(int plane, int kt, int r, int c) const {
+    int j = row0 + r;
+    j = j < rows ? j : rows - 1;
+    const int t = kt / tps;
+    const int off = (kt - t * tps) * 64;
+    const int phys = slot_map ? slot_map[t] : t;
+    const bf16_t* b = plane ? lo : hi;
+    return reinterpret_cast<const u32x4_t*>(b + (long)phys * slot_stride + (long)j * ld + off + c * 8);
+  }
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
+  using Cfg = GemmCfg<128, 128, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ctile = blockIdx.x, qtile = blockIdx.y, z = blockIdx.z;
+  const int tps = a.Npad / 64;
+  int k_lo, k_hi;
+  if (a.mode == 0) {
+    k_lo = 0;
+    k_hi = a.T * tps;
+  } else {
+    int t_lo, t_hi;
+    band_tiles(qtile, a.N, a.h, a.w, t_lo, t_hi);
+    k_lo = 2 * t_lo;
+    k_hi = 2 * t_hi;
+  }
+  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
+  int lo = k_lo + z * per, hi = lo + per;
+  if (hi > k_hi) hi = k_hi;
+
+  PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 128};
+  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, a.slot_map, tps, ctile * 128, a.ncols};
+
+  GemmFrag<Cfg> f;
+  f.zero();
+  gemm_mainloop<Cfg>(f, lx, ly, lo, hi, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  float* out = a.part + (long)z * a.Npad * a.ncols;
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
+    if (col >= a.ncols) continue;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
+        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
+      }
+  }
+}
+
+template <int NS>
+static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
+  using Cfg = GemmCfg<128, 128, NS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel<NS>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    attr_set = true;
+  }
+  dim3 grid((a.ncols + 127) / 128, a.Npad / 128, a.ksplits);
+  hipLaunchKernelGGL((pv_kernel<NS>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
+  if (!ap) return RMEM_ERR_INVALID;
+  const rmem_pv_args& a = *ap;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
+  if (!a.ph || !a.vh || !a.part || a.ncols <= 0) return RMEM_ERR_INVALID;
+  if (a.mode == 1 && (a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
+  if (a.nsplit == 3) {
+    if (!a.pl || !a.vl) return RMEM_ERR_INVALID;
+    return launch_pv<3>(a, s);
+  }
+  if (a.nsplit == 1) return launch_pv<1>(a, s);
+  return RMEM_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------ combine + gate (+ mass)
+__global__ __launch_bounds__(256) void combine_kernel(rmem_combine_args a) {
+  __shared__ float slot_sum[64];
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tps = a.Npad / 64;
+  const float* lp = a.lpart + (long)q * a.nparts;
+  int nslots = a.T;
+  for (int t = wave; t < nslots; t += 4) {
+    int p_lo = t * tps, p_hi = (t + 1) * tps;
+    if (a.mode == 1) {
+      int t_lo, t_hi;
+      band_tiles(q / 128, a.N, a.h, a.w, t_lo, t_hi);
+      p_lo = 2 * t_lo;
+      p_hi = 2 * t_hi;
+    }
+    float s = 0.f;
+    for (int p = p_lo + lane; p < p_hi; p += 64) s += lp[p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) slot_sum[t] = s;
+  }
+  __syncthreads();
+  float l = 0.f;
+  for (int t = 0; t < nslots; ++t) l += slot_sum[t];
+  const float inv_l = 1.0f / l;
+  if (a.mass && tid < nslots) a.mass[(long)q * a.T + tid] = slot_sum[tid] * inv_l;
+
+  for (int c = tid * 4; c < a.ncols; c += 1024) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < a.ksplits; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(a.part + ((long)z * a.Npad + q) * a.ncols + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float4 u = *reinterpret_cast<const float4*>(a.U + (long)q * a.ldu + c);
+    float4 g;
+    g.x = acc.x * inv_l * u.x;
+    g.y = acc.y * inv_l * u.y;
+    g.z = acc.z * inv_l * u.z;
+    g.w = acc.w * inv_l * u.w;
+    *reinterpret_cast<float4*>(a.G + (long)q * a.ldg + c) = g;
+  }
+}
+
+extern "C" int rmem_attn_combine(const rmem_combine_args* ap, void* stream) {
+  if (!ap) return RMEM_ERR_INVALID;
+  const rmem_combine_args& a = *ap;
+  if (a.N <= 0 || a.T <= 0 || a.T > 64 || (a.ncols % 4) != 0 || !a.part || !a.lpart || !a.U || !a.G)
+    return RMEM_ERR_INVALID;
+  if ((a.ldu % 4) || (a.ldg % 4)) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(combine_kernel, dim3(a.N), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ temporal-PE bias
+struct PeRows { int row[16]; };
+
+__global__ void pe_bias_kernel(const float* Q, long ldq, const float* cur_pe, const float* mem_pe,
+                               PeRows rows, int T, int N, int d, float* bias) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= N) return;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64)
+      s += (Q[(long)q * ldq + c] + cur_pe[c]) * mem_pe[(long)rows.row[t] * d + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) bias[(long)q * T + t] = s;
+  }
+}
+
+extern "C" int rmem_pe_bias(const float* Q, int64_t ldq, const float* cur_pe, const float* mem_pe,
+                            const int32_t* pe_row_host, int32_t T, int32_t N, int32_t d, float* bias,
+                            void* stream) {
+  if (!Q || !cur_pe || !mem_pe || !pe_row_host || !bias || T <= 0 || T > 16 || N <= 0) return RMEM_ERR_INVALID;
+  PeRows rows;
+  for (int t = 0; t < 16; ++t) rows.row[t] = t < T ? pe_row_host[t] : 0;
+  hipLaunchKernelGGL(pe_bias_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), Q,
+                     (long)ldq, cur_pe, mem_pe, rows, T, N, d, bias);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}

@@ -1,0 +1,307 @@
+// pointwise.hip -- bandwidth-bound kernels of the hot path: LayerNorm -> planes,
+// depth-wise 5x5 -> planes, final GroupNorm, ID assignment (gather-conv + LayerNorm),
+// RMem attention-mass reduction, fp32 -> planes.  See include/rmem_hip.h.
+#include "../../include/rmem_hip.h"
+#include "rmem_common.h"
+
+// ------------------------------------------------------------------ LayerNorm -> planes
+// one wave per row, C = 256: 4 consecutive channels per lane (16-byte loads)
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, long ldx, const float* gamma,
+                                                              const float* beta, int N, float eps,
+                                                              bf16_t* oh, bf16_t* ol, long ldo, float* of32,
+                                                              long ldof) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N) return;
+  const float4 v = *reinterpret_cast<const float4*>(x + (long)row * ldx + lane * 4);
+  float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / 256.0f);
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  float ss = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  const float4 b = *reinterpret_cast<const float4*>(beta + lane * 4);
+  float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
+  if (of32) *reinterpret_cast<float4*>(of32 + (long)row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
+  if (oh) {
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(y[e], hi[e], lo[e]);
+    uint2 vh, vl;
+    vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+    vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+    vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+    *reinterpret_cast<uint2*>(oh + (long)row * ldo + lane * 4) = vh;
+    if (ol) *reinterpret_cast<uint2*>(ol + (long)row * ldo + lane * 4) = vl;
+  }
+}
+
+extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                    int32_t N, int32_t C, float eps, rmem_bf16* oh, rmem_bf16* ol,
+                                    int64_t ldo, float* of32, int64_t ldof, void* stream) {
+  if (!x || !gamma || !beta || N <= 0 || C != 256 || (ldx % 4) || (ldo % 4) || (ldof % 4)) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(layernorm_split_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     (long)ldx, gamma, beta, N, eps, oh, ol, (long)ldo, of32, (long)ldof);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ depth-wise 5x5 -> planes
+// block = one token x (256 threads x 4 channels); grid.y covers C / 1024
+__global__ __launch_bounds__(256) void dwconv5x5_split_kernel(const float* g, long ldg, const float* wt, int h,
+                                                              int w, int C, bf16_t* oh, bf16_t* ol, long ldo) {
+  const int p = blockIdx.x;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  const int y = p / w, x = p - y * w;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= h) continue;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= w) continue;
+      const float4 v = *reinterpret_cast<const float4*>(g + (long)(yy * w + xx) * ldg + c);
+      const float4 k = *reinterpret_cast<const float4*>(wt + (long)((dy + 2) * 5 + dx + 2) * C + c);
+      acc.x += v.x * k.x;
+      acc.y += v.y * k.y;
+      acc.z += v.z * k.z;
+      acc.w += v.w * k.w;
+    }
+  }
+  const float yv[4] = {acc.x, acc.y, acc.z, acc.w};
+  bf16_t hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_bf16(yv[e], hi[e], lo[e]);
+  uint2 vh, vl;
+  vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+  vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+  vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+  vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+  *reinterpret_cast<uint2*>(oh + (long)p * ldo + c) = vh;
+  if (ol) *reinterpret_cast<uint2*>(ol + (long)p * ldo + c) = vl;
+}
+
+extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt, int32_t h, int32_t w,
+                                    int32_t C, rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, void* stream) {
+  if (!g || !wt || !oh || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(dwconv5x5_split_kernel, dim3(h * w, (C + 1023) / 1024), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, (long)ldg, wt, h, w, C, oh, ol, (long)ldo);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ final GroupNorm (2 groups)
+// pass A: per-block (64 tokens) double partial (sum, sumsq) for both groups
+__global__ __launch_bounds__(256) void gn2_stats_kernel(const float* tgt, const float* tgt_id, int N, int C,
+                                                        double* ws) {
+  __shared__ double red[2][2][4];
+  const int t0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s[2] = {0, 0}, q[2] = {0, 0};
+  for (int i = tid; i < 64 * (C / 4); i += 256) {
+    const int tok = t0 + i / (C / 4);
+    const int c = (i % (C / 4)) * 4;
+    if (tok >= N) continue;
+    const float4 a = *reinterpret_cast<const float4*>(tgt + (long)tok * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(tgt_id + (long)tok * C + c);
+    s[0] += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
+    q[0] += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    s[1] += (double)b.x + (double)b.y + (double)b.z + (double)b.w;
+    q[1] += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
+  }
+#pragma unroll
+  for (int gidx = 0; gidx < 2; ++gidx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s[gidx] += __shfl_xor(s[gidx], o);
+      q[gidx] += __shfl_xor(q[gidx], o);
+    }
+    if (lane == 0) {
+      red[gidx][0][wave] = s[gidx];
+      red[gidx][1][wave] = q[gidx];
+    }
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const int gidx = tid >> 1, k = tid & 1;
+    ws[(long)blockIdx.x * 4 + tid] = red[gidx][k][0] + red[gidx][k][1] + red[gidx][k][2] + red[gidx][k][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void gn2_apply_kernel(const float* tgt, const float* tgt_id, int N, int C,
+                                                        const float* gamma, const float* beta, float eps,
+                                                        const double* ws, int nblk, float* out, long ldo) {
+  __shared__ float stat[4];  // mean0, rstd0, mean1, rstd1
+  const int tid = threadIdx.x;
+  if (tid < 2) {
+    double s = 0, q = 0;
+    for (int b = 0; b < nblk; ++b) {
+      s += ws[(long)b * 4 + tid * 2 + 0];
+      q += ws[(long)b * 4 + tid * 2 + 1];
+    }
+    const double cnt = (double)N * C;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0) var = 0;
+    stat[tid * 2 + 0] = (float)mean;
+    stat[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int t0 = blockIdx.x * 64;
+  for (int i = tid; i < 64 * (C / 4); i += 256) {
+    const int tok = t0 + i / (C / 4);
+    const int c = (i % (C / 4)) * 4;
+    if (tok >= N) continue;
+#pragma unroll
+    for (int gidx = 0; gidx < 2; ++gidx) {
+      const float* src = gidx ? tgt_id : tgt;
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)tok * C + c);
+      const float4 g = *reinterpret_cast<const float4*>(gamma + gidx * C + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + gidx * C + c);
+      const float m = stat[gidx * 2], r = stat[gidx * 2 + 1];
+      float4 o;
+      o.x = (v.x - m) * r * g.x + b.x;
+      o.y = (v.y - m) * r * g.y + b.y;
+      o.z = (v.z - m) * r * g.z + b.z;
+      o.w = (v.w - m) * r * g.w + b.w;
+      *reinterpret_cast<float4*>(out + (long)tok * ldo + gidx * C + c) = o;
+    }
+  }
+}
+
+extern "C" int rmem_groupnorm2(const float* tgt, const float* tgt_id, int32_t N, int32_t C, const float* gamma,
+                               const float* beta, float eps, double* ws, float* out, int64_t ldo, void* stream) {
+  if (!tgt || !tgt_id || !gamma || !beta || !ws || !out || N <= 0 || (C % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
+  const int nblk = (N + 63) / 64;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn2_stats_kernel, dim3(nblk), dim3(256), 0, s, tgt, tgt_id, N, C, ws);
+  hipLaunchKernelGGL(gn2_apply_kernel, dim3(nblk), dim3(256), 0, s, tgt, tgt_id, N, C, gamma, beta, eps, ws, nblk,
+                     out, (long)ldo);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ ID assignment
+// block = one output token, thread = one of C = 256 channels; gather-sum over the
+// k x k receptive field of the one-hot(+ignore) label map, then LayerNorm over C.
+__global__ __launch_bounds__(256) void id_assign_kernel(const uint8_t* label, int H, int W, const float* wt,
+                                                        const float* bias, int ncls, int ksize, int stride,
+                                                        int pad, int ew, const float* gamma, const float* beta,
+                                                        float eps, bf16_t* oh, bf16_t* ol, long ldo, float* of32,
+                                                        long ldof) {
+  __shared__ float red[4];
+  __shared__ float red2[4];
+  const int tok = blockIdx.x;
+  const int oy = tok / ew, ox = tok - oy * ew;
+  const int c = threadIdx.x;
+  const int lane = c & 63, wave = c >> 6;
+  float acc = bias[c];
+  for (int dy = 0; dy < ksize; ++dy) {
+    const int y = oy * stride - pad + dy;
+    if (y < 0 || y >= H) continue;
+    for (int dx = 0; dx < ksize; ++dx) {
+      const int x = ox * stride - pad + dx;
+      if (x < 0 || x >= W) continue;
+      int cls = label[(long)y * W + x];   // block-uniform
+      if (cls == 255) cls = ncls - 1;     // ignore channel is the last one
+      else if (cls >= ncls - 1) continue; // ids above max_obj have no one-hot channel
+      acc += wt[((long)(cls * ksize + dy) * ksize + dx) * 256 + c];
+    }
+  }
+  float yv = acc;
+  if (gamma) {
+    float s = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / 256.0f);
+    const float d = acc - mean;
+    float ss = d * d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) red2[wave] = ss;
+    __syncthreads();
+    const float var = (red2[0] + red2[1] + red2[2] + red2[3]) * (1.0f / 256.0f);
+    yv = d / sqrtf(var + eps) * gamma[c] + beta[c];
+  }
+  if (of32) of32[(long)tok * ldof + c] = yv;
+  if (oh) {
+    bf16_t hi, lo;
+    split_bf16(yv, hi, lo);
+    oh[(long)tok * ldo + c] = hi;
+    if (ol) ol[(long)tok * ldo + c] = lo;
+  }
+}
+
+extern "C" int rmem_id_assign(const uint8_t* label, int32_t H, int32_t W, const float* wt, const float* bias,
+                              int32_t ncls, int32_t ksize, int32_t stride, int32_t pad, int32_t eh, int32_t ew,
+                              int32_t C, const float* gamma, const float* beta, float eps, rmem_bf16* oh,
+                              rmem_bf16* ol, int64_t ldo, float* of32, int64_t ldof, void* stream) {
+  if (!label || !wt || !bias || C != 256 || eh <= 0 || ew <= 0 || ncls < 2) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(id_assign_kernel, dim3(eh * ew), dim3(256), 0, static_cast<hipStream_t>(stream), label, H, W,
+                     wt, bias, ncls, ksize, stride, pad, ew, gamma, beta, eps, oh, ol, (long)ldo, of32,
+                     (long)ldof);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ RMem relevance reduce
+__global__ __launch_bounds__(1024) void mass_reduce_kernel(const float* mass, int N, int T, const float* fg,
+                                                           float* out) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f;
+    for (int q = tid; q < N; q += 1024) s += mass[(long)q * T + t] * fg[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float r = 0.f;
+      for (int i = 0; i < 16; ++i) r += red[i];
+      out[t] = r;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int rmem_attn_mass_reduce(const float* mass, int32_t N, int32_t T, const float* fg, float* out,
+                                     void* stream) {
+  if (!mass || !fg || !out || N <= 0 || T <= 0) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(mass_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), mass, N, T, fg,
+                     out);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ fp32 -> planes
+__global__ void split_planes_kernel(const float* x, long n, bf16_t* hi, bf16_t* lo) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    bf16_t h, l;
+    split_bf16(x[i], h, l);
+    hi[i] = h;
+    if (lo) lo[i] = l;
+  }
+}
+
+extern "C" int rmem_split_planes(const float* x, int64_t n, rmem_bf16* hi, rmem_bf16* lo, void* stream) {
+  if (!x || !hi || n <= 0) return RMEM_ERR_INVALID;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, (long)n, hi, lo);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_abi_version(void) { return 1; }

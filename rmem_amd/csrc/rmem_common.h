@@ -1,0 +1,56 @@
+// rmem_common.h -- shared device helpers for the RMem gfx950 kernels.
+//
+// Numeric convention ("split-bf16"): an fp32 value x is carried as two bf16 planes
+// hi = bf16(x), lo = bf16(x - hi).  A product of two such values evaluated on the
+// bf16 MFMA pipe as  hi*lo' + lo*hi' + hi*hi'  (NSPLIT = 3) has a relative error of
+// ~2^-17 per product, i.e. fp32-class, at 3 MFMA issues; NSPLIT = 1 uses hi*hi' only
+// (plain bf16).  All accumulation is fp32 in the MFMA accumulators.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RMEM_OK 0
+#define RMEM_ERR_INVALID (-1)
+#define RMEM_ERR_LAUNCH (-2)
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// native vector (HIP's uint4 struct keeps register arrays in scratch)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+#define RMEM_CHECK_LAUNCH()                                      \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) return RMEM_ERR_LAUNCH;               \
+  } while (0)
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f2bf(x);
+  lo = f2bf(x - bf2f(hi));
+}
+
+// Monotone float <-> uint encoding so that atomicMax on the uint orders like the
+// float; 0 encodes "below every float" (lets a plain memset(0) reset the buffer).
+__device__ __forceinline__ uint32_t enc_ordered(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// exact floor(k / w) for 0 <= k < 2^20, 1 <= w ((k+0.5)/w is never
+// closer than 0.5/w to an integer, far above fp32 rounding).
+__device__ __forceinline__ int fast_div(int k, float inv_w) {
+  return (int)(((float)k + 0.5f) * inv_w);
+}

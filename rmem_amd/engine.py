@@ -1,0 +1,227 @@
+"""Inference engines with the reference's API, backed by the HIP LSTT.
+
+Drop-in for /root/reference/aot_plus/networks/engines:
+``build_engine(name, phase='eval', aot_model=..., gpu_id=..., long_term_mem_gap=...)``
+returns an object exposing ``restart_engine / add_reference_frame /
+match_propogate_one_frame / update_memory``, the writable ``long_term_mem_gap`` and the
+read attributes ``input_size_2d / enc_size_2d / enc_hw`` -- the surface
+``managers/evaluator.py:344-523`` and ``tools/demo.py:113-190`` drive.
+
+Encoder and FPN decoder run through PyTorch-ROCm/MIOpen unchanged; everything between
+them (LSTT, ID assignment, memory bank, RMem eviction) is rmem_amd.lstt / csrc.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .lstt import DeAOTLSTT
+
+
+class DeAOTEngine(nn.Module):
+    """One engine = up to MODEL_MAX_OBJ_NUM objects (engines/aot_engine.py:18-568)."""
+
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1,
+                 nsplit: int = 3):
+        super().__init__()
+        if short_term_mem_skip != 1:
+            raise NotImplementedError("short_term_mem_skip != 1 (reference evaluator always uses 1)")
+        self.cfg = aot_model.cfg
+        self.align_corners = self.cfg.MODEL_ALIGN_CORNERS
+        self.AOT = aot_model
+        self.max_obj_num = aot_model.max_obj_num
+        self.gpu_id = gpu_id
+        self.long_term_mem_gap = long_term_mem_gap
+        self.nsplit = nsplit
+        self.lstt: Optional[DeAOTLSTT] = None
+        self.restart_engine()
+
+    def restart_engine(self):                                   # aot_engine.py:533-563
+        self.frame_step = 0
+        self.last_mem_step = -1
+        self.obj_nums = None
+        self.enc_size_2d = None
+        self.enc_hw = None
+        self.input_size_2d = None
+        self.long_memories_indexes: List[int] = []
+        self.pred_id_logits = None
+        if self.lstt is not None:
+            self.lstt.clear_memory()
+
+    def update_size(self, input_size, enc_size):                # aot_engine.py:565-568
+        self.input_size_2d = tuple(int(v) for v in input_size)
+        self.enc_size_2d = tuple(int(v) for v in enc_size)
+        self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
+        if self.lstt is None or (self.lstt.h, self.lstt.w) != self.enc_size_2d:
+            dev = next(self.AOT.parameters()).device
+            self.lstt = DeAOTLSTT(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
+
+    def _label_u8(self, mask: torch.Tensor) -> torch.Tensor:
+        """[1,1,H,W] (or [1,H,W]) label ids -> contiguous uint8 [H,W] on device."""
+        m = mask
+        while m.dim() > 2:
+            m = m[0]
+        return m.to(torch.uint8).contiguous()
+
+    def _tokens(self, enc_last: torch.Tensor) -> torch.Tensor:
+        """bchw_2_lbc (utils/tensor.py:3-6) for batch 1: [1,C,h,w] -> [N,C]."""
+        return enc_last[0].flatten(1).t().contiguous()
+
+    @torch.no_grad()
+    def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
+        """aot_engine.py:241-325."""
+        if self.obj_nums is None and obj_nums is None:
+            raise ValueError("No objects for reference frame!")
+        if obj_nums is not None:
+            self.obj_nums = obj_nums
+        if frame_step == -1:
+            frame_step = self.frame_step
+        if mask is None:
+            raise ValueError("No mask for reference frame!")
+        enc = self.AOT.encode_image(img) if img_embs is None else img_embs
+        if enc is None:
+            raise ValueError("No image for reference frame!")
+        if self.input_size_2d is None:
+            self.update_size(img.shape[2:], enc[-1].shape[2:])
+        self.lstt.assign_identity(self._label_u8(mask))
+        out = self.lstt.forward(self._tokens(enc[-1]), ref_frame=True)
+        self.last_mem_step = frame_step
+        self.long_memories_indexes.append(self.frame_step)
+        self.decode_current_logits(enc, out)
+
+    @torch.no_grad()
+    def match_propogate_one_frame(self, img=None, img_embs=None, mask=None, output_size=None):
+        """aot_engine.py:398-436."""
+        self.frame_step += 1
+        enc = self.AOT.encode_image(img) if img_embs is None else img_embs
+        out = self.lstt.forward(self._tokens(enc[-1]), ref_frame=False)
+        return self.decode_current_logits(enc, out, output_size)
+
+    def decode_current_logits(self, enc, lstt_out, output_size=None):      # aot_engine.py:438-465
+        logits = self.AOT.decode_id_logits(lstt_out, enc)
+        for batch_idx, obj_num in enumerate(self.obj_nums):
+            logits[batch_idx, (obj_num + 1):] = -1e10
+        self.pred_id_logits = logits
+        if output_size is not None:
+            logits = F.interpolate(logits, size=output_size, mode="bilinear",
+                                   align_corners=self.align_corners)
+        return logits
+
+    @torch.no_grad()
+    def update_short_term_memory(self, curr_mask, curr_id_emb=None, step=0):
+        """aot_engine.py:327-369."""
+        if curr_mask.dim() == 4 and curr_mask.shape[1] > 1:
+            raise NotImplementedError("probability masks are a training-only input (aot_engine.py:333-334)")
+        self.lstt.assign_identity(self._label_u8(curr_mask))
+        update_long = False
+        if (not self.cfg.NO_LONG_MEMORY) and \
+                self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            update_long = True
+            self.last_mem_step = self.frame_step
+        self.lstt.update_short_memories(update_long)
+        if update_long:
+            self.long_memories_indexes.append(self.frame_step)
+            lg = F.interpolate(self.pred_id_logits, size=self.enc_size_2d, mode="bilinear",
+                               align_corners=True)
+            fg = (1 - torch.softmax(lg, dim=1)[:, 0]).reshape(-1).contiguous()
+            self.lstt.restrict_long_memories(self.long_memories_indexes, fg)
+
+
+class DeAOTInferEngine(nn.Module):
+    """Multi-object wrapper (engines/aot_engine.py:571-725, deaot_engine.py:20-56)."""
+
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1,
+                 max_aot_obj_num=None, nsplit: int = 3):
+        super().__init__()
+        self.cfg = aot_model.cfg
+        self.AOT = aot_model
+        if max_aot_obj_num is None or max_aot_obj_num > aot_model.max_obj_num:
+            self.max_aot_obj_num = aot_model.max_obj_num
+        else:
+            self.max_aot_obj_num = max_aot_obj_num
+        self.gpu_id = gpu_id
+        self.long_term_mem_gap = long_term_mem_gap
+        self.short_term_mem_skip = short_term_mem_skip
+        self.nsplit = nsplit
+        self.aot_engines: List[DeAOTEngine] = []
+        self._pool: List[DeAOTEngine] = []     # engines (and their HBM buffers) are reused across clips
+        self.restart_engine()
+
+    def restart_engine(self):                                   # aot_engine.py:598-602
+        for e in self.aot_engines:
+            e.restart_engine()
+        self._pool = self.aot_engines + [e for e in self._pool if e not in self.aot_engines]
+        self.aot_engines = []
+        self.obj_nums = None
+
+    def separate_mask(self, mask):                              # aot_engine.py:604-628
+        if mask is None:
+            return [None] * len(self.aot_engines)
+        if len(self.aot_engines) == 1:
+            return [mask]
+        if mask.dim() == 3 or mask.shape[0] == 1:
+            out = []
+            for idx in range(len(self.aot_engines)):
+                start_id = idx * self.max_aot_obj_num + 1
+                end_id = (idx + 1) * self.max_aot_obj_num
+                fg = ((mask >= start_id) & (mask <= end_id)).float()
+                out.append((fg * mask - start_id + 1) * fg)
+            return out
+        raise NotImplementedError("probability masks are a training-only input")
+
+    def soft_logit_aggregation(self, all_logits):               # aot_engine.py:650-673
+        if len(all_logits) == 1:
+            return all_logits[0]
+        fg_probs, bg_probs = [], []
+        for logit in all_logits:
+            prob = torch.softmax(logit, dim=1)
+            bg_probs.append(prob[:, 0:1])
+            fg_probs.append(prob[:, 1:1 + self.max_aot_obj_num])
+        bg_prob = torch.prod(torch.cat(bg_probs, dim=1), dim=1, keepdim=True)
+        merged = torch.cat([bg_prob] + fg_probs, dim=1).clamp(1e-5, 1 - 1e-5)
+        return torch.logit(merged)
+
+    def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):     # deaot_engine.py:30-56
+        if isinstance(obj_nums, list):
+            obj_nums = obj_nums[0]
+        self.obj_nums = obj_nums
+        aot_num = max(int(np.ceil(obj_nums / self.max_aot_obj_num)), 1)
+        while aot_num > len(self.aot_engines):
+            if self._pool:
+                eng = self._pool.pop(0)
+                eng.long_term_mem_gap = self.long_term_mem_gap
+            else:
+                eng = DeAOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap,
+                                  self.short_term_mem_skip, self.nsplit)
+            eng.eval()
+            self.aot_engines.append(eng)
+        for eng, m in zip(self.aot_engines, self.separate_mask(mask)):
+            eng.add_reference_frame(img, m, obj_nums=[self.max_aot_obj_num], frame_step=frame_step)
+        self.update_size()
+
+    def match_propogate_one_frame(self, img=None, mask=None, output_size=None):   # aot_engine.py:704-712
+        all_logits = [e.match_propogate_one_frame(img, mask=mask, output_size=output_size)
+                      for e in self.aot_engines]
+        return self.soft_logit_aggregation(all_logits)
+
+    def update_memory(self, curr_mask):                         # aot_engine.py:714-720
+        for eng, m in zip(self.aot_engines, self.separate_mask(curr_mask)):
+            eng.update_short_term_memory(m)
+
+    def update_size(self):                                      # aot_engine.py:722-725
+        self.input_size_2d = self.aot_engines[0].input_size_2d
+        self.enc_size_2d = self.aot_engines[0].enc_size_2d
+        self.enc_hw = self.aot_engines[0].enc_hw
+
+
+def build_engine(name, phase="eval", **kwargs):
+    """engines/__init__.py:5-21 (inference phases only; training is out of scope)."""
+    if phase != "eval":
+        raise NotImplementedError("only phase='eval' is built (training is out of the hot-path scope)")
+    if name == "deaotengine":
+        return DeAOTInferEngine(**kwargs)
+    raise NotImplementedError(name)

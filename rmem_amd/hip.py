@@ -1,0 +1,180 @@
+"""ctypes binding of librmem_hip.so (include/rmem_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this
+module raises.  Tensors are passed as raw device pointers (``tensor.data_ptr()``) and
+the launch stream is torch's current HIP stream, so calls are capturable in a hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librmem_hip.so")
+
+c_p = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+
+
+class RmemError(RuntimeError):
+    pass
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [
+        ("xh", c_p), ("xl", c_p), ("ldx", i64),
+        ("xh2", c_p), ("xl2", c_p), ("ldx2", i64), ("kx_split", i32),
+        ("yh", c_p), ("yl", c_p), ("ldy", i64),
+        ("yh2", c_p), ("yl2", c_p), ("ldy2", i64), ("ky_split", i32),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("bias", c_p), ("bias_per_row", i32), ("act", i32),
+        ("d0", c_p), ("ldd0", i64), ("d1", c_p), ("ldd1", i64),
+        ("csplit", i32), ("accumulate", i32),
+        ("pah", c_p), ("pal", c_p), ("ldpa", i64),
+        ("pbh", c_p), ("pbl", c_p), ("ldpb", i64), ("addvec", c_p),
+        ("nbatch", i32), ("bsx", i64), ("bsy", i64), ("bsd", i64), ("bsbias", i64), ("bspa", i64),
+        ("nsplit", i32), ("tile", i32),
+    ]
+
+
+class ScoresArgs(C.Structure):
+    _fields_ = [
+        ("mode", i32), ("pass_", i32),
+        ("kh", c_p), ("kl", c_p), ("k_slot_stride", i64),
+        ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32),
+        ("qh", c_p), ("ql", c_p), ("scale", f32),
+        ("bias", c_p), ("R", c_p), ("ldr", i32), ("h", i32), ("w", i32),
+        ("rowmax", c_p), ("ph", c_p), ("pl", c_p),
+        ("lpart", c_p), ("nparts", i32), ("nsplit", i32),
+    ]
+
+
+class PVArgs(C.Structure):
+    _fields_ = [
+        ("mode", i32), ("ph", c_p), ("pl", c_p),
+        ("vh", c_p), ("vl", c_p), ("v_slot_stride", i64),
+        ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32),
+        ("ncols", i32), ("h", i32), ("w", i32),
+        ("part", c_p), ("ksplits", i32), ("nsplit", i32),
+    ]
+
+
+class CombineArgs(C.Structure):
+    _fields_ = [
+        ("mode", i32), ("T", i32), ("N", i32), ("Npad", i32), ("ncols", i32), ("h", i32), ("w", i32),
+        ("part", c_p), ("ksplits", i32), ("lpart", c_p), ("nparts", i32),
+        ("U", c_p), ("ldu", i64), ("G", c_p), ("ldg", i64), ("mass", c_p),
+    ]
+
+
+EXPORTS = [
+    "rmem_abi_version", "rmem_linear", "rmem_attn_scores", "rmem_attn_pv", "rmem_attn_combine",
+    "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
+    "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes",
+]
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load librmem_hip.so (built in-tree by rmem_amd.build).  Raises if missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise RmemError(f"{_LIB_PATH} not found: run `python -m rmem_amd.build` (hipcc, gfx950). "
+                        "There is no CPU fallback for the RMem hot path.")
+    lib = C.CDLL(_LIB_PATH)
+    for name in EXPORTS:
+        getattr(lib, name).restype = C.c_int
+    lib.rmem_linear.argtypes = [C.POINTER(LinearArgs), c_p]
+    lib.rmem_attn_scores.argtypes = [C.POINTER(ScoresArgs), c_p]
+    lib.rmem_attn_pv.argtypes = [C.POINTER(PVArgs), c_p]
+    lib.rmem_attn_combine.argtypes = [C.POINTER(CombineArgs), c_p]
+    lib.rmem_pe_bias.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]
+    lib.rmem_layernorm_split.argtypes = [c_p, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64, c_p, i64, c_p]
+    lib.rmem_dwconv5x5_split.argtypes = [c_p, i64, c_p, i32, i32, i32, c_p, c_p, i64, c_p]
+    lib.rmem_groupnorm2.argtypes = [c_p, c_p, i32, i32, c_p, c_p, f32, c_p, c_p, i64, c_p]
+    lib.rmem_id_assign.argtypes = [c_p, i32, i32, c_p, c_p, i32, i32, i32, i32, i32, i32, i32,
+                                   c_p, c_p, f32, c_p, c_p, i64, c_p, i64, c_p]
+    lib.rmem_attn_mass_reduce.argtypes = [c_p, i32, i32, c_p, c_p, c_p]
+    lib.rmem_split_planes.argtypes = [c_p, i64, c_p, c_p, c_p]
+    _LIB = lib
+    return lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RmemError(f"{what} failed with status {rc}")
+
+
+class Planes:
+    """An fp32 tensor carried as two bf16 planes (hi, lo)."""
+
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi: torch.Tensor, lo: torch.Tensor):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def empty(shape, device):
+        return Planes(torch.zeros(shape, dtype=torch.bfloat16, device=device),
+                      torch.zeros(shape, dtype=torch.bfloat16, device=device))
+
+    @staticmethod
+    def from_f32(x: torch.Tensor):
+        hi = x.to(torch.bfloat16)
+        lo = (x - hi.float()).to(torch.bfloat16)
+        return Planes(hi.contiguous(), lo.contiguous())
+
+    def float(self):
+        return self.hi.float() + self.lo.float()
+
+    def __getitem__(self, idx):
+        return Planes(self.hi[idx], self.lo[idx])
+
+
+# ------------------------------------------------------------------ thin call wrappers
+def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=False, act=0,
+           d0=None, ldd0=0, d1=None, ldd1=0, csplit=0, accumulate=False,
+           pa: Planes = None, ldpa=0, pb: Planes = None, ldpb=0, addvec=None,
+           x2: Planes = None, ldx2=0, kx_split=0, y2: Planes = None, ldy2=0, ky_split=0,
+           nbatch=1, bsx=0, bsy=0, bsd=0, bsbias=0, bspa=0, nsplit=3, tile=0,
+           x_off=0, y_off=0):
+    """x_off / y_off: element offsets into the plane tensors (column windows)."""
+    a = LinearArgs()
+    eb = 2  # bytes per bf16
+    a.xh, a.xl, a.ldx = x.hi.data_ptr() + x_off * eb, x.lo.data_ptr() + x_off * eb, ldx
+    if x2 is not None:
+        a.xh2, a.xl2, a.ldx2, a.kx_split = x2.hi.data_ptr(), x2.lo.data_ptr(), ldx2, kx_split
+    a.yh, a.yl, a.ldy = y.hi.data_ptr() + y_off * eb, y.lo.data_ptr() + y_off * eb, ldy
+    if y2 is not None:
+        a.yh2, a.yl2, a.ldy2, a.ky_split = y2.hi.data_ptr(), y2.lo.data_ptr(), ldy2, ky_split
+    a.M, a.N, a.K = M, N, K
+    a.bias, a.bias_per_row, a.act = ptr(bias), int(bias_per_row), act
+    a.d0, a.ldd0, a.d1, a.ldd1 = d0, ldd0, d1, ldd1
+    a.csplit, a.accumulate = csplit, int(accumulate)
+    if pa is not None:
+        a.pah, a.pal, a.ldpa = pa.hi.data_ptr(), pa.lo.data_ptr(), ldpa
+    if pb is not None:
+        a.pbh, a.pbl, a.ldpb, a.addvec = pb.hi.data_ptr(), pb.lo.data_ptr(), ldpb, ptr(addvec)
+    a.nbatch, a.bsx, a.bsy, a.bsd, a.bsbias, a.bspa = nbatch, bsx, bsy, bsd, bsbias, bspa
+    a.nsplit, a.tile = nsplit, tile
+    check(load().rmem_linear(C.byref(a), stream_ptr()), "rmem_linear")

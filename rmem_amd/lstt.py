@@ -1,0 +1,413 @@
+"""DeAOT LSTT (DualBranchGPM) executor on the HIP kernels of librmem_hip.so.
+
+Host-side mirror of the reference's ``DualBranchGPM`` / ``GatedPropagationModule``
+(/root/reference/aot_plus/networks/layers/transformer.py:700-1249): same operations,
+same state (long-term bank, short-term frame, EMA / visit dictionaries), but
+
+  * the memory bank is a pre-allocated ring of ``cap + 2`` physical slots per layer
+    (K planes [slot][Npad][128], V^T planes [slot][1024][Npad]); append / evict only
+    edit a logical->physical map, no ``torch.cat`` re-allocation (transformer.py:859-878,
+    :967-989);
+  * stored keys are PE-free, the temporal positional embedding enters the logits as a
+    per-(query, slot) bias (transformer.py:1140-1172);
+  * there is no D2H sync inside a frame; the RMem relevance vector (<= 16 floats) is
+    read back once per long-memory update (transformer.py:906).
+
+PyTorch here is only device memory + streams; every FLOP of the LSTT runs in
+rmem_amd/csrc.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import hip
+from .hip import Planes
+
+
+def temporal_pe_rows(T: int) -> List[int]:
+    """mem_pos_emb row for bank position t (transformer.py:1144-1167):
+    T<=4 -> t; T>4 -> 3 - floor((T-1-t)*4/T)."""
+    if T <= 4:
+        return list(range(T))
+    return [3 - ((T - 1 - t) * 4) // T for t in range(T)]
+
+
+def rmem_policy_step(w: np.ndarray, indexes: List[int], ema_prev: Dict[int, float],
+                     visits_prev: Dict[int, int], former: int):
+    """EMA(0.8) + UCB eviction rule in float32 (transformer.py:909-964).
+
+    ``w``: normalised fg-weighted attention mass of the attended slots
+    (len(indexes) - 1 entries; the slot appended this frame was not attended).
+    Returns (drop_position, ema, visits)."""
+    f = np.float32
+    n_att = len(w)
+    ema: Dict[int, float] = {}
+    wv = np.array(w, dtype=f)
+    for i in range(n_att):
+        idx = indexes[i]
+        if idx in ema_prev:
+            wv[i] = f(f(1 - 0.8) * f(ema_prev[idx])) + f(f(0.8) * wv[i])
+        ema[idx] = f(wv[i])
+    visits = {idx: (1 + visits_prev[idx]) if idx in visits_prev else 1 for idx in indexes}
+    c = np.array([visits[idx] for idx in indexes[:-1]], dtype=f)
+    c[0] = f(len(c))
+    bonus = f(1.5) * np.sqrt(np.log(c.sum(dtype=f)) / (c + f(8)))
+    score = wv + bonus.astype(f)
+    drop = former
+    if score.size > 1:
+        drop = int(np.argmin(score[1:])) + 1
+    return drop, ema, visits
+
+
+class _LayerWeights:
+    pass
+
+
+class DeAOTLSTT:
+    """HIP-backed DualBranchGPM for one clip geometry (h x w tokens)."""
+
+    D = 256
+    DATT = 128
+    E = 512          # expanded width per branch
+    WIN = 225
+
+    def __init__(self, model, h: int, w: int, device, nsplit: int = 3):
+        hip.load()
+        self.cfg = model.cfg
+        self.h, self.w = int(h), int(w)
+        self.N = self.h * self.w
+        self.Npad = (self.N + 127) // 128 * 128
+        self.dev = torch.device(device)
+        self.L = self.cfg.MODEL_LSTT_NUM
+        self.cap = self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN
+        self.Tmax = self.cap + 1          # bank momentarily holds cap+1 before eviction
+        if self.Tmax > 16:
+            raise hip.RmemError("bank of more than 15 slots is not supported (temporal-PE rows array)")
+        self.S = self.cap + 2             # physical slots
+        self.nsplit = int(nsplit)
+        self.scale = 1.0 / math.sqrt(self.DATT)
+        self._pack_weights(model)
+        self._alloc()
+        self.clear_memory()
+
+    # ------------------------------------------------------------------ weights
+    def _pl(self, t: torch.Tensor) -> Planes:
+        return Planes.from_f32(t.detach().to(self.dev, torch.float32).contiguous())
+
+    def _f(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(self.dev, torch.float32).contiguous()
+
+    def _pack_weights(self, model):
+        sd = model.state_dict()
+        self.cur_pe = self._f(sd["cur_pos_emb"][0])
+        self.mem_pe = self._f(sd["mem_pos_emb"])
+        kb = sd["patch_wise_id_bank.weight"]                      # [256, ncls, k, k]
+        self.id_ksize = kb.shape[-1]
+        self.id_ncls = kb.shape[1]
+        self.id_stride, self.id_pad = (16, 8) if self.cfg.MODEL_ALIGN_CORNERS else (16, 0)
+        self.id_wt = self._f(kb.permute(1, 2, 3, 0))               # [ncls][k][k][256]
+        self.id_bias = self._f(sd["patch_wise_id_bank.bias"])
+        self.id_gamma, self.id_beta = self._f(sd["id_norm.weight"]), self._f(sd["id_norm.bias"])
+        self.gn_gamma = self._f(sd["LSTT.decoder_norms.0.gn.weight"])
+        self.gn_beta = self._f(sd["LSTT.decoder_norms.0.gn.bias"])
+        self.lw = []
+        for l in range(self.L):
+            p = f"LSTT.layers.{l}."
+            W = _LayerWeights()
+            g = lambda k: sd[p + k]
+            W.ln1 = (self._f(g("norm1.weight")), self._f(g("norm1.bias")))
+            W.ln2 = (self._f(g("norm2.weight")), self._f(g("norm2.bias")))
+            W.lnid2 = (self._f(g("id_norm2.weight")), self._f(g("id_norm2.bias")))
+            qv_w, qv_b = g("linear_QV.weight"), g("linear_QV.bias")
+            W.Wq, W.bq = self._pl(qv_w[:self.DATT]), self._f(qv_b[:self.DATT])
+            W.Wv, W.bv = self._pl(qv_w[self.DATT:]), self._f(qv_b[self.DATT:])
+            W.Wu, W.bu = self._pl(g("linear_U.weight")), self._f(g("linear_U.bias"))
+            W.Widv, W.bidv = self._pl(g("linear_ID_V.weight")), self._f(g("linear_ID_V.bias"))
+            if l > 0:
+                W.lnid1 = (self._f(g("id_norm1.weight")), self._f(g("id_norm1.bias")))
+                W.Widu, W.bidu = self._pl(g("linear_ID_U.weight")), self._f(g("linear_ID_U.bias"))
+            dw = lambda k: self._f(g(k).reshape(-1, 25).t())          # [1024,1,5,5] -> [25][1024]
+            W.dw_lt, W.dw_st, W.dw_self = (dw("long_term_attn.dw_conv.conv.weight"),
+                                           dw("short_term_attn.dw_conv.conv.weight"),
+                                           dw("self_attn.dw_conv.conv.weight"))
+            W.Wp_ls = self._pl(torch.cat([g("long_term_attn.projection.weight"),
+                                          g("short_term_attn.projection.weight")], dim=1))  # [512][2048]
+            W.bp_ls = self._f(g("long_term_attn.projection.bias") + g("short_term_attn.projection.bias"))
+            W.Wrel = self._pl(g("short_term_attn.relative_emb_k.weight").reshape(self.WIN, self.DATT))
+            W.brel = self._f(g("short_term_attn.relative_emb_k.bias"))
+            W.Wqk, W.bqk = self._pl(g("self_attn.linear_QK.weight")), self._f(g("self_attn.linear_QK.bias"))
+            W.Wv12 = self._pl(torch.cat([g("self_attn.linear_V1.weight"), g("self_attn.linear_V2.weight")], 0))
+            W.bv12 = self._f(torch.cat([g("self_attn.linear_V1.bias"), g("self_attn.linear_V2.bias")], 0))
+            W.Wu12 = self._pl(torch.cat([g("self_attn.linear_U1.weight"), g("self_attn.linear_U2.weight")], 0))
+            W.bu12 = self._f(torch.cat([g("self_attn.linear_U1.bias"), g("self_attn.linear_U2.bias")], 0))
+            W.Wp_self, W.bp_self = (self._pl(g("self_attn.projection.weight")),
+                                    self._f(g("self_attn.projection.bias")))
+            self.lw.append(W)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self):
+        N, Np, dev = self.N, self.Npad, self.dev
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        self.tgt, self.tgt_id = z(N, 256), z(N, 256)
+        self.x_pl = Planes.empty((Np, 256), dev)
+        self.z_pl = [Planes.empty((Np, 256), dev) for _ in range(self.L)]
+        self.idemb_pl = Planes.empty((Np, 256), dev)
+        self.Qf32 = z(N, 128)
+        self.Qpe = Planes.empty((Np, 128), dev)
+        self.bankK = [Planes.empty((self.S, Np, 128), dev) for _ in range(self.L)]
+        self.bankV = [Planes.empty((self.S, 1024, Np), dev) for _ in range(self.L)]
+        self.Ucat0 = z(N, 1024)
+        self.Ucat0[:, 512:] = 1.0                                 # layer 0: gate of the ID half is 1
+        self.Ucat = z(N, 1024)
+        self.bias_pe = z(N, self.Tmax)
+        self.rowmax = z(3, Np, dt=torch.int32)
+        kb_max = self.Tmax * Np // 32
+        self.P = Planes.empty((kb_max, Np, 32), dev)
+        self.nparts_max = self.Tmax * Np // 64
+        self.lpart = z(Np, self.nparts_max)
+        self.ksplits_max = 8
+        self.part = z(self.ksplits_max, Np, 1024)
+        self.G = z(N, 1024)
+        self.Ylt = Planes.empty((Np, 1024), dev)
+        self.Yst = Planes.empty((Np, 1024), dev)
+        self.ldr = 232
+        self.R = z(N, self.ldr)
+        self.s_pl = Planes.empty((Np, 512), dev)
+        self.selfQK = Planes.empty((1, Np, 128), dev)
+        self.selfV = Planes.empty((1, 1024, Np), dev)
+        self.Uself = z(N, 1024)
+        self.out = z(N, 512)
+        self.gn_ws = z(4 * ((N + 63) // 64), dt=torch.float64)
+        self.mass = z(N, self.Tmax)
+        self.w_out = z(self.Tmax)
+        self.maps = z(32, dt=torch.int32)                         # [0:16] bank map, [16] short slot
+        self.k_slot_stride = Np * 128
+        self.v_slot_stride = 1024 * Np
+
+    def clear_memory(self):                                        # transformer.py:1000-1007
+        self.bank: List[int] = []          # logical -> physical slot
+        self.short: Optional[int] = None
+        self.cur: int = 0
+        self.mass_T = 0
+        self.ema: Dict[int, float] = {}
+        self.visits: Dict[int, int] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _sync_maps(self):
+        m = torch.zeros(32, dtype=torch.int32)
+        for i, s in enumerate(self.bank):
+            m[i] = s
+        m[16] = self.short if self.short is not None else 0
+        self.maps.copy_(m, non_blocking=False)
+
+    def _free_slot(self) -> int:
+        used = set(self.bank)
+        if self.short is not None:
+            used.add(self.short)
+        for s in range(self.S):
+            if s not in used:
+                return s
+        raise hip.RmemError("no free bank slot (internal error)")
+
+    def _ksplits(self, ktiles: int) -> int:
+        blocks = 8 * (self.Npad // 128)
+        ks = max(1, min(self.ksplits_max, (512 + blocks - 1) // blocks, ktiles))
+        return ks
+
+    def _ln(self, x, gb, out: Planes, ldo, col_off=0):
+        rc = hip.load().rmem_layernorm_split(
+            x.data_ptr(), 256, gb[0].data_ptr(), gb[1].data_ptr(), self.N, 256, 1e-5,
+            out.hi.data_ptr() + col_off * 2, out.lo.data_ptr() + col_off * 2, ldo, None, 0, hip.stream_ptr())
+        hip.check(rc, "rmem_layernorm_split")
+
+    def _attention(self, mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr, qpl: Planes,
+                   bias, U, want_mass: bool, which: int):
+        """scores(pass0, pass1) + pv + combine -> self.G."""
+        lib, st = hip.load(), hip.stream_ptr()
+        Np = self.Npad
+        nparts = T * Np // 64
+        sa = hip.ScoresArgs()
+        sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, kpl.hi.data_ptr(), kpl.lo.data_ptr(), self.k_slot_stride
+        sa.slot_map, sa.T, sa.N, sa.Npad = slot_map_ptr, T, self.N, Np
+        sa.qh, sa.ql, sa.scale = qpl.hi.data_ptr(), qpl.lo.data_ptr(), self.scale
+        sa.bias = bias.data_ptr() if bias is not None else None
+        sa.R, sa.ldr, sa.h, sa.w = (self.R.data_ptr() if mode == 1 else None), self.ldr, self.h, self.w
+        sa.rowmax = self.rowmax[which].data_ptr()
+        sa.ph, sa.pl = self.P.hi.data_ptr(), self.P.lo.data_ptr()
+        sa.lpart, sa.nparts, sa.nsplit = self.lpart.data_ptr(), nparts, self.nsplit
+        sa.pass_ = 0
+        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 0)")
+        sa.pass_ = 1
+        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 1)")
+        ktiles = T * Np // 64 if mode == 0 else 16
+        ks = self._ksplits(ktiles)
+        pa = hip.PVArgs()
+        pa.mode, pa.ph, pa.pl = mode, self.P.hi.data_ptr(), self.P.lo.data_ptr()
+        pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
+        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = slot_map_ptr, T, self.N, Np, 1024
+        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = self.h, self.w, self.part.data_ptr(), ks, self.nsplit
+        hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
+        ca = hip.CombineArgs()
+        ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, self.N, Np, 1024, self.h, self.w
+        ca.part, ca.ksplits, ca.lpart, ca.nparts = self.part.data_ptr(), ks, self.lpart.data_ptr(), nparts
+        ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, self.G.data_ptr(), 1024
+        ca.mass = self.mass.data_ptr() if want_mass else None
+        hip.check(lib.rmem_attn_combine(C.byref(ca), st), "rmem_attn_combine")
+
+    def _dwconv(self, wt, out: Planes):
+        rc = hip.load().rmem_dwconv5x5_split(self.G.data_ptr(), 1024, wt.data_ptr(), self.h, self.w, 1024,
+                                            out.hi.data_ptr(), out.lo.data_ptr(), 1024, hip.stream_ptr())
+        hip.check(rc, "rmem_dwconv5x5_split")
+
+    def _idv(self, l: int, slot: int):
+        """ID_V = silu(linear_ID_V([z | id_emb])) -> V^T rows 512.. of `slot`
+        (fuse_key_value_id, transformer.py:1238-1244)."""
+        W, N, Np = self.lw[l], self.N, self.Npad
+        dst = self.bankV[l][slot]
+        pa = Planes(dst.hi[512:], dst.lo[512:])
+        if l == 0:
+            hip.linear(W.Widv, self.idemb_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bidv,
+                       bias_per_row=True, act=1, pa=pa, ldpa=Np, nsplit=self.nsplit)
+        else:
+            hip.linear(W.Widv, self.z_pl[l], 512, N, 512, ldx=512, ldy=256, y2=self.idemb_pl, ldy2=256,
+                       ky_split=256, bias=W.bidv, bias_per_row=True, act=1, pa=pa, ldpa=Np,
+                       nsplit=self.nsplit)
+
+    # ------------------------------------------------------------------ ID assignment
+    def assign_identity(self, label_u8: torch.Tensor):
+        """label [H][W] uint8 on device -> id_emb planes (aot_engine.py:208-232, deaot.py:65-69)."""
+        H, Wd = label_u8.shape
+        rc = hip.load().rmem_id_assign(
+            label_u8.data_ptr(), H, Wd, self.id_wt.data_ptr(), self.id_bias.data_ptr(), self.id_ncls,
+            self.id_ksize, self.id_stride, self.id_pad, self.h, self.w, 256, self.id_gamma.data_ptr(),
+            self.id_beta.data_ptr(), 1e-5, self.idemb_pl.hi.data_ptr(), self.idemb_pl.lo.data_ptr(), 256,
+            None, 0, hip.stream_ptr())
+        hip.check(rc, "rmem_id_assign")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, emb_nc: torch.Tensor, ref_frame: bool = False) -> torch.Tensor:
+        """DualBranchGPM.forward (transformer.py:765-824).  emb_nc: [N,256] fp32 on device.
+        ref_frame=True is the curr_id_emb branch (:1125-1135): the frame attends itself
+        and becomes bank slot 0; ``assign_identity`` must have been called before."""
+        N, Np, ns = self.N, self.Npad, self.nsplit
+        lib, st = hip.load(), hip.stream_ptr()
+        self.tgt.copy_(emb_nc)
+        self.tgt_id.zero_()
+        self.cur = self._free_slot()
+        cur = self.cur
+        if ref_frame:
+            bank_map, short = [cur], cur
+        else:
+            bank_map, short = self.bank, self.short
+        T = len(bank_map)
+        m = torch.zeros(32, dtype=torch.int32)
+        m[:T] = torch.tensor(bank_map, dtype=torch.int32)
+        m[16] = short
+        self.maps.copy_(m)
+        map_bank = self.maps.data_ptr()
+        map_short = self.maps.data_ptr() + 16 * 4
+        rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
+        self.rowmax.zero_()   # one memset per frame would do; kept per call for clarity
+
+        for l in range(self.L):
+            W = self.lw[l]
+            Ucat = self.Ucat0 if l == 0 else self.Ucat
+            if l > 0:
+                self.rowmax.zero_()
+            curK = self.bankK[l][cur]
+            curV = self.bankV[l][cur]
+            # -- norms + projections (transformer.py:1104-1123)
+            self._ln(self.tgt, W.ln1, self.x_pl, 256)
+            if l > 0:
+                self._ln(self.tgt_id, W.lnid1, self.z_pl[l], 256)
+            hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
+                       d0=self.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128,
+                       pb=self.Qpe, ldpb=128, addvec=self.cur_pe, nsplit=ns)
+            hip.linear(W.Wv, self.x_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True,
+                       act=1, pa=Planes(curV.hi[:512], curV.lo[:512]), ldpa=Np, nsplit=ns)
+            hip.linear(self.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1,
+                       d0=Ucat.data_ptr(), ldd0=1024, nsplit=ns)
+            if l > 0:
+                hip.linear(self.z_pl[l], W.Widu, N, 512, 256, ldx=256, ldy=256, bias=W.bidu, act=1,
+                           d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns)
+            if ref_frame:
+                self._idv(l, cur)
+            # -- long-term memory read (transformer.py:1140-1192, attention.py:174-209)
+            hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
+                                       self.mem_pe.data_ptr(), rows, T, N, 128,
+                                       self.bias_pe.data_ptr(), st), "rmem_pe_bias")
+            self._attention(0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe, self.bias_pe, Ucat,
+                            want_mass=(l == 0), which=0)
+            self._dwconv(W.dw_lt, self.Ylt)
+            # -- short-term windowed read (transformer.py:1199, attention.py:289-358)
+            hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
+                       d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
+            self._attention(1, 1, self.bankK[l], self.bankV[l], map_short, curK, None, Ucat,
+                            want_mass=False, which=1)
+            self._dwconv(W.dw_st, self.Yst)
+            # -- both projections + residual adds (transformer.py:1212-1220)
+            hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
+                       kx_split=1024, bias=W.bp_ls, d0=self.tgt.data_ptr(), ldd0=256,
+                       d1=self.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns)
+            # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
+            self._ln(self.tgt, W.ln2, self.s_pl, 512, 0)
+            self._ln(self.tgt_id, W.lnid2, self.s_pl, 512, 256)
+            sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
+            hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
+                       nsplit=ns)
+            sV = Planes(self.selfV.hi[0], self.selfV.lo[0])
+            hip.linear(W.Wv12, self.s_pl, 512, N, 256, ldx=256, ldy=512, bias=W.bv12, bias_per_row=True,
+                       act=1, pa=sV, ldpa=Np, nbatch=2, bsx=512 * 256, bsy=256, bsbias=512,
+                       bspa=512 * Np, nsplit=ns)
+            hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
+                       d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
+                       bsbias=512, bsd=512, nsplit=ns)
+            self._attention(0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
+                            want_mass=False, which=2)
+            self._dwconv(W.dw_self, self.Ylt)
+            hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
+                       d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,
+                       csplit=256, accumulate=True, nsplit=ns)
+        # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
+        hip.check(lib.rmem_groupnorm2(self.tgt.data_ptr(), self.tgt_id.data_ptr(), N, 256,
+                                      self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
+                                      self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
+                  "rmem_groupnorm2")
+        self.mass_T = T
+        if ref_frame:                      # init_memory (transformer.py:993-998)
+            self.bank, self.short = [cur], cur
+            self.ema, self.visits = {}, {}
+        return self.out
+
+    # ------------------------------------------------------------------ memory update
+    def update_short_memories(self, update_long: bool):
+        """update_short_memories + update_long_term_memory (transformer.py:826-878).
+        ``assign_identity`` must have been called with the current mask."""
+        for l in range(self.L):
+            self._idv(l, self.cur)
+        self.short = self.cur
+        if update_long:
+            self.bank = self.bank + [self.cur]
+
+    def restrict_long_memories(self, indexes: List[int], fg: torch.Tensor) -> Optional[int]:
+        """restrict_long_memories (transformer.py:880-991).  fg: [N] fp32 on device.
+        Mutates ``indexes`` like the reference; returns the dropped position or None."""
+        T = self.mass_T
+        hip.check(hip.load().rmem_attn_mass_reduce(self.mass.data_ptr(), self.N, T, fg.data_ptr(),
+                                                   self.w_out.data_ptr(), hip.stream_ptr()),
+                  "rmem_attn_mass_reduce")
+        w = self.w_out[:T].cpu().numpy().astype(np.float32)        # the one D2H per long update
+        w = w / w.sum(dtype=np.float32)
+        drop, self.ema, self.visits = rmem_policy_step(w, indexes, self.ema, self.visits,
+                                                       self.cfg.FORMER_MEM_LEN)
+        self.last_policy = dict(w=w.tolist(), drop=drop)
+        if len(self.bank) > self.cap:
+            del self.bank[drop]
+            indexes.remove(indexes[drop])
+            return drop
+        return None

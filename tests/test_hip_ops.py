@@ -1,0 +1,300 @@
+"""GPU: every C-ABI kernel of librmem_hip.so against an fp64 / oracle reference on
+seeded inputs (op-level parity).  All calls go through the C ABI
+(rmem_amd.hip ctypes binding)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rmem_amd import hip as H
+    H.load()
+    return H
+
+
+def _rand(rs, *shape, scale=1.0):
+    return torch.from_numpy(rs.standard_normal(shape).astype(np.float32) * np.float32(scale))
+
+
+def _planes(H, x):
+    return H.Planes.from_f32(x.to(DEV).contiguous())
+
+
+def _silu(x):
+    return x * torch.sigmoid(x)
+
+
+# tolerance for nsplit=3 (fp32-class) and nsplit=1 (plain bf16) relative to max|ref|
+def _tol(nsplit):
+    return 3e-5 if nsplit == 3 else 2e-2
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("M,N,K", [(200, 130, 256), (64, 64, 64), (333, 225, 128)])
+def test_linear_basic(hip, nsplit, tile, M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    X, Y, b = _rand(rs, M, K), _rand(rs, N, K), _rand(rs, N)
+    ref = (X.double() @ Y.double().t() + b.double())
+    d = torch.full((M, N + 3), 7.0, device=DEV)
+    pa = hip.Planes.empty((M, N + 5), DEV)
+    pb = hip.Planes.empty((M, N), DEV)
+    addv = _rand(rs, N).to(DEV)
+    hip.linear(_planes(hip, X), _planes(hip, Y), M, N, K, ldx=K, ldy=K, bias=b.to(DEV),
+               d0=d.data_ptr(), ldd0=N + 3, pa=pa, ldpa=N + 5, pb=pb, ldpb=N, addvec=addv,
+               nsplit=nsplit, tile=tile)
+    torch.cuda.synchronize()
+    out = d[:, :N].cpu().double()
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() < _tol(nsplit) * scale
+    assert torch.all(d[:, N:] == 7.0)                      # no writes outside [M][N]
+    assert (pa.float()[:, :N].cpu().double() - ref).abs().max().item() < (_tol(nsplit) + 2e-5) * scale
+    refb = ref + addv.cpu().double()
+    assert (pb.float().cpu().double() - refb).abs().max().item() < (_tol(nsplit) + 2e-5) * refb.abs().max().item()
+
+
+def test_linear_swapped_silu_batch_segments(hip):
+    """bias per row + SiLU + nbatch=2 + two K segments + accumulate/csplit."""
+    rs = np.random.RandomState(5)
+    # swapped, batched (self-attn V^T pattern): D_b[512][Ntok] = silu(W_b . S[:, 256b:256b+256]^T + bias_b)
+    ntok, Np = 150, 256
+    Wt, S, b = _rand(rs, 1024, 256, scale=0.1), _rand(rs, ntok, 512), _rand(rs, 1024)
+    pa = hip.Planes.empty((1024, Np), DEV)
+    hip.linear(_planes(hip, Wt), _planes(hip, S), 512, ntok, 256, ldx=256, ldy=512, bias=b.to(DEV),
+               bias_per_row=True, act=1, pa=pa, ldpa=Np, nbatch=2, bsx=512 * 256, bsy=256, bsbias=512,
+               bspa=512 * Np)
+    torch.cuda.synchronize()
+    ref = torch.cat([_silu(Wt[:512].double() @ S[:, :256].double().t() + b[:512, None].double()),
+                     _silu(Wt[512:].double() @ S[:, 256:].double().t() + b[512:, None].double())], 0)
+    got = pa.float()[:, :ntok].cpu().double()
+    assert (got - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
+    assert torch.all(pa.hi[:, ntok:] == 0)
+
+    # two K segments on X, accumulate into two destinations split at column 256
+    M, N = 170, 512
+    X1, X2, Wp, bias = _rand(rs, M, 1024), _rand(rs, M, 1024), _rand(rs, N, 2048, scale=0.05), _rand(rs, N)
+    t0, t1 = _rand(rs, M, 256).to(DEV), _rand(rs, M, 256).to(DEV)
+    r0, r1 = t0.clone(), t1.clone()
+    hip.linear(_planes(hip, X1), _planes(hip, Wp), M, N, 2048, ldx=1024, ldy=2048, x2=_planes(hip, X2),
+               ldx2=1024, kx_split=1024, bias=bias.to(DEV), d0=t0.data_ptr(), ldd0=256,
+               d1=t1.data_ptr(), ldd1=256, csplit=256, accumulate=True)
+    torch.cuda.synchronize()
+    ref = torch.cat([X1, X2], 1).double() @ Wp.double().t() + bias.double()
+    assert (t0.cpu().double() - (r0.cpu().double() + ref[:, :256])).abs().max().item() < 1e-4
+    assert (t1.cpu().double() - (r1.cpu().double() + ref[:, 256:])).abs().max().item() < 1e-4
+
+    # two K segments on Y (ID_V pattern): D[512][ntok] = W[512][512] . [Z | E]^T
+    Wi, Z, E = _rand(rs, 512, 512, scale=0.1), _rand(rs, ntok, 256), _rand(rs, ntok, 256)
+    pa = hip.Planes.empty((512, Np), DEV)
+    hip.linear(_planes(hip, Wi), _planes(hip, Z), 512, ntok, 512, ldx=512, ldy=256, y2=_planes(hip, E),
+               ldy2=256, ky_split=256, pa=pa, ldpa=Np)
+    torch.cuda.synchronize()
+    ref = Wi.double() @ torch.cat([Z, E], 1).double().t()
+    assert (pa.float()[:, :ntok].cpu().double() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
+
+
+def _unblock_P(P, T, Npad, N):
+    """blocked [key/32][Npad][32] -> dense [N][T*Npad]."""
+    kb = T * Npad // 32
+    return P[:kb].permute(1, 0, 2).reshape(Npad, T * Npad)[:N]
+
+
+def _run_attention(hip, mode, T, N, Npad, K, V, slot_map, Q, bias, U, h, w, R, nsplit, ksplits=3):
+    """K: [S][Npad][128] planes, V: [S][1024][Npad] planes, Q planes [Npad][128]."""
+    lib, st = hip.load(), hip.stream_ptr()
+    rowmax = torch.zeros(Npad, dtype=torch.int32, device=DEV)
+    P = hip.Planes.empty((T * Npad // 32, Npad, 32), DEV)
+    nparts = T * Npad // 64
+    lpart = torch.zeros(Npad, nparts, device=DEV)
+    part = torch.zeros(ksplits, Npad, 1024, device=DEV)
+    G = torch.zeros(N, 1024, device=DEV)
+    mass = torch.zeros(N, T, device=DEV)
+    sm = torch.tensor(slot_map, dtype=torch.int32, device=DEV) if slot_map is not None else None
+    sa = hip.ScoresArgs()
+    sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, K.hi.data_ptr(), K.lo.data_ptr(), Npad * 128
+    sa.slot_map, sa.T, sa.N, sa.Npad = (sm.data_ptr() if sm is not None else None), T, N, Npad
+    sa.qh, sa.ql, sa.scale = Q.hi.data_ptr(), Q.lo.data_ptr(), 1.0 / math.sqrt(128)
+    sa.bias = bias.data_ptr() if bias is not None else None
+    if R is not None:
+        sa.R, sa.ldr = R.data_ptr(), R.shape[1]
+    sa.h, sa.w = h, w
+    sa.rowmax, sa.ph, sa.pl = rowmax.data_ptr(), P.hi.data_ptr(), P.lo.data_ptr()
+    sa.lpart, sa.nparts, sa.nsplit = lpart.data_ptr(), nparts, nsplit
+    sa.pass_ = 0
+    hip.check(lib.rmem_attn_scores(C.byref(sa), st), "scores0")
+    sa.pass_ = 1
+    hip.check(lib.rmem_attn_scores(C.byref(sa), st), "scores1")
+    pa = hip.PVArgs()
+    pa.mode, pa.ph, pa.pl = mode, P.hi.data_ptr(), P.lo.data_ptr()
+    pa.vh, pa.vl, pa.v_slot_stride = V.hi.data_ptr(), V.lo.data_ptr(), 1024 * Npad
+    pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = sa.slot_map, T, N, Npad, 1024
+    pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = h, w, part.data_ptr(), ksplits, nsplit
+    hip.check(lib.rmem_attn_pv(C.byref(pa), st), "pv")
+    ca = hip.CombineArgs()
+    ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, N, Npad, 1024, h, w
+    ca.part, ca.ksplits, ca.lpart, ca.nparts = part.data_ptr(), ksplits, lpart.data_ptr(), nparts
+    ca.U, ca.ldu, ca.G, ca.ldg, ca.mass = U.data_ptr(), 1024, G.data_ptr(), 1024, mass.data_ptr()
+    hip.check(lib.rmem_attn_combine(C.byref(ca), st), "combine")
+    torch.cuda.synchronize()
+    return G, mass, P, rowmax, lpart
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("T,h,w", [(1, 9, 13), (3, 9, 13), (5, 12, 17)])
+def test_attention_bank(hip, nsplit, T, h, w):
+    """Long-term / self read: softmax(scale*(Q.K^T + bias)) . V * U, attention mass per slot."""
+    rs = np.random.RandomState(T * 100 + h)
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    S = T + 2
+    slot_map = list(rs.permutation(S)[:T])
+    Kf = torch.zeros(S, Npad, 128)
+    Vf = torch.zeros(S, 1024, Npad)
+    Kf[:, :N] = _rand(rs, S, N, 128, scale=1.5)
+    Vf[:, :, :N] = _rand(rs, S, 1024, N)
+    Kf[:, N:] = 37.0      # padding rows must be ignored (masked), not merely zero
+    Vf[:, :, N:] = -53.0
+    Qf = torch.zeros(Npad, 128)
+    Qf[:N] = _rand(rs, N, 128, scale=1.5)
+    bias = _rand(rs, N, T, scale=3.0)
+    U = _rand(rs, N, 1024)
+    G, mass, P, rowmax, lpart = _run_attention(
+        hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, Vf), slot_map, _planes(hip, Qf),
+        bias.to(DEV), U.to(DEV), h, w, None, nsplit)
+    # fp64 reference on the logical bank
+    Kl = torch.stack([Kf[s, :N] for s in slot_map]).double()            # [T][N][128]
+    Vl = torch.stack([Vf[s, :, :N].t() for s in slot_map]).double()     # [T][N][1024]
+    S_ = torch.einsum("qc,tkc->qtk", Qf[:N].double(), Kl) + bias.double()[:, :, None]
+    S_ = S_ / math.sqrt(128)
+    A = torch.softmax(S_.reshape(N, T * N), dim=1).reshape(N, T, N)
+    ref = torch.einsum("qtk,tkc->qc", A, Vl) * U.double()
+    tol = 5e-5 if nsplit == 3 else 3e-2
+    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, f"G rel err {err}"
+    assert (mass.cpu().double() - A.sum(dim=2)).abs().max().item() < (1e-5 if nsplit == 3 else 2e-2)
+    # probabilities (unnormalised, relative to the running max) are zero on padding keys
+    Pd = _unblock_P(P.float().cpu(), T, Npad, N).reshape(N, T, Npad)
+    assert torch.all(Pd[:, :, N:] == 0)
+    if nsplit == 3:   # attention logits within 1e-3 (north star): log P - log P_ref is the logit error
+        l = Pd[:, :, :N].double().sum(dim=(1, 2))
+        An = Pd[:, :, :N].double() / l[:, None, None]
+        big = A > 1e-6
+        logit_err = (torch.log(An[big]) - torch.log(A[big])).abs().max().item()
+        assert logit_err < 1e-3, logit_err
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("h,w", [(9, 13), (20, 23), (31, 54)])
+def test_attention_window(hip, nsplit, h, w):
+    """Short-term 15x15 windowed read against the oracle's LocalGatedPropagation core."""
+    from oracle import lstt_ref as R
+    rs = np.random.RandomState(h * 10 + w)
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    q, k = _rand(rs, N, 128, scale=1.5), _rand(rs, N, 128, scale=1.5)
+    v, u = _rand(rs, N, 1024), _rand(rs, N, 1024)
+    rel_w, rel_b = _rand(rs, 225, 128, scale=0.15), _rand(rs, 225, scale=0.1)
+    # oracle pieces (no dwconv / projection here)
+    idx, inside = R.local_window_index(h, w)
+    rel = q.double() @ rel_w.double().t() + rel_b.double()
+    kg = k.double()[idx.clamp(min=0)] * inside.unsqueeze(-1)
+    qk = torch.einsum("nc,noc->no", q.double() / math.sqrt(128), kg) + rel
+    qk = qk.masked_fill(~inside, -1e8)
+    attn = torch.softmax(qk, dim=1)
+    vg = v.double()[idx.clamp(min=0)] * inside.unsqueeze(-1)
+    ref = torch.einsum("no,noc->nc", attn, vg) * u.double()
+
+    Kf, Vf, Qf = torch.zeros(2, Npad, 128), torch.zeros(2, 1024, Npad), torch.zeros(Npad, 128)
+    Kf[1, :N], Vf[1, :, :N], Qf[:N] = k, v.t(), q
+    Kf[0] = 99.0
+    Rm = torch.zeros(N, 232)
+    Rm[:, :225] = rel.float()
+    G, mass, P, rowmax, lpart = _run_attention(
+        hip, 1, 1, N, Npad, _planes(hip, Kf), _planes(hip, Vf), [1], _planes(hip, Qf), None,
+        u.to(DEV), h, w, Rm.to(DEV), nsplit, ksplits=2)
+    tol = 5e-5 if nsplit == 3 else 3e-2
+    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, f"G rel err {err}"
+
+
+def test_pe_bias_layernorm_dwconv_groupnorm(hip):
+    from oracle import lstt_ref as R
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(3)
+    h, w = 7, 9
+    N = h * w
+    # pe bias
+    Q, cur, mem = _rand(rs, N, 128), _rand(rs, 128, scale=0.5), _rand(rs, 4, 128, scale=0.5)
+    rows = [0, 1, 2, 3, 3]
+    out = torch.zeros(N, 5, device=DEV)
+    arr = (C.c_int32 * 16)(*(rows + [0] * 11))
+    hip.check(lib.rmem_pe_bias(Q.to(DEV).data_ptr(), 128, cur.to(DEV).data_ptr(), mem.to(DEV).data_ptr(),
+                               arr, 5, N, 128, out.data_ptr(), st), "pe_bias")
+    ref = (Q.double() + cur.double()) @ mem.double()[rows].t()
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-4
+    # layernorm -> planes (+ fp32)
+    x, g, b = _rand(rs, N, 256, scale=2.0) + 0.5, _rand(rs, 256) * 0.2 + 1, _rand(rs, 256) * 0.1
+    pl = hip.Planes.empty((N, 512), DEV)
+    of = torch.zeros(N, 256, device=DEV)
+    hip.check(lib.rmem_layernorm_split(x.to(DEV).data_ptr(), 256, g.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+                                       N, 256, 1e-5, pl.hi.data_ptr() + 256 * 2, pl.lo.data_ptr() + 256 * 2,
+                                       512, of.data_ptr(), 256, st), "ln")
+    ref = R.layer_norm(x, g, b)
+    assert (of.cpu() - ref).abs().max().item() < 2e-6
+    assert (pl.float()[:, 256:].cpu() - ref).abs().max().item() < 3e-5
+    assert torch.all(pl.hi[:, :256] == 0)
+    # depth-wise conv
+    gin, wdw = _rand(rs, N, 1024), _rand(rs, 1024, 1, 5, 5, scale=0.25)
+    pl = hip.Planes.empty((N, 1024), DEV)
+    wt = wdw.reshape(1024, 25).t().contiguous().to(DEV)
+    hip.check(lib.rmem_dwconv5x5_split(gin.to(DEV).data_ptr(), 1024, wt.data_ptr(), h, w, 1024,
+                                       pl.hi.data_ptr(), pl.lo.data_ptr(), 1024, st), "dwconv")
+    ref = R.dwconv5x5(gin, wdw, h, w)
+    assert (pl.float().cpu() - ref).abs().max().item() < 3e-5
+    # group norm (2 groups)
+    t0, t1 = _rand(rs, N, 256, scale=1.5) + 0.3, _rand(rs, N, 256, scale=0.7) - 0.2
+    gg, gb = _rand(rs, 512) * 0.2 + 1, _rand(rs, 512) * 0.1
+    ws = torch.zeros(4 * ((N + 63) // 64), dtype=torch.float64, device=DEV)
+    o = torch.zeros(N, 512, device=DEV)
+    hip.check(lib.rmem_groupnorm2(t0.to(DEV).data_ptr(), t1.to(DEV).data_ptr(), N, 256, gg.to(DEV).data_ptr(),
+                                  gb.to(DEV).data_ptr(), 1e-5, ws.data_ptr(), o.data_ptr(), 512, st), "gn")
+    ref = R.group_norm_tokens(torch.cat([t0, t1], 1), gg, gb, 2)
+    assert (o.cpu() - ref).abs().max().item() < 5e-6
+    # mass reduce
+    mass, fg = torch.rand(N, 3), torch.rand(N)
+    wo = torch.zeros(3, device=DEV)
+    hip.check(lib.rmem_attn_mass_reduce(mass.to(DEV).data_ptr(), N, 3, fg.to(DEV).data_ptr(), wo.data_ptr(), st),
+              "mass_reduce")
+    assert (wo.cpu() - (mass * fg[:, None]).sum(0)).abs().max().item() < 1e-4
+
+
+def test_id_assign_vs_golden(hip, deaot_model, golden_dir):
+    """Bit-for-bit index work (label -> class gather) + fp32 LayerNorm, against the
+    reference's own output (tests/golden/idassign_*.npz)."""
+    import os
+    from inputs import IDASSIGN_CASES, idassign_label
+    lib, st = hip.load(), hip.stream_ptr()
+    sd = deaot_model.state_dict()
+    wt = sd["patch_wise_id_bank.weight"].permute(1, 2, 3, 0).contiguous().to(DEV)
+    for (H, W) in IDASSIGN_CASES:
+        gold = np.load(os.path.join(golden_dir, f"idassign_{H}x{W}.npz"))
+        eh, ew = int(gold["eh"]), int(gold["ew"])
+        lab = idassign_label(H, W)[0, 0].to(torch.uint8).to(DEV).contiguous()
+        of = torch.zeros(eh * ew, 256, device=DEV)
+        pl = hip.Planes.empty((eh * ew, 256), DEV)
+        hip.check(lib.rmem_id_assign(lab.data_ptr(), H, W, wt.data_ptr(),
+                                     sd["patch_wise_id_bank.bias"].to(DEV).data_ptr(), 12, 17, 16, 8, eh, ew,
+                                     256, sd["id_norm.weight"].to(DEV).data_ptr(),
+                                     sd["id_norm.bias"].to(DEV).data_ptr(), 1e-5, pl.hi.data_ptr(),
+                                     pl.lo.data_ptr(), 256, of.data_ptr(), 256, st), "id_assign")
+        torch.cuda.synchronize()
+        assert np.abs(of.cpu().numpy() - gold["id_emb"]).max() < 2e-5
+        assert np.abs(pl.float().cpu().numpy() - gold["id_emb"]).max() < 5e-5
