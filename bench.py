@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/sec/GPU of the RMem hot path (BASELINE.json metric).
+
+Workload (config.workload): R50-DeAOTL + RMem, 480p (481x849 -> 31x54 = 1674 tokens),
+K=4 memory slots (FORMER_MEM_LEN=1, LATTER_MEM_LEN=3), one synthetic clip per GPU,
+random-init (name-keyed synthetic) weights, fp32 I/O.  A "step" is one frame through the
+reference's timing window (managers/evaluator.py:399-404,525-527):
+match_propogate_one_frame -> softmax/argmax -> nearest resize -> update_memory, with the
+bank in steady state (T = K, one long-memory update + eviction every `gap` frames).
+Frames are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 40 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the
+dominant kernel (HIP-event timed inside the timed region) and `cpu_baseline` (the
+oracle's CPU restatement timed on a bounded sample of the same workload, rank 0, N=1).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H_IN, W_IN = 481, 849          # 480x854 after MultiRestrictSize (dataloaders/video_transforms.py:604-622)
+H_OUT, W_OUT = 480, 854
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gap", type=int, default=5, help="long_term_mem_gap (evaluator rule gives 5 for clips <= 165 frames)")
+    ap.add_argument("--nsplit", type=int, default=int(os.environ.get("RMEM_NSPLIT", "3")),
+                    help="3 = split-bf16 (fp32-class), 1 = plain bf16 attention/linears")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from rmem_amd.config import get_config
+    from rmem_amd.engine import build_engine
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+
+    cfg = get_config("r50_deaotl", 1, 3)
+    cpu_model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(cpu_model)
+    model = copy.deepcopy(cpu_model).to(dev)
+    engine = build_engine("deaotengine", phase="eval", aot_model=model, gpu_id=local_rank,
+                          long_term_mem_gap=args.gap, nsplit=args.nsplit)
+    engine.eval()
+
+    # one independent clip per rank (seed = rank); a ring of 8 distinct frames in HBM
+    ring = 8
+    imgs, label0 = synth_clip(rank, ring, H_IN, W_IN, 3)
+    imgs = [im.to(dev) for im in imgs]
+    label0 = label0.to(dev)
+
+    def frame_step(t, masks_out=None):
+        logit = engine.match_propogate_one_frame(imgs[t % ring], output_size=(H_OUT, W_OUT))
+        prob = torch.softmax(logit, dim=1)
+        pred = torch.argmax(prob, dim=1, keepdim=True).float()
+        cur = F.interpolate(pred, size=engine.input_size_2d, mode="nearest")
+        engine.update_memory(cur)
+        if masks_out is not None:
+            masks_out[t % masks_out.shape[0]] = pred[0, 0].to(torch.uint8)
+
+    # ---- setup: reference frame + pre-roll until the bank holds K slots (steady state)
+    engine.restart_engine()
+    engine.add_reference_frame(imgs[0], label0, obj_nums=[3], frame_step=0)
+    t = 1
+    sub = engine.aot_engines[0]
+    while len(sub.lstt.bank) < cfg.mem_cap:
+        frame_step(t)
+        t += 1
+    for _ in range(args.warmup):
+        frame_step(t)
+        t += 1
+
+    masks = torch.zeros(args.steps, H_OUT, W_OUT, dtype=torch.uint8, device=dev)
+    lstt = sub.lstt
+    lstt.enable_kernel_timing(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        frame_step(t + k, masks)
+    if dist is not None:                      # collect per-clip masks (the only exchange step)
+        gathered = torch.empty(world * args.steps, H_OUT, W_OUT, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, masks)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lstt.enable_kernel_timing(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    fps = world * args.steps / elapsed
+    out = {
+        "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref",
+        "value": fps, "unit": "frames/s (whole job)", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)" if args.nsplit == 3 else "bf16 (MFMA, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": "R50-DeAOTL + RMem, 480p (481x849, 1674 tokens), K=4 memory, batch=1 clip per GPU, "
+                               f"long_term_mem_gap={args.gap}, steady-state bank (T=4)",
+                   "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
+                   "parallelism": f"clips sharded 1-per-GPU x{world}, all-gather of masks"},
+    }
+    if rank == 0:
+        out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cpu_model, args)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cpu_model, args):
+    """Oracle (CPU restatement of the reference path, fp32 PyTorch-CPU) on a bounded
+    sample of the same workload: same clip generator, geometry and K; the bank is
+    pre-filled to T=K with gap=1, then `cpu_frames` steady-state frames are timed with
+    the reference's timing window."""
+    from oracle.engine_ref import OracleDeAOTEngine
+    from rmem_amd.synth import synth_clip
+    torch.set_num_threads(os.cpu_count() or 1)
+    ora = OracleDeAOTEngine(cpu_model, long_term_mem_gap=1)
+    n = args.cpu_frames
+    imgs, lab = synth_clip(0, 4 + n, H_IN, W_IN, 3)
+    ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+
+    def step(t):
+        logit = ora.match_propogate_one_frame(imgs[t], output_size=(H_OUT, W_OUT))
+        pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float()
+        ora.update_memory(F.interpolate(pred, size=ora.input_size_2d, mode="nearest"))
+
+    for t in range(1, 4):
+        step(t)
+    ora.long_term_mem_gap = args.gap
+    t0 = time.perf_counter()
+    for t in range(4, 4 + n):
+        step(t)
+    el = time.perf_counter() - t0
+    return {"value": n / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steady-state frames (T=4) of the same 480p K=4 workload, oracle/ on PyTorch-CPU fp32"}
+
+
+if __name__ == "__main__":
+    main()

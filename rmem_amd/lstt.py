@@ -90,6 +90,8 @@ class DeAOTLSTT:
             raise hip.RmemError("bank of more than 15 slots is not supported (temporal-PE rows array)")
         self.S = self.cap + 2             # physical slots
         self.nsplit = int(nsplit)
+        self._timing = False
+        self._events = []
         self.scale = 1.0 / math.sqrt(self.DATT)
         self._pack_weights(model)
         self._alloc()
@@ -189,6 +191,29 @@ class DeAOTLSTT:
         self.k_slot_stride = Np * 128
         self.v_slot_stride = 1024 * Np
 
+    # ------------------------------------------------------------------ measurement
+    def enable_kernel_timing(self, on: bool):
+        """HIP-event pairs around the dominant kernel (long-term P.V) on the launch stream."""
+        self._timing = bool(on)
+        if on:
+            self._events = []
+
+    def roofline_report(self, mfma_peak_tflops: float):
+        """Roofline entry for the long-term P.V kernel: algorithmic FLOPs per launch
+        = 2 * N * (T*N) * 1024 over the mean HIP-event duration."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b, _ in self._events]
+        T = self._events[0][2]
+        flops = 2.0 * self.N * (T * self.N) * 1024
+        mean_ms = sum(ms) / len(ms)
+        ach = flops / (mean_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": f"pv_kernel<{self.nsplit}> (long-term A.V, T={T})",
+                "achieved": ach, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach / mfma_peak_tflops,
+                "traffic": None, "launches": len(ms), "mean_us": 1e3 * mean_ms,
+                "algorithmic_flops_per_launch": flops}
+
     def clear_memory(self):                                        # transformer.py:1000-1007
         self.bank: List[int] = []          # logical -> physical slot
         self.short: Optional[int] = None
@@ -251,7 +276,14 @@ class DeAOTLSTT:
         pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
         pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = slot_map_ptr, T, self.N, Np, 1024
         pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = self.h, self.w, self.part.data_ptr(), ks, self.nsplit
+        timed = self._timing and mode == 0 and which == 0
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
+        if timed:
+            e1.record()
+            self._events.append((e0, e1, T))
         ca = hip.CombineArgs()
         ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, self.N, Np, 1024, self.h, self.w
         ca.part, ca.ksplits, ca.lpart, ca.nparts = self.part.data_ptr(), ks, self.lpart.data_ptr(), nparts

@@ -231,20 +231,23 @@ def test_pe_bias_layernorm_dwconv_groupnorm(hip):
     rs = np.random.RandomState(3)
     h, w = 7, 9
     N = h * w
+    g_ = lambda t: t.to(DEV).contiguous()      # keep device tensors alive across the launch
     # pe bias
     Q, cur, mem = _rand(rs, N, 128), _rand(rs, 128, scale=0.5), _rand(rs, 4, 128, scale=0.5)
+    dQ, dcur, dmem = g_(Q), g_(cur), g_(mem)
     rows = [0, 1, 2, 3, 3]
     out = torch.zeros(N, 5, device=DEV)
     arr = (C.c_int32 * 16)(*(rows + [0] * 11))
-    hip.check(lib.rmem_pe_bias(Q.to(DEV).data_ptr(), 128, cur.to(DEV).data_ptr(), mem.to(DEV).data_ptr(),
+    hip.check(lib.rmem_pe_bias(dQ.data_ptr(), 128, dcur.data_ptr(), dmem.data_ptr(),
                                arr, 5, N, 128, out.data_ptr(), st), "pe_bias")
     ref = (Q.double() + cur.double()) @ mem.double()[rows].t()
     assert (out.cpu().double() - ref).abs().max().item() < 1e-4
     # layernorm -> planes (+ fp32)
     x, g, b = _rand(rs, N, 256, scale=2.0) + 0.5, _rand(rs, 256) * 0.2 + 1, _rand(rs, 256) * 0.1
+    dx, dg, db = g_(x), g_(g), g_(b)
     pl = hip.Planes.empty((N, 512), DEV)
     of = torch.zeros(N, 256, device=DEV)
-    hip.check(lib.rmem_layernorm_split(x.to(DEV).data_ptr(), 256, g.to(DEV).data_ptr(), b.to(DEV).data_ptr(),
+    hip.check(lib.rmem_layernorm_split(dx.data_ptr(), 256, dg.data_ptr(), db.data_ptr(),
                                        N, 256, 1e-5, pl.hi.data_ptr() + 256 * 2, pl.lo.data_ptr() + 256 * 2,
                                        512, of.data_ptr(), 256, st), "ln")
     ref = R.layer_norm(x, g, b)
@@ -253,25 +256,28 @@ def test_pe_bias_layernorm_dwconv_groupnorm(hip):
     assert torch.all(pl.hi[:, :256] == 0)
     # depth-wise conv
     gin, wdw = _rand(rs, N, 1024), _rand(rs, 1024, 1, 5, 5, scale=0.25)
+    dgin = g_(gin)
     pl = hip.Planes.empty((N, 1024), DEV)
     wt = wdw.reshape(1024, 25).t().contiguous().to(DEV)
-    hip.check(lib.rmem_dwconv5x5_split(gin.to(DEV).data_ptr(), 1024, wt.data_ptr(), h, w, 1024,
+    hip.check(lib.rmem_dwconv5x5_split(dgin.data_ptr(), 1024, wt.data_ptr(), h, w, 1024,
                                        pl.hi.data_ptr(), pl.lo.data_ptr(), 1024, st), "dwconv")
     ref = R.dwconv5x5(gin, wdw, h, w)
     assert (pl.float().cpu() - ref).abs().max().item() < 3e-5
     # group norm (2 groups)
     t0, t1 = _rand(rs, N, 256, scale=1.5) + 0.3, _rand(rs, N, 256, scale=0.7) - 0.2
     gg, gb = _rand(rs, 512) * 0.2 + 1, _rand(rs, 512) * 0.1
+    dt0, dt1, dgg, dgb = g_(t0), g_(t1), g_(gg), g_(gb)
     ws = torch.zeros(4 * ((N + 63) // 64), dtype=torch.float64, device=DEV)
     o = torch.zeros(N, 512, device=DEV)
-    hip.check(lib.rmem_groupnorm2(t0.to(DEV).data_ptr(), t1.to(DEV).data_ptr(), N, 256, gg.to(DEV).data_ptr(),
-                                  gb.to(DEV).data_ptr(), 1e-5, ws.data_ptr(), o.data_ptr(), 512, st), "gn")
+    hip.check(lib.rmem_groupnorm2(dt0.data_ptr(), dt1.data_ptr(), N, 256, dgg.data_ptr(),
+                                  dgb.data_ptr(), 1e-5, ws.data_ptr(), o.data_ptr(), 512, st), "gn")
     ref = R.group_norm_tokens(torch.cat([t0, t1], 1), gg, gb, 2)
     assert (o.cpu() - ref).abs().max().item() < 5e-6
     # mass reduce
     mass, fg = torch.rand(N, 3), torch.rand(N)
+    dmass, dfg = g_(mass), g_(fg)
     wo = torch.zeros(3, device=DEV)
-    hip.check(lib.rmem_attn_mass_reduce(mass.to(DEV).data_ptr(), N, 3, fg.to(DEV).data_ptr(), wo.data_ptr(), st),
+    hip.check(lib.rmem_attn_mass_reduce(dmass.data_ptr(), N, 3, dfg.data_ptr(), wo.data_ptr(), st),
               "mass_reduce")
     assert (wo.cpu() - (mass * fg[:, None]).sum(0)).abs().max().item() < 1e-4
 
@@ -290,10 +296,12 @@ def test_id_assign_vs_golden(hip, deaot_model, golden_dir):
         lab = idassign_label(H, W)[0, 0].to(torch.uint8).to(DEV).contiguous()
         of = torch.zeros(eh * ew, 256, device=DEV)
         pl = hip.Planes.empty((eh * ew, 256), DEV)
+        kb, g1, g2 = (sd["patch_wise_id_bank.bias"].to(DEV), sd["id_norm.weight"].to(DEV),
+                      sd["id_norm.bias"].to(DEV))
         hip.check(lib.rmem_id_assign(lab.data_ptr(), H, W, wt.data_ptr(),
-                                     sd["patch_wise_id_bank.bias"].to(DEV).data_ptr(), 12, 17, 16, 8, eh, ew,
-                                     256, sd["id_norm.weight"].to(DEV).data_ptr(),
-                                     sd["id_norm.bias"].to(DEV).data_ptr(), 1e-5, pl.hi.data_ptr(),
+                                     kb.data_ptr(), 12, 17, 16, 8, eh, ew,
+                                     256, g1.data_ptr(),
+                                     g2.data_ptr(), 1e-5, pl.hi.data_ptr(),
                                      pl.lo.data_ptr(), 256, of.data_ptr(), 256, st), "id_assign")
         torch.cuda.synchronize()
         assert np.abs(of.cpu().numpy() - gold["id_emb"]).max() < 2e-5
