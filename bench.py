@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--nsplit", type=int, default=int(os.environ.get("RMEM_NSPLIT", "3")),
                     help="3 = split-bf16 (fp32-class), 1 = plain bf16 attention/linears")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
 
 
@@ -158,7 +158,9 @@ def cpu_baseline(cpu_model, args):
     the reference's timing window."""
     from oracle.engine_ref import OracleDeAOTEngine
     from rmem_amd.synth import synth_clip
-    torch.set_num_threads(os.cpu_count() or 1)
+    # all cores is slower than a few dozen on many-core hosts for these op sizes (measured:
+    # 256 threads -> 112 s/frame); use at most 32 and report the count actually used.
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     ora = OracleDeAOTEngine(cpu_model, long_term_mem_gap=1)
     n = args.cpu_frames
     imgs, lab = synth_clip(0, 4 + n, H_IN, W_IN, 3)
