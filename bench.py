@@ -116,8 +116,8 @@ def main():
     for k in range(args.steps):
         frame_step(t + k, masks)
     if dist is not None:                      # collect per-clip masks (the only exchange step)
-        gathered = torch.empty(world * args.steps, H_OUT, W_OUT, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, masks)
+        from rmem_amd.driver import gather_masks
+        gathered = gather_masks(masks[None], world)          # [world, steps, H, W] uint8 over RCCL
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
