@@ -171,6 +171,13 @@ int rmem_id_assign(const uint8_t *label, int32_t H, int32_t W, const float *wt, 
 int rmem_attn_mass_reduce(const float *mass, int32_t N, int32_t T, const float *fg, float *out,
                           void *stream);
 
+/* Support op outside the LSTT: GroupNorm(groups) (+ optional ReLU) on a contiguous NCHW
+ * tensor of batch 1, as used by the FPN head's ConvGN blocks (decoders/fpn.py:43-62,
+ * layers/basic.py:60-70).  Requires (C/groups)*HW % 4 == 0.  ws: >= 2*32*groups doubles. */
+int rmem_groupnorm_nchw(const float *x, float *y, int32_t C, int64_t HW, int32_t groups,
+                        const float *gamma, const float *beta, float eps, int32_t relu, double *ws,
+                        void *stream);
+
 /* fp32 -> planes (weights at load time, fixtures in tests) */
 int rmem_split_planes(const float *x, int64_t n, rmem_bf16 *hi, rmem_bf16 *lo, void *stream);
 

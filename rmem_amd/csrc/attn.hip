@@ -189,10 +189,13 @@ struct PBlockedOperand {
   const bf16_t* lo;
   long npad;
   int row0;
-  __device__ __forceinline__ const u32x4_t* ptr(int plane, int kt, int r, int c) const {
-    const long kb = (long)kt * 2 + (c >> 2);
-    const bf16_t* b = plane ? lo : hi;
-    return reinterpret_cast<const u32x4_t*>(b + (kb * npad + row0 + r) * 32 + (c & 3) * 8);
+  __device__ __forceinline__ TileView tile(int kt) const {
+    const long off = (long)kt * 2 * npad * 32;
+    return TileView{hi + off, lo ? lo + off : nullptr, npad * 32};   // ld = one 32-key block
+  }
+  __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
+    const bf16_t* b = plane ? t.lo : t.hi;
+    return reinterpret_cast<const u32x4_t*>(b + (c >> 2) * t.ld + (long)(row0 + r) * 32 + (c & 3) * 8);
   }
 };
 
@@ -203,22 +206,43 @@ struct VtOperand {
   const int* slot_map;
   int tps;  // 64-key tiles per slot
   int row0, rows;
-  __device__ __forceinline__ const u32x4_t* ptr(int plane, int kt, int r, int c) const {
+  __device__ __forceinline__ TileView tile(int kt) const {
+    const int t = kt / tps;
+    const int phys = slot_map ? slot_map[t] : t;
+    const long off = (long)phys * slot_stride + (kt - t * tps) * 64;
+    return TileView{hi + off, lo ? lo + off : nullptr, ld};
+  }
+  __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
     int j = row0 + r;
     j = j < rows ? j : rows - 1;
-    const int t = kt / tps;
-    const int off = (kt - t * tps) * 64;
-    const int phys = slot_map ? slot_map[t] : t;
-    const bf16_t* b = plane ? lo : hi;
-    return reinterpret_cast<const u32x4_t*>(b + (long)phys * slot_stride + (long)j * ld + off + c * 8);
+    const bf16_t* b = plane ? t.lo : t.hi;
+    return reinterpret_cast<const u32x4_t*>(b + (long)j * t.ld + c * 8);
   }
 };
+
+// Work decomposition of P.V: unit = (query tile, key split, column tile).  Units are
+// laid out so that the 8 XCDs (block b runs on XCD b % 8 -- observed placement, used for
+// speed only) each own a contiguous chunk of (split, query tile) pairs, split-major, and
+// the ncols/128 column tiles of a pair are co-resident on that XCD: the P tile of a pair is
+// fetched from the Infinity Cache once and hit in the XCD's L2 by the other column tiles,
+// and pairs of one XCD share a key split, i.e. the same V^T key range.
+__host__ __device__ inline int pv_chunk(int npairs) { return (npairs + 7) / 8; }
 
 template <int NS>
 __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   using Cfg = GemmCfg<128, 128, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int ctile = blockIdx.x, qtile = blockIdx.y, z = blockIdx.z;
+  const int nct = (a.ncols + 127) / 128;
+  const int nq = a.Npad / 128;
+  const int npairs = nq * a.ksplits;
+  const int chunk = pv_chunk(npairs);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int pl = j / nct;
+  const int ctile = j - pl * nct;
+  const int pair = xcd * chunk + pl;
+  if (pl >= chunk || pair >= npairs) return;
+  const int z = pair / nq;
+  const int qtile = pair - z * nq;
   const int tps = a.Npad / 64;
   int k_lo, k_hi;
   if (a.mode == 0) {
@@ -267,7 +291,9 @@ static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     attr_set = true;
   }
-  dim3 grid((a.ncols + 127) / 128, a.Npad / 128, a.ksplits);
+  const int nct = (a.ncols + 127) / 128;
+  const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
+  dim3 grid(8 * chunk * nct);
   hipLaunchKernelGGL((pv_kernel<NS>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;

@@ -49,6 +49,15 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Per-k-tile view of an operand: everything that is uniform over the tile (segment
+// choice, slot lookup, divisions) is resolved ONCE per k-tile in tile(); ptr() is then
+// pure per-lane address arithmetic, so the 8-16 staging loads of a tile issue back to back.
+struct TileView {
+  const bf16_t* hi;
+  const bf16_t* lo;
+  long ld;
+};
+
 // Row-major operand [rows][ld] (bf16 planes), optionally continued by a second source
 // for k-tiles >= kt_split (used to concatenate two activations along K).
 struct RowMajorOperand {
@@ -61,15 +70,15 @@ struct RowMajorOperand {
   int kt_split;   // number of k-tiles served by the first source
   int row0;       // first row of this block's tile
   int rows;       // valid rows (loads are clamped to rows-1)
-  __device__ __forceinline__ const u32x4_t* ptr(int plane, int kt, int r, int c) const {
+  __device__ __forceinline__ TileView tile(int kt) const {
+    if (kt < kt_split) return TileView{hi + kt * 64, lo ? lo + kt * 64 : nullptr, ld};
+    return TileView{hi2 + (kt - kt_split) * 64, lo2 ? lo2 + (kt - kt_split) * 64 : nullptr, ld2};
+  }
+  __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
     int gr = row0 + r;
     gr = gr < rows ? gr : rows - 1;
-    if (kt < kt_split) {
-      const bf16_t* b = plane ? lo : hi;
-      return reinterpret_cast<const u32x4_t*>(b + (long)gr * ld + kt * 64 + c * 8);
-    }
-    const bf16_t* b = plane ? lo2 : hi2;
-    return reinterpret_cast<const u32x4_t*>(b + (long)gr * ld2 + (kt - kt_split) * 64 + c * 8);
+    const bf16_t* b = plane ? t.lo : t.hi;
+    return reinterpret_cast<const u32x4_t*>(b + (long)gr * t.ld + c * 8);
   }
 };
 
@@ -109,14 +118,16 @@ __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, co
   // arrays are promoted to VGPRs (a rolled loop here puts them in scratch).
   u32x4_t xr[NPL * XCH], yr[NPL * YCH];
   auto gload = [&](int kt) __attribute__((always_inline)) {
+    const TileView tx = lx.tile(kt);
+    const TileView ty = ly.tile(kt);
     static_for<NPL>([&](auto P) {
       static_for<XCH>([&](auto I) {
         const int id = tid + I.value * Cfg::THREADS;
-        xr[P.value * XCH + I.value] = *lx.ptr(P.value, kt, id >> 3, id & 7);
+        xr[P.value * XCH + I.value] = *lx.ptr(tx, P.value, id >> 3, id & 7);
       });
       static_for<YCH>([&](auto I) {
         const int id = tid + I.value * Cfg::THREADS;
-        yr[P.value * YCH + I.value] = *ly.ptr(P.value, kt, id >> 3, id & 7);
+        yr[P.value * YCH + I.value] = *ly.ptr(ty, P.value, id >> 3, id & 7);
       });
     });
   };

@@ -52,47 +52,76 @@ extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* ga
 }
 
 // ------------------------------------------------------------------ depth-wise 5x5 -> planes
-// block = one token x (256 threads x 4 channels); grid.y covers C / 1024
+// thread = 4 channels x a run of RX output tokens along x; the 5 x (RX+4) input window is
+// loaded once (sliding-window reuse: 50 loads for 6 outputs instead of 150) and the 25
+// taps of its channels stay in registers.  block = 256 threads = 1024 channels.
+template <int RX>
 __global__ __launch_bounds__(256) void dwconv5x5_split_kernel(const float* g, long ldg, const float* wt, int h,
                                                               int w, int C, bf16_t* oh, bf16_t* ol, long ldo) {
-  const int p = blockIdx.x;
-  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+  const int x0 = blockIdx.x * RX, y = blockIdx.y;
+  const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
   if (c >= C) return;
-  const int y = p / w, x = p - y * w;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 k[25];
 #pragma unroll
-  for (int dy = -2; dy <= 2; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= h) continue;
+  for (int t = 0; t < 25; ++t) k[t] = *reinterpret_cast<const float4*>(wt + (long)t * C + c);
+  float4 acc[RX];
 #pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) {
-      const int xx = x + dx;
-      if (xx < 0 || xx >= w) continue;
-      const float4 v = *reinterpret_cast<const float4*>(g + (long)(yy * w + xx) * ldg + c);
-      const float4 k = *reinterpret_cast<const float4*>(wt + (long)((dy + 2) * 5 + dx + 2) * C + c);
-      acc.x += v.x * k.x;
-      acc.y += v.y * k.y;
-      acc.z += v.z * k.z;
-      acc.w += v.w * k.w;
+  for (int o = 0; o < RX; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int iy = 0; iy < 5; ++iy) {
+    const int yy = y + iy - 2;
+    const bool vy = yy >= 0 && yy < h;
+    const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+    // all loads of the row first (unconditional, clamped addresses) so they are in flight
+    // together; out-of-image taps are zeroed by a select afterwards.
+    float4 v[RX + 4];
+#pragma unroll
+    for (int ix = 0; ix < RX + 4; ++ix) {
+      const int xx = x0 + ix - 2;
+      const int xc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      v[ix] = *reinterpret_cast<const float4*>(g + (long)(yc * w + xc) * ldg + c);
+    }
+#pragma unroll
+    for (int ix = 0; ix < RX + 4; ++ix) {
+      const int xx = x0 + ix - 2;
+      const bool ok = vy && xx >= 0 && xx < w;
+      const float4 vv = ok ? v[ix] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int o = 0; o < RX; ++o) {
+        const int dx = ix - o;  // tap column for output o
+        if (dx < 0 || dx > 4) continue;
+        const float4 kk = k[iy * 5 + dx];
+        acc[o].x += vv.x * kk.x;
+        acc[o].y += vv.y * kk.y;
+        acc[o].z += vv.z * kk.z;
+        acc[o].w += vv.w * kk.w;
+      }
     }
   }
-  const float yv[4] = {acc.x, acc.y, acc.z, acc.w};
-  bf16_t hi[4], lo[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split_bf16(yv[e], hi[e], lo[e]);
-  uint2 vh, vl;
-  vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
-  vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
-  vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
-  vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
-  *reinterpret_cast<uint2*>(oh + (long)p * ldo + c) = vh;
-  if (ol) *reinterpret_cast<uint2*>(ol + (long)p * ldo + c) = vl;
+  for (int o = 0; o < RX; ++o) {
+    const int x = x0 + o;
+    if (x >= w) continue;
+    const long p = (long)y * w + x;
+    const float yv[4] = {acc[o].x, acc[o].y, acc[o].z, acc[o].w};
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(yv[e], hi[e], lo[e]);
+    uint2 vh, vl;
+    vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+    vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+    vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+    *reinterpret_cast<uint2*>(oh + p * ldo + c) = vh;
+    if (ol) *reinterpret_cast<uint2*>(ol + p * ldo + c) = vl;
+  }
 }
 
 extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt, int32_t h, int32_t w,
                                     int32_t C, rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, void* stream) {
   if (!g || !wt || !oh || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
-  hipLaunchKernelGGL(dwconv5x5_split_kernel, dim3(h * w, (C + 1023) / 1024), dim3(256), 0,
+  constexpr int RX = 6;
+  hipLaunchKernelGGL(dwconv5x5_split_kernel<RX>, dim3((w + RX - 1) / RX, h, (C + 1023) / 1024), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g, (long)ldg, wt, h, w, C, oh, ol, (long)ldo);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
@@ -199,22 +228,32 @@ __global__ __launch_bounds__(256) void id_assign_kernel(const uint8_t* label, in
                                                         long ldof) {
   __shared__ float red[4];
   __shared__ float red2[4];
+  __shared__ int cls_s[1024];          // class per tap of the receptive field (-1 = no channel)
   const int tok = blockIdx.x;
   const int oy = tok / ew, ox = tok - oy * ew;
   const int c = threadIdx.x;
   const int lane = c & 63, wave = c >> 6;
-  float acc = bias[c];
-  for (int dy = 0; dy < ksize; ++dy) {
-    const int y = oy * stride - pad + dy;
-    if (y < 0 || y >= H) continue;
-    for (int dx = 0; dx < ksize; ++dx) {
-      const int x = ox * stride - pad + dx;
-      if (x < 0 || x >= W) continue;
-      int cls = label[(long)y * W + x];   // block-uniform
-      if (cls == 255) cls = ncls - 1;     // ignore channel is the last one
-      else if (cls >= ncls - 1) continue; // ids above max_obj have no one-hot channel
-      acc += wt[((long)(cls * ksize + dy) * ksize + dx) * 256 + c];
+  const int ntap = ksize * ksize;
+  for (int t = c; t < ntap; t += 256) {
+    const int dy = t / ksize, dx = t - dy * ksize;
+    const int y = oy * stride - pad + dy, x = ox * stride - pad + dx;
+    int cls = -1;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      cls = label[(long)y * W + x];
+      if (cls == 255) cls = ncls - 1;      // ignore channel is the last one
+      else if (cls >= ncls - 1) cls = -1;  // ids above max_obj have no one-hot channel
     }
+    cls_s[t] = cls;
+  }
+  __syncthreads();
+  // taps are summed in conv order; the loads are independent of each other, so the
+  // unrolled loop keeps 8 weight rows in flight.
+  float acc = bias[c];
+#pragma unroll 8
+  for (int t = 0; t < ntap; ++t) {
+    const int cls = cls_s[t];              // LDS broadcast, block-uniform
+    const float wv = cls >= 0 ? wt[((long)cls * ntap + t) * 256 + c] : 0.f;
+    acc += wv;
   }
   float yv = acc;
   if (gamma) {
@@ -246,7 +285,8 @@ extern "C" int rmem_id_assign(const uint8_t* label, int32_t H, int32_t W, const 
                               int32_t ncls, int32_t ksize, int32_t stride, int32_t pad, int32_t eh, int32_t ew,
                               int32_t C, const float* gamma, const float* beta, float eps, rmem_bf16* oh,
                               rmem_bf16* ol, int64_t ldo, float* of32, int64_t ldof, void* stream) {
-  if (!label || !wt || !bias || C != 256 || eh <= 0 || ew <= 0 || ncls < 2) return RMEM_ERR_INVALID;
+  if (!label || !wt || !bias || C != 256 || eh <= 0 || ew <= 0 || ncls < 2 || ksize <= 0 || ksize > 32)
+    return RMEM_ERR_INVALID;
   hipLaunchKernelGGL(id_assign_kernel, dim3(eh * ew), dim3(256), 0, static_cast<hipStream_t>(stream), label, H, W,
                      wt, bias, ncls, ksize, stride, pad, ew, gamma, beta, eps, oh, ol, (long)ldo, of32,
                      (long)ldof);
@@ -300,6 +340,113 @@ extern "C" int rmem_split_planes(const float* x, int64_t n, rmem_bf16* hi, rmem_
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      x, (long)n, hi, lo);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+
+// ------------------------------------------------------------------ GroupNorm on NCHW (+ReLU)
+// Support kernel for the FPN head (outside the LSTT): PyTorch's GroupNorm forward runs one
+// workgroup per (image, group) -- 8 workgroups at batch 1 -- and costs ~100 us per call on
+// MI355X.  Here a group (a contiguous segment of (C/G)*HW floats) is reduced by `ns` blocks
+// into double partials, and the apply pass fuses the affine and the ReLU.
+__global__ __launch_bounds__(256) void gn_nchw_stats_kernel(const float* x, long seg, int ns, double* ws) {
+  __shared__ double red[2][4];
+  const int g = blockIdx.y, sidx = blockIdx.x;
+  const long per = ((seg / 4 + ns - 1) / ns) * 4;
+  long lo = (long)sidx * per, hi = lo + per;
+  if (hi > seg) hi = seg;
+  const float* xb = x + (long)g * seg;
+  double s = 0, q = 0;
+  for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+    if (i + 3 < hi) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + i);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      for (long j = i; j < hi; ++j) {
+        s += xb[j];
+        q += (double)xb[j] * xb[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    ws[((long)g * ns + sidx) * 2 + threadIdx.x] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(256) void gn_nchw_apply_kernel(const float* x, float* y, long seg, int cpg, long hw,
+                                                            int ns, const double* ws, const float* gamma,
+                                                            const float* beta, float eps, int relu) {
+  __shared__ float stat[2];
+  const int g = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double s = 0, q = 0;
+    for (int i = 0; i < ns; ++i) {
+      s += ws[((long)g * ns + i) * 2];
+      q += ws[((long)g * ns + i) * 2 + 1];
+    }
+    const double mean = s / (double)seg;
+    double var = q / (double)seg - mean * mean;
+    if (var < 0) var = 0;
+    stat[0] = (float)mean;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  const float* xb = x + (long)g * seg;
+  float* yb = y + (long)g * seg;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < seg; i += (long)gridDim.x * 1024) {
+    float v[4];
+    const bool full = i + 3 < seg;
+    if (full) {
+      const float4 t = *reinterpret_cast<const float4*>(xb + i);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      for (int e = 0; e < 4; ++e) v[e] = (i + e < seg) ? xb[i + e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = g * cpg + (int)((i + e) / hw);
+      const int cc = c < (g + 1) * cpg ? c : (g + 1) * cpg - 1;
+      float o = (v[e] - mean) * rstd * gamma[cc] + beta[cc];
+      if (relu) o = o > 0.f ? o : 0.f;
+      v[e] = o;
+    }
+    if (full) {
+      *reinterpret_cast<float4*>(yb + i) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (i + e < seg) yb[i + e] = v[e];
+    }
+  }
+}
+
+extern "C" int rmem_groupnorm_nchw(const float* x, float* y, int32_t C, int64_t HW, int32_t groups,
+                                   const float* gamma, const float* beta, float eps, int32_t relu, double* ws,
+                                   void* stream) {
+  if (!x || !y || !gamma || !beta || !ws || C <= 0 || groups <= 0 || (C % groups) || HW <= 0) return RMEM_ERR_INVALID;
+  const int cpg = C / groups;
+  const long seg = (long)cpg * HW;
+  if ((seg % 4) != 0) return RMEM_ERR_INVALID;   // keeps every group segment 16-byte aligned
+  const int ns = 32;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_nchw_stats_kernel, dim3(ns, groups), dim3(256), 0, s, x, seg, ns, ws);
+  long ab = (seg / 4 + 255) / 256;
+  if (ab > 64) ab = 64;
+  hipLaunchKernelGGL(gn_nchw_apply_kernel, dim3((unsigned)ab, groups), dim3(256), 0, s, x, y, seg, cpg, (long)HW, ns,
+                     ws, gamma, beta, eps, relu);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }

@@ -135,10 +135,13 @@ class DeAOTInferEngine(nn.Module):
     """Multi-object wrapper (engines/aot_engine.py:571-725, deaot_engine.py:20-56)."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1,
-                 max_aot_obj_num=None, nsplit: int = 3):
+                 max_aot_obj_num=None, nsplit: int = 3, fold_bn: bool = True):
         super().__init__()
         self.cfg = aot_model.cfg
         self.AOT = aot_model
+        if fold_bn and hasattr(aot_model, "optimize_for_inference") and \
+                next(aot_model.parameters()).is_cuda:
+            aot_model.optimize_for_inference(True)     # weights must already be loaded / on device
         if max_aot_obj_num is None or max_aot_obj_num > aot_model.max_obj_num:
             self.max_aot_obj_num = aot_model.max_obj_num
         else:

@@ -74,7 +74,7 @@ class CombineArgs(C.Structure):
 EXPORTS = [
     "rmem_abi_version", "rmem_linear", "rmem_attn_scores", "rmem_attn_pv", "rmem_attn_combine",
     "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
-    "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes",
+    "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
 ]
 
 
@@ -105,6 +105,7 @@ def load():
                                    c_p, c_p, f32, c_p, c_p, i64, c_p, i64, c_p]
     lib.rmem_attn_mass_reduce.argtypes = [c_p, i32, i32, c_p, c_p, c_p]
     lib.rmem_split_planes.argtypes = [c_p, i64, c_p, c_p, c_p]
+    lib.rmem_groupnorm_nchw.argtypes = [c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]
     _LIB = lib
     return lib
 
@@ -178,3 +179,23 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
     a.nbatch, a.bsx, a.bsy, a.bsd, a.bsbias, a.bspa = nbatch, bsx, bsy, bsd, bsbias, bspa
     a.nsplit, a.tile = nsplit, tile
     check(load().rmem_linear(C.byref(a), stream_ptr()), "rmem_linear")
+
+
+_GN_WS = {}
+
+
+def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool) -> torch.Tensor:
+    """GroupNorm(+ReLU) of a batch-1 NCHW fp32 tensor through rmem_groupnorm_nchw."""
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    if n != 1 or x.dtype != torch.float32 or ((c // gn.num_groups) * h * w) % 4:
+        y = torch.nn.functional.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
+        return torch.relu_(y) if relu else y
+    ws = _GN_WS.get(x.device)
+    if ws is None:
+        ws = _GN_WS[x.device] = torch.zeros(2 * 32 * 64, dtype=torch.float64, device=x.device)
+    y = torch.empty_like(x)
+    check(load().rmem_groupnorm_nchw(x.data_ptr(), y.data_ptr(), c, h * w, gn.num_groups, gn.weight.data_ptr(),
+                                     gn.bias.data_ptr(), gn.eps, int(relu), ws.data_ptr(), stream_ptr()),
+          "rmem_groupnorm_nchw")
+    return y

@@ -68,6 +68,16 @@ class _LayerWeights:
     pass
 
 
+class _AttnWS:
+    """Per-stream attention workspace: P planes (blocked), partial row sums, split partials, G."""
+
+    def __init__(self, T, N, Np, ksplits, dev):
+        self.P = Planes.empty((T * Np // 32, Np, 32), dev)
+        self.lpart = torch.zeros(Np, T * Np // 64, device=dev)
+        self.part = torch.zeros(ksplits, Np, 1024, device=dev)
+        self.G = torch.zeros(N, 1024, device=dev)
+
+
 class DeAOTLSTT:
     """HIP-backed DualBranchGPM for one clip geometry (h x w tokens)."""
 
@@ -168,13 +178,13 @@ class DeAOTLSTT:
         self.Ucat = z(N, 1024)
         self.bias_pe = z(N, self.Tmax)
         self.rowmax = z(3, Np, dt=torch.int32)
-        kb_max = self.Tmax * Np // 32
-        self.P = Planes.empty((kb_max, Np, 32), dev)
-        self.nparts_max = self.Tmax * Np // 64
-        self.lpart = z(Np, self.nparts_max)
         self.ksplits_max = 8
-        self.part = z(self.ksplits_max, Np, 1024)
-        self.G = z(N, 1024)
+        # attention workspaces: main stream (long-term, self) and side stream (short-term window)
+        self.ws_main = _AttnWS(self.Tmax, N, Np, self.ksplits_max, dev)
+        self.ws_side = _AttnWS(1, N, Np, self.ksplits_max, dev)
+        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.ev_ready = torch.cuda.Event() if dev.type == "cuda" else None
+        self.ev_side = torch.cuda.Event() if dev.type == "cuda" else None
         self.Ylt = Planes.empty((Np, 1024), dev)
         self.Yst = Planes.empty((Np, 1024), dev)
         self.ldr = 232
@@ -240,9 +250,10 @@ class DeAOTLSTT:
         raise hip.RmemError("no free bank slot (internal error)")
 
     def _ksplits(self, ktiles: int) -> int:
-        blocks = 8 * (self.Npad // 128)
-        ks = max(1, min(self.ksplits_max, (512 + blocks - 1) // blocks, ktiles))
-        return ks
+        """Key splits of P.V: ~56 (query tile, split) pairs = 7 per XCD x 8 column tiles
+        = one resident wave of 448 blocks (2 per CU); see pv_kernel's work mapping."""
+        nq = self.Npad // 128
+        return max(1, min(self.ksplits_max, int(round(56.0 / nq)), ktiles))
 
     def _ln(self, x, gb, out: Planes, ldo, col_off=0):
         rc = hip.load().rmem_layernorm_split(
@@ -250,9 +261,9 @@ class DeAOTLSTT:
             out.hi.data_ptr() + col_off * 2, out.lo.data_ptr() + col_off * 2, ldo, None, 0, hip.stream_ptr())
         hip.check(rc, "rmem_layernorm_split")
 
-    def _attention(self, mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr, qpl: Planes,
-                   bias, U, want_mass: bool, which: int):
-        """scores(pass0, pass1) + pv + combine -> self.G."""
+    def _attention(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
+                   qpl: Planes, bias, U, want_mass: bool, which: int):
+        """scores(pass0, pass1) + pv + combine -> ws.G."""
         lib, st = hip.load(), hip.stream_ptr()
         Np = self.Npad
         nparts = T * Np // 64
@@ -263,8 +274,8 @@ class DeAOTLSTT:
         sa.bias = bias.data_ptr() if bias is not None else None
         sa.R, sa.ldr, sa.h, sa.w = (self.R.data_ptr() if mode == 1 else None), self.ldr, self.h, self.w
         sa.rowmax = self.rowmax[which].data_ptr()
-        sa.ph, sa.pl = self.P.hi.data_ptr(), self.P.lo.data_ptr()
-        sa.lpart, sa.nparts, sa.nsplit = self.lpart.data_ptr(), nparts, self.nsplit
+        sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+        sa.lpart, sa.nparts, sa.nsplit = ws.lpart.data_ptr(), nparts, self.nsplit
         sa.pass_ = 0
         hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 0)")
         sa.pass_ = 1
@@ -272,10 +283,10 @@ class DeAOTLSTT:
         ktiles = T * Np // 64 if mode == 0 else 16
         ks = self._ksplits(ktiles)
         pa = hip.PVArgs()
-        pa.mode, pa.ph, pa.pl = mode, self.P.hi.data_ptr(), self.P.lo.data_ptr()
+        pa.mode, pa.ph, pa.pl = mode, ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
         pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
         pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = slot_map_ptr, T, self.N, Np, 1024
-        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = self.h, self.w, self.part.data_ptr(), ks, self.nsplit
+        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = self.h, self.w, ws.part.data_ptr(), ks, self.nsplit
         timed = self._timing and mode == 0 and which == 0
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -286,13 +297,13 @@ class DeAOTLSTT:
             self._events.append((e0, e1, T))
         ca = hip.CombineArgs()
         ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, self.N, Np, 1024, self.h, self.w
-        ca.part, ca.ksplits, ca.lpart, ca.nparts = self.part.data_ptr(), ks, self.lpart.data_ptr(), nparts
-        ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, self.G.data_ptr(), 1024
+        ca.part, ca.ksplits, ca.lpart, ca.nparts = ws.part.data_ptr(), ks, ws.lpart.data_ptr(), nparts
+        ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, ws.G.data_ptr(), 1024
         ca.mass = self.mass.data_ptr() if want_mass else None
         hip.check(lib.rmem_attn_combine(C.byref(ca), st), "rmem_attn_combine")
 
-    def _dwconv(self, wt, out: Planes):
-        rc = hip.load().rmem_dwconv5x5_split(self.G.data_ptr(), 1024, wt.data_ptr(), self.h, self.w, 1024,
+    def _dwconv(self, ws: "_AttnWS", wt, out: Planes):
+        rc = hip.load().rmem_dwconv5x5_split(ws.G.data_ptr(), 1024, wt.data_ptr(), self.h, self.w, 1024,
                                             out.hi.data_ptr(), out.lo.data_ptr(), 1024, hip.stream_ptr())
         hip.check(rc, "rmem_dwconv5x5_split")
 
@@ -369,19 +380,26 @@ class DeAOTLSTT:
                            d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns)
             if ref_frame:
                 self._idv(l, cur)
+            # -- short-term windowed read on the side stream (transformer.py:1199,
+            #    attention.py:289-358); independent of the long-term chain until the projection
+            self.ev_ready.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_ready)
+                hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
+                           d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
+                self._attention(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
+                                Ucat, want_mass=False, which=1)
+                self._dwconv(self.ws_side, W.dw_st, self.Yst)
+                self.ev_side.record()
             # -- long-term memory read (transformer.py:1140-1192, attention.py:174-209)
+            st = hip.stream_ptr()
             hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
                                        self.mem_pe.data_ptr(), rows, T, N, 128,
                                        self.bias_pe.data_ptr(), st), "rmem_pe_bias")
-            self._attention(0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe, self.bias_pe, Ucat,
-                            want_mass=(l == 0), which=0)
-            self._dwconv(W.dw_lt, self.Ylt)
-            # -- short-term windowed read (transformer.py:1199, attention.py:289-358)
-            hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
-                       d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
-            self._attention(1, 1, self.bankK[l], self.bankV[l], map_short, curK, None, Ucat,
-                            want_mass=False, which=1)
-            self._dwconv(W.dw_st, self.Yst)
+            self._attention(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
+                            self.bias_pe, Ucat, want_mass=(l == 0), which=0)
+            self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
+            torch.cuda.current_stream().wait_event(self.ev_side)
             # -- both projections + residual adds (transformer.py:1212-1220)
             hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
                        kx_split=1024, bias=W.bp_ls, d0=self.tgt.data_ptr(), ldd0=256,
@@ -399,9 +417,9 @@ class DeAOTLSTT:
             hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
                        d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
                        bsbias=512, bsd=512, nsplit=ns)
-            self._attention(0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
+            self._attention(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
                             want_mass=False, which=2)
-            self._dwconv(W.dw_self, self.Ylt)
+            self._dwconv(self.ws_main, W.dw_self, self.Ylt)
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
                        d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,
                        csplit=256, accumulate=True, nsplit=ns)

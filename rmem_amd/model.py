@@ -120,9 +120,17 @@ class DeAOT(nn.Module):
         self.cur_pos_emb = nn.Parameter(torch.zeros(1, d // 2))
         self.mem_pos_emb = nn.Parameter(torch.zeros(4, d // 2))
 
+    def optimize_for_inference(self, fold_bn: bool = True):
+        """Build the inference-time encoder (FrozenBN folded into the convs).  Call after the
+        weights are loaded; call again if they change."""
+        # kept out of nn.Module registration so that state_dict() keeps the reference's keys
+        object.__setattr__(self, "_enc_infer", self.encoder.folded() if fold_bn else None)
+        return self
+
     # -- pass-throughs to PyTorch (models/aot.py:116-134, deaot.py:57-63)
     def encode_image(self, img):
-        xs = self.encoder(img)
+        enc = self.__dict__.get("_enc_infer") or self.encoder
+        xs = enc(img)
         xs[-1] = self.encoder_projector(xs[-1])
         return xs
 

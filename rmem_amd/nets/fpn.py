@@ -14,8 +14,13 @@ class _ConvGN(nn.Module):
         self.conv = nn.Conv2d(cin, cout, k, padding=k // 2)
         self.gn = nn.GroupNorm(groups, cout)
 
-    def forward(self, x):
-        return self.gn(self.conv(x))
+    def forward(self, x, relu=False):
+        y = self.conv(x)
+        if y.is_cuda and not torch.is_grad_enabled():
+            from ..hip import groupnorm_nchw      # GroupNorm+ReLU in one HIP pass (inference)
+            return groupnorm_nchw(y, self.gn, relu)
+        y = self.gn(y)
+        return F.relu(y) if relu else y
 
 
 class FPNHead(nn.Module):
@@ -41,8 +46,8 @@ class FPNHead(nn.Module):
 
     def forward(self, inputs, shortcuts):
         x = torch.cat(inputs, dim=1) if self.decode_intermediate_input else inputs[-1]
-        x = F.relu(self.conv_in(x))
-        x = F.relu(self.conv_16x(self.adapter_16x(shortcuts[-2]) + x))
-        x = F.relu(self.conv_8x(self.adapter_8x(shortcuts[-3]) + self._up(x, shortcuts[-3])))
-        x = F.relu(self.conv_4x(self.adapter_4x(shortcuts[-4]) + self._up(x, shortcuts[-4])))
+        x = self.conv_in(x, relu=True)
+        x = self.conv_16x(self.adapter_16x(shortcuts[-2]) + x, relu=True)
+        x = self.conv_8x(self.adapter_8x(shortcuts[-3]) + self._up(x, shortcuts[-3]), relu=True)
+        x = self.conv_4x(self.adapter_4x(shortcuts[-4]) + self._up(x, shortcuts[-4]), relu=True)
         return self.conv_out(x)

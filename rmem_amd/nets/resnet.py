@@ -29,6 +29,17 @@ class FrozenBN(nn.Module):
                             self.bias, training=False, eps=self.eps)
 
 
+def _fold(conv: nn.Conv2d, bn: "FrozenBN") -> nn.Conv2d:
+    """conv followed by a frozen BN -> one conv with bias (inference-time folding)."""
+    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                    conv.dilation, conv.groups, bias=True).to(conv.weight.device)
+    with torch.no_grad():
+        out.weight.copy_(conv.weight * scale.view(-1, 1, 1, 1))
+        out.bias.copy_(bn.bias - bn.running_mean * scale)
+    return out
+
+
 class _Bottleneck(nn.Module):
     def __init__(self, cin, width, stride=1, dilation=1, proj=False):
         super().__init__()
@@ -72,6 +83,22 @@ class ResNet50Encoder(nn.Module):
         self.layer1 = _stage(64, 64, 3, 1, 1)
         self.layer2 = _stage(256, 128, 4, 2, 1)
         self.layer3 = _stage(512, 256, 6, 2, 1)
+
+    def folded(self) -> "ResNet50Encoder":
+        """Inference copy with every FrozenBN folded into the preceding conv (same function up
+        to fp32 rounding; removes 43 BatchNorm launches per frame).  Keys no longer match the
+        reference's state_dict, so this is built from the loaded model, never loaded into."""
+        import copy
+        m = copy.deepcopy(self)
+        m.conv1, m.bn1 = _fold(m.conv1, m.bn1), nn.Identity()
+        for stage in (m.layer1, m.layer2, m.layer3):
+            for blk in stage:
+                blk.conv1, blk.bn1 = _fold(blk.conv1, blk.bn1), nn.Identity()
+                blk.conv2, blk.bn2 = _fold(blk.conv2, blk.bn2), nn.Identity()
+                blk.conv3, blk.bn3 = _fold(blk.conv3, blk.bn3), nn.Identity()
+                if blk.downsample is not None:
+                    blk.downsample = nn.Sequential(_fold(blk.downsample[0], blk.downsample[1]))
+        return m.eval()
 
     def forward(self, img):
         x = self.maxpool(F.relu(self.bn1(self.conv1(img))))

@@ -306,3 +306,19 @@ def test_id_assign_vs_golden(hip, deaot_model, golden_dir):
         torch.cuda.synchronize()
         assert np.abs(of.cpu().numpy() - gold["id_emb"]).max() < 2e-5
         assert np.abs(pl.float().cpu().numpy() - gold["id_emb"]).max() < 5e-5
+
+
+def test_groupnorm_nchw_relu(hip):
+    """FPN support kernel: GroupNorm(8)+ReLU on NCHW against torch (fp64 statistics)."""
+    rs = np.random.RandomState(9)
+    for (c, h, w) in [(256, 31, 54), (128, 61, 107), (128, 7, 9)]:
+        x = _rand(rs, 1, c, h, w, scale=2.0) + 0.7
+        gn = torch.nn.GroupNorm(8, c)
+        with torch.no_grad():
+            gn.weight.copy_(_rand(rs, c) * 0.2 + 1)
+            gn.bias.copy_(_rand(rs, c) * 0.3)
+        ref = torch.relu(torch.nn.functional.group_norm(x.double(), 8, gn.weight.double(), gn.bias.double(), gn.eps))
+        gn = gn.to(DEV)
+        y = hip.groupnorm_nchw(x.to(DEV), gn, True)
+        torch.cuda.synchronize()
+        assert (y.cpu().double() - ref).abs().max().item() < 5e-6

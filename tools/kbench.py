@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmark of the hot-path kernels at the 480p K=4 (or 720p K=8)
+problem sizes, each timed in isolation with HIP events (median of `--iters` launches).
+Used to iterate on kernel performance; results land in profiles/ when worth keeping."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timeit(fn, iters):
+    """Back-to-back launches between two events: per-launch time with the queue kept full
+    (includes the ~1.5 us kernel boundary, excludes host launch latency)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--h", type=int, default=31)
+    ap.add_argument("--w", type=int, default=54)
+    ap.add_argument("--cap", type=int, default=4)
+    ap.add_argument("--nsplit", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=30)
+    args = ap.parse_args()
+    from rmem_amd import hip
+    from rmem_amd.config import get_config
+    from rmem_amd.lstt import DeAOTLSTT, temporal_pe_rows
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    dev = torch.device("cuda:0")
+    cfg = get_config("r50_deaotl", 1, args.cap - 1)
+    model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(model)
+    model = model.to(dev)
+    L = DeAOTLSTT(model, args.h, args.w, dev, nsplit=args.nsplit)
+    N, Np, T = L.N, L.Npad, args.cap
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for l in range(L.L):
+        for pl in (L.bankK[l], L.bankV[l]):
+            x = torch.randn(pl.hi.shape, generator=g) * 1.0
+            p = hip.Planes.from_f32(x.to(dev))
+            pl.hi.copy_(p.hi)
+            pl.lo.copy_(p.lo)
+    L.bank, L.short, L.cur = list(range(T)), T - 1, T
+    L.tgt.normal_()
+    L.tgt_id.normal_()
+    L.maps.copy_(torch.tensor(list(range(16)) + [T - 1] + [0] * 15, dtype=torch.int32))
+    L.Ucat.normal_()
+    L.Qf32.normal_()
+    q = hip.Planes.from_f32(torch.randn(Np, 128, device=dev))
+    L.Qpe.hi.copy_(q.hi); L.Qpe.lo.copy_(q.lo)
+    W = L.lw[1]
+    res = {}
+    lib = hip.load()
+    rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
+    map_bank, map_short = L.maps.data_ptr(), L.maps.data_ptr() + 64
+    curK = L.bankK[1][T]
+    # --- attention pieces (long-term): build args once via the executor's own path
+    import types
+    calls = {}
+
+    def attention(ws, mode, Tn, kpl, vpl, smap, qpl, bias, U, which):
+        L.rowmax.zero_()
+        L._attention(ws, mode, Tn, kpl, vpl, smap, qpl, bias, U, False, which)
+
+    res["attn_long_total"] = timeit(lambda: attention(L.ws_main, 0, T, L.bankK[1], L.bankV[1], map_bank, L.Qpe,
+                                                      L.bias_pe, L.Ucat, 0), args.iters)
+    res["attn_window_total"] = timeit(lambda: attention(L.ws_side, 1, 1, L.bankK[1], L.bankV[1], map_short, curK,
+                                                        None, L.Ucat, 1), args.iters)
+    res["attn_self_total"] = timeit(lambda: attention(L.ws_main, 0, 1, L.selfQK, L.selfV, None,
+                                                      hip.Planes(L.selfQK.hi[0], L.selfQK.lo[0]), None, L.Uself, 2),
+                                    args.iters)
+
+    # individual kernels through the C ABI
+    def scores(mode, Tn, pass_, ws, kpl, smap, qpl, bias):
+        sa = hip.ScoresArgs()
+        sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, kpl.hi.data_ptr(), kpl.lo.data_ptr(), L.k_slot_stride
+        sa.slot_map, sa.T, sa.N, sa.Npad = smap, Tn, N, Np
+        sa.qh, sa.ql, sa.scale = qpl.hi.data_ptr(), qpl.lo.data_ptr(), L.scale
+        sa.bias = bias.data_ptr() if bias is not None else None
+        sa.R, sa.ldr, sa.h, sa.w = (L.R.data_ptr() if mode == 1 else None), L.ldr, L.h, L.w
+        sa.rowmax = L.rowmax[0].data_ptr()
+        sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+        sa.lpart, sa.nparts, sa.nsplit, sa.pass_ = ws.lpart.data_ptr(), Tn * Np // 64, L.nsplit, pass_
+        return lambda: hip.check(lib.rmem_attn_scores(C.byref(sa), hip.stream_ptr()), "scores")
+
+    def pv(mode, Tn, ws, vpl, smap, ks):
+        pa = hip.PVArgs()
+        pa.mode, pa.ph, pa.pl = mode, ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+        pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), L.v_slot_stride
+        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = smap, Tn, N, Np, 1024
+        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = L.h, L.w, ws.part.data_ptr(), ks, L.nsplit
+        return lambda: hip.check(lib.rmem_attn_pv(C.byref(pa), hip.stream_ptr()), "pv")
+
+    ksl = L._ksplits(T * Np // 64)
+    res["scores_long_pass0"] = timeit(scores(0, T, 0, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe), args.iters)
+    res["scores_long_pass1"] = timeit(scores(0, T, 1, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe), args.iters)
+    res["pv_long"] = timeit(pv(0, T, L.ws_main, L.bankV[1], map_bank, ksl), args.iters)
+    for ks in (1, 2, 4, 8):
+        res[f"pv_long_ks{ks}"] = timeit(pv(0, T, L.ws_main, L.bankV[1], map_bank, ks), args.iters)
+    res["scores_win_pass0"] = timeit(scores(1, 1, 0, L.ws_side, L.bankK[1], map_short, curK, None), args.iters)
+    res["scores_win_pass1"] = timeit(scores(1, 1, 1, L.ws_side, L.bankK[1], map_short, curK, None), args.iters)
+    res["pv_win"] = timeit(pv(1, 1, L.ws_side, L.bankV[1], map_short, L._ksplits(16)), args.iters)
+    res["pv_self"] = timeit(pv(0, 1, L.ws_main, L.selfV, None, L._ksplits(Np // 64)), args.iters)
+    flops = 2.0 * N * T * N * 1024
+    res["pv_long_TFLOPs_algorithmic"] = flops / res["pv_long"] / 1e6
+    res["dwconv"] = timeit(lambda: L._dwconv(L.ws_main, W.dw_lt, L.Ylt), args.iters)
+    ns = L.nsplit
+    res["ln"] = timeit(lambda: L._ln(L.tgt, W.ln1, L.x_pl, 256), args.iters)
+    res["gemm_Q(128x256)"] = timeit(lambda: hip.linear(L.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
+                                                       d0=L.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128, pb=L.Qpe,
+                                                       ldpb=128, addvec=L.cur_pe, nsplit=ns), args.iters)
+    curV = L.bankV[1][T]
+    res["gemm_Vt(512x256,swapped)"] = timeit(lambda: hip.linear(
+        W.Wv, L.x_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True, act=1,
+        pa=hip.Planes(curV.hi[:512], curV.lo[:512]), ldpa=Np, nsplit=ns), args.iters)
+    res["gemm_U(512x256)"] = timeit(lambda: hip.linear(L.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1,
+                                                       d0=L.Ucat.data_ptr(), ldd0=1024, nsplit=ns), args.iters)
+    res["gemm_proj_ls(512x2048)"] = timeit(lambda: hip.linear(
+        L.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=L.Yst, ldx2=1024, kx_split=1024, bias=W.bp_ls,
+        d0=L.tgt.data_ptr(), ldd0=256, d1=L.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns),
+        args.iters)
+    res["gemm_proj_self(512x1024)"] = timeit(lambda: hip.linear(
+        L.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, d0=L.tgt.data_ptr(), ldd0=256,
+        d1=L.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns), args.iters)
+    res["gemm_R(225x128)"] = timeit(lambda: hip.linear(curK, W.Wrel, N, 225, 128, ldx=128, ldy=128, bias=W.brel,
+                                                       d0=L.R.data_ptr(), ldd0=L.ldr, nsplit=ns), args.iters)
+    lab = torch.randint(0, 11, (481, 849), dtype=torch.uint8, device=dev) if (args.h, args.w) == (31, 54) else \
+        torch.randint(0, 11, ((args.h - 1) * 16 + 1, (args.w - 1) * 16 + 1), dtype=torch.uint8, device=dev)
+    res["id_assign"] = timeit(lambda: L.assign_identity(lab), args.iters)
+    emb = torch.randn(N, 256, device=dev)
+    res["lstt_forward_frame"] = timeit(lambda: L.forward(emb), max(5, args.iters // 3))
+    L.cur = T
+    print(json.dumps({k: round(v, 2) for k, v in res.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
