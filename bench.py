@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--gap", type=int, default=5, help="long_term_mem_gap (evaluator rule gives 5 for clips <= 165 frames)")
     ap.add_argument("--nsplit", type=int, default=int(os.environ.get("RMEM_NSPLIT", "3")),
                     help="3 = split-bf16 (fp32-class), 1 = plain bf16 attention/linears")
+    ap.add_argument("--config", choices=["480p_k4", "720p_k8"], default="480p_k4",
+                    help="480p_k4 = BASELINE.json configs[1] (the headline metric); 720p_k8 = configs[2] (stress)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
@@ -70,7 +72,11 @@ def main():
     from rmem_amd.model import build_vos_model
     from rmem_amd.synth import load_synthetic_weights, synth_clip
 
-    cfg = get_config("r50_deaotl", 1, 3)
+    global H_IN, W_IN, H_OUT, W_OUT
+    mem_k = 4
+    if args.config == "720p_k8":      # 720x1280 -> 721x1281 -> 46x81 tokens, K=8, 3 objects
+        H_IN, W_IN, H_OUT, W_OUT, mem_k = 721, 1281, 720, 1280, 8
+    cfg = get_config("r50_deaotl", 1, mem_k - 1)
     cpu_model = build_vos_model("deaot", cfg).eval()
     load_synthetic_weights(cpu_model)
     model = copy.deepcopy(cpu_model).to(dev)
@@ -131,19 +137,26 @@ def main():
 
     fps = world * args.steps / elapsed
     out = {
-        "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref",
+        "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref" if args.config == "480p_k4"
+        else "frames/sec/GPU (720p, K=8 memory, 3 objects) R50-DeAOTL+RMem",
         "value": fps, "unit": "frames/s (whole job)", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)" if args.nsplit == 3 else "bf16 (MFMA, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "R50-DeAOTL + RMem, 480p (481x849, 1674 tokens), K=4 memory, batch=1 clip per GPU, "
-                               f"long_term_mem_gap={args.gap}, steady-state bank (T=4)",
+        "config": {"workload": f"R50-DeAOTL + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
+                               f"batch=1 clip per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
                    "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
                    "parallelism": f"clips sharded 1-per-GPU x{world}, all-gather of masks"},
     }
     if rank == 0:
         out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
+        # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
+        pmc = os.path.join(ROOT, "profiles", "r01_b_pmc_pv_long.json")
+        if out["roofline"] and args.config == "480p_k4" and args.nsplit == 3 and os.path.exists(pmc):
+            out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/r01_b_pmc_pv_long.json)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_model, args)
         print(json.dumps(out))

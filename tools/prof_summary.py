@@ -20,9 +20,31 @@ def from_csv(path):
     return rows
 
 
+def from_trace(path, frames):
+    """Steady-state summary from a rocprofv3 kernel_trace CSV: only the dispatches of the last
+    `frames` frames (delimited by the once-per-frame gn2_apply_kernel) are counted, which
+    excludes MIOpen find-mode / first-call kernels of the warm-up."""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("gn2_apply_kernel")]
+    start = marks[-frames - 1] + 1 if len(marks) > frames else 0
+    end = marks[-1] + 1
+    agg = {}
+    for r in rows[start:end]:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = agg.setdefault(r["Kernel_Name"], [0, 0.0])
+        a[0] += 1
+        a[1] += d
+    tot = sum(v[1] for v in agg.values())
+    return [(k, v[0], v[1], v[1] / v[0], 100 * v[1] / tot) for k, v in agg.items()]
+
+
 def main():
     path, frames = sys.argv[1], int(sys.argv[2])
-    rows = from_csv(path) if path.endswith(".csv") else from_db(path)
+    if path.endswith("kernel_trace.csv"):
+        rows = from_trace(path, frames)
+    else:
+        rows = from_csv(path) if path.endswith(".csv") else from_db(path)
     rows.sort(key=lambda r: -r[2])
     tot = sum(r[2] for r in rows)
     ours = ("linear_kernel", "pv_kernel", "scores_kernel", "combine_kernel", "dwconv5x5", "layernorm_split",
