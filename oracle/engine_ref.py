@@ -101,6 +101,72 @@ class OracleDeAOTEngine:
             self.policy_log.append(log)
 
 
+class OracleAOTEngine(OracleDeAOTEngine):
+    """Same state machine for the AOT model (models/aot.py): sine positional embedding once
+    per clip (aot_engine.py:289-292), ID embedding without LayerNorm, the decoder consumes the
+    encoder embedding plus all three normed LSTT outputs, and the AOT restriction returns
+    early while the bank is within its cap (transformer.py:332-334)."""
+
+    def __init__(self, model, long_term_mem_gap: int = 5):
+        from . import aot_ref as A
+        self.A = A
+        super().__init__(model, long_term_mem_gap)
+        self.lstt = A.AOTOracle(self.sd, self.cfg.MODEL_LSTT_NUM)
+        self.pos = None
+
+    def restart_engine(self):
+        super().restart_engine()
+        self.pos = None
+
+    def _tokens(self, enc):
+        h, w = self.enc_size_2d
+        return enc[-1][0].permute(1, 2, 0).reshape(h * w, -1)
+
+    @torch.no_grad()
+    def add_reference_frame(self, img, mask, obj_nums=None, frame_step=-1):
+        if frame_step == -1:
+            frame_step = self.frame_step
+        enc = self.model.encode_image(img)
+        if self.input_size_2d is None:
+            self.input_size_2d = tuple(img.shape[2:])
+            self.enc_size_2d = tuple(enc[-1].shape[2:])
+            self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
+        h, w = self.enc_size_2d
+        if self.pos is None:
+            self.pos = self.A.sine_pos_emb(h, w)
+        id_emb = self.A.aot_id_assign(mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM)
+        outs = self.lstt.forward(self._tokens(enc), h, w, self.pos, curr_id_emb=id_emb, trace=self.trace)
+        self.last_mem_step = frame_step
+        self.lstt.init_memory()
+        self.long_memories_indexes.append(self.frame_step)
+        self._decode(enc, outs, None)
+
+    @torch.no_grad()
+    def match_propogate_one_frame(self, img, mask=None, output_size=None):
+        self.frame_step += 1
+        enc = self.model.encode_image(img)
+        h, w = self.enc_size_2d
+        outs = self.lstt.forward(self._tokens(enc), h, w, self.pos, trace=self.trace)
+        self.last_lstt_out = outs
+        return self._decode(enc, outs, output_size)
+
+    @torch.no_grad()
+    def update_memory(self, curr_mask):
+        h, w = self.enc_size_2d
+        id_emb = self.A.aot_id_assign(curr_mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM)
+        update_long = False
+        if (not self.cfg.NO_LONG_MEMORY) and \
+                self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            update_long = True
+            self.last_mem_step = self.frame_step
+        self.lstt.update_short_memories(id_emb, update_long)
+        if update_long:
+            self.long_memories_indexes.append(self.frame_step)
+            fg = R.foreground_proba(self.pred_id_logits, h, w)
+            self.lstt.restrict_long_memories(self.cfg.FORMER_MEM_LEN, self.cfg.LATTER_MEM_LEN,
+                                             self.long_memories_indexes, fg)
+
+
 def run_clip(engine, imgs, label0, out_hw=None):
     """The evaluator's per-frame protocol (networks/managers/evaluator.py:384-441,
     518-523): reference frame, then per frame match -> softmax -> argmax -> nearest

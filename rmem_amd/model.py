@@ -141,7 +141,100 @@ class DeAOT(nn.Module):
         return self.decoder([shortcuts[-1], emb], shortcuts)
 
 
+class _MHA(nn.Module):
+    """Holder for MultiheadAttention params (layers/attention.py:8-26)."""
+
+    def __init__(self, d, use_linear):
+        super().__init__()
+        if use_linear:
+            self.linear_Q = nn.Linear(d, d)
+            self.linear_K = nn.Linear(d, d)
+            self.linear_V = nn.Linear(d, d)
+        self.projection = nn.Linear(d, d)
+
+
+class _GNAct(nn.Module):
+    """Holder for GNActDWConv2d params (layers/basic.py:15-25)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.gn = nn.GroupNorm(32, c)
+        self.conv = nn.Conv2d(c, c, 5, padding=2, groups=c, bias=False)
+
+
+class _AOTBlock(nn.Module):
+    """Holder for SimplifiedTransformerBlock params, linear_q=False
+    (layers/transformer.py:466-517)."""
+
+    def __init__(self, d, ff=1024):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(d)
+        self.self_attn = _MHA(d, True)
+        self.norm2 = nn.LayerNorm(d)
+        self.linear_Q = nn.Linear(d, d)
+        self.linear_V = nn.Linear(d, d)
+        self.linear_QMem = nn.Linear(d, d)
+        self.linear_VMem = nn.Linear(d, d)
+        self.norm4 = nn.LayerNorm(d)
+        self.linear_KMem = nn.Linear(d, d)     # present in checkpoints, never used (:494)
+        self.long_term_attn = _MHA(d, False)
+        self.short_term_attn = _MHA(d, False)
+        self.norm3 = nn.LayerNorm(d)
+        self.linear1 = nn.Linear(d, ff)
+        self.activation = _GNAct(ff)
+        self.linear2 = nn.Linear(ff, d)
+
+
+class _LSTT(nn.Module):
+    """Holder for LongShortTermTransformer params (layers/transformer.py:133-197)."""
+
+    def __init__(self, num_layers, d):
+        super().__init__()
+        self.layers = nn.ModuleList(_AOTBlock(d) for _ in range(num_layers))
+        self.decoder_norms = nn.ModuleList(nn.LayerNorm(d) for _ in range(num_layers))
+
+
+class AOT(nn.Module):
+    """AOT + RMem model (models/aot.py:12-103), 8 heads x 32, stage pre_vost
+    (MODEL_LINEAR_Q=False -> norm4 short-term variant, 12-channel ID bank)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        if cfg.MODEL_ENCODER != "resnet50":
+            raise NotImplementedError(cfg.MODEL_ENCODER)
+        if cfg.MODEL_ATT_HEADS != 8 or cfg.MODEL_SELF_HEADS != 8 or cfg.MODEL_LINEAR_Q:
+            raise NotImplementedError("AOT hot path is built for 8 heads, MODEL_LINEAR_Q=False")
+        self.cfg = cfg
+        self.max_obj_num = cfg.MODEL_MAX_OBJ_NUM
+        d = cfg.MODEL_ENCODER_EMBEDDING_DIM
+        self.encoder = ResNet50Encoder()
+        self.encoder_projector = nn.Conv2d(cfg.MODEL_ENCODER_DIM[-1], d, 1)
+        self.LSTT = _LSTT(cfg.MODEL_LSTT_NUM, d)
+        self.decoder = FPNHead(d * (cfg.MODEL_LSTT_NUM + 1), cfg.MODEL_MAX_OBJ_NUM + 1, hidden_dim=d,
+                               shortcut_dims=cfg.MODEL_ENCODER_DIM, align_corners=cfg.MODEL_ALIGN_CORNERS,
+                               decode_intermediate_input=True)
+        id_dim = cfg.MODEL_MAX_OBJ_NUM + (2 if cfg.MODEL_IGNORE_TOKEN else 1)
+        if cfg.MODEL_ALIGN_CORNERS:
+            self.patch_wise_id_bank = nn.Conv2d(id_dim, d, 17, stride=16, padding=8)
+        else:
+            self.patch_wise_id_bank = nn.Conv2d(id_dim, d, 16, stride=16, padding=0)
+        self.use_temporal_pe = True
+        self.cur_pos_emb = nn.Parameter(torch.zeros(1, d))
+        self.mem_pos_emb = nn.Parameter(torch.zeros(4, d))
+
+    optimize_for_inference = DeAOT.optimize_for_inference
+    encode_image = DeAOT.encode_image
+
+    def decode_id_logits(self, lstt_embs, shortcuts):
+        """lstt_embs: list of 3 token-major [N, d] tensors (models/aot.py:136-142)."""
+        n, _, h, w = shortcuts[-1].shape
+        ins = [shortcuts[-1]] + [e.view(h, w, n, -1).permute(2, 3, 0, 1) for e in lstt_embs]
+        return self.decoder(ins, shortcuts)
+
+
 def build_vos_model(name, cfg, **kwargs):
     if name == "deaot":
         return DeAOT(cfg, **kwargs)
+    if name == "aot":
+        return AOT(cfg, **kwargs)
     raise NotImplementedError(name)

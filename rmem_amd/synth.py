@@ -71,6 +71,8 @@ def synth_tensor(name: str, shape, salt: int = 0) -> torch.Tensor:
         t[:128] *= 2.0
     if name.endswith("linear_QK.weight"):
         t *= 2.0
+    if name.endswith(".linear_Q.weight") or name.endswith(".linear_K.weight"):   # AOT blocks (8 x 32 heads)
+        t *= 2.0
     return t
 
 

@@ -38,3 +38,21 @@ def idassign_label(H, W):
     label = torch.nn.functional.interpolate(coarse, size=(H, W), mode="nearest")
     label[:, :, 10:20, 5:25] = 255
     return label
+
+
+AOT_BLOCK_CASES = [  # (layer, T, h, w, ref_frame)
+    (0, 1, 5, 7, False), (1, 2, 6, 7, False), (2, 4, 8, 11, False), (1, 5, 6, 9, False),
+    (0, 1, 8, 11, True), (2, 1, 5, 7, True),
+]
+
+
+def aot_block_case_name(layer, T, h, w, ref_frame):
+    return f"aot_block_l{layer}_T{T}_{h}x{w}{'_ref' if ref_frame else ''}"
+
+
+def aot_block_inputs(layer, T, h, w, ref_frame):
+    rs = np.random.RandomState(3000 + 13 * layer + T * 5 + h + (500 if ref_frame else 0))
+    n = h * w
+    r = lambda *s: torch.from_numpy(rs.standard_normal(s).astype(np.float32))
+    return dict(tgt=r(n, 256), bank_K=r(T, n, 256) * 1.5, bank_V=r(T, n, 256) * 0.7,
+                short_K=r(n, 256) * 1.5, short_V=r(n, 256) * 0.7, id_emb=r(n, 256) * 0.5)

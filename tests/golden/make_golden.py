@@ -29,8 +29,8 @@ sys.path.insert(0, HERE)
 
 import refharness as rh  # noqa: E402
 from rmem_amd.synth import synth_clip  # noqa: E402
-from inputs import (BLOCK_CASES, IDASSIGN_CASES, block_case_name, block_inputs,  # noqa: E402
-                    idassign_label)
+from inputs import (AOT_BLOCK_CASES, BLOCK_CASES, IDASSIGN_CASES, aot_block_case_name,  # noqa: E402
+                    aot_block_inputs, block_case_name, block_inputs, idassign_label)
 
 
 def sha(t: torch.Tensor) -> str:
@@ -95,6 +95,63 @@ def gen_idassign(model):
             emb = eng.assign_identity(oh, ign)      # [N,1,256]
         np.savez_compressed(os.path.join(HERE, f"idassign_{H}x{W}.npz"),
                             id_emb=emb[:, 0].numpy(), eh=eh, ew=ew)
+
+
+def gen_aot_blocks(model):
+    """Direct calls of the reference AOT block (SimplifiedTransformerBlock.forward)."""
+    from oracle.aot_ref import sine_pos_emb
+    temporal = torch.cat((model.cur_pos_emb, model.mem_pos_emb), dim=0)
+    for layer, T, h, w, ref_frame in AOT_BLOCK_CASES:
+        blk = model.LSTT.layers[layer]
+        i = aot_block_inputs(layer, T, h, w, ref_frame)
+        with torch.no_grad():
+            pos_ref = model.get_pos_emb(torch.zeros(1, 256, h, w)).view(1, -1, h * w).permute(2, 0, 1)
+        assert (pos_ref[:, 0] - sine_pos_emb(h, w)).abs().max() < 1e-6
+        kw = dict(self_pos=pos_ref, size_2d=(h, w), temporal_encoding=temporal,
+                  save_atten_weights=not ref_frame)
+        with torch.no_grad(), rh.quiet():
+            if ref_frame:
+                out = blk(i["tgt"][:, None], None, None, curr_id_emb=i["id_emb"][:, None], **kw)
+            else:
+                out = blk(i["tgt"][:, None], [i["bank_K"][:, :, None], i["bank_V"][:, :, None]],
+                          [i["short_K"][:, None], i["short_V"][:, None]], **kw)
+        o_tgt, mems = out
+        curr, glob, loc = mems
+        d = dict(out_tgt=o_tgt[:, 0].numpy(), curr_K=curr[0][:, 0].numpy(), curr_V=curr[1][:, 0].numpy(),
+                 local_K=loc[0][:, 0].numpy(), local_V=loc[1][:, 0].numpy(), pos=pos_ref[:, 0].numpy())
+        if ref_frame:
+            d.update(glob_V=glob[1][0, :, 0].numpy())
+        else:
+            d.update(mass=blk.record_attn_weight.numpy())
+        np.savez_compressed(os.path.join(HERE, aot_block_case_name(layer, T, h, w, ref_frame) + ".npz"), **d)
+
+
+def gen_aot_clips():
+    """BASELINE.json configs[0]: R50-AOTL + RMem, one synthetic 480p clip x 16 frames, K=4
+    (gap 5 = evaluator rule, no eviction in 16 frames) plus small clips that do evict."""
+    small = [("aot_k4_gap2", 97, 129, 16, 2, 1, 3), ("aot_k2_gap1", 81, 97, 10, 1, 1, 1)]
+    for name, H, W, frames, gap, former, latter in small:
+        cfg, model, engine = rh.build_reference("r50_aotl", former, latter, gap)
+        imgs, lab = synth_clip(11, frames, H, W, 3)
+        rec = run_reference_clip(engine, imgs, lab, (H, W), capture_logits=(frames - 1,))
+        meta = dict(H=H, W=W, frames=frames, gap=gap, former=former, latter=latter, seed=11,
+                    indexes=rec["indexes"], ema=rec["ema"], visits=rec["visits"], hist=rec["hist"],
+                    label_sha=[sha(l) for l in rec["labels"]])
+        json.dump(meta, open(os.path.join(HERE, f"clip_{name}.json"), "w"))
+        np.savez_compressed(os.path.join(HERE, f"clip_{name}.npz"), labels=torch.stack(rec["labels"]).numpy(),
+                            last_logits=rec["logits"][frames - 1].numpy())
+        print("clip", name, "indexes", rec["indexes"][-1])
+    cfg, model, engine = rh.build_reference("r50_aotl", 1, 3, 5)
+    H, W, frames = 481, 849, 16
+    imgs, lab = synth_clip(0, frames, H, W, 3)
+    rec = run_reference_clip(engine, imgs, lab, (480, 854), capture_logits=(1, 15))
+    meta = dict(H=H, W=W, out_hw=[480, 854], frames=frames, gap=5, former=1, latter=3, seed=0,
+                indexes=rec["indexes"], hist=rec["hist"], label_sha=[sha(l) for l in rec["labels"]])
+    json.dump(meta, open(os.path.join(HERE, "clip_aot_480p.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, "clip_aot_480p.npz"),
+                        **{f"logits_{t}": v.numpy().astype(np.float16) for t, v in rec["logits"].items()},
+                        labels=torch.stack(rec["labels"]).numpy())
+    print("clip aot 480p indexes", rec["indexes"][-1])
 
 
 def run_reference_clip(engine, imgs, label0, out_hw, capture_logits=()):
@@ -164,11 +221,17 @@ def gen_clips():
 
 def main():
     torch.manual_seed(0)
-    cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
-    gen_manifest(model)
-    gen_blocks(model)
-    gen_idassign(model)
-    gen_clips()
+    if "--aot-only" not in sys.argv:
+        cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
+        gen_manifest(model)
+        gen_blocks(model)
+        gen_idassign(model)
+        gen_clips()
+    cfg, model, engine = rh.build_reference("r50_aotl", 1, 3, 5)
+    man = {k: list(v.shape) for k, v in model.state_dict().items()}
+    json.dump(man, open(os.path.join(HERE, "manifest_r50_aotl.json"), "w"), indent=0, sort_keys=True)
+    gen_aot_blocks(model)
+    gen_aot_clips()
     os.system(f"du -sh {HERE}")
 
 
