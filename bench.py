@@ -47,6 +47,8 @@ def parse():
                     help="3 = split-bf16 (fp32-class), 1 = plain bf16 attention/linears")
     ap.add_argument("--config", choices=["480p_k4", "720p_k8"], default="480p_k4",
                     help="480p_k4 = BASELINE.json configs[1] (the headline metric); 720p_k8 = configs[2] (stress)")
+    ap.add_argument("--model", choices=["r50_deaotl", "r50_aotl"], default="r50_deaotl",
+                    help="r50_deaotl = headline metric; r50_aotl = AOT block (BASELINE.json configs[0] on GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
@@ -76,11 +78,11 @@ def main():
     mem_k = 4
     if args.config == "720p_k8":      # 720x1280 -> 721x1281 -> 46x81 tokens, K=8, 3 objects
         H_IN, W_IN, H_OUT, W_OUT, mem_k = 721, 1281, 720, 1280, 8
-    cfg = get_config("r50_deaotl", 1, mem_k - 1)
-    cpu_model = build_vos_model("deaot", cfg).eval()
+    cfg = get_config(args.model, 1, mem_k - 1)
+    cpu_model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
     load_synthetic_weights(cpu_model)
     model = copy.deepcopy(cpu_model).to(dev)
-    engine = build_engine("deaotengine", phase="eval", aot_model=model, gpu_id=local_rank,
+    engine = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=model, gpu_id=local_rank,
                           long_term_mem_gap=args.gap, nsplit=args.nsplit)
     engine.eval()
 
@@ -137,14 +139,16 @@ def main():
 
     fps = world * args.steps / elapsed
     out = {
-        "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref" if args.config == "480p_k4"
+        "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref"
+        if (args.config == "480p_k4" and args.model == "r50_deaotl") else f"frames/sec/GPU ({args.config}) {args.model}+RMem"
+        if args.model != "r50_deaotl"
         else "frames/sec/GPU (720p, K=8 memory, 3 objects) R50-DeAOTL+RMem",
         "value": fps, "unit": "frames/s (whole job)", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)" if args.nsplit == 3 else "bf16 (MFMA, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"R50-DeAOTL + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
+        "config": {"workload": f"{'R50-DeAOTL' if args.model == 'r50_deaotl' else 'R50-AOTL'} + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
                                f"batch=1 clip per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
                    "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
                    "parallelism": f"clips sharded 1-per-GPU x{world}, all-gather of masks"},
@@ -154,10 +158,11 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
         # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
         pmc = os.path.join(ROOT, "profiles", "r01_b_pmc_pv_long.json")
-        if out["roofline"] and args.config == "480p_k4" and args.nsplit == 3 and os.path.exists(pmc):
+        if out["roofline"] and args.config == "480p_k4" and args.nsplit == 3 and args.model == "r50_deaotl" \
+                and os.path.exists(pmc):
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/r01_b_pmc_pv_long.json)"
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "r50_deaotl":
             out["cpu_baseline"] = cpu_baseline(cpu_model, args)
         print(json.dumps(out))
     if dist is not None:

@@ -139,12 +139,72 @@ int rmem_pe_bias(const float *Q, int64_t ldq, const float *cur_pe, const float *
                  const int32_t *pe_row_host, int32_t T, int32_t N, int32_t d, float *bias,
                  void *stream);
 
+/* ------------------------------------------------------------------ AOT multi-head attention
+ * MultiheadAttention.forward of the AOT block (layers/attention.py:28-81; 8 heads x 32,
+ * call sites layers/transformer.py:561, 632-635, 656-662) as a fused flash-style kernel with
+ * key splits, followed by rmem_mha_combine (merge splits, normalise, head-averaged per-slot
+ * attention mass = record_attn_weight, transformer.py:636-644).
+ * Layouts: Q planes [Npad][ldq] (head h = columns 32h..32h+31), K planes [slot][Npad][ldk],
+ * V^T planes [slot][heads*32][ldv] (ldv >= Npad, keys contiguous).  bias: [N][heads][T]
+ * temporal-PE bias or NULL.  opart: [ksplits][Npad][heads*32] fp32, ml: [ksplits][Npad][heads][2],
+ * slot_ml: [ksplits][Npad][heads][T][2] zero-filled by the caller (or NULL when no mass is needed).
+ */
+typedef struct {
+  const rmem_bf16 *qh, *ql; int64_t ldq;
+  const rmem_bf16 *kh, *kl; int64_t k_slot_stride, ldk;
+  const rmem_bf16 *vh, *vl; int64_t v_slot_stride, ldv;
+  const int32_t *slot_map; int32_t T, N, Npad, heads;
+  float scale;                              /* 1/sqrt(32)                               */
+  const float *bias;
+  int32_t ksplits;
+  float *opart; float *ml; float *slot_ml;
+  int32_t nsplit;
+} rmem_mha_args;
+
+int rmem_mha_flash(const rmem_mha_args *a, void *stream);
+
+typedef struct {
+  int32_t N, Npad, heads, T, ksplits;
+  const float *opart; const float *ml; const float *slot_ml;
+  rmem_bf16 *oh, *ol; float *of32; int64_t ldo;   /* out [N][heads*32]: planes (+ optional fp32) */
+  float *mass;                                     /* [N][T] or NULL                            */
+} rmem_mha_combine_args;
+
+int rmem_mha_combine(const rmem_mha_combine_args *a, void *stream);
+
 /* ------------------------------------------------------------------ pointwise / norms */
 /* LayerNorm over C=256 channels -> planes (+ optional fp32); nn.LayerNorm of
  * layers/transformer.py:1104,1120,1223-1224 and models/deaot.py:41. */
 int rmem_layernorm_split(const float *x, int64_t ldx, const float *gamma, const float *beta,
                          int32_t N, int32_t C, float eps, rmem_bf16 *oh, rmem_bf16 *ol,
                          int64_t ldo, float *of32, int64_t ldof, void *stream);
+
+/* LayerNorm with fused adds: y = LN(x + x2) * gamma + beta + post  (x2 / post may be NULL).
+ * AOT: q = k = norm1(tgt) + pos (transformer.py:558-560), norm4(local_K + curr_K) (:656-662),
+ * norm2(tgt) + id_emb as the input of linear_V (:586, :277-280). */
+int rmem_layernorm_ex(const float *x, int64_t ldx, const float *x2, int64_t ldx2, const float *gamma,
+                      const float *beta, int32_t N, int32_t C, float eps, const float *post,
+                      int64_t ldpost, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32,
+                      int64_t ldof, void *stream);
+
+/* planes [N][C] (ld) -> transposed planes [C][ldo]  (AOT: V operand of the short-term attention) */
+int rmem_transpose_planes(const rmem_bf16 *ih, const rmem_bf16 *il, int64_t ld, int32_t N, int32_t C,
+                          rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, void *stream);
+
+/* dst (fp32, optional, may alias a) = a + b ; planes of the sum (optional).  n elements. */
+int rmem_add_split(const float *a, const float *b, int64_t n, float *dst, rmem_bf16 *oh,
+                   rmem_bf16 *ol, void *stream);
+
+/* GNActDWConv2d front half (layers/basic.py:27-32): GroupNorm(groups) over token-major
+ * [N][C] (statistics over C/groups channels x N tokens) followed by exact GELU -> fp32.
+ * ws: >= 2*16*groups doubles. */
+int rmem_gn_gelu_tokens(const float *x, int32_t N, int32_t C, int32_t groups, const float *gamma,
+                        const float *beta, float eps, double *ws, float *y, void *stream);
+
+/* temporal-PE bias per head: bias[q][h][t] = sum_{c in head h} (Q[q][c]+cur_pe[c]) * mem_pe[pe_row[t]][c] */
+int rmem_pe_bias_heads(const float *Q, int64_t ldq, const float *cur_pe, const float *mem_pe,
+                       const int32_t *pe_row_host, int32_t T, int32_t N, int32_t heads, float *bias,
+                       void *stream);
 
 /* Depth-wise 5x5, pad 2, no bias, on token-major [h*w][C] (layers/basic.py:38-57);
  * wt is [25][C] (tap-major).  Output planes. */

@@ -1,0 +1,233 @@
+// mha.hip -- 8-head x 32 MultiheadAttention of the AOT block (layers/attention.py:28-81) as a
+// fused flash-style kernel: no probability matrix is materialised (with d_head = 32 it would
+// be 8x the DeAOT one), the O^T accumulator of a wave is a single 32x32 MFMA tile.
+//
+// One wave = 32 queries of one head; key tiles of 32.  Both contractions run "swapped":
+//   S^T[key][query] = K_tile . Q^T          (A = K rows, B = Q rows, k = head dim 32)
+//   O^T[chan][query] += V^T_tile . P^T      (A = V^T rows = channels, B = P^T, k = 32 keys)
+// so the softmax statistics of a query live in one lane (+ its lane^32 partner) and the
+// accumulator registers of S^T are already the B operand of the second MFMA: accumulator
+// register r of lane (query j, half hi) is key (r&3) + 8(r>>2) + 4hi; k-step s, element e of
+// the B operand is register 8s+e, i.e. keys {16s+4hi+0..3, 16s+8+4hi+0..3} -- the A operand
+// (V^T) is loaded with exactly that key permutation (two 8-byte loads per k-step), so no
+// cross-lane shuffle is needed.  No LDS, no barriers: latency is hidden by occupancy.
+// Key splits (flash-decoding style) write unnormalised partials + (max, sum); rmem_mha_combine
+// merges them, normalises, averages the per-slot attention mass over heads.
+#include "../../include/rmem_hip.h"
+#include "rmem_common.h"
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+template <int NS>
+__global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
+  constexpr int NPL = NS == 1 ? 1 : 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, j = lane & 31;
+  const int h = blockIdx.y, z = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + j;   // this lane's query (column of S^T / O^T)
+  const int tps = a.Npad / 32;                       // 32-key tiles per slot
+  const int ntiles = a.T * tps;
+  const int per = (ntiles + a.ksplits - 1) / a.ksplits;
+  int lo = z * per, hi_t = lo + per;
+  if (hi_t > ntiles) hi_t = ntiles;
+
+  const bf16_t* qp[2] = {a.qh, a.ql};
+  const bf16_t* kp[2] = {a.kh, a.kl};
+  const bf16_t* vp[2] = {a.vh, a.vl};
+  bf16x8_t qf[NPL][2];
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[p][ks] = *reinterpret_cast<const bf16x8_t*>(qp[p] + (long)q * a.ldq + h * 32 + ks * 16 + hi * 8);
+
+  f32x16_t o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -3.0e38f, l = 0.f, lslot = 0.f, bias_t = 0.f;
+  int cur_t = -1;
+  const bool qvalid = q < a.N;
+  float* sml = a.slot_ml ? a.slot_ml + (((long)z * a.Npad + q) * a.heads + h) * a.T * 2 : nullptr;
+
+  for (int tile = lo; tile < hi_t; ++tile) {
+    const int t = tile / tps;
+    const int tok0 = (tile - t * tps) * 32;
+    const int phys = a.slot_map ? a.slot_map[t] : t;
+    if (t != cur_t) {
+      if (sml && cur_t >= 0 && hi == 0) {
+        sml[cur_t * 2] = lslot;
+        sml[cur_t * 2 + 1] = m;
+      }
+      lslot = 0.f;
+      cur_t = t;
+      bias_t = (a.bias && qvalid) ? a.bias[((long)q * a.heads + h) * a.T + t] : 0.f;
+    }
+    // ---- S^T = K . Q^T over the head dim (2 k-steps of 16)
+    f32x16_t s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    bf16x8_t kf[NPL][2];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        kf[p][ks] = *reinterpret_cast<const bf16x8_t*>(kp[p] + (long)phys * a.k_slot_stride +
+                                                       (long)(tok0 + j) * a.ldk + h * 32 + ks * 16 + hi * 8);
+    // ---- V^T fragments (issued early; consumed after the softmax)
+    bf16x8_t vf[NPL][2];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16_t* base = vp[p] + (long)phys * a.v_slot_stride + (long)(h * 32 + j) * a.ldv + tok0 + ks * 16 + hi * 4;
+        const u32x2_t g0 = *reinterpret_cast<const u32x2_t*>(base);
+        const u32x2_t g1 = *reinterpret_cast<const u32x2_t*>(base + 8);
+        u32x4_t w;
+        w[0] = g0[0]; w[1] = g0[1]; w[2] = g1[0]; w[3] = g1[1];
+        vf[p][ks] = __builtin_bit_cast(bf16x8_t, w);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (NS == 3) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[1][ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks], qf[0][ks], s, 0, 0, 0);
+      }
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[0][ks], s, 0, 0, 0);
+    }
+    // ---- online softmax for this lane's query
+    float sv[16];
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      sv[r] = tok < a.N ? a.scale * (s[r] + bias_t) : -3.0e38f;
+      tmax = fmaxf(tmax, sv[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = expf(m - m_new);
+    float psum = 0.f;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = sv[r] > -2.9e38f ? expf(sv[r] - m_new) : 0.f;
+      psum += pv[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    lslot = lslot * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    // ---- P^T as the B operand: k-step s, element e = register 8s+e
+    bf16x8_t pf[NPL][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t wh, wl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf16_t h0, l0, h1, l1;
+        split_bf16(pv[8 * ks + 2 * e], h0, l0);
+        split_bf16(pv[8 * ks + 2 * e + 1], h1, l1);
+        wh[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        wl[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      }
+      pf[0][ks] = __builtin_bit_cast(bf16x8_t, wh);
+      if constexpr (NPL == 2) pf[1][ks] = __builtin_bit_cast(bf16x8_t, wl);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (NS == 3) {
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[1][ks], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][ks], pf[0][ks], o, 0, 0, 0);
+      }
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[0][ks], o, 0, 0, 0);
+    }
+  }
+  if (sml && cur_t >= 0 && hi == 0) {
+    sml[cur_t * 2] = lslot;
+    sml[cur_t * 2 + 1] = m;
+  }
+  // ---- partial outputs: O^T rows (channels) of this lane are 4 runs of 4 consecutive channels
+  float* op = a.opart + ((long)z * a.Npad + q) * (a.heads * 32) + h * 32 + 4 * hi;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(op + 8 * g) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+  if (hi == 0) {
+    float* mlp = a.ml + (((long)z * a.Npad + q) * a.heads + h) * 2;
+    mlp[0] = m;
+    mlp[1] = l;
+  }
+}
+
+extern "C" int rmem_mha_flash(const rmem_mha_args* ap, void* stream) {
+  if (!ap) return RMEM_ERR_INVALID;
+  const rmem_mha_args& a = *ap;
+  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) || a.T <= 0 || a.heads <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
+  if (!a.qh || !a.kh || !a.vh || !a.opart || !a.ml) return RMEM_ERR_INVALID;
+  if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 4)) return RMEM_ERR_INVALID;
+  dim3 grid(a.Npad / 128, a.heads, a.ksplits);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.nsplit == 3) {
+    if (!a.ql || !a.kl || !a.vl) return RMEM_ERR_INVALID;
+    hipLaunchKernelGGL(mha_flash_kernel<3>, grid, dim3(256), 0, s, a);
+  } else if (a.nsplit == 1) {
+    hipLaunchKernelGGL(mha_flash_kernel<1>, grid, dim3(256), 0, s, a);
+  } else {
+    return RMEM_ERR_INVALID;
+  }
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ merge key splits
+__global__ __launch_bounds__(256) void mha_combine_kernel(rmem_mha_combine_args a) {
+  __shared__ float mh[8], Lh[8];
+  const int q = blockIdx.x;
+  const int c = threadIdx.x;           // channel (heads * 32 = 256)
+  const int h = c >> 5;
+  float m = -3.0e38f;
+  for (int s = 0; s < a.ksplits; ++s) m = fmaxf(m, a.ml[(((long)s * a.Npad + q) * a.heads + h) * 2]);
+  float L = 0.f, O = 0.f;
+  for (int s = 0; s < a.ksplits; ++s) {
+    const float* mlp = a.ml + (((long)s * a.Npad + q) * a.heads + h) * 2;
+    const float f = expf(mlp[0] - m);
+    L += f * mlp[1];
+    O += f * a.opart[((long)s * a.Npad + q) * (a.heads * 32) + c];
+  }
+  const float y = O / L;
+  if (a.of32) a.of32[(long)q * a.ldo + c] = y;
+  bf16_t hi, lo;
+  split_bf16(y, hi, lo);
+  a.oh[(long)q * a.ldo + c] = hi;
+  if (a.ol) a.ol[(long)q * a.ldo + c] = lo;
+  if (a.mass) {
+    if ((c & 31) == 0) {
+      mh[h] = m;
+      Lh[h] = L;
+    }
+    __syncthreads();
+    if (c < a.T) {
+      float acc = 0.f;
+      for (int hh = 0; hh < a.heads; ++hh) {
+        float sl = 0.f;
+        for (int s = 0; s < a.ksplits; ++s) {
+          const float* e = a.slot_ml + ((((long)s * a.Npad + q) * a.heads + hh) * a.T + c) * 2;
+          if (e[0] != 0.f) sl += e[0] * expf(e[1] - mh[hh]);
+        }
+        acc += sl / Lh[hh];
+      }
+      a.mass[(long)q * a.T + c] = acc / (float)a.heads;
+    }
+  }
+}
+
+extern "C" int rmem_mha_combine(const rmem_mha_combine_args* ap, void* stream) {
+  if (!ap) return RMEM_ERR_INVALID;
+  const rmem_mha_combine_args& a = *ap;
+  if (a.N <= 0 || a.heads != 8 || a.ksplits <= 0 || !a.opart || !a.ml || !a.oh || a.T > 64) return RMEM_ERR_INVALID;
+  if (a.mass && !a.slot_ml) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(mha_combine_kernel, dim3(a.N), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}

@@ -5,15 +5,21 @@
 #include "rmem_common.h"
 
 // ------------------------------------------------------------------ LayerNorm -> planes
-// one wave per row, C = 256: 4 consecutive channels per lane (16-byte loads)
-__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, long ldx, const float* gamma,
-                                                              const float* beta, int N, float eps,
+// one wave per row, C = 256: 4 consecutive channels per lane (16-byte loads).
+// y = LN(x + x2) * gamma + beta + post  (x2, post optional)
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, long ldx, const float* x2, long ldx2,
+                                                              const float* gamma, const float* beta, int N,
+                                                              float eps, const float* post, long ldpost,
                                                               bf16_t* oh, bf16_t* ol, long ldo, float* of32,
                                                               long ldof) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
-  const float4 v = *reinterpret_cast<const float4*>(x + (long)row * ldx + lane * 4);
+  float4 v = *reinterpret_cast<const float4*>(x + (long)row * ldx + lane * 4);
+  if (x2) {
+    const float4 w = *reinterpret_cast<const float4*>(x2 + (long)row * ldx2 + lane * 4);
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
   float s = v.x + v.y + v.z + v.w;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -26,6 +32,10 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, lo
   const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
   const float4 b = *reinterpret_cast<const float4*>(beta + lane * 4);
   float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
+  if (post) {
+    const float4 w = *reinterpret_cast<const float4*>(post + (long)row * ldpost + lane * 4);
+    y[0] += w.x; y[1] += w.y; y[2] += w.z; y[3] += w.w;
+  }
   if (of32) *reinterpret_cast<float4*>(of32 + (long)row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
   if (oh) {
     bf16_t hi[4], lo[4];
@@ -41,14 +51,24 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, lo
   }
 }
 
+extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, int64_t ldx2, const float* gamma,
+                                 const float* beta, int32_t N, int32_t C, float eps, const float* post,
+                                 int64_t ldpost, rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, float* of32,
+                                 int64_t ldof, void* stream) {
+  if (!x || !gamma || !beta || N <= 0 || C != 256 || (ldx % 4) || (ldo % 4) || (ldof % 4) || (ldx2 % 4) ||
+      (ldpost % 4))
+    return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(layernorm_split_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     (long)ldx, x2, (long)ldx2, gamma, beta, N, eps, post, (long)ldpost, oh, ol, (long)ldo, of32,
+                     (long)ldof);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                     int32_t N, int32_t C, float eps, rmem_bf16* oh, rmem_bf16* ol,
                                     int64_t ldo, float* of32, int64_t ldof, void* stream) {
-  if (!x || !gamma || !beta || N <= 0 || C != 256 || (ldx % 4) || (ldo % 4) || (ldof % 4)) return RMEM_ERR_INVALID;
-  hipLaunchKernelGGL(layernorm_split_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     (long)ldx, gamma, beta, N, eps, oh, ol, (long)ldo, of32, (long)ldof);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  return rmem_layernorm_ex(x, ldx, nullptr, 0, gamma, beta, N, C, eps, nullptr, 0, oh, ol, ldo, of32, ldof, stream);
 }
 
 // ------------------------------------------------------------------ depth-wise 5x5 -> planes
@@ -451,4 +471,176 @@ extern "C" int rmem_groupnorm_nchw(const float* x, float* y, int32_t C, int64_t 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 1; }
+// ------------------------------------------------------------------ planes transpose
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const bf16_t* ih, const bf16_t* il, long ld, int N,
+                                                               int C, bf16_t* oh, bf16_t* ol, long ldo) {
+  __shared__ bf16_t th[64][66];
+  __shared__ bf16_t tl[64][66];
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const bool ok = n0 + r < N && c0 + c < C;
+    th[r][c] = ok ? ih[(long)(n0 + r) * ld + c0 + c] : (bf16_t)0;
+    if (il) tl[r][c] = ok ? il[(long)(n0 + r) * ld + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < C && n0 + r < N) {
+      oh[(long)(c0 + c) * ldo + n0 + r] = th[r][c];
+      if (ol) ol[(long)(c0 + c) * ldo + n0 + r] = tl[r][c];
+    }
+  }
+}
+
+extern "C" int rmem_transpose_planes(const rmem_bf16* ih, const rmem_bf16* il, int64_t ld, int32_t N, int32_t C,
+                                     rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, void* stream) {
+  if (!ih || !oh || N <= 0 || C <= 0) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(transpose_planes_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), ih, il, (long)ld, N, C, oh, ol, (long)ldo);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ a + b -> fp32 / planes
+__global__ void add_split_kernel(const float* a, const float* b, long n, float* dst, bf16_t* oh, bf16_t* ol) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = a[i] + (b ? b[i] : 0.f);
+    if (dst) dst[i] = v;
+    if (oh) {
+      bf16_t h, l;
+      split_bf16(v, h, l);
+      oh[i] = h;
+      if (ol) ol[i] = l;
+    }
+  }
+}
+
+extern "C" int rmem_add_split(const float* a, const float* b, int64_t n, float* dst, rmem_bf16* oh, rmem_bf16* ol,
+                              void* stream) {
+  if (!a || n <= 0 || (!dst && !oh)) return RMEM_ERR_INVALID;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(add_split_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, b,
+                     (long)n, dst, oh, ol);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ GroupNorm over tokens + GELU
+// x token-major [N][C]; group g = channels [g*cpg, (g+1)*cpg) of every token.
+__global__ __launch_bounds__(256) void gn_tok_stats_kernel(const float* x, int N, int C, int cpg, int ns,
+                                                           double* ws) {
+  __shared__ double red[2][4];
+  const int g = blockIdx.y, sidx = blockIdx.x;
+  const int per = (N + ns - 1) / ns;
+  const int t0 = sidx * per;
+  int t1 = t0 + per;
+  if (t1 > N) t1 = N;
+  double s = 0, q = 0;
+  const int tot = (t1 - t0) * cpg;
+  for (int i = threadIdx.x; i < tot; i += 256) {
+    const int tok = t0 + i / cpg, c = g * cpg + i % cpg;
+    const float v = x[(long)tok * C + c];
+    s += v;
+    q += (double)v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    ws[((long)g * ns + sidx) * 2 + threadIdx.x] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(256) void gn_tok_gelu_kernel(const float* x, int N, int C, int cpg, int ns,
+                                                          const double* ws, const float* gamma, const float* beta,
+                                                          float eps, float* y) {
+  extern __shared__ float stat[];   // [groups][2]
+  const int groups = C / cpg;
+  for (int g = threadIdx.x; g < groups; g += 256) {
+    double s = 0, q = 0;
+    for (int i = 0; i < ns; ++i) {
+      s += ws[((long)g * ns + i) * 2];
+      q += ws[((long)g * ns + i) * 2 + 1];
+    }
+    const double cnt = (double)N * cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0) var = 0;
+    stat[g * 2] = (float)mean;
+    stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const long n4 = (long)N * C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int c = (int)((i * 4) % C);
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+    const int g = c / cpg;              // cpg % 4 == 0: the 4 channels share a group
+    const float m = stat[g * 2], r = stat[g * 2 + 1];
+    float o[4] = {(v.x - m) * r * gm.x + bt.x, (v.y - m) * r * gm.y + bt.y, (v.z - m) * r * gm.z + bt.z,
+                  (v.w - m) * r * gm.w + bt.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = 0.5f * o[e] * (1.0f + erff(o[e] * 0.70710678118654752440f));
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int rmem_gn_gelu_tokens(const float* x, int32_t N, int32_t C, int32_t groups, const float* gamma,
+                                   const float* beta, float eps, double* ws, float* y, void* stream) {
+  if (!x || !y || !ws || !gamma || !beta || N <= 0 || groups <= 0 || (C % groups) || ((C / groups) % 4))
+    return RMEM_ERR_INVALID;
+  const int cpg = C / groups, ns = 16;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_tok_stats_kernel, dim3(ns, groups), dim3(256), 0, s, x, N, C, cpg, ns, ws);
+  long blocks = ((long)N * C / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gn_tok_gelu_kernel, dim3((unsigned)blocks), dim3(256), groups * 2 * sizeof(float), s, x, N, C,
+                     cpg, ns, ws, gamma, beta, eps, y);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ temporal-PE bias per head
+struct PeRowsH { int row[16]; };
+__global__ void pe_bias_heads_kernel(const float* Q, long ldq, const float* cur_pe, const float* mem_pe,
+                                     PeRowsH rows, int T, int N, int heads, float* bias) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= N) return;
+  const int d = heads * 32;
+  for (int t = 0; t < T; ++t) {
+    for (int c0 = 0; c0 < d; c0 += 64) {      // lanes 0-31 -> head c0/32, lanes 32-63 -> head c0/32 + 1
+      const int c = c0 + lane;
+      float s = (Q[(long)q * ldq + c] + cur_pe[c]) * mem_pe[(long)rows.row[t] * d + c];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if ((lane & 31) == 0) bias[((long)q * heads + (c >> 5)) * T + t] = s;
+    }
+  }
+}
+
+extern "C" int rmem_pe_bias_heads(const float* Q, int64_t ldq, const float* cur_pe, const float* mem_pe,
+                                  const int32_t* pe_row_host, int32_t T, int32_t N, int32_t heads, float* bias,
+                                  void* stream) {
+  if (!Q || !cur_pe || !mem_pe || !pe_row_host || !bias || T <= 0 || T > 16 || N <= 0 || heads <= 0 || (heads % 2))
+    return RMEM_ERR_INVALID;
+  PeRowsH rows;
+  for (int t = 0; t < 16; ++t) rows.row[t] = t < T ? pe_row_host[t] : 0;
+  hipLaunchKernelGGL(pe_bias_heads_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), Q,
+                     (long)ldq, cur_pe, mem_pe, rows, T, N, heads, bias);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_abi_version(void) { return 2; }

@@ -20,10 +20,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .lstt import DeAOTLSTT
+from .lstt_aot import AOTLSTT
 
 
 class DeAOTEngine(nn.Module):
-    """One engine = up to MODEL_MAX_OBJ_NUM objects (engines/aot_engine.py:18-568)."""
+    """One engine = up to MODEL_MAX_OBJ_NUM objects (engines/aot_engine.py:18-568); serves both
+    the DeAOT (rmem_amd.lstt.DeAOTLSTT) and the AOT (rmem_amd.lstt_aot.AOTLSTT) models."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1,
                  nsplit: int = 3):
@@ -58,7 +60,8 @@ class DeAOTEngine(nn.Module):
         self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
         if self.lstt is None or (self.lstt.h, self.lstt.w) != self.enc_size_2d:
             dev = next(self.AOT.parameters()).device
-            self.lstt = DeAOTLSTT(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
+            cls = DeAOTLSTT if self.cfg.MODEL_VOS == "deaot" else AOTLSTT
+            self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
 
     def _label_u8(self, mask: torch.Tensor) -> torch.Tensor:
         """[1,1,H,W] (or [1,H,W]) label ids -> contiguous uint8 [H,W] on device."""
@@ -225,6 +228,6 @@ def build_engine(name, phase="eval", **kwargs):
     """engines/__init__.py:5-21 (inference phases only; training is out of scope)."""
     if phase != "eval":
         raise NotImplementedError("only phase='eval' is built (training is out of the hot-path scope)")
-    if name == "deaotengine":
+    if name in ("deaotengine", "aotengine"):     # one engine class; the LSTT follows cfg.MODEL_VOS
         return DeAOTInferEngine(**kwargs)
     raise NotImplementedError(name)

@@ -71,10 +71,31 @@ class CombineArgs(C.Structure):
     ]
 
 
+class MHAArgs(C.Structure):
+    _fields_ = [
+        ("qh", c_p), ("ql", c_p), ("ldq", i64),
+        ("kh", c_p), ("kl", c_p), ("k_slot_stride", i64), ("ldk", i64),
+        ("vh", c_p), ("vl", c_p), ("v_slot_stride", i64), ("ldv", i64),
+        ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32), ("heads", i32),
+        ("scale", f32), ("bias", c_p), ("ksplits", i32),
+        ("opart", c_p), ("ml", c_p), ("slot_ml", c_p), ("nsplit", i32),
+    ]
+
+
+class MHACombineArgs(C.Structure):
+    _fields_ = [
+        ("N", i32), ("Npad", i32), ("heads", i32), ("T", i32), ("ksplits", i32),
+        ("opart", c_p), ("ml", c_p), ("slot_ml", c_p),
+        ("oh", c_p), ("ol", c_p), ("of32", c_p), ("ldo", i64), ("mass", c_p),
+    ]
+
+
 EXPORTS = [
     "rmem_abi_version", "rmem_linear", "rmem_attn_scores", "rmem_attn_pv", "rmem_attn_combine",
     "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
+    "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
+    "rmem_gn_gelu_tokens", "rmem_pe_bias_heads",
 ]
 
 
@@ -106,6 +127,14 @@ def load():
     lib.rmem_attn_mass_reduce.argtypes = [c_p, i32, i32, c_p, c_p, c_p]
     lib.rmem_split_planes.argtypes = [c_p, i64, c_p, c_p, c_p]
     lib.rmem_groupnorm_nchw.argtypes = [c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]
+    lib.rmem_mha_flash.argtypes = [C.POINTER(MHAArgs), c_p]
+    lib.rmem_mha_combine.argtypes = [C.POINTER(MHACombineArgs), c_p]
+    lib.rmem_layernorm_ex.argtypes = [c_p, i64, c_p, i64, c_p, c_p, i32, i32, f32, c_p, i64, c_p, c_p, i64,
+                                      c_p, i64, c_p]
+    lib.rmem_transpose_planes.argtypes = [c_p, c_p, i64, i32, i32, c_p, c_p, i64, c_p]
+    lib.rmem_add_split.argtypes = [c_p, c_p, i64, c_p, c_p, c_p, c_p]
+    lib.rmem_gn_gelu_tokens.argtypes = [c_p, i32, i32, i32, c_p, c_p, f32, c_p, c_p, c_p]
+    lib.rmem_pe_bias_heads.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]
     _LIB = lib
     return lib
 

@@ -1,0 +1,243 @@
+"""GPU: AOT path -- flash MHA kernel, support kernels and
+the AOT engine against the oracle / the reference's golden vectors, through the C ABI."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rmem_amd import hip as H
+    H.load()
+    return H
+
+
+def _rand(rs, *shape, scale=1.0):
+    return torch.from_numpy(rs.standard_normal(shape).astype(np.float32) * np.float32(scale))
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("T,N,ks", [(1, 77, 2), (3, 150, 4), (5, 300, 3)])
+def test_mha_flash(hip, nsplit, T, N, ks):
+    """8 heads x 32, slot-mapped bank, per-(query, head, slot) bias, pad keys, head-mean mass."""
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(N + T)
+    Np = (N + 127) // 128 * 128
+    S = T + 2
+    smap = list(rs.permutation(S)[:T])
+    Q = torch.zeros(Np, 256); Q[:N] = _rand(rs, N, 256, scale=1.2)
+    K = torch.full((S, Np, 256), 31.0); K[:, :N] = _rand(rs, S, N, 256, scale=1.2)
+    Vt = torch.full((S, 256, Np), -17.0); Vt[:, :, :N] = _rand(rs, S, 256, N)
+    bias = _rand(rs, N, 8, T, scale=2.0)
+    P = hip.Planes.from_f32
+    q, k, v = P(Q.to(DEV)), P(K.to(DEV)), P(Vt.to(DEV))
+    dbias = bias.to(DEV).contiguous()
+    dmap = torch.tensor(smap, dtype=torch.int32, device=DEV)
+    opart = torch.zeros(ks, Np, 256, device=DEV)
+    ml = torch.zeros(ks, Np, 8, 2, device=DEV)
+    sml = torch.zeros(ks, Np, 8, T, 2, device=DEV)
+    a = hip.MHAArgs()
+    a.qh, a.ql, a.ldq = q.hi.data_ptr(), q.lo.data_ptr(), 256
+    a.kh, a.kl, a.k_slot_stride, a.ldk = k.hi.data_ptr(), k.lo.data_ptr(), Np * 256, 256
+    a.vh, a.vl, a.v_slot_stride, a.ldv = v.hi.data_ptr(), v.lo.data_ptr(), 256 * Np, Np
+    a.slot_map, a.T, a.N, a.Npad, a.heads = dmap.data_ptr(), T, N, Np, 8
+    a.scale, a.bias, a.ksplits = 1 / math.sqrt(32), dbias.data_ptr(), ks
+    a.opart, a.ml, a.slot_ml, a.nsplit = opart.data_ptr(), ml.data_ptr(), sml.data_ptr(), nsplit
+    hip.check(lib.rmem_mha_flash(C.byref(a), st), "mha")
+    out = hip.Planes.empty((Np, 256), DEV)
+    of = torch.zeros(N, 256, device=DEV)
+    mass = torch.zeros(N, T, device=DEV)
+    c = hip.MHACombineArgs()
+    c.N, c.Npad, c.heads, c.T, c.ksplits = N, Np, 8, T, ks
+    c.opart, c.ml, c.slot_ml = opart.data_ptr(), ml.data_ptr(), sml.data_ptr()
+    c.oh, c.ol, c.of32, c.ldo, c.mass = out.hi.data_ptr(), out.lo.data_ptr(), of.data_ptr(), 256, mass.data_ptr()
+    hip.check(lib.rmem_mha_combine(C.byref(c), st), "combine")
+    torch.cuda.synchronize()
+    Kl = torch.stack([K[s, :N] for s in smap]).double().view(T, N, 8, 32)
+    Vl = torch.stack([Vt[s, :, :N].t() for s in smap]).double().view(T, N, 8, 32)
+    Qd = Q[:N].double().view(N, 8, 32)
+    S_ = (torch.einsum("qhc,tkhc->hqtk", Qd, Kl) + bias.double().permute(1, 0, 2)[:, :, :, None]) / math.sqrt(32)
+    A = torch.softmax(S_.reshape(8, N, T * N), dim=-1).reshape(8, N, T, N)
+    ref = torch.einsum("hqtk,tkhc->qhc", A, Vl).reshape(N, 256)
+    err = (of.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (5e-5 if nsplit == 3 else 3e-2), err
+    assert (out.float()[:N].cpu().double() - ref).abs().max().item() / ref.abs().max().item() < (8e-5 if nsplit == 3 else 3e-2)
+    mref = A.sum(dim=3).mean(dim=0)
+    assert (mass.cpu().double() - mref).abs().max().item() < (1e-5 if nsplit == 3 else 2e-2)
+
+
+def test_aot_support_kernels(hip):
+    from oracle import lstt_ref as R
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(11)
+    h, w = 7, 9
+    N = h * w
+    g_ = lambda t: t.to(DEV).contiguous()
+    # layernorm_ex: LN(x + x2) + post
+    x, x2, post = _rand(rs, N, 256, scale=2) + 0.3, _rand(rs, N, 256), _rand(rs, N, 256)
+    gm, bt = _rand(rs, 256) * 0.2 + 1, _rand(rs, 256) * 0.1
+    dx, dx2, dpost, dgm, dbt = g_(x), g_(x2), g_(post), g_(gm), g_(bt)
+    pl = hip.Planes.empty((N, 256), DEV)
+    of = torch.zeros(N, 256, device=DEV)
+    hip.check(lib.rmem_layernorm_ex(dx.data_ptr(), 256, dx2.data_ptr(), 256, dgm.data_ptr(), dbt.data_ptr(), N, 256,
+                                    1e-5, dpost.data_ptr(), 256, pl.hi.data_ptr(), pl.lo.data_ptr(), 256,
+                                    of.data_ptr(), 256, st), "ln_ex")
+    ref = R.layer_norm(x + x2, gm, bt) + post
+    assert (of.cpu() - ref).abs().max().item() < 3e-6
+    assert (pl.float().cpu() - ref).abs().max().item() < 5e-5
+    # transpose planes
+    tp = hip.Planes.empty((256, 128), DEV)
+    hip.check(lib.rmem_transpose_planes(pl.hi.data_ptr(), pl.lo.data_ptr(), 256, N, 256, tp.hi.data_ptr(),
+                                        tp.lo.data_ptr(), 128, st), "transpose")
+    torch.cuda.synchronize()
+    assert torch.equal(tp.hi[:, :N].cpu(), pl.hi.cpu().t()) and torch.equal(tp.lo[:, :N].cpu(), pl.lo.cpu().t())
+    assert torch.all(tp.hi[:, N:] == 0)
+    # add_split
+    a_, b_ = _rand(rs, N, 256), _rand(rs, N, 256)
+    da, db = g_(a_), g_(b_)
+    pl2 = hip.Planes.empty((N, 256), DEV)
+    hip.check(lib.rmem_add_split(da.data_ptr(), db.data_ptr(), N * 256, da.data_ptr(), pl2.hi.data_ptr(),
+                                 pl2.lo.data_ptr(), st), "add_split")
+    assert (da.cpu() - (a_ + b_)).abs().max().item() == 0
+    assert (pl2.float().cpu() - (a_ + b_)).abs().max().item() < 6e-5
+    # GroupNorm(32) over tokens + GELU (layers/basic.py:27-32)
+    xa = _rand(rs, N, 1024, scale=1.5) + 0.2
+    gg, gb = _rand(rs, 1024) * 0.2 + 1, _rand(rs, 1024) * 0.1
+    dxa, dgg, dgb = g_(xa), g_(gg), g_(gb)
+    ws = torch.zeros(2 * 16 * 32, dtype=torch.float64, device=DEV)
+    y = torch.zeros(N, 1024, device=DEV)
+    hip.check(lib.rmem_gn_gelu_tokens(dxa.data_ptr(), N, 1024, 32, dgg.data_ptr(), dgb.data_ptr(), 1e-5, ws.data_ptr(),
+                                      y.data_ptr(), st), "gn_gelu")
+    x4 = xa.view(h, w, 1024).permute(2, 0, 1).unsqueeze(0)
+    ref = F.gelu(F.group_norm(x4.double(), 32, gg.double(), gb.double(), 1e-5))[0].permute(1, 2, 0).reshape(N, 1024)
+    assert (y.cpu().double() - ref).abs().max().item() < 5e-6
+    # per-head temporal PE bias
+    Q, cur, mem = _rand(rs, N, 256), _rand(rs, 256, scale=0.5), _rand(rs, 4, 256, scale=0.5)
+    dQ, dcur, dmem = g_(Q), g_(cur), g_(mem)
+    rows = [0, 1, 2, 3, 3]
+    arr = (C.c_int32 * 16)(*(rows + [0] * 11))
+    out = torch.zeros(N, 8, 5, device=DEV)
+    hip.check(lib.rmem_pe_bias_heads(dQ.data_ptr(), 256, dcur.data_ptr(), dmem.data_ptr(), arr, 5, N, 8,
+                                     out.data_ptr(), st), "pe_bias_heads")
+    ref = torch.einsum("qhc,thc->qht", (Q + cur).double().view(N, 8, 32), mem.double()[rows].view(5, 8, 32))
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+def _build_aot(former=1, latter=3, gap=2, nsplit=3):
+    import copy
+    from rmem_amd.config import get_config
+    from rmem_amd.engine import build_engine
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    cfg = get_config("r50_aotl", former, latter)
+    model = build_vos_model("aot", cfg).eval()
+    load_synthetic_weights(model)
+    eng = build_engine("aotengine", phase="eval", aot_model=copy.deepcopy(model).to(DEV), gpu_id=0,
+                       long_term_mem_gap=gap, nsplit=nsplit)
+    eng.eval()
+    return model, eng
+
+
+def test_aot_lstt_vs_oracle_tokens():
+    from oracle import aot_ref as A
+    from rmem_amd.lstt_aot import AOTLSTT
+    import copy
+    model, eng = _build_aot()
+    h, w = 12, 17
+    N = h * w
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    ora = A.AOTOracle(sd, 3)
+    lstt = AOTLSTT(eng.AOT, h, w, DEV, nsplit=3)
+    pos = A.sine_pos_emb(h, w)
+    assert (lstt.pos.cpu() - pos).abs().max().item() < 1e-5
+    rs = np.random.RandomState(0)
+    H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
+    worst = {}
+    for t in range(5):
+        emb = torch.from_numpy(rs.standard_normal((N, 256)).astype(np.float32))
+        label = torch.from_numpy(rs.randint(0, 4, (1, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
+        label = F.interpolate(label, size=(H, W), mode="nearest")
+        id_emb = A.aot_id_assign(label, sd)
+        lab_u8 = label[0, 0].to(torch.uint8).to(DEV).contiguous()
+        trace = {}
+        if t == 0:
+            ref = ora.forward(emb, h, w, pos, curr_id_emb=id_emb, trace=trace)
+            ora.init_memory()
+            lstt.assign_identity(lab_u8)
+            outs = lstt.forward(emb.to(DEV), ref_frame=True)
+        else:
+            ref = ora.forward(emb, h, w, pos, trace=trace)
+            outs = lstt.forward(emb.to(DEV))
+            upd = (t % 2 == 0)
+            ora.update_short_memories(id_emb, upd)
+            lstt.assign_identity(lab_u8)
+            lstt.update_short_memories(upd)
+        torch.cuda.synchronize()
+        err = max((o.cpu() - r).abs().max().item() for o, r in zip(outs, ref))
+        worst[f"out{t}"] = err
+        if t > 0:
+            T = trace["l0.mass"].shape[1]
+            merr = (lstt.mass.flatten()[:N * T].view(N, T).cpu() - trace["l0.mass"]).abs().max().item()
+            worst[f"mass{t}"] = merr
+            assert merr < 1e-4, (t, merr)
+        assert err < 3e-4, (t, err, worst)
+    print("AOT LSTT vs oracle max abs err:", worst)
+
+
+@pytest.mark.parametrize("name", ["aot_k4_gap2", "aot_k2_gap1"])
+def test_aot_small_clip_teacher_forced(name, golden_dir):
+    from rmem_amd.synth import synth_clip
+    meta = json.load(open(os.path.join(golden_dir, f"clip_{name}.json")))
+    gold = np.load(os.path.join(golden_dir, f"clip_{name}.npz"))
+    model, eng = _build_aot(meta["former"], meta["latter"], meta["gap"])
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    eng.restart_engine()
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    idx_hist, mism = [], []
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(meta["H"], meta["W"]))
+        pred = torch.argmax(logit, dim=1)[0]
+        mism.append(int((pred.cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        idx_hist.append(list(eng.aot_engines[0].long_memories_indexes))
+    print(name, "mismatching pixels per frame:", mism)
+    assert idx_hist == meta["indexes"]
+    assert max(mism) <= 2, mism
+    lerr = np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max()
+    assert lerr < 2e-3, lerr
+
+
+def test_aot_480p_clip_teacher_forced(golden_dir):
+    """BASELINE.json configs[0] geometry: R50-AOTL + RMem, 481x849, 16 frames, K=4, gap 5."""
+    from rmem_amd.synth import synth_clip
+    meta = json.load(open(os.path.join(golden_dir, "clip_aot_480p.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_aot_480p.npz"))
+    model, eng = _build_aot(meta["former"], meta["latter"], meta["gap"])
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    eng.restart_engine()
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    mism, idx_hist, lerrs = [], [], {}
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=tuple(meta["out_hw"]))
+        pred = torch.argmax(logit, dim=1)[0]
+        mism.append(int((pred.cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        if f"logits_{t}" in gold:
+            lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() -
+                                    gold[f"logits_{t}"].astype(np.float32)).max())
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        idx_hist.append(list(eng.aot_engines[0].long_memories_indexes))
+    print("AOT 480p mismatching pixels per frame (of 409920):", mism, "logit err:", lerrs)
+    assert idx_hist == meta["indexes"]
+    assert max(mism) <= 12, mism
+    assert max(lerrs.values()) < 2e-2
