@@ -67,9 +67,17 @@ typedef struct {
   int64_t bsx, bsy, bsd, bsbias, bspa;
   int32_t nsplit;                          /* 1 or 3                                   */
   int32_t tile;                            /* 0 auto, 64 or 128                        */
+  int32_t ksplits;                         /* >1: split K; raw partial sums (+bias in split 0) go to
+                                              parts[split][M][N] instead of the outputs above; the
+                                              consumer sums them in split order (rmem_layernorm_red) */
+  float *parts; int64_t part_stride;       /* elements between splits (>= M*N)          */
 } rmem_linear_args;
 
 int rmem_linear(const rmem_linear_args *a, void *stream);
+
+/* Up to 8 independent problems (same nsplit, 64x64 tiles) in ONE launch: the small projections
+ * of one LSTT stage share their input and individually cannot fill 256 CUs. */
+int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
 
 /* ------------------------------------------------------------------ attention
  * Memory-read attention of GatedPropagation.forward (layers/attention.py:174-206) in
@@ -186,6 +194,15 @@ int rmem_layernorm_ex(const float *x, int64_t ldx, const float *x2, int64_t ldx2
                       const float *beta, int32_t N, int32_t C, float eps, const float *post,
                       int64_t ldpost, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32,
                       int64_t ldof, void *stream);
+
+/* Residual reduce + LayerNorm: x[row][:] += sum_z parts[z][row][:]  (z in split order, written
+ * back to x), then y = LN(x)*gamma+beta -> planes (+ optional fp32).  Consumes the split-K
+ * partials of the projection GEMM that precedes norm2/id_norm2/norm1/id_norm1
+ * (layers/transformer.py:1212-1224, 1231-1232).  nparts = 0 is a plain LayerNorm. */
+int rmem_layernorm_red(float *x, int64_t ldx, const float *parts, int32_t nparts, int64_t part_stride,
+                       int64_t ldpart, const float *gamma, const float *beta, int32_t N, int32_t C,
+                       float eps, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32, int64_t ldof,
+                       void *stream);
 
 /* planes [N][C] (ld) -> transposed planes [C][ldo]  (AOT: V operand of the short-term attention) */
 int rmem_transpose_planes(const rmem_bf16 *ih, const rmem_bf16 *il, int64_t ld, int32_t N, int32_t C,

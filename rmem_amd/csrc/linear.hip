@@ -3,12 +3,14 @@
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
 
+// One BM x BN output tile of problem `a`.  bz = batch index (nbatch > 1) or K-split index
+// (ksplits > 1, raw partial sums to a.parts, bias added by split 0 only).
 template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void linear_kernel(rmem_linear_args a) {
+__device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, int ny, int bzz, char* smem) {
   using Cfg = GemmCfg<BM, BN, NS>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int bz = blockIdx.z;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const bool splitk = a.ksplits > 1;
+  const int bz = splitk ? 0 : bzz;
+  const int m0 = mx * BM, n0 = ny * BN;
 
   RowMajorOperand lx, ly;
   lx.hi = a.xh + bz * a.bsx;
@@ -32,10 +34,34 @@ __global__ __launch_bounds__(256) void linear_kernel(rmem_linear_args a) {
 
   GemmFrag<Cfg> f;
   f.zero();
-  gemm_mainloop<Cfg>(f, lx, ly, 0, a.K / 64, smem);
+  int kt0 = 0, kt1 = a.K / 64;
+  if (splitk) {
+    const int per = (kt1 + a.ksplits - 1) / a.ksplits;
+    kt0 = bzz * per;
+    kt1 = kt0 + per < kt1 ? kt0 + per : kt1;
+  }
+  gemm_mainloop<Cfg>(f, lx, ly, kt0, kt1, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  if (splitk) {   // raw partials [split][M][N]; the consumer (rmem_layernorm_red) sums them in order
+    float* out = a.parts + (long)bzz * a.part_stride;
+    const float* b0 = (a.bias && bzz == 0) ? a.bias : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < Cfg::TN; ++tn) {
+      const int col = n0 + frag_col<Cfg>(wc, tn, lane);
+      if (col >= a.N) continue;
+      const float bc = b0 ? b0[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + frag_row<Cfg>(wr, tm, r, lane);
+          if (row < a.M) out[(long)row * a.N + col] = f.acc[tm][tn][r] + bc;
+        }
+    }
+    return;
+  }
   const float* bias = a.bias ? a.bias + bz * a.bsbias : nullptr;
   float* d0 = a.d0 ? a.d0 + bz * a.bsd : nullptr;
   float* d1 = a.d1 ? a.d1 + bz * a.bsd : nullptr;
@@ -86,9 +112,38 @@ __global__ __launch_bounds__(256) void linear_kernel(rmem_linear_args a) {
 }
 
 template <int BM, int BN, int NS>
+__global__ __launch_bounds__(256) void linear_kernel(rmem_linear_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  linear_body<BM, BN, NS>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Several independent small problems in one launch (the projections of one LSTT stage share
+// their input): 16-byte kernel boundaries and 54-216-block grids are replaced by one grid
+// that fills the chip.  tile_start[i] = first block of problem i.
+struct GroupedLinear {
+  int n;
+  int tile_start[9];
+  rmem_linear_args p[8];
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void linear_grouped_kernel(GroupedLinear g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.tile_start[i + 1]) ++i;
+  const rmem_linear_args& a = g.p[i];
+  int local = blockIdx.x - g.tile_start[i];
+  const int mt = (a.M + 63) / 64, nt = (a.N + 63) / 64;
+  const int bz = local / (mt * nt);
+  local -= bz * mt * nt;
+  const int ny = local / mt, mx = local - ny * mt;
+  linear_body<64, 64, NS>(a, mx, ny, bz, smem);
+}
+
+template <int BM, int BN, int NS>
 static int launch_linear(const rmem_linear_args& a, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, NS>;
-  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.nbatch > 0 ? a.nbatch : 1);
+  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, NS>),
@@ -100,10 +155,7 @@ static int launch_linear(const rmem_linear_args& a, hipStream_t s) {
   return RMEM_OK;
 }
 
-extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
-  if (!ap) return RMEM_ERR_INVALID;
-  rmem_linear_args a = *ap;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+static int validate_linear(rmem_linear_args& a) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K % 64) != 0) return RMEM_ERR_INVALID;
   if (!a.xh || !a.yh) return RMEM_ERR_INVALID;
   if (a.nsplit != 1 && a.nsplit != 3) return RMEM_ERR_INVALID;
@@ -112,9 +164,45 @@ extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
   if (a.yh2 && ((a.ky_split % 64) != 0 || a.ky_split <= 0 || a.ky_split >= a.K)) return RMEM_ERR_INVALID;
   if ((a.ldx % 8) || (a.ldy % 8)) return RMEM_ERR_INVALID;
   if (a.csplit <= 0 || a.csplit > a.N) a.csplit = a.N;
+  if (a.ksplits > 1 && (!a.parts || a.nbatch > 1 || a.act != 0 || a.bias_per_row || a.ksplits > a.K / 64))
+    return RMEM_ERR_INVALID;
+  return RMEM_OK;
+}
+
+extern "C" int rmem_linear_grouped(const rmem_linear_args* args, int32_t n, void* stream) {
+  if (!args || n <= 0 || n > 8) return RMEM_ERR_INVALID;
+  GroupedLinear g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = args[i];
+    if (validate_linear(g.p[i]) != RMEM_OK || g.p[i].nsplit != args[0].nsplit) return RMEM_ERR_INVALID;
+    const rmem_linear_args& a = g.p[i];
+    g.tile_start[i] = total;
+    total += ((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
+  }
+  g.tile_start[n] = total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (args[0].nsplit == 3) {
+    using Cfg = GemmCfg<64, 64, 3>;
+    hipLaunchKernelGGL(linear_grouped_kernel<3>, dim3(total), dim3(256), Cfg::LDS_BYTES, s, g);
+  } else {
+    using Cfg = GemmCfg<64, 64, 1>;
+    hipLaunchKernelGGL(linear_grouped_kernel<1>, dim3(total), dim3(256), Cfg::LDS_BYTES, s, g);
+  }
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
+  if (!ap) return RMEM_ERR_INVALID;
+  rmem_linear_args a = *ap;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (validate_linear(a) != RMEM_OK) return RMEM_ERR_INVALID;
   int tile = a.tile;
   if (tile == 0) {
-    const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.nbatch > 0 ? a.nbatch : 1);
+    const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) *
+                           (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
     tile = blocks128 >= 256 ? 128 : 64;
   }
   if (tile == 128) return a.nsplit == 3 ? launch_linear<128, 128, 3>(a, s) : launch_linear<128, 128, 1>(a, s);

@@ -65,6 +65,61 @@ extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, i
   return RMEM_OK;
 }
 
+// residual reduce (split-K partials, fixed order) + LayerNorm
+__global__ __launch_bounds__(256) void layernorm_red_kernel(float* x, long ldx, const float* parts, int nparts,
+                                                            long part_stride, long ldpart, const float* gamma,
+                                                            const float* beta, int N, float eps, bf16_t* oh,
+                                                            bf16_t* ol, long ldo, float* of32, long ldof) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N) return;
+  float4 v = *reinterpret_cast<const float4*>(x + (long)row * ldx + lane * 4);
+  for (int z = 0; z < nparts; ++z) {
+    const float4 w = *reinterpret_cast<const float4*>(parts + (long)z * part_stride + (long)row * ldpart + lane * 4);
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
+  if (nparts > 0) *reinterpret_cast<float4*>(x + (long)row * ldx + lane * 4) = v;
+  float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / 256.0f);
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  float ss = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  const float4 b = *reinterpret_cast<const float4*>(beta + lane * 4);
+  const float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
+  if (of32) *reinterpret_cast<float4*>(of32 + (long)row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
+  if (oh) {
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(y[e], hi[e], lo[e]);
+    uint2 vh, vl;
+    vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+    vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+    vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+    *reinterpret_cast<uint2*>(oh + (long)row * ldo + lane * 4) = vh;
+    if (ol) *reinterpret_cast<uint2*>(ol + (long)row * ldo + lane * 4) = vl;
+  }
+}
+
+extern "C" int rmem_layernorm_red(float* x, int64_t ldx, const float* parts, int32_t nparts, int64_t part_stride,
+                                  int64_t ldpart, const float* gamma, const float* beta, int32_t N, int32_t C,
+                                  float eps, rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, float* of32, int64_t ldof,
+                                  void* stream) {
+  if (!x || !gamma || !beta || N <= 0 || C != 256 || (ldx % 4) || (ldo % 4) || (ldof % 4) || nparts < 0 ||
+      (nparts > 0 && (!parts || (ldpart % 4) || (part_stride % 4))))
+    return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(layernorm_red_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     (long)ldx, parts, nparts, (long)part_stride, (long)ldpart, gamma, beta, N, eps, oh, ol,
+                     (long)ldo, of32, (long)ldof);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                     int32_t N, int32_t C, float eps, rmem_bf16* oh, rmem_bf16* ol,
                                     int64_t ldo, float* of32, int64_t ldof, void* stream) {
@@ -643,4 +698,4 @@ extern "C" int rmem_pe_bias_heads(const float* Q, int64_t ldq, const float* cur_
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 2; }
+extern "C" int rmem_abi_version(void) { return 3; }

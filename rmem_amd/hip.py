@@ -38,6 +38,7 @@ class LinearArgs(C.Structure):
         ("pbh", c_p), ("pbl", c_p), ("ldpb", i64), ("addvec", c_p),
         ("nbatch", i32), ("bsx", i64), ("bsy", i64), ("bsd", i64), ("bsbias", i64), ("bspa", i64),
         ("nsplit", i32), ("tile", i32),
+        ("ksplits", i32), ("parts", c_p), ("part_stride", i64),
     ]
 
 
@@ -95,7 +96,7 @@ EXPORTS = [
     "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
-    "rmem_gn_gelu_tokens", "rmem_pe_bias_heads",
+    "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red",
 ]
 
 
@@ -115,6 +116,9 @@ def load():
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
     lib.rmem_linear.argtypes = [C.POINTER(LinearArgs), c_p]
+    lib.rmem_linear_grouped.argtypes = [C.POINTER(LinearArgs), i32, c_p]
+    lib.rmem_layernorm_red.argtypes = [c_p, i64, c_p, i32, i64, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64,
+                                       c_p, i64, c_p]
     lib.rmem_attn_scores.argtypes = [C.POINTER(ScoresArgs), c_p]
     lib.rmem_attn_pv.argtypes = [C.POINTER(PVArgs), c_p]
     lib.rmem_attn_combine.argtypes = [C.POINTER(CombineArgs), c_p]
@@ -187,8 +191,9 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
            pa: Planes = None, ldpa=0, pb: Planes = None, ldpb=0, addvec=None,
            x2: Planes = None, ldx2=0, kx_split=0, y2: Planes = None, ldy2=0, ky_split=0,
            nbatch=1, bsx=0, bsy=0, bsd=0, bsbias=0, bspa=0, nsplit=3, tile=0,
-           x_off=0, y_off=0):
-    """x_off / y_off: element offsets into the plane tensors (column windows)."""
+           x_off=0, y_off=0, ksplits=1, parts=None, part_stride=0, launch=True):
+    """x_off / y_off: element offsets into the plane tensors (column windows).
+    launch=False returns the filled argument struct (for linear_grouped)."""
     a = LinearArgs()
     eb = 2  # bytes per bf16
     a.xh, a.xl, a.ldx = x.hi.data_ptr() + x_off * eb, x.lo.data_ptr() + x_off * eb, ldx
@@ -207,7 +212,16 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
         a.pbh, a.pbl, a.ldpb, a.addvec = pb.hi.data_ptr(), pb.lo.data_ptr(), ldpb, ptr(addvec)
     a.nbatch, a.bsx, a.bsy, a.bsd, a.bsbias, a.bspa = nbatch, bsx, bsy, bsd, bsbias, bspa
     a.nsplit, a.tile = nsplit, tile
+    a.ksplits, a.parts, a.part_stride = ksplits, ptr(parts), part_stride
+    if not launch:
+        return a
     check(load().rmem_linear(C.byref(a), stream_ptr()), "rmem_linear")
+
+
+def linear_grouped(args):
+    """One launch for up to 8 problems built with linear(..., launch=False)."""
+    arr = (LinearArgs * len(args))(*args)
+    check(load().rmem_linear_grouped(arr, len(args), stream_ptr()), "rmem_linear_grouped")
 
 
 _GN_WS = {}

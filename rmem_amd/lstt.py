@@ -187,6 +187,8 @@ class DeAOTLSTT:
         self.ev_side = torch.cuda.Event() if dev.type == "cuda" else None
         self.Ylt = Planes.empty((Np, 1024), dev)
         self.Yst = Planes.empty((Np, 1024), dev)
+        self.KS = 4                                                # split-K of the projection GEMMs
+        self.parts = z(self.KS, N, 512)
         self.ldr = 232
         self.R = z(N, self.ldr)
         self.s_pl = Planes.empty((Np, 512), dev)
@@ -255,11 +257,14 @@ class DeAOTLSTT:
         nq = self.Npad // 128
         return max(1, min(self.ksplits_max, int(round(56.0 / nq)), ktiles))
 
-    def _ln(self, x, gb, out: Planes, ldo, col_off=0):
-        rc = hip.load().rmem_layernorm_split(
-            x.data_ptr(), 256, gb[0].data_ptr(), gb[1].data_ptr(), self.N, 256, 1e-5,
+    def _ln(self, x, gb, out: Planes, ldo, col_off=0, parts_col=None):
+        """LayerNorm -> planes; parts_col = column offset into the split-K partials of the
+        preceding projection GEMM, which are first summed into x (fixed order)."""
+        np_, pp = (self.KS, self.parts.data_ptr() + parts_col * 4) if parts_col is not None else (0, None)
+        rc = hip.load().rmem_layernorm_red(
+            x.data_ptr(), 256, pp, np_, self.N * 512, 512, gb[0].data_ptr(), gb[1].data_ptr(), self.N, 256, 1e-5,
             out.hi.data_ptr() + col_off * 2, out.lo.data_ptr() + col_off * 2, ldo, None, 0, hip.stream_ptr())
-        hip.check(rc, "rmem_layernorm_split")
+        hip.check(rc, "rmem_layernorm_red")
 
     def _attention(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
                    qpl: Planes, bias, U, want_mass: bool, which: int):
@@ -307,19 +312,19 @@ class DeAOTLSTT:
                                             out.hi.data_ptr(), out.lo.data_ptr(), 1024, hip.stream_ptr())
         hip.check(rc, "rmem_dwconv5x5_split")
 
-    def _idv(self, l: int, slot: int):
+    def _idv(self, l: int, slot: int, launch: bool = True):
         """ID_V = silu(linear_ID_V([z | id_emb])) -> V^T rows 512.. of `slot`
         (fuse_key_value_id, transformer.py:1238-1244)."""
         W, N, Np = self.lw[l], self.N, self.Npad
         dst = self.bankV[l][slot]
         pa = Planes(dst.hi[512:], dst.lo[512:])
         if l == 0:
-            hip.linear(W.Widv, self.idemb_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bidv,
-                       bias_per_row=True, act=1, pa=pa, ldpa=Np, nsplit=self.nsplit)
-        else:
-            hip.linear(W.Widv, self.z_pl[l], 512, N, 512, ldx=512, ldy=256, y2=self.idemb_pl, ldy2=256,
-                       ky_split=256, bias=W.bidv, bias_per_row=True, act=1, pa=pa, ldpa=Np,
-                       nsplit=self.nsplit)
+            return hip.linear(W.Widv, self.idemb_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bidv,
+                              bias_per_row=True, act=1, pa=pa, ldpa=Np, nsplit=self.nsplit, tile=64,
+                              launch=launch)
+        return hip.linear(W.Widv, self.z_pl[l], 512, N, 512, ldx=512, ldy=256, y2=self.idemb_pl, ldy2=256,
+                          ky_split=256, bias=W.bidv, bias_per_row=True, act=1, pa=pa, ldpa=Np,
+                          nsplit=self.nsplit, tile=64, launch=launch)
 
     # ------------------------------------------------------------------ ID assignment
     def assign_identity(self, label_u8: torch.Tensor):
@@ -364,20 +369,26 @@ class DeAOTLSTT:
                 self.rowmax.zero_()
             curK = self.bankK[l][cur]
             curV = self.bankV[l][cur]
-            # -- norms + projections (transformer.py:1104-1123)
-            self._ln(self.tgt, W.ln1, self.x_pl, 256)
+            # -- norms + projections (transformer.py:1104-1123); the norms first fold in the
+            #    split-K partials of the previous layer's self-attention projection
+            prev = 0 if l > 0 else None
+            self._ln(self.tgt, W.ln1, self.x_pl, 256, parts_col=prev)
             if l > 0:
-                self._ln(self.tgt_id, W.lnid1, self.z_pl[l], 256)
-            hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
-                       d0=self.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128,
-                       pb=self.Qpe, ldpb=128, addvec=self.cur_pe, nsplit=ns)
-            hip.linear(W.Wv, self.x_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True,
-                       act=1, pa=Planes(curV.hi[:512], curV.lo[:512]), ldpa=Np, nsplit=ns)
-            hip.linear(self.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1,
-                       d0=Ucat.data_ptr(), ldd0=1024, nsplit=ns)
+                self._ln(self.tgt_id, W.lnid1, self.z_pl[l], 256, parts_col=256)
+            grp = [
+                hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
+                           d0=self.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128,
+                           pb=self.Qpe, ldpb=128, addvec=self.cur_pe, nsplit=ns, tile=64, launch=False),
+                hip.linear(W.Wv, self.x_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True,
+                           act=1, pa=Planes(curV.hi[:512], curV.lo[:512]), ldpa=Np, nsplit=ns, tile=64,
+                           launch=False),
+                hip.linear(self.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1,
+                           d0=Ucat.data_ptr(), ldd0=1024, nsplit=ns, tile=64, launch=False)]
             if l > 0:
-                hip.linear(self.z_pl[l], W.Widu, N, 512, 256, ldx=256, ldy=256, bias=W.bidu, act=1,
-                           d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns)
+                grp.append(hip.linear(self.z_pl[l], W.Widu, N, 512, 256, ldx=256, ldy=256, bias=W.bidu, act=1,
+                                      d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns, tile=64,
+                                      launch=False))
+            hip.linear_grouped(grp)
             if ref_frame:
                 self._idv(l, cur)
             # -- short-term windowed read on the side stream (transformer.py:1199,
@@ -400,29 +411,35 @@ class DeAOTLSTT:
                             self.bias_pe, Ucat, want_mass=(l == 0), which=0)
             self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
             torch.cuda.current_stream().wait_event(self.ev_side)
-            # -- both projections + residual adds (transformer.py:1212-1220)
+            # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
+            #    adds happen in the norms that follow (rmem_layernorm_red)
             hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
-                       kx_split=1024, bias=W.bp_ls, d0=self.tgt.data_ptr(), ldd0=256,
-                       d1=self.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns)
+                       kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=64, ksplits=self.KS, parts=self.parts,
+                       part_stride=N * 512)
             # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
-            self._ln(self.tgt, W.ln2, self.s_pl, 512, 0)
-            self._ln(self.tgt_id, W.lnid2, self.s_pl, 512, 256)
+            self._ln(self.tgt, W.ln2, self.s_pl, 512, 0, parts_col=0)
+            self._ln(self.tgt_id, W.lnid2, self.s_pl, 512, 256, parts_col=256)
             sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
-            hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
-                       nsplit=ns)
             sV = Planes(self.selfV.hi[0], self.selfV.lo[0])
-            hip.linear(W.Wv12, self.s_pl, 512, N, 256, ldx=256, ldy=512, bias=W.bv12, bias_per_row=True,
-                       act=1, pa=sV, ldpa=Np, nbatch=2, bsx=512 * 256, bsy=256, bsbias=512,
-                       bspa=512 * Np, nsplit=ns)
-            hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
-                       d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
-                       bsbias=512, bsd=512, nsplit=ns)
+            hip.linear_grouped([
+                hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
+                           nsplit=ns, tile=64, launch=False),
+                hip.linear(W.Wv12, self.s_pl, 512, N, 256, ldx=256, ldy=512, bias=W.bv12, bias_per_row=True,
+                           act=1, pa=sV, ldpa=Np, nbatch=2, bsx=512 * 256, bsy=256, bsbias=512,
+                           bspa=512 * Np, nsplit=ns, tile=64, launch=False),
+                hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
+                           d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
+                           bsbias=512, bsd=512, nsplit=ns, tile=64, launch=False)])
             self._attention(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
                             want_mass=False, which=2)
             self._dwconv(self.ws_main, W.dw_self, self.Ylt)
-            hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
-                       d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,
-                       csplit=256, accumulate=True, nsplit=ns)
+            if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
+                hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
+                           tile=64, ksplits=self.KS, parts=self.parts, part_stride=N * 512)
+            else:                  # last layer: the GroupNorm reads tgt / tgt_id directly
+                hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
+                           d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,
+                           csplit=256, accumulate=True, nsplit=ns)
         # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
         hip.check(lib.rmem_groupnorm2(self.tgt.data_ptr(), self.tgt_id.data_ptr(), N, 256,
                                       self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
@@ -438,8 +455,7 @@ class DeAOTLSTT:
     def update_short_memories(self, update_long: bool):
         """update_short_memories + update_long_term_memory (transformer.py:826-878).
         ``assign_identity`` must have been called with the current mask."""
-        for l in range(self.L):
-            self._idv(l, self.cur)
+        hip.linear_grouped([self._idv(l, self.cur, launch=False) for l in range(self.L)])
         self.short = self.cur
         if update_long:
             self.bank = self.bank + [self.cur]

@@ -76,34 +76,38 @@ def test_lstt_forward_vs_oracle_tokens():
 
 
 @pytest.mark.parametrize("name", ["k4_gap2", "k8_gap2", "k2_gap1"])
-def test_small_clip_free_running(name, golden_dir):
-    """Closed loop on the small golden clips: eviction sequence identical, integer label
-    maps compared pixel by pixel with the reference's."""
+def test_small_clip(name, golden_dir):
+    """Small golden clips (12.5k pixels/frame), two runs:
+    (a) teacher-forced (update_memory fed the reference's label): integer label maps compared
+        pixel by pixel with the reference's, eviction sequence, last-frame decoder logits;
+    (b) closed loop: with synthetic weights the loop is chaotic (a single near-tie flip grows,
+        tests/test_oracle_golden.py), so only the eviction sequence and the first frame are
+        asserted and the per-frame mismatch is reported."""
     from rmem_amd.synth import synth_clip
     meta = json.load(open(os.path.join(golden_dir, f"clip_small_{name}.json")))
     gold = np.load(os.path.join(golden_dir, f"clip_small_{name}.npz"))
     cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"])
     imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
-    eng.restart_engine()
-    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
-    idx_hist, mism = [], []
-    for t in range(1, meta["frames"]):
-        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(meta["H"], meta["W"]))
-        pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float()
-        eng.update_memory(F.interpolate(pred, size=eng.input_size_2d, mode="nearest"))
-        idx_hist.append(list(eng.aot_engines[0].long_memories_indexes))
-        mism.append(int((pred[0, 0].cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
-    print(name, "mismatching pixels per frame:", mism)
-    assert idx_hist == meta["indexes"]
-    last = eng.aot_engines[0].pred_id_logits.cpu().numpy()
-    lerr = np.abs(last - gold["last_logits"]).max()
-    print(name, "last-frame logit max abs err:", lerr)
-    # Closed loop with synthetic weights is chaotic (tests/test_oracle_golden.py): a single
-    # near-tie flip grows; the eviction sequence must still agree and most clips stay exact.
-    if name != "k8_gap2":
-        assert sum(mism) == 0, mism
-        assert lerr < 2e-3
-    assert mism[0] == 0
+    for teacher in (True, False):
+        eng.restart_engine()
+        eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+        idx_hist, mism = [], []
+        for t in range(1, meta["frames"]):
+            logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(meta["H"], meta["W"]))
+            pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float()
+            fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV) if teacher else pred
+            eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+            idx_hist.append(list(eng.aot_engines[0].long_memories_indexes))
+            mism.append(int((pred[0, 0].cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        print(name, "teacher-forced" if teacher else "closed-loop", "mismatching pixels per frame:", mism)
+        assert idx_hist == meta["indexes"]
+        if teacher:
+            assert max(mism) <= 1, mism
+            lerr = np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max()
+            print(name, "last-frame logit max abs err:", lerr)
+            assert lerr < 2e-3
+        else:
+            assert mism[0] == 0
 
 
 @pytest.mark.parametrize("nsplit", [3, 1])
