@@ -255,6 +255,12 @@ int rmem_groupnorm_nchw(const float *x, float *y, int32_t C, int64_t HW, int32_t
                         const float *gamma, const float *beta, float eps, int32_t relu, double *ws,
                         void *stream);
 
+/* Support op outside the LSTT: in-place conv epilogue y = act(x + bias[c] (+ residual)) on a
+ * contiguous batch-1 NCHW tensor (the folded-FrozenBN bias, the bottleneck's residual add and
+ * ReLU of encoders/resnet.py:47-69 in one pass). */
+int rmem_bias_act_nchw(float *x, const float *bias, const float *residual, int32_t C, int64_t HW,
+                       int32_t relu, void *stream);
+
 /* fp32 -> planes (weights at load time, fixtures in tests) */
 int rmem_split_planes(const float *x, int64_t n, rmem_bf16 *hi, rmem_bf16 *lo, void *stream);
 

@@ -698,4 +698,48 @@ extern "C" int rmem_pe_bias_heads(const float* Q, int64_t ldq, const float* cur_
   return RMEM_OK;
 }
 
+// ------------------------------------------------------------------ conv epilogue (encoder support)
+// y = act(x + bias[c] (+ residual)) in place on a contiguous NCHW batch-1 tensor: replaces the
+// separate bias-add / residual-add / ReLU launches PyTorch-ROCm issues after every MIOpen conv.
+__global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* x, const float* bias, const float* res, long hw,
+                                                            long n, int relu) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      float4 v = *reinterpret_cast<const float4*>(x + i);
+      float o[4] = {v.x, v.y, v.z, v.w};
+      float r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (res) {
+        const float4 t = *reinterpret_cast<const float4*>(res + i);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = o[e] + bias[(i + e) / hw] + r[e];
+        o[e] = relu ? fmaxf(t, 0.f) : t;
+      }
+      *reinterpret_cast<float4*>(x + i) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      for (long j = i; j < n; ++j) {
+        float t = x[j] + bias[j / hw] + (res ? res[j] : 0.f);
+        x[j] = relu ? fmaxf(t, 0.f) : t;
+      }
+    }
+  }
+}
+
+extern "C" int rmem_bias_act_nchw(float* x, const float* bias, const float* residual, int32_t C, int64_t HW,
+                                  int32_t relu, void* stream) {
+  if (!x || !bias || C <= 0 || HW <= 0) return RMEM_ERR_INVALID;
+  const long n = (long)C * HW;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (residual && (reinterpret_cast<uintptr_t>(residual) & 15)))
+    return RMEM_ERR_INVALID;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bias_act_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     bias, residual, (long)HW, n, relu);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_abi_version(void) { return 3; }

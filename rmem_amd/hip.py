@@ -96,7 +96,7 @@ EXPORTS = [
     "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
-    "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red",
+    "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw",
 ]
 
 
@@ -119,6 +119,7 @@ def load():
     lib.rmem_linear_grouped.argtypes = [C.POINTER(LinearArgs), i32, c_p]
     lib.rmem_layernorm_red.argtypes = [c_p, i64, c_p, i32, i64, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64,
                                        c_p, i64, c_p]
+    lib.rmem_bias_act_nchw.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p]
     lib.rmem_attn_scores.argtypes = [C.POINTER(ScoresArgs), c_p]
     lib.rmem_attn_pv.argtypes = [C.POINTER(PVArgs), c_p]
     lib.rmem_attn_combine.argtypes = [C.POINTER(CombineArgs), c_p]
@@ -242,3 +243,17 @@ def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool) -> torch
                                      gn.bias.data_ptr(), gn.eps, int(relu), ws.data_ptr(), stream_ptr()),
           "rmem_groupnorm_nchw")
     return y
+
+
+def bias_act_nchw_(x: torch.Tensor, bias: torch.Tensor, residual=None, relu: bool = True) -> torch.Tensor:
+    """In-place x = act(x + bias[c] (+ residual)) for a contiguous batch-1 NCHW fp32 tensor."""
+    n, c, h, w = x.shape
+    if n != 1 or not x.is_contiguous() or x.dtype != torch.float32 or \
+            (residual is not None and not residual.is_contiguous()):
+        y = x + bias.view(1, -1, 1, 1)
+        if residual is not None:
+            y = y + residual
+        return torch.relu_(y) if relu else y
+    check(load().rmem_bias_act_nchw(x.data_ptr(), bias.data_ptr(), ptr(residual), c, h * w, int(relu),
+                                    stream_ptr()), "rmem_bias_act_nchw")
+    return x

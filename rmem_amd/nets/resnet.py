@@ -29,15 +29,57 @@ class FrozenBN(nn.Module):
                             self.bias, training=False, eps=self.eps)
 
 
-def _fold(conv: nn.Conv2d, bn: "FrozenBN") -> nn.Conv2d:
-    """conv followed by a frozen BN -> one conv with bias (inference-time folding)."""
-    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-    out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
-                    conv.dilation, conv.groups, bias=True).to(conv.weight.device)
-    with torch.no_grad():
-        out.weight.copy_(conv.weight * scale.view(-1, 1, 1, 1))
-        out.bias.copy_(bn.bias - bn.running_mean * scale)
-    return out
+class _FoldedConv(nn.Module):
+    """conv + frozen BN folded into (bias-free conv, per-channel bias); the bias, the optional
+    residual and the ReLU are applied by one HIP pass on the GPU (rmem_bias_act_nchw)."""
+
+    def __init__(self, conv: nn.Conv2d, bn: "FrozenBN"):
+        super().__init__()
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        self.conv = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                              conv.dilation, conv.groups, bias=False).to(conv.weight.device)
+        with torch.no_grad():
+            self.conv.weight.copy_(conv.weight * scale.view(-1, 1, 1, 1))
+        self.register_buffer("bias", (bn.bias - bn.running_mean * scale).detach().clone())
+
+    def forward(self, x, residual=None, relu=True):
+        y = self.conv(x)
+        if y.is_cuda and not torch.is_grad_enabled():
+            from ..hip import bias_act_nchw_
+            return bias_act_nchw_(y.contiguous(), self.bias, residual, relu)
+        y = y + self.bias.view(1, -1, 1, 1)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
+class _FoldedBottleneck(nn.Module):
+    def __init__(self, b: "_Bottleneck"):
+        super().__init__()
+        self.c1, self.c2, self.c3 = _FoldedConv(b.conv1, b.bn1), _FoldedConv(b.conv2, b.bn2), _FoldedConv(b.conv3, b.bn3)
+        self.down = _FoldedConv(b.downsample[0], b.downsample[1]) if b.downsample is not None else None
+
+    def forward(self, x):
+        s = x if self.down is None else self.down(x, relu=False)
+        y = self.c2(self.c1(x))
+        return self.c3(y, residual=s.contiguous(), relu=True)
+
+
+class _FoldedResNet(nn.Module):
+    def __init__(self, m: "ResNet50Encoder"):
+        super().__init__()
+        self.stem = _FoldedConv(m.conv1, m.bn1)
+        self.maxpool = m.maxpool
+        self.layer1 = nn.Sequential(*[_FoldedBottleneck(b) for b in m.layer1])
+        self.layer2 = nn.Sequential(*[_FoldedBottleneck(b) for b in m.layer2])
+        self.layer3 = nn.Sequential(*[_FoldedBottleneck(b) for b in m.layer3])
+
+    def forward(self, img):
+        x = self.maxpool(self.stem(img))
+        c4 = self.layer1(x)
+        c8 = self.layer2(c4)
+        c16 = self.layer3(c8)
+        return [c4, c8, c16, c16]
 
 
 class _Bottleneck(nn.Module):
@@ -84,21 +126,11 @@ class ResNet50Encoder(nn.Module):
         self.layer2 = _stage(256, 128, 4, 2, 1)
         self.layer3 = _stage(512, 256, 6, 2, 1)
 
-    def folded(self) -> "ResNet50Encoder":
-        """Inference copy with every FrozenBN folded into the preceding conv (same function up
-        to fp32 rounding; removes 43 BatchNorm launches per frame).  Keys no longer match the
-        reference's state_dict, so this is built from the loaded model, never loaded into."""
-        import copy
-        m = copy.deepcopy(self)
-        m.conv1, m.bn1 = _fold(m.conv1, m.bn1), nn.Identity()
-        for stage in (m.layer1, m.layer2, m.layer3):
-            for blk in stage:
-                blk.conv1, blk.bn1 = _fold(blk.conv1, blk.bn1), nn.Identity()
-                blk.conv2, blk.bn2 = _fold(blk.conv2, blk.bn2), nn.Identity()
-                blk.conv3, blk.bn3 = _fold(blk.conv3, blk.bn3), nn.Identity()
-                if blk.downsample is not None:
-                    blk.downsample = nn.Sequential(_fold(blk.downsample[0], blk.downsample[1]))
-        return m.eval()
+    def folded(self) -> nn.Module:
+        """Inference copy with every FrozenBN folded into the preceding conv and the bias /
+        residual / ReLU epilogues fused (same function up to fp32 rounding; removes ~110
+        pointwise launches per frame).  Built from the loaded model, never loaded into."""
+        return _FoldedResNet(self).eval()
 
     def forward(self, img):
         x = self.maxpool(F.relu(self.bn1(self.conv1(img))))
