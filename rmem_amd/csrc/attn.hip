@@ -3,12 +3,15 @@
 // See include/rmem_hip.h for the contract and DESIGN.md for the roofline accounting.
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
+#include <stdlib.h>
 
-// Key-tile band [t_lo, t_hi) (units of 128 keys) visible to query tile `qtile`
-// (128 queries) under the 15x15 window: rows y(q_lo)-7 .. y(q_hi)+7.
+// Key-tile band [t_lo, t_hi) (units of 128 keys) visible under the 15x15 window to the
+// 256-query super-tile that contains query tile `qtile` (128 queries): rows y(q_lo)-7 ..
+// y(q_hi)+7.  The band is defined per 256 queries so that the scores kernel (128-query tiles)
+// writes -- zeros where masked -- everything the 256-row P.V tile reads.
 __host__ __device__ inline void band_tiles(int qtile, int N, int h, int w, int& t_lo, int& t_hi) {
-  const int q_lo = qtile * 128;
-  int q_hi = qtile * 128 + 127;
+  const int q_lo = (qtile >> 1) * 256;
+  int q_hi = q_lo + 255;
   if (q_hi > N - 1) q_hi = N - 1;
   int y_lo = q_lo / w - 7;
   if (y_lo < 0) y_lo = 0;
@@ -193,9 +196,17 @@ struct PBlockedOperand {
     const long off = (long)kt * 2 * npad * 32;
     return TileView{hi + off, lo ? lo + off : nullptr, npad * 32};   // ld = one 32-key block
   }
+  // 32-key k-tile = exactly one key block: row r is 64 contiguous bytes (4 chunks)
+  __device__ __forceinline__ TileView tile32(int kt) const {
+    const long off = (long)kt * npad * 32;
+    return TileView{hi + off, lo ? lo + off : nullptr, 32};
+  }
   __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
     const bf16_t* b = plane ? t.lo : t.hi;
-    return reinterpret_cast<const u32x4_t*>(b + (c >> 2) * t.ld + (long)(row0 + r) * 32 + (c & 3) * 8);
+    long q = row0 + r;
+    q = q < npad ? q : npad - 1;
+    if (t.ld == 32) return reinterpret_cast<const u32x4_t*>(b + q * 32 + c * 8);      // tile32
+    return reinterpret_cast<const u32x4_t*>(b + (c >> 2) * t.ld + q * 32 + (c & 3) * 8);
   }
 };
 
@@ -210,6 +221,12 @@ struct VtOperand {
     const int t = kt / tps;
     const int phys = slot_map ? slot_map[t] : t;
     const long off = (long)phys * slot_stride + (kt - t * tps) * 64;
+    return TileView{hi + off, lo ? lo + off : nullptr, ld};
+  }
+  __device__ __forceinline__ TileView tile32(int kt) const {      // kt in units of 32 keys
+    const int t = kt / (2 * tps);
+    const int phys = slot_map ? slot_map[t] : t;
+    const long off = (long)phys * slot_stride + (kt - t * 2 * tps) * 32;
     return TileView{hi + off, lo ? lo + off : nullptr, ld};
   }
   __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
@@ -282,6 +299,77 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   }
 }
 
+// P.V, 256 x 128 tile, 8 waves, BK = 32 double-buffered (gemm_mainloop_db).  Work units
+// (query tile of 256, key split, column tile) are dealt to the 8 XCDs in contiguous ranges so
+// that the column tiles of one (query tile, split) pair run on one XCD (shared P tile in L2).
+template <int NS>
+__global__ __launch_bounds__(512) void pv_kernel2(rmem_pv_args a) {
+  using Cfg = GemmCfgDB<256, 128, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nct = (a.ncols + 127) / 128;
+  const int nq = (a.Npad + 255) / 256;
+  const int units = nq * a.ksplits * nct;
+  const int per_xcd = (units + 7) / 8;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int unit = xcd * per_xcd + j;
+  if (j >= per_xcd || unit >= units) return;
+  const int pair = unit / nct, ctile = unit - pair * nct;
+  const int z = pair / nq, qtile = pair - z * nq;
+  const int tps = a.Npad / 32;                 // 32-key tiles per slot
+  int k_lo, k_hi;
+  if (a.mode == 0) {
+    k_lo = 0;
+    k_hi = a.T * tps;
+  } else {
+    int t_lo, t_hi;
+    band_tiles(2 * qtile, a.N, a.h, a.w, t_lo, t_hi);
+    k_lo = 4 * t_lo;
+    k_hi = 4 * t_hi;
+  }
+  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
+  int lo = k_lo + z * per, hi = lo + per;
+  if (hi > k_hi) hi = k_hi;
+
+  PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 256};
+  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, a.slot_map, a.Npad / 64, ctile * 128, a.ncols};
+  GemmFrag<Cfg> f;
+  f.zero();
+  gemm_mainloop_db<Cfg>(f, lx, ly, lo, hi, smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / Cfg::WGN, wc = wave % Cfg::WGN;
+  float* out = a.part + (long)z * a.Npad * a.ncols;
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int col = ctile * 128 + wc * 64 + tn * 32 + (lane & 31);
+    if (col >= a.ncols) continue;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qtile * 256 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (q < a.Npad) out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
+      }
+  }
+}
+
+template <int NS>
+static int launch_pv2(const rmem_pv_args& a, hipStream_t s) {
+  using Cfg = GemmCfgDB<256, 128, NS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel2<NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    attr_set = true;
+  }
+  const int nct = (a.ncols + 127) / 128;
+  const int units = ((a.Npad + 255) / 256) * a.ksplits * nct;
+  dim3 grid(8 * ((units + 7) / 8));
+  hipLaunchKernelGGL((pv_kernel2<NS>), grid, dim3(512), Cfg::LDS_BYTES, s, a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 template <int NS>
 static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
   using Cfg = GemmCfg<128, 128, NS>;
@@ -306,11 +394,15 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
   if (!a.ph || !a.vh || !a.part || a.ncols <= 0) return RMEM_ERR_INVALID;
   if (a.mode == 1 && (a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
+  // pv_kernel (128x128, 4 waves, 2 blocks/CU) is the default; pv_kernel2 (256x128, 8 waves,
+  // BK=32 double-buffered) measures the same 80 us on the long-term read (both are co-limited by
+  // LDS traffic + MFMA issue) and is kept selectable for A/B runs.
+  static const bool use_v2 = getenv("RMEM_PV_V2") != nullptr;
   if (a.nsplit == 3) {
     if (!a.pl || !a.vl) return RMEM_ERR_INVALID;
-    return launch_pv<3>(a, s);
+    return use_v2 ? launch_pv2<3>(a, s) : launch_pv<3>(a, s);
   }
-  if (a.nsplit == 1) return launch_pv<1>(a, s);
+  if (a.nsplit == 1) return use_v2 ? launch_pv2<1>(a, s) : launch_pv<1>(a, s);
   return RMEM_ERR_INVALID;
 }
 

@@ -285,7 +285,7 @@ class DeAOTLSTT:
         hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 0)")
         sa.pass_ = 1
         hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 1)")
-        ktiles = T * Np // 64 if mode == 0 else 16
+        ktiles = T * Np // 64 if mode == 0 else 20
         ks = self._ksplits(ktiles)
         pa = hip.PVArgs()
         pa.mode, pa.ph, pa.pl = mode, ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
