@@ -123,6 +123,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         frame_step(t + k, masks)
+    host_issue = time.perf_counter() - t0     # host-side launch time (GPU work still in flight)
     if dist is not None:                      # collect per-clip masks (the only exchange step)
         from rmem_amd.driver import gather_masks
         gathered = gather_masks(masks[None], world)          # [world, steps, H, W] uint8 over RCCL
@@ -151,6 +152,7 @@ def main():
         "config": {"workload": f"{'R50-DeAOTL' if args.model == 'r50_deaotl' else 'R50-AOTL'} + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
                                f"batch=1 clip per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
                    "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
+                   "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
                    "parallelism": f"clips sharded 1-per-GPU x{world}, all-gather of masks"},
     }
     if rank == 0:

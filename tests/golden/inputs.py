@@ -56,3 +56,15 @@ def aot_block_inputs(layer, T, h, w, ref_frame):
     r = lambda *s: torch.from_numpy(rs.standard_normal(s).astype(np.float32))
     return dict(tgt=r(n, 256), bank_K=r(T, n, 256) * 1.5, bank_V=r(T, n, 256) * 0.7,
                 short_K=r(n, 256) * 1.5, short_V=r(n, 256) * 0.7, id_emb=r(n, 256) * 0.5)
+
+
+def multiobj_label(H, W, n_obj=12):
+    """n_obj rectangles on a 4-column grid (ids 1..n_obj) -> [1,1,H,W] float."""
+    lab = torch.zeros(1, 1, H, W)
+    rows = (n_obj + 3) // 4
+    for o in range(n_obj):
+        r, c = o // 4, o % 4
+        y0, y1 = int(H * (0.05 + 0.9 * r / rows)), int(H * (0.05 + 0.9 * (r + 0.8) / rows))
+        x0, x1 = int(W * (0.03 + 0.24 * c)), int(W * (0.03 + 0.24 * c + 0.19))
+        lab[:, :, y0:y1, x0:x1] = o + 1
+    return lab

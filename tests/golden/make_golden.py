@@ -154,6 +154,14 @@ def gen_aot_clips():
     print("clip aot 480p indexes", rec["indexes"][-1])
 
 
+# NOTE (>10 objects): the reference's multi-engine path cannot produce a golden vector -- all
+# sub-engines of AOTInferEngine share one model and therefore ONE LSTT memory state
+# (layers/transformer.py:1000-1007 lives on the shared module), so the second engine's
+# update_short_memories re-fuses already fused memories and raises a shape error
+# (transformer.py:1241: 63x768 vs 256x512) for 12 objects.  rmem_amd keeps the state per
+# engine; tests/test_hip_engine.py::test_multi_object_engines checks it by property instead.
+
+
 def run_reference_clip(engine, imgs, label0, out_hw, capture_logits=()):
     """Drives the reference engine with the evaluator's protocol
     (managers/evaluator.py:384-441,518-523) and records state after every frame."""

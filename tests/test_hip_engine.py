@@ -141,3 +141,38 @@ def test_480p_teacher_forced(nsplit, golden_dir):
     else:
         assert max(mism) <= 4000, mism        # plain bf16: ~1e-3..1e-2 logit noise near ties
     assert max(lerrs.values()) < (2e-2 if nsplit == 3 else 0.2)
+
+
+def test_multi_object_engines():
+    """12 objects -> two sub-engines (engines/aot_engine.py:604-712).  The reference cannot run
+    this case (its sub-engines share one LSTT memory state and crash, see
+    tests/golden/make_golden.py), so the property checked is: the aggregated logits equal the
+    soft aggregation of two independent single-engine runs on the separated masks."""
+    from inputs import multiobj_label
+    from rmem_amd.synth import synth_clip
+    H, W, frames = 97, 129, 5
+    imgs, _ = synth_clip(21, frames, H, W, 3)
+    lab = multiobj_label(H, W, 12).to(DEV)
+    cfg, cpu_model, gpu_model, eng = _build(1, 3, 2)
+    eng.add_reference_frame(imgs[0].to(DEV), lab, obj_nums=[12], frame_step=0)
+    assert len(eng.aot_engines) == 2
+    singles = []
+    for idx in range(2):
+        _, _, _, e1 = _build(1, 3, 2)
+        start = idx * 10 + 1
+        fg = ((lab >= start) & (lab <= start + 9)).float()
+        e1.add_reference_frame(imgs[0].to(DEV), (fg * lab - start + 1) * fg, obj_nums=[10], frame_step=0)
+        singles.append(e1)
+    for t in range(1, frames):
+        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(H, W))
+        assert logit.shape[1] == 21
+        parts = [e.match_propogate_one_frame(imgs[t].to(DEV), output_size=(H, W)) for e in singles]
+        ref = eng.soft_logit_aggregation(parts)
+        assert (logit - ref).abs().max().item() < 1e-4
+        pred = torch.argmax(logit, dim=1, keepdim=True).float()
+        cur = F.interpolate(pred, size=eng.input_size_2d, mode="nearest")
+        eng.update_memory(cur)
+        for idx, e1 in enumerate(singles):
+            start = idx * 10 + 1
+            fg = ((cur >= start) & (cur <= start + 9)).float()
+            e1.update_memory((fg * cur - start + 1) * fg)
