@@ -47,7 +47,7 @@ def parse():
                     help="3 = split-bf16 (fp32-class), 1 = plain bf16 attention/linears")
     ap.add_argument("--config", choices=["480p_k4", "720p_k8"], default="480p_k4",
                     help="480p_k4 = BASELINE.json configs[1] (the headline metric); 720p_k8 = configs[2] (stress)")
-    ap.add_argument("--model", choices=["r50_deaotl", "r50_aotl"], default="r50_deaotl",
+    ap.add_argument("--model", choices=["r50_deaotl", "r50_aotl", "swinb_aotl"], default="r50_deaotl",
                     help="r50_deaotl = headline metric; r50_aotl = AOT block (BASELINE.json configs[0] on GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
@@ -78,6 +78,8 @@ def main():
     mem_k = 4
     if args.config == "720p_k8":      # 720x1280 -> 721x1281 -> 46x81 tokens, K=8, 3 objects
         H_IN, W_IN, H_OUT, W_OUT, mem_k = 721, 1281, 720, 1280, 8
+    if args.model == "swinb_aotl" and args.config == "480p_k4":   # align_corners=False: 480x848 -> 30x53
+        H_IN, W_IN, H_OUT, W_OUT = 480, 848, 480, 854
     cfg = get_config(args.model, 1, mem_k - 1)
     cpu_model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
     load_synthetic_weights(cpu_model)
@@ -149,7 +151,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)" if args.nsplit == 3 else "bf16 (MFMA, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"{'R50-DeAOTL' if args.model == 'r50_deaotl' else 'R50-AOTL'} + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
+        "config": {"workload": f"{ {'r50_deaotl': 'R50-DeAOTL', 'r50_aotl': 'R50-AOTL', 'swinb_aotl': 'SwinB-AOTL'}[args.model] } + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
                                f"batch=1 clip per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
                    "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
                    "host_issue_ms_per_step": 1e3 * host_issue / args.steps,

@@ -357,10 +357,13 @@ def rmem_policy_step(w: List[float], indexes: List[int], ema_prev: Dict[int, flo
 
 # ----------------------------------------------------------------------------- B5
 def id_assign(label: Tensor, sd: SD, max_obj: int = 10, deaot: bool = True,
-              stride: int = 16, ksize: int = 17, pad: int = 8) -> Tensor:
+              stride: int = 16, ksize: int = 0, pad: int = -1) -> Tensor:
     """one_hot_mask + assign_identity + get_id_emb
     (utils/image.py:69-74, engines/aot_engine.py:208-232, models/deaot.py:65-69,
     models/aot.py:67-74,111-114).  label [1,1,H,W] float ids (255 = ignore) -> [N,256]."""
+    if ksize == 0:      # k17/p8 with MODEL_ALIGN_CORNERS, k16/p0 without (models/aot.py:67-84)
+        ksize = sd["patch_wise_id_bank.weight"].shape[-1]
+        pad = 8 if ksize == 17 else 0
     ids = torch.arange(0, max_obj + 1).view(1, -1, 1, 1).to(label.dtype)
     onehot = (label == ids).float()
     ign = (label == 255).float()

@@ -62,6 +62,15 @@ class ModelConfig:
             self.MODEL_ENGINE = "aotengine"
             self.MODEL_ENCODER = "resnet50"
             self.MODEL_ENCODER_DIM = [256, 512, 1024, 1024]
+        elif model == "swinb_aotl":
+            # configs/models/swinb_aotl.py:7-16 + the RMem attributes of r50_aotl.py:7-28: the
+            # shipped swinb config lacks them and AOT.__init__ raises
+            self.MODEL_NAME = "SwinB_AOTL_Temp_pe_Slot_4"
+            self.MODEL_VOS = "aot"
+            self.MODEL_ENGINE = "aotengine"
+            self.MODEL_ENCODER = "swin_base"
+            self.MODEL_ALIGN_CORNERS = False
+            self.MODEL_ENCODER_DIM = [128, 256, 512, 512]
         else:
             raise NotImplementedError(
                 f"model config '{model}' is not part of the hot-path scope")

@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .nets import ResNet50Encoder, FPNHead
+from .nets import ResNet50Encoder, FPNHead, SwinBEncoder
 
 
 class _DW(nn.Module):
@@ -200,14 +200,14 @@ class AOT(nn.Module):
 
     def __init__(self, cfg):
         super().__init__()
-        if cfg.MODEL_ENCODER != "resnet50":
+        if cfg.MODEL_ENCODER not in ("resnet50", "swin_base"):
             raise NotImplementedError(cfg.MODEL_ENCODER)
         if cfg.MODEL_ATT_HEADS != 8 or cfg.MODEL_SELF_HEADS != 8 or cfg.MODEL_LINEAR_Q:
             raise NotImplementedError("AOT hot path is built for 8 heads, MODEL_LINEAR_Q=False")
         self.cfg = cfg
         self.max_obj_num = cfg.MODEL_MAX_OBJ_NUM
         d = cfg.MODEL_ENCODER_EMBEDDING_DIM
-        self.encoder = ResNet50Encoder()
+        self.encoder = ResNet50Encoder() if cfg.MODEL_ENCODER == "resnet50" else SwinBEncoder()
         self.encoder_projector = nn.Conv2d(cfg.MODEL_ENCODER_DIM[-1], d, 1)
         self.LSTT = _LSTT(cfg.MODEL_LSTT_NUM, d)
         self.decoder = FPNHead(d * (cfg.MODEL_LSTT_NUM + 1), cfg.MODEL_MAX_OBJ_NUM + 1, hidden_dim=d,

@@ -5,5 +5,6 @@ that a reference checkpoint's ``state_dict`` loads by name.
 """
 from .resnet import ResNet50Encoder, FrozenBN
 from .fpn import FPNHead
+from .swin import SwinBEncoder
 
-__all__ = ["ResNet50Encoder", "FrozenBN", "FPNHead"]
+__all__ = ["ResNet50Encoder", "FrozenBN", "FPNHead", "SwinBEncoder"]

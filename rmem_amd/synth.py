@@ -39,6 +39,10 @@ def synth_tensor(name: str, shape, salt: int = 0) -> torch.Tensor:
         if leaf == "weight" and len(shape) == 1:      # FrozenBN scale
             base = 0.35 if ".bn3." in name else 1.0   # damp residual growth
             return torch.from_numpy((base * (1.0 + 0.1 * (rs.rand(*shape) - 0.5))).astype(np.float32))
+        if "relative_position_bias_table" in name:     # Swin window attention bias
+            return normal(0.5)
+        if len(shape) == 2:                             # Swin linears (qkv, proj, mlp, reduction)
+            return normal(1.0 / shape[1] ** 0.5)
         fan_in = shape[1] * shape[2] * shape[3]
         return normal((2.0 / fan_in) ** 0.5)
     if name in ("cur_pos_emb", "mem_pos_emb"):

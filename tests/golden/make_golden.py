@@ -162,6 +162,26 @@ def gen_aot_clips():
 # engine; tests/test_hip_engine.py::test_multi_object_engines checks it by property instead.
 
 
+def gen_swin():
+    """BASELINE.json configs[4] (SwinB-AOTL + RMem attributes injected): encoder features and a
+    small clip through the reference engine."""
+    cfg, model, engine = rh.build_reference("swinb_aotl", 1, 3, 2)
+    json.dump({k: list(v.shape) for k, v in model.state_dict().items()},
+              open(os.path.join(HERE, "manifest_swinb_aotl.json"), "w"), indent=0, sort_keys=True)
+    H, W, frames = 128, 160, 12
+    imgs, lab = synth_clip(7, frames, H, W, 3)
+    with torch.no_grad():
+        feats = model.encoder(imgs[0])
+    rec = run_reference_clip(engine, imgs, lab, (H, W), capture_logits=(frames - 1,))
+    meta = dict(H=H, W=W, frames=frames, gap=2, former=1, latter=3, seed=7, indexes=rec["indexes"],
+                hist=rec["hist"])
+    json.dump(meta, open(os.path.join(HERE, "clip_swin_k4_gap2.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, "clip_swin_k4_gap2.npz"), labels=torch.stack(rec["labels"]).numpy(),
+                        last_logits=rec["logits"][frames - 1].numpy(),
+                        enc16=feats[2].numpy().astype(np.float16), enc4_mean=feats[0].mean(dim=(2, 3)).numpy())
+    print("swin clip indexes", rec["indexes"][-1], "labels", sorted(set(torch.stack(rec["labels"]).flatten().tolist())))
+
+
 def run_reference_clip(engine, imgs, label0, out_hw, capture_logits=()):
     """Drives the reference engine with the evaluator's protocol
     (managers/evaluator.py:384-441,518-523) and records state after every frame."""
@@ -229,7 +249,7 @@ def gen_clips():
 
 def main():
     torch.manual_seed(0)
-    if "--aot-only" not in sys.argv:
+    if "--aot-only" not in sys.argv and "--swin-only" not in sys.argv:
         cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
         gen_manifest(model)
         gen_blocks(model)
@@ -238,8 +258,10 @@ def main():
     cfg, model, engine = rh.build_reference("r50_aotl", 1, 3, 5)
     man = {k: list(v.shape) for k, v in model.state_dict().items()}
     json.dump(man, open(os.path.join(HERE, "manifest_r50_aotl.json"), "w"), indent=0, sort_keys=True)
-    gen_aot_blocks(model)
-    gen_aot_clips()
+    if "--swin-only" not in sys.argv:
+        gen_aot_blocks(model)
+        gen_aot_clips()
+    gen_swin()
     os.system(f"du -sh {HERE}")
 
 

@@ -101,6 +101,14 @@ def build_reference(model_name="r50_deaotl", former=1, latter=3, gap=5, salt=0):
     ref = import_reference()
     with contextlib.redirect_stdout(io.StringIO()):
         cfg = ref["get_config"]("pre_vost", "golden", model_name)
+    if model_name == "swinb_aotl":
+        # the shipped swinb config lacks the RMem attributes (AOT.__init__ raises at aot.py:23);
+        # inject the r50_aotl values, as SURVEY.md section 7 prescribes
+        import importlib
+        donor = importlib.import_module("configs.models.r50_aotl").ModelConfig()
+        for k, v in donor.__dict__.items():
+            if not hasattr(cfg, k):
+                setattr(cfg, k, v)
     cfg.FORMER_MEM_LEN = former
     cfg.LATTER_MEM_LEN = latter
     with contextlib.redirect_stdout(io.StringIO()):

@@ -241,3 +241,33 @@ def test_aot_480p_clip_teacher_forced(golden_dir):
     assert idx_hist == meta["indexes"]
     assert max(mism) <= 12, mism
     assert max(lerrs.values()) < 2e-2
+
+
+def test_swin_aot_clip_teacher_forced(golden_dir):
+    """BASELINE.json configs[4]: SwinB-AOTL + RMem (MODEL_ALIGN_CORNERS=False: 16x16/stride-16 ID
+    bank, N = (H/16)*(W/16)) through the HIP engine against the reference's golden label maps."""
+    import copy
+    from rmem_amd.config import get_config
+    from rmem_amd.engine import build_engine
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+    meta = json.load(open(os.path.join(golden_dir, "clip_swin_k4_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_swin_k4_gap2.npz"))
+    model = build_vos_model("aot", get_config("swinb_aotl", meta["former"], meta["latter"])).eval()
+    load_synthetic_weights(model)
+    eng = build_engine("aotengine", phase="eval", aot_model=copy.deepcopy(model).to(DEV), gpu_id=0,
+                       long_term_mem_gap=meta["gap"])
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    mism, idx = [], []
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(meta["H"], meta["W"]))
+        pred = torch.argmax(logit, dim=1)[0]
+        mism.append(int((pred.cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        idx.append(list(eng.aot_engines[0].long_memories_indexes))
+    print("swin mismatching pixels per frame (of %d):" % (meta["H"] * meta["W"]), mism)
+    assert idx == meta["indexes"]
+    assert max(mism) <= 3, mism
+    assert np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max() < 3e-3

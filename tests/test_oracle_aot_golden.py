@@ -99,3 +99,33 @@ def test_aot_480p_clip(aot_model, golden_dir):
     assert mism.max() <= 4
     for t in (1, 15):
         assert np.abs(rec["logits"][t].numpy() - gold[f"logits_{t}"].astype(np.float32)).max() < 2e-2
+
+
+def test_swin_aot_clip(golden_dir):
+    """BASELINE.json configs[4]: SwinB-AOTL + RMem.  Our Swin-B module (same state_dict keys)
+    + the AOT oracle against the reference's encoder features and label maps (teacher-forced)."""
+    meta = json.load(open(os.path.join(golden_dir, "clip_swin_k4_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_swin_k4_gap2.npz"))
+    torch.manual_seed(0)
+    model = build_vos_model("aot", get_config("swinb_aotl", meta["former"], meta["latter"])).eval()
+    load_synthetic_weights(model)
+    man = json.load(open(os.path.join(golden_dir, "manifest_swinb_aotl.json")))
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == man
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    with torch.no_grad():
+        feats = model.encoder(imgs[0])
+    assert np.abs(feats[2].numpy() - gold["enc16"].astype(np.float32)).max() < 5e-3      # fp16-stored gold
+    assert np.abs(feats[0].mean(dim=(2, 3)).numpy() - gold["enc4_mean"]).max() < 1e-5
+    eng = OracleAOTEngine(model, long_term_mem_gap=meta["gap"])
+    eng.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    mism, idx = [], []
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t], output_size=(meta["H"], meta["W"]))
+        pred = torch.argmax(logit, dim=1)[0]
+        mism.append(int((pred.numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None]
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        idx.append(list(eng.long_memories_indexes))
+    assert idx == meta["indexes"]
+    assert max(mism) <= 1, mism
+    assert np.abs(eng.pred_id_logits.numpy() - gold["last_logits"]).max() < 1e-4
