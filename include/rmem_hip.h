@@ -261,6 +261,10 @@ int rmem_groupnorm_nchw(const float *x, float *y, int32_t C, int64_t HW, int32_t
 int rmem_bias_act_nchw(float *x, const float *bias, const float *residual, int32_t C, int64_t HW,
                        int32_t relu, void *stream);
 
+/* dst[0..n) = host_vals[0..n) (n <= 32), stream-ordered, payload in the kernel arguments: how
+ * the logical->physical slot map of the bank is published without a blocking H2D copy. */
+int rmem_set_ints(int32_t *dst, const int32_t *host_vals, int32_t n, void *stream);
+
 /* fp32 -> planes (weights at load time, fixtures in tests) */
 int rmem_split_planes(const float *x, int64_t n, rmem_bf16 *hi, rmem_bf16 *lo, void *stream);
 

@@ -742,4 +742,22 @@ extern "C" int rmem_bias_act_nchw(float* x, const float* bias, const float* resi
   return RMEM_OK;
 }
 
+// ------------------------------------------------------------------ slot map publish
+// The logical->physical slot map is tiny host state; writing it with a kernel whose payload
+// travels in the kernel arguments keeps the update stream-ordered WITHOUT the host-blocking
+// pageable H2D copy (which serialised host and GPU once per frame).
+struct IntPayload { int v[32]; };
+__global__ void set_ints_kernel(int* dst, IntPayload p, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+
+extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, void* stream) {
+  if (!dst || !host_vals || n <= 0 || n > 32) return RMEM_ERR_INVALID;
+  IntPayload p;
+  for (int i = 0; i < 32; ++i) p.v[i] = i < n ? host_vals[i] : 0;
+  hipLaunchKernelGGL(set_ints_kernel, dim3(1), dim3(32), 0, static_cast<hipStream_t>(stream), dst, p, n);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_abi_version(void) { return 3; }

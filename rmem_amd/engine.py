@@ -12,6 +12,7 @@ them (LSTT, ID assignment, memory bank, RMem eviction) is rmem_amd.lstt / csrc.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -28,8 +29,14 @@ class DeAOTEngine(nn.Module):
     the DeAOT (rmem_amd.lstt.DeAOTLSTT) and the AOT (rmem_amd.lstt_aot.AOTLSTT) models."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1,
-                 nsplit: int = 3):
+                 nsplit: int = 3, use_graphs: Optional[bool] = None):
         super().__init__()
+        if use_graphs is None:
+            use_graphs = os.environ.get("RMEM_NO_GRAPHS") is None
+        self.use_graphs = bool(use_graphs)
+        self._fg, self._ug = {}, {}          # hipGraphs: frame graphs / update graphs by key
+        self._g_img, self._g_lab = {}, {}    # static graph inputs per shape (graphs keep their address)
+        self._eager_frames = 0
         if short_term_mem_skip != 1:
             raise NotImplementedError("short_term_mem_skip != 1 (reference evaluator always uses 1)")
         self.cfg = aot_model.cfg
@@ -62,6 +69,8 @@ class DeAOTEngine(nn.Module):
             dev = next(self.AOT.parameters()).device
             cls = DeAOTLSTT if self.cfg.MODEL_VOS == "deaot" else AOTLSTT
             self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
+            self._fg, self._ug = {}, {}      # graphs hold pointers into the old LSTT buffers
+            self._g_img, self._g_lab = {}, {}
 
     def _label_u8(self, mask: torch.Tensor) -> torch.Tensor:
         """[1,1,H,W] (or [1,H,W]) label ids -> contiguous uint8 [H,W] on device."""
@@ -100,9 +109,60 @@ class DeAOTEngine(nn.Module):
     def match_propogate_one_frame(self, img=None, img_embs=None, mask=None, output_size=None):
         """aot_engine.py:398-436."""
         self.frame_step += 1
+        if self._graph_ok(img, img_embs):
+            return self._graphed_frame(img, output_size)
+        self._eager_frames += 1
         enc = self.AOT.encode_image(img) if img_embs is None else img_embs
         out = self.lstt.forward(self._tokens(enc[-1]), ref_frame=False)
         return self.decode_current_logits(enc, out, output_size)
+
+    # ------------------------------------------------------------------ hipGraph replay
+    # One frame = encoder -> LSTT -> decoder -> upsample is ~270 launches; issued eagerly the host
+    # needs as long as the GPU (DESIGN.md section 6).  In steady state the whole frame is replayed
+    # from a hipGraph instead.  A graph bakes in everything that is not read from device memory:
+    # the slot the frame is written to, the bank depth T and the tensor shapes -- that tuple is the
+    # cache key (<= cap + 2 graphs per clip geometry); the logical->physical slot map stays in a
+    # device array, so appends / evictions never invalidate a graph.
+    def _graph_ok(self, img, img_embs) -> bool:
+        return (self.use_graphs and img_embs is None and img is not None and img.is_cuda
+                and self._eager_frames >= 2 and not self.lstt._timing)
+
+    def _graphed_frame(self, img, output_size):
+        l = self.lstt
+        l._prepare(False)
+        osz = tuple(int(v) for v in output_size) if output_size is not None else None
+        key = (l.graph_key(), osz, tuple(img.shape))
+        g_img = self._g_img.get(tuple(img.shape))
+        if g_img is None:
+            g_img = self._g_img[tuple(img.shape)] = torch.empty_like(img)
+        g_img.copy_(img)
+        ent = self._fg.get(key)
+        if ent is None:
+            # capture every slot variant for this (T, shapes) at once: capture executes nothing,
+            # so the memory state is untouched, and no capture lands in a later frame
+            torch.cuda.synchronize()
+            saved = {k: getattr(l, k) for k in l.graph_variants()[0]}
+            for var in l.graph_variants():
+                for k, v in var.items():
+                    setattr(l, k, v)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    enc = self.AOT.encode_image(g_img)
+                    l.tgt.copy_(enc[-1][0].flatten(1).t())
+                    l._forward_device(False)
+                    logits = self.AOT.decode_id_logits(l.out, enc)
+                    for batch_idx, obj_num in enumerate(self.obj_nums):
+                        logits[batch_idx, (obj_num + 1):] = -1e10
+                    up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
+                                                                  align_corners=self.align_corners)
+                self._fg[(l.graph_key(), osz, tuple(img.shape))] = (g, logits, up)
+            for k, v in saved.items():
+                setattr(l, k, v)
+            ent = self._fg[key]
+        ent[0].replay()
+        l._finish(False)
+        self.pred_id_logits = ent[1]
+        return ent[2]
 
     def decode_current_logits(self, enc, lstt_out, output_size=None):      # aot_engine.py:438-465
         logits = self.AOT.decode_id_logits(lstt_out, enc)
@@ -119,13 +179,43 @@ class DeAOTEngine(nn.Module):
         """aot_engine.py:327-369."""
         if curr_mask.dim() == 4 and curr_mask.shape[1] > 1:
             raise NotImplementedError("probability masks are a training-only input (aot_engine.py:333-334)")
-        self.lstt.assign_identity(self._label_u8(curr_mask))
         update_long = False
         if (not self.cfg.NO_LONG_MEMORY) and \
                 self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
             update_long = True
             self.last_mem_step = self.frame_step
-        self.lstt.update_short_memories(update_long)
+        lab = self._label_u8(curr_mask)
+        l = self.lstt
+        if self.use_graphs and lab.is_cuda and self._eager_frames >= 2 and not l._timing:
+            g_lab = self._g_lab.get(tuple(lab.shape))
+            if g_lab is None:
+                g_lab = self._g_lab[tuple(lab.shape)] = torch.empty_like(lab)
+            g_lab.copy_(lab)
+            key = (l.update_key(update_long), tuple(lab.shape))
+            g = self._ug.get(key)
+            if g is None:
+                torch.cuda.synchronize()
+                saved = {k: getattr(l, k) for k in l.graph_variants()[0]}
+                for var in l.graph_variants():
+                    for k, v in var.items():
+                        setattr(l, k, v)
+                    for ul in (False, True):
+                        k2 = (l.update_key(ul), tuple(lab.shape))
+                        if k2 in self._ug:
+                            continue
+                        gg = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gg):
+                            l.assign_identity(g_lab)
+                            l._update_device(ul)
+                        self._ug[k2] = gg
+                for k, v in saved.items():
+                    setattr(l, k, v)
+                g = self._ug[key]
+            g.replay()
+            l._update_host(update_long)
+        else:
+            l.assign_identity(lab)
+            l.update_short_memories(update_long)
         if update_long:
             self.long_memories_indexes.append(self.frame_step)
             lg = F.interpolate(self.pred_id_logits, size=self.enc_size_2d, mode="bilinear",
@@ -138,8 +228,10 @@ class DeAOTInferEngine(nn.Module):
     """Multi-object wrapper (engines/aot_engine.py:571-725, deaot_engine.py:20-56)."""
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1,
-                 max_aot_obj_num=None, nsplit: int = 3, fold_bn: bool = True):
+                 max_aot_obj_num=None, nsplit: int = 3, fold_bn: bool = True,
+                 use_graphs: Optional[bool] = None):
         super().__init__()
+        self.use_graphs = use_graphs
         self.cfg = aot_model.cfg
         self.AOT = aot_model
         if fold_bn and hasattr(aot_model, "optimize_for_inference") and \
@@ -202,7 +294,7 @@ class DeAOTInferEngine(nn.Module):
                 eng.long_term_mem_gap = self.long_term_mem_gap
             else:
                 eng = DeAOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap,
-                                  self.short_term_mem_skip, self.nsplit)
+                                  self.short_term_mem_skip, self.nsplit, self.use_graphs)
             eng.eval()
             self.aot_engines.append(eng)
         for eng, m in zip(self.aot_engines, self.separate_mask(mask)):

@@ -96,7 +96,7 @@ EXPORTS = [
     "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
-    "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw",
+    "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
 ]
 
 
@@ -120,6 +120,7 @@ def load():
     lib.rmem_layernorm_red.argtypes = [c_p, i64, c_p, i32, i64, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64,
                                        c_p, i64, c_p]
     lib.rmem_bias_act_nchw.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p]
+    lib.rmem_set_ints.argtypes = [c_p, C.POINTER(i32), i32, c_p]
     lib.rmem_attn_scores.argtypes = [C.POINTER(ScoresArgs), c_p]
     lib.rmem_attn_pv.argtypes = [C.POINTER(PVArgs), c_p]
     lib.rmem_attn_combine.argtypes = [C.POINTER(CombineArgs), c_p]
@@ -257,3 +258,9 @@ def bias_act_nchw_(x: torch.Tensor, bias: torch.Tensor, residual=None, relu: boo
     check(load().rmem_bias_act_nchw(x.data_ptr(), bias.data_ptr(), ptr(residual), c, h * w, int(relu),
                                     stream_ptr()), "rmem_bias_act_nchw")
     return x
+
+
+def set_ints(dst: torch.Tensor, values):
+    """dst[:len(values)] = values (int32 device tensor), stream-ordered, no host-blocking copy."""
+    arr = (i32 * 32)(*(list(values) + [0] * (32 - len(values))))
+    check(load().rmem_set_ints(dst.data_ptr(), arr, 32, stream_ptr()), "rmem_set_ints")

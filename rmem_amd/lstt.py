@@ -342,25 +342,51 @@ class DeAOTLSTT:
         """DualBranchGPM.forward (transformer.py:765-824).  emb_nc: [N,256] fp32 on device.
         ref_frame=True is the curr_id_emb branch (:1125-1135): the frame attends itself
         and becomes bank slot 0; ``assign_identity`` must have been called before."""
-        N, Np, ns = self.N, self.Npad, self.nsplit
-        lib, st = hip.load(), hip.stream_ptr()
         self.tgt.copy_(emb_nc)
-        self.tgt_id.zero_()
+        self._prepare(ref_frame)
+        self._forward_device(ref_frame)
+        return self._finish(ref_frame)
+
+    def _prepare(self, ref_frame: bool):
+        """Host part of a forward pass: pick the slot the frame is written to and publish the
+        logical->physical slot map (one small H2D copy).  Nothing here is baked into a graph."""
         self.cur = self._free_slot()
-        cur = self.cur
         if ref_frame:
-            bank_map, short = [cur], cur
+            bank_map, short = [self.cur], self.cur
         else:
             bank_map, short = self.bank, self.short
-        T = len(bank_map)
-        m = torch.zeros(32, dtype=torch.int32)
-        m[:T] = torch.tensor(bank_map, dtype=torch.int32)
-        m[16] = short
-        self.maps.copy_(m)
+        self._T = len(bank_map)
+        vals = list(bank_map) + [0] * (16 - self._T) + [short]
+        hip.set_ints(self.maps, vals)
+
+    def _finish(self, ref_frame: bool):
+        self.mass_T = self._T
+        if ref_frame:                      # init_memory (transformer.py:993-998)
+            self.bank, self.short = [self.cur], self.cur
+            self.ema, self.visits = {}, {}
+        return self.out
+
+    def graph_key(self):
+        """Everything a captured forward depends on besides device memory contents."""
+        return (self._T, self.cur)
+
+    def graph_variants(self):
+        """Host states (attribute dicts) that differ only in graph_key() for the current T:
+        all of them are captured together the first time one is needed."""
+        return [{"cur": c} for c in range(self.S)]
+
+    def _forward_device(self, ref_frame: bool = False):
+        """Device part of a forward pass (reads self.tgt, writes self.out): kernel launches and
+        device-side memsets only -- hipGraph-capturable; depends on the host only through
+        graph_key() = (T, cur)."""
+        N, Np, ns = self.N, self.Npad, self.nsplit
+        lib, st = hip.load(), hip.stream_ptr()
+        self.tgt_id.zero_()
+        cur, T = self.cur, self._T
         map_bank = self.maps.data_ptr()
         map_short = self.maps.data_ptr() + 16 * 4
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
-        self.rowmax.zero_()   # one memset per frame would do; kept per call for clarity
+        self.rowmax.zero_()
 
         for l in range(self.L):
             W = self.lw[l]
@@ -445,17 +471,22 @@ class DeAOTLSTT:
                                       self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
                                       self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
                   "rmem_groupnorm2")
-        self.mass_T = T
-        if ref_frame:                      # init_memory (transformer.py:993-998)
-            self.bank, self.short = [cur], cur
-            self.ema, self.visits = {}, {}
-        return self.out
 
     # ------------------------------------------------------------------ memory update
     def update_short_memories(self, update_long: bool):
         """update_short_memories + update_long_term_memory (transformer.py:826-878).
         ``assign_identity`` must have been called with the current mask."""
+        self._update_device(update_long)
+        self._update_host(update_long)
+
+    def update_key(self, update_long: bool):
+        return (self.cur,)
+
+    def _update_device(self, update_long: bool):
+        """Capturable device part: the three ID_V GEMMs into the current slot (one launch)."""
         hip.linear_grouped([self._idv(l, self.cur, launch=False) for l in range(self.L)])
+
+    def _update_host(self, update_long: bool):
         self.short = self.cur
         if update_long:
             self.bank = self.bank + [self.cur]

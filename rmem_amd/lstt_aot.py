@@ -171,7 +171,7 @@ class AOTLSTT:
 
     def clear_memory(self):
         self.bank: List[int] = []
-        self.short_valid = False
+        self._flip = 0
         self.cur = 0
         self.mass_T = 0
         self.ema: Dict[int, float] = {}
@@ -240,19 +240,49 @@ class AOTLSTT:
     def forward(self, emb_nc: torch.Tensor, ref_frame: bool = False):
         """LongShortTermTransformer.forward (transformer.py:199-267): returns the three
         per-layer outputs after their LayerNorms, each [N,256] fp32."""
+        self.tgt.copy_(emb_nc)
+        self._prepare(ref_frame)
+        self._forward_device(ref_frame)
+        return self._finish(ref_frame)
+
+    def _prepare(self, ref_frame: bool):
+        self.cur = self._free_slot()
+        bank_map = [self.cur] if ref_frame else self.bank
+        self._T = len(bank_map)
+        hip.set_ints(self.maps, list(bank_map))
+
+    def _finish(self, ref_frame: bool):
+        self.mass_T = self._T
+        if ref_frame:                                                                   # init_memory (:438-453)
+            self.bank = [self.cur]
+            self._swap_short()
+            self.ema, self.visits = {}, {}
+        return self.outs
+
+    def _swap_short(self):
+        self._flip ^= 1
+
+    def graph_key(self):
+        # the short-term buffers alternate between two sets, so their parity is part of the key
+        return (self._T, self.cur, self._flip)
+
+    def graph_variants(self):
+        return [{"cur": c, "_flip": f} for c in range(self.S) for f in (0, 1)]
+
+    @property
+    def out(self):
+        return self.outs
+
+    def _forward_device(self, ref_frame: bool = False):
+        """Capturable device part (reads self.tgt, writes self.outs)."""
         N, Np, ns = self.N, self.Npad, self.nsplit
         lib = hip.load()
-        self.tgt.copy_(emb_nc)
-        self.cur = self._free_slot()
-        cur = self.cur
-        bank_map = [cur] if ref_frame else self.bank
-        T = len(bank_map)
-        m = torch.zeros(32, dtype=torch.int32)
-        m[:T] = torch.tensor(bank_map, dtype=torch.int32)
-        self.maps.copy_(m)
+        cur, T = self.cur, self._T
         map_bank = self.maps.data_ptr()
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
         kss = Np * 256
+        sK, sV = (self.sK, self.sV) if self._flip == 0 else (self.nsK, self.nsV)        # current short memory
+        nK, nV = (self.nsK, self.nsV) if self._flip == 0 else (self.sK, self.sV)        # written this frame
         for l in range(self.L):
             W = self.lw[l]
             curK, curV = self.bankK[l][cur], self.bankV[l][cur]
@@ -278,7 +308,7 @@ class AOTLSTT:
                            ldd0=256, nsplit=ns)
                 local_K, local_V = self.Qc, self.refV
             else:
-                local_K, local_V = self.sK[l], self.sV[l]
+                local_K, local_V = sK[l], sV[l]
             hip.check(lib.rmem_pe_bias_heads(self.Qc.data_ptr(), 256, self.cur_pe.data_ptr(), self.mem_pe.data_ptr(),
                                              rows, T, N, self.HEADS, self.bias_h.data_ptr(), hip.stream_ptr()),
                       "rmem_pe_bias_heads")
@@ -296,12 +326,12 @@ class AOTLSTT:
             hip.linear(self.ao_pl, W.Wp_st, N, 256, 256, ldx=256, ldy=256, bias=W.bp_st,
                        d0=self.tgt3[l].data_ptr(), ldd0=256, pa=self.t3_pl, ldpa=256, nsplit=ns)
             self._add_split(self.tgt, self.tgt3[l], dst=self.tgt)                       # tgt += tgt3 (:680)
-            hip.linear(self.t3_pl, W.Wqm, N, 256, 256, ldx=256, ldy=256, bias=W.bqm, d0=self.nsK[l].data_ptr(),
+            hip.linear(self.t3_pl, W.Wqm, N, 256, 256, ldx=256, ldy=256, bias=W.bqm, d0=nK[l].data_ptr(),
                        ldd0=256, nsplit=ns)                                             # local_K (:675)
             if ref_frame:
                 self._add_split(self.tgt3[l], self.idemb, out=self.t3id_pl)
                 hip.linear(self.t3id_pl, W.Wvm, N, 256, 256, ldx=256, ldy=256, bias=W.bvm,
-                           d0=self.nsV[l].data_ptr(), ldd0=256, nsplit=ns)
+                           d0=nV[l].data_ptr(), ldd0=256, nsplit=ns)
             # -- feed forward (transformer.py:683-687, basic.py:15-35)
             self._ln(self.tgt, W.norm3, self.z_pl)
             hip.linear(self.z_pl, W.W1, N, self.FF, 256, ldx=256, ldy=256, bias=W.b1, d0=self.a.data_ptr(),
@@ -315,18 +345,19 @@ class AOTLSTT:
             hip.linear(self.gdw_pl, W.W2, N, 256, self.FF, ldx=self.FF, ldy=self.FF, bias=W.b2,
                        d0=self.tgt.data_ptr(), ldd0=256, accumulate=True, nsplit=ns)
             self._ln(self.tgt, W.dnorm, None, of32=self.outs[l])                        # :248-259
-        self.mass_T = T
-        if ref_frame:                                                                   # init_memory (:438-453)
-            self.bank = [cur]
-            self.sK, self.nsK = self.nsK, self.sK
-            self.sV, self.nsV = self.nsV, self.sV
-            self.ema, self.visits = {}, {}
-        return self.outs
 
     # ------------------------------------------------------------------ memory update
     def update_short_memories(self, update_long: bool):
         """update_short_memories + update_long_term_memory (transformer.py:269-322)."""
+        self._update_device(update_long)
+        self._update_host(update_long)
+
+    def update_key(self, update_long: bool):
+        return (self.cur, self._flip, bool(update_long))
+
+    def _update_device(self, update_long: bool):
         N, Np, ns = self.N, self.Npad, self.nsplit
+        nV = self.nsV if self._flip == 0 else self.sV
         for l in range(self.L):
             W = self.lw[l]
             if update_long:      # curr_V <- linear_V(curr_V + id_emb) (only consumed by the long bank)
@@ -334,10 +365,11 @@ class AOTLSTT:
                 hip.linear(W.Wv, self.yid_pl, 256, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True,
                            pa=self.bankV[l][self.cur], ldpa=Np, nsplit=ns)
             self._add_split(self.tgt3[l], self.idemb, out=self.t3id_pl)
-            hip.linear(self.t3id_pl, W.Wvm, N, 256, 256, ldx=256, ldy=256, bias=W.bvm, d0=self.nsV[l].data_ptr(),
+            hip.linear(self.t3id_pl, W.Wvm, N, 256, 256, ldx=256, ldy=256, bias=W.bvm, d0=nV[l].data_ptr(),
                        ldd0=256, nsplit=ns)
-        self.sK, self.nsK = self.nsK, self.sK
-        self.sV, self.nsV = self.nsV, self.sV
+
+    def _update_host(self, update_long: bool):
+        self._swap_short()
         if update_long:
             self.bank = self.bank + [self.cur]
 

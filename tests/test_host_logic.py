@@ -148,3 +148,32 @@ def test_gather_masks_world2_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert got == unshard_order(4, 2)
+
+
+def test_c_abi_rejects_invalid_arguments():
+    """Argument validation happens before any launch, so it is testable without a GPU: every
+    entry point returns RMEM_ERR_INVALID (-1) instead of launching on bad arguments."""
+    import ctypes as C
+    from rmem_amd import hip
+    lib = hip.load()
+    a = hip.LinearArgs()
+    assert lib.rmem_linear(None, None) == -1
+    assert lib.rmem_linear(C.byref(a), None) == -1                      # M = N = K = 0
+    a.M, a.N, a.K, a.xh, a.yh, a.nsplit = 64, 64, 100, 1 << 20, 1 << 20, 1
+    assert lib.rmem_linear(C.byref(a), None) == -1                      # K not a multiple of 64
+    a.K, a.nsplit = 128, 2
+    assert lib.rmem_linear(C.byref(a), None) == -1                      # nsplit must be 1 or 3
+    a.nsplit = 3
+    assert lib.rmem_linear(C.byref(a), None) == -1                      # nsplit 3 needs lo planes
+    s = hip.ScoresArgs()
+    s.N, s.Npad, s.T = 100, 100, 1
+    assert lib.rmem_attn_scores(C.byref(s), None) == -1                 # Npad not a multiple of 128
+    p = hip.PVArgs()
+    assert lib.rmem_attn_pv(C.byref(p), None) == -1
+    m = hip.MHAArgs()
+    assert lib.rmem_mha_flash(C.byref(m), None) == -1
+    assert lib.rmem_pe_bias(None, 0, None, None, None, 0, 0, 0, None, None) == -1
+    assert lib.rmem_layernorm_split(None, 0, None, None, 0, 256, 1e-5, None, None, 0, None, 0, None) == -1
+    assert lib.rmem_id_assign(None, 0, 0, None, None, 12, 17, 16, 8, 1, 1, 256, None, None, 1e-5,
+                              None, None, 0, None, 0, None) == -1
+    assert lib.rmem_set_ints(None, None, 0, None) == -1
