@@ -245,7 +245,7 @@ struct VtOperand {
 // and pairs of one XCD share a key split, i.e. the same V^T key range.
 __host__ __device__ inline int pv_chunk(int npairs) { return (npairs + 7) / 8; }
 
-template <int NS>
+template <int NS, int ABL = 0>
 __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   using Cfg = GemmCfg<128, 128, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
 
   GemmFrag<Cfg> f;
   f.zero();
-  gemm_mainloop<Cfg>(f, lx, ly, lo, hi, smem);
+  gemm_mainloop<Cfg, PBlockedOperand, VtOperand, ABL>(f, lx, ly, lo, hi, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -297,6 +297,158 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
         out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
       }
   }
+}
+
+// P.V v3 -- the default.  Ablations of pv_kernel (tools/kbench.py, RMEM_PV_ABL) showed the
+// 128x128 LDS-staged loop is bound by LDS traffic, not by MFMA issue or L2: fragment reads
+// cost 40 us and staging writes 22 us of its 80 us, removing the MFMAs changes nothing.  Here
+// the P operand never touches LDS: its blocked layout [key/32][Npad][32] is exactly the MFMA
+// A-fragment shape (lane (row, kg) reads 16 contiguous bytes), so every wave loads its own A
+// fragments from L2 straight into registers, each k-step's registers being refilled for the
+// next k-tile right after their MFMAs issue (a full k-tile of latency cover).  Only V^T goes
+// through LDS -- half the fragment reads, half the staging writes -- and, at 32 KB per stage,
+// double-buffered with ONE barrier per k-tile.
+template <int NS>
+__global__ __launch_bounds__(256) void pv_kernel3(rmem_pv_args a) {
+  constexpr int NPL = NS == 1 ? 1 : 2;
+  constexpr int Y_BYTES = 128 * 128;            // 128 columns x 64 keys bf16
+  constexpr int STAGE = NPL * Y_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nct = (a.ncols + 127) / 128;
+  const int nq = a.Npad / 128;
+  const int npairs = nq * a.ksplits;
+  const int chunk = pv_chunk(npairs);
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int pl = jb / nct;
+  const int ctile = jb - pl * nct;
+  const int pair = xcd * chunk + pl;
+  if (pl >= chunk || pair >= npairs) return;
+  const int z = pair / nq;
+  const int qtile = pair - z * nq;
+  const int tps = a.Npad / 64;
+  int k_lo, k_hi;
+  if (a.mode == 0) {
+    k_lo = 0;
+    k_hi = a.T * tps;
+  } else {
+    int t_lo, t_hi;
+    band_tiles(qtile, a.N, a.h, a.w, t_lo, t_hi);
+    k_lo = 2 * t_lo;
+    k_hi = 2 * t_hi;
+  }
+  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
+  int lo = k_lo + z * per, hi = lo + per;
+  if (hi > k_hi) hi = k_hi;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  using Cfg = GemmCfg<128, 128, NS>;   // fragment-index helpers only
+  GemmFrag<Cfg> f;
+  f.zero();
+  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, a.slot_map, tps, ctile * 128, a.ncols};
+  const bf16_t* pp[2] = {a.ph, a.pl};
+  // this lane's A-fragment source: row (query) and the 16-byte slot inside a 32-key block
+  const long arow[2] = {(long)(qtile * 128 + wr * 64 + (lane & 31)) * 32 + (lane >> 5) * 8,
+                        (long)(qtile * 128 + wr * 64 + 32 + (lane & 31)) * 32 + (lane >> 5) * 8};
+  const long kbstride = (long)a.Npad * 32;
+
+  if (lo < hi) {
+    u32x4_t yr[NPL * 4];
+    bf16x8_t af[4][NPL][2];      // [k-step][plane][tm]
+    auto gload_v = [&](int kt) __attribute__((always_inline)) {
+      const TileView ty = ly.tile(kt);
+      static_for<NPL>([&](auto P) {
+        static_for<4>([&](auto I) {
+          const int id = tid + I.value * 256;
+          yr[P.value * 4 + I.value] = *ly.ptr(ty, P.value, id >> 3, id & 7);
+        });
+      });
+    };
+    auto lstore_v = [&](char* stage) __attribute__((always_inline)) {
+      static_for<NPL>([&](auto P) {
+        static_for<4>([&](auto I) {
+          const int id = tid + I.value * 256;
+          *reinterpret_cast<u32x4_t*>(stage + P.value * Y_BYTES + lds_swz(id >> 3, id & 7)) = yr[P.value * 4 + I.value];
+        });
+      });
+    };
+    auto gload_a = [&](int kt, auto KS) __attribute__((always_inline)) {
+      constexpr int ks = decltype(KS)::value;
+      const long off = ((long)kt * 2 + (ks >> 1)) * kbstride + (ks & 1) * 16;
+      static_for<NPL>([&](auto P) {
+        static_for<2>([&](auto TMi) {
+          af[ks][P.value][TMi.value] =
+              *reinterpret_cast<const bf16x8_t*>(pp[P.value] + off + arow[TMi.value]);
+        });
+      });
+    };
+    gload_v(lo);
+    static_for<4>([&](auto KS) { gload_a(lo, KS); });
+    lstore_v(smem);
+    if (lo + 1 < hi) gload_v(lo + 1);
+    __syncthreads();
+    for (int kt = lo; kt < hi; ++kt) {
+      char* cur = smem + ((kt - lo) & 1) * STAGE;
+      char* nxt = smem + (((kt - lo) & 1) ^ 1) * STAGE;
+      const bool more = kt + 1 < hi;
+      if (more) {
+        lstore_v(nxt);                         // V^T tile kt+1 (loaded during the previous iteration)
+        if (kt + 2 < hi) gload_v(kt + 2);
+      }
+      static_for<4>([&](auto KS) {
+        constexpr int ks = decltype(KS)::value;
+        const int chunkb = ks * 2 + (lane >> 5);
+        bf16x8_t b[NPL][2];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            b[p][j] = *reinterpret_cast<const bf16x8_t*>(cur + p * Y_BYTES +
+                                                         lds_swz(wc * 64 + j * 32 + (lane & 31), chunkb));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (NS == 3) {
+              f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], b[1][j], f.acc[i][j], 0, 0, 0);
+              f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], b[0][j], f.acc[i][j], 0, 0, 0);
+            }
+            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], b[0][j], f.acc[i][j], 0, 0, 0);
+          }
+        if (more) gload_a(kt + 1, KS);           // refill this k-step's A registers for the next k-tile
+      });
+      __syncthreads();
+    }
+  }
+  float* out = a.part + (long)z * a.Npad * a.ncols;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
+    if (col >= a.ncols) continue;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
+        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
+      }
+  }
+}
+
+template <int NS>
+static int launch_pv3(const rmem_pv_args& a, hipStream_t s) {
+  constexpr int LDS = 2 * (NS == 1 ? 1 : 2) * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel3<NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int nct = (a.ncols + 127) / 128;
+  const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
+  hipLaunchKernelGGL((pv_kernel3<NS>), dim3(8 * chunk * nct), dim3(256), LDS, s, a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
 }
 
 // P.V, 256 x 128 tile, 8 waves, BK = 32 double-buffered (gemm_mainloop_db).  Work units
@@ -370,19 +522,19 @@ static int launch_pv2(const rmem_pv_args& a, hipStream_t s) {
   return RMEM_OK;
 }
 
-template <int NS>
+template <int NS, int ABL = 0>
 static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
   using Cfg = GemmCfg<128, 128, NS>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel<NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel<NS, ABL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     attr_set = true;
   }
   const int nct = (a.ncols + 127) / 128;
   const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
   dim3 grid(8 * chunk * nct);
-  hipLaunchKernelGGL((pv_kernel<NS>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pv_kernel<NS, ABL>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }
@@ -398,11 +550,18 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   // BK=32 double-buffered) measures the same 80 us on the long-term read (both are co-limited by
   // LDS traffic + MFMA issue) and is kept selectable for A/B runs.
   static const bool use_v2 = getenv("RMEM_PV_V2") != nullptr;
+  static const bool use_v3 = getenv("RMEM_PV_V3") != nullptr;
+  static const int abl = getenv("RMEM_PV_ABL") ? atoi(getenv("RMEM_PV_ABL")) : 0;   // kbench ablations
   if (a.nsplit == 3) {
     if (!a.pl || !a.vl) return RMEM_ERR_INVALID;
+    if (abl == 1) return launch_pv<3, 1>(a, s);
+    if (abl == 2) return launch_pv<3, 2>(a, s);
+    if (abl == 3) return launch_pv<3, 3>(a, s);
+    if (abl == 4) return launch_pv<3, 4>(a, s);
+    if (use_v3) return launch_pv3<3>(a, s);
     return use_v2 ? launch_pv2<3>(a, s) : launch_pv<3>(a, s);
   }
-  if (a.nsplit == 1) return use_v2 ? launch_pv2<1>(a, s) : launch_pv<1>(a, s);
+  if (a.nsplit == 1) return use_v3 ? launch_pv3<1>(a, s) : (use_v2 ? launch_pv2<1>(a, s) : launch_pv<1>(a, s));
   return RMEM_ERR_INVALID;
 }
 

@@ -105,7 +105,9 @@ __device__ __forceinline__ int frag_col(int wc, int tn, int lane) {
   return wc * Cfg::WN + tn * 32 + (lane & 31);
 }
 
-template <class Cfg, class LX, class LY>
+// ABL: timing ablations for tools/kbench.py (results are garbage): 1 = no global loads in the
+// loop, 2 = no LDS staging writes in the loop, 3 = no MFMAs, 4 = no fragment reads + no MFMAs.
+template <class Cfg, class LX, class LY, int ABL = 0>
 __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, const LY& ly,
                                               int kt_begin, int kt_end, char* smem) {
   constexpr int NPL = Cfg::NPL, XCH = Cfg::XCH, YCH = Cfg::YCH, TM = Cfg::TM, TN = Cfg::TN;
@@ -147,11 +149,15 @@ __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, co
   };
 
   gload(kt_begin);
+  if constexpr (ABL == 2) lstore();
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     __syncthreads();  // all waves finished reading the previous tile
-    lstore();
+    if constexpr (ABL != 2) lstore();
     __syncthreads();
-    if (kt + 1 < kt_end) gload(kt + 1);  // in flight while this tile is multiplied
+    if constexpr (ABL != 1) {
+      if (kt + 1 < kt_end) gload(kt + 1);  // in flight while this tile is multiplied
+    }
+    if constexpr (ABL == 4) continue;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int chunk = ks * 2 + (lane >> 5);

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--cap", type=int, default=4)
     ap.add_argument("--nsplit", type=int, default=3)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default="", help="pv: run only the long-term scores + P.V kernels (for --pmc runs)")
     args = ap.parse_args()
     from rmem_amd import hip
     from rmem_amd.config import get_config
@@ -80,6 +81,33 @@ def main():
         L.rowmax.zero_()
         L._attention(ws, mode, Tn, kpl, vpl, smap, qpl, bias, U, False, which)
 
+    if args.only == "pv":
+        ksl = L._ksplits(T * Np // 64)
+        f0 = None
+
+        def scores(mode, Tn, pass_, ws, kpl, smap, qpl, bias):
+            sa = hip.ScoresArgs()
+            sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, kpl.hi.data_ptr(), kpl.lo.data_ptr(), L.k_slot_stride
+            sa.slot_map, sa.T, sa.N, sa.Npad = smap, Tn, N, Np
+            sa.qh, sa.ql, sa.scale = qpl.hi.data_ptr(), qpl.lo.data_ptr(), L.scale
+            sa.bias = bias.data_ptr() if bias is not None else None
+            sa.ldr, sa.h, sa.w = L.ldr, L.h, L.w
+            sa.rowmax = L.rowmax[0].data_ptr()
+            sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+            sa.lpart, sa.nparts, sa.nsplit, sa.pass_ = ws.lpart.data_ptr(), Tn * Np // 64, L.nsplit, pass_
+            hip.check(lib.rmem_attn_scores(C.byref(sa), hip.stream_ptr()), "scores")
+        L.rowmax.zero_()
+        scores(0, T, 0, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe)
+        scores(0, T, 1, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe)
+        pa = hip.PVArgs()
+        pa.mode, pa.ph, pa.pl = 0, L.ws_main.P.hi.data_ptr(), L.ws_main.P.lo.data_ptr()
+        pa.vh, pa.vl, pa.v_slot_stride = L.bankV[1].hi.data_ptr(), L.bankV[1].lo.data_ptr(), L.v_slot_stride
+        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = map_bank, T, N, Np, 1024
+        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = L.h, L.w, L.ws_main.part.data_ptr(), ksl, L.nsplit
+        for _ in range(args.iters):
+            hip.check(lib.rmem_attn_pv(C.byref(pa), hip.stream_ptr()), "pv")
+        torch.cuda.synchronize()
+        return
     res["attn_long_total"] = timeit(lambda: attention(L.ws_main, 0, T, L.bankK[1], L.bankV[1], map_bank, L.Qpe,
                                                       L.bias_pe, L.Ucat, 0), args.iters)
     res["attn_window_total"] = timeit(lambda: attention(L.ws_side, 1, 1, L.bankK[1], L.bankV[1], map_short, curK,
