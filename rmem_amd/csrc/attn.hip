@@ -3,7 +3,6 @@
 // See include/rmem_hip.h for the contract and DESIGN.md for the roofline accounting.
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
-#include <stdlib.h>
 
 // Key-tile band [t_lo, t_hi) (units of 128 keys) visible under the 15x15 window to the
 // 256-query super-tile that contains query tile `qtile` (128 queries): rows y(q_lo)-7 ..
@@ -196,16 +195,10 @@ struct PBlockedOperand {
     const long off = (long)kt * 2 * npad * 32;
     return TileView{hi + off, lo ? lo + off : nullptr, npad * 32};   // ld = one 32-key block
   }
-  // 32-key k-tile = exactly one key block: row r is 64 contiguous bytes (4 chunks)
-  __device__ __forceinline__ TileView tile32(int kt) const {
-    const long off = (long)kt * npad * 32;
-    return TileView{hi + off, lo ? lo + off : nullptr, 32};
-  }
   __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
     const bf16_t* b = plane ? t.lo : t.hi;
     long q = row0 + r;
     q = q < npad ? q : npad - 1;
-    if (t.ld == 32) return reinterpret_cast<const u32x4_t*>(b + q * 32 + c * 8);      // tile32
     return reinterpret_cast<const u32x4_t*>(b + (c >> 2) * t.ld + q * 32 + (c & 3) * 8);
   }
 };
@@ -221,12 +214,6 @@ struct VtOperand {
     const int t = kt / tps;
     const int phys = slot_map ? slot_map[t] : t;
     const long off = (long)phys * slot_stride + (kt - t * tps) * 64;
-    return TileView{hi + off, lo ? lo + off : nullptr, ld};
-  }
-  __device__ __forceinline__ TileView tile32(int kt) const {      // kt in units of 32 keys
-    const int t = kt / (2 * tps);
-    const int phys = slot_map ? slot_map[t] : t;
-    const long off = (long)phys * slot_stride + (kt - t * 2 * tps) * 32;
     return TileView{hi + off, lo ? lo + off : nullptr, ld};
   }
   __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
@@ -245,7 +232,7 @@ struct VtOperand {
 // and pairs of one XCD share a key split, i.e. the same V^T key range.
 __host__ __device__ inline int pv_chunk(int npairs) { return (npairs + 7) / 8; }
 
-template <int NS, int ABL = 0>
+template <int NS>
 __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   using Cfg = GemmCfg<128, 128, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,7 +267,7 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
 
   GemmFrag<Cfg> f;
   f.zero();
-  gemm_mainloop<Cfg, PBlockedOperand, VtOperand, ABL>(f, lx, ly, lo, hi, smem);
+  gemm_mainloop<Cfg>(f, lx, ly, lo, hi, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -299,242 +286,19 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   }
 }
 
-// P.V v3 -- the default.  Ablations of pv_kernel (tools/kbench.py, RMEM_PV_ABL) showed the
-// 128x128 LDS-staged loop is bound by LDS traffic, not by MFMA issue or L2: fragment reads
-// cost 40 us and staging writes 22 us of its 80 us, removing the MFMAs changes nothing.  Here
-// the P operand never touches LDS: its blocked layout [key/32][Npad][32] is exactly the MFMA
-// A-fragment shape (lane (row, kg) reads 16 contiguous bytes), so every wave loads its own A
-// fragments from L2 straight into registers, each k-step's registers being refilled for the
-// next k-tile right after their MFMAs issue (a full k-tile of latency cover).  Only V^T goes
-// through LDS -- half the fragment reads, half the staging writes -- and, at 32 KB per stage,
-// double-buffered with ONE barrier per k-tile.
 template <int NS>
-__global__ __launch_bounds__(256) void pv_kernel3(rmem_pv_args a) {
-  constexpr int NPL = NS == 1 ? 1 : 2;
-  constexpr int Y_BYTES = 128 * 128;            // 128 columns x 64 keys bf16
-  constexpr int STAGE = NPL * Y_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nct = (a.ncols + 127) / 128;
-  const int nq = a.Npad / 128;
-  const int npairs = nq * a.ksplits;
-  const int chunk = pv_chunk(npairs);
-  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int pl = jb / nct;
-  const int ctile = jb - pl * nct;
-  const int pair = xcd * chunk + pl;
-  if (pl >= chunk || pair >= npairs) return;
-  const int z = pair / nq;
-  const int qtile = pair - z * nq;
-  const int tps = a.Npad / 64;
-  int k_lo, k_hi;
-  if (a.mode == 0) {
-    k_lo = 0;
-    k_hi = a.T * tps;
-  } else {
-    int t_lo, t_hi;
-    band_tiles(qtile, a.N, a.h, a.w, t_lo, t_hi);
-    k_lo = 2 * t_lo;
-    k_hi = 2 * t_hi;
-  }
-  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
-  int lo = k_lo + z * per, hi = lo + per;
-  if (hi > k_hi) hi = k_hi;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  using Cfg = GemmCfg<128, 128, NS>;   // fragment-index helpers only
-  GemmFrag<Cfg> f;
-  f.zero();
-  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, a.slot_map, tps, ctile * 128, a.ncols};
-  const bf16_t* pp[2] = {a.ph, a.pl};
-  // this lane's A-fragment source: row (query) and the 16-byte slot inside a 32-key block
-  const long arow[2] = {(long)(qtile * 128 + wr * 64 + (lane & 31)) * 32 + (lane >> 5) * 8,
-                        (long)(qtile * 128 + wr * 64 + 32 + (lane & 31)) * 32 + (lane >> 5) * 8};
-  const long kbstride = (long)a.Npad * 32;
-
-  if (lo < hi) {
-    u32x4_t yr[NPL * 4];
-    bf16x8_t af[4][NPL][2];      // [k-step][plane][tm]
-    auto gload_v = [&](int kt) __attribute__((always_inline)) {
-      const TileView ty = ly.tile(kt);
-      static_for<NPL>([&](auto P) {
-        static_for<4>([&](auto I) {
-          const int id = tid + I.value * 256;
-          yr[P.value * 4 + I.value] = *ly.ptr(ty, P.value, id >> 3, id & 7);
-        });
-      });
-    };
-    auto lstore_v = [&](char* stage) __attribute__((always_inline)) {
-      static_for<NPL>([&](auto P) {
-        static_for<4>([&](auto I) {
-          const int id = tid + I.value * 256;
-          *reinterpret_cast<u32x4_t*>(stage + P.value * Y_BYTES + lds_swz(id >> 3, id & 7)) = yr[P.value * 4 + I.value];
-        });
-      });
-    };
-    auto gload_a = [&](int kt, auto KS) __attribute__((always_inline)) {
-      constexpr int ks = decltype(KS)::value;
-      const long off = ((long)kt * 2 + (ks >> 1)) * kbstride + (ks & 1) * 16;
-      static_for<NPL>([&](auto P) {
-        static_for<2>([&](auto TMi) {
-          af[ks][P.value][TMi.value] =
-              *reinterpret_cast<const bf16x8_t*>(pp[P.value] + off + arow[TMi.value]);
-        });
-      });
-    };
-    gload_v(lo);
-    static_for<4>([&](auto KS) { gload_a(lo, KS); });
-    lstore_v(smem);
-    if (lo + 1 < hi) gload_v(lo + 1);
-    __syncthreads();
-    for (int kt = lo; kt < hi; ++kt) {
-      char* cur = smem + ((kt - lo) & 1) * STAGE;
-      char* nxt = smem + (((kt - lo) & 1) ^ 1) * STAGE;
-      const bool more = kt + 1 < hi;
-      if (more) {
-        lstore_v(nxt);                         // V^T tile kt+1 (loaded during the previous iteration)
-        if (kt + 2 < hi) gload_v(kt + 2);
-      }
-      static_for<4>([&](auto KS) {
-        constexpr int ks = decltype(KS)::value;
-        const int chunkb = ks * 2 + (lane >> 5);
-        bf16x8_t b[NPL][2];
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            b[p][j] = *reinterpret_cast<const bf16x8_t*>(cur + p * Y_BYTES +
-                                                         lds_swz(wc * 64 + j * 32 + (lane & 31), chunkb));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if constexpr (NS == 3) {
-              f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], b[1][j], f.acc[i][j], 0, 0, 0);
-              f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], b[0][j], f.acc[i][j], 0, 0, 0);
-            }
-            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], b[0][j], f.acc[i][j], 0, 0, 0);
-          }
-        if (more) gload_a(kt + 1, KS);           // refill this k-step's A registers for the next k-tile
-      });
-      __syncthreads();
-    }
-  }
-  float* out = a.part + (long)z * a.Npad * a.ncols;
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
-    if (col >= a.ncols) continue;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
-        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
-      }
-  }
-}
-
-template <int NS>
-static int launch_pv3(const rmem_pv_args& a, hipStream_t s) {
-  constexpr int LDS = 2 * (NS == 1 ? 1 : 2) * 128 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel3<NS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  const int nct = (a.ncols + 127) / 128;
-  const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
-  hipLaunchKernelGGL((pv_kernel3<NS>), dim3(8 * chunk * nct), dim3(256), LDS, s, a);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
-}
-
-// P.V, 256 x 128 tile, 8 waves, BK = 32 double-buffered (gemm_mainloop_db).  Work units
-// (query tile of 256, key split, column tile) are dealt to the 8 XCDs in contiguous ranges so
-// that the column tiles of one (query tile, split) pair run on one XCD (shared P tile in L2).
-template <int NS>
-__global__ __launch_bounds__(512) void pv_kernel2(rmem_pv_args a) {
-  using Cfg = GemmCfgDB<256, 128, NS>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nct = (a.ncols + 127) / 128;
-  const int nq = (a.Npad + 255) / 256;
-  const int units = nq * a.ksplits * nct;
-  const int per_xcd = (units + 7) / 8;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int unit = xcd * per_xcd + j;
-  if (j >= per_xcd || unit >= units) return;
-  const int pair = unit / nct, ctile = unit - pair * nct;
-  const int z = pair / nq, qtile = pair - z * nq;
-  const int tps = a.Npad / 32;                 // 32-key tiles per slot
-  int k_lo, k_hi;
-  if (a.mode == 0) {
-    k_lo = 0;
-    k_hi = a.T * tps;
-  } else {
-    int t_lo, t_hi;
-    band_tiles(2 * qtile, a.N, a.h, a.w, t_lo, t_hi);
-    k_lo = 4 * t_lo;
-    k_hi = 4 * t_hi;
-  }
-  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
-  int lo = k_lo + z * per, hi = lo + per;
-  if (hi > k_hi) hi = k_hi;
-
-  PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 256};
-  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, a.slot_map, a.Npad / 64, ctile * 128, a.ncols};
-  GemmFrag<Cfg> f;
-  f.zero();
-  gemm_mainloop_db<Cfg>(f, lx, ly, lo, hi, smem);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave / Cfg::WGN, wc = wave % Cfg::WGN;
-  float* out = a.part + (long)z * a.Npad * a.ncols;
-#pragma unroll
-  for (int tn = 0; tn < Cfg::TN; ++tn) {
-    const int col = ctile * 128 + wc * 64 + tn * 32 + (lane & 31);
-    if (col >= a.ncols) continue;
-#pragma unroll
-    for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = qtile * 256 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (q < a.Npad) out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
-      }
-  }
-}
-
-template <int NS>
-static int launch_pv2(const rmem_pv_args& a, hipStream_t s) {
-  using Cfg = GemmCfgDB<256, 128, NS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel2<NS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    attr_set = true;
-  }
-  const int nct = (a.ncols + 127) / 128;
-  const int units = ((a.Npad + 255) / 256) * a.ksplits * nct;
-  dim3 grid(8 * ((units + 7) / 8));
-  hipLaunchKernelGGL((pv_kernel2<NS>), grid, dim3(512), Cfg::LDS_BYTES, s, a);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
-}
-
-template <int NS, int ABL = 0>
 static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
   using Cfg = GemmCfg<128, 128, NS>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel<NS, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel<NS>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     attr_set = true;
   }
   const int nct = (a.ncols + 127) / 128;
   const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
   dim3 grid(8 * chunk * nct);
-  hipLaunchKernelGGL((pv_kernel<NS, ABL>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pv_kernel<NS>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }
@@ -546,22 +310,11 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
   if (!a.ph || !a.vh || !a.part || a.ncols <= 0) return RMEM_ERR_INVALID;
   if (a.mode == 1 && (a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
-  // pv_kernel (128x128, 4 waves, 2 blocks/CU) is the default; pv_kernel2 (256x128, 8 waves,
-  // BK=32 double-buffered) measures the same 80 us on the long-term read (both are co-limited by
-  // LDS traffic + MFMA issue) and is kept selectable for A/B runs.
-  static const bool use_v2 = getenv("RMEM_PV_V2") != nullptr;
-  static const bool use_v3 = getenv("RMEM_PV_V3") != nullptr;
-  static const int abl = getenv("RMEM_PV_ABL") ? atoi(getenv("RMEM_PV_ABL")) : 0;   // kbench ablations
   if (a.nsplit == 3) {
     if (!a.pl || !a.vl) return RMEM_ERR_INVALID;
-    if (abl == 1) return launch_pv<3, 1>(a, s);
-    if (abl == 2) return launch_pv<3, 2>(a, s);
-    if (abl == 3) return launch_pv<3, 3>(a, s);
-    if (abl == 4) return launch_pv<3, 4>(a, s);
-    if (use_v3) return launch_pv3<3>(a, s);
-    return use_v2 ? launch_pv2<3>(a, s) : launch_pv<3>(a, s);
+    return launch_pv<3>(a, s);
   }
-  if (a.nsplit == 1) return use_v3 ? launch_pv3<1>(a, s) : (use_v2 ? launch_pv2<1>(a, s) : launch_pv<1>(a, s));
+  if (a.nsplit == 1) return launch_pv<1>(a, s);
   return RMEM_ERR_INVALID;
 }
 

@@ -105,9 +105,7 @@ __device__ __forceinline__ int frag_col(int wc, int tn, int lane) {
   return wc * Cfg::WN + tn * 32 + (lane & 31);
 }
 
-// ABL: timing ablations for tools/kbench.py (results are garbage): 1 = no global loads in the
-// loop, 2 = no LDS staging writes in the loop, 3 = no MFMAs, 4 = no fragment reads + no MFMAs.
-template <class Cfg, class LX, class LY, int ABL = 0>
+template <class Cfg, class LX, class LY>
 __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, const LY& ly,
                                               int kt_begin, int kt_end, char* smem) {
   constexpr int NPL = Cfg::NPL, XCH = Cfg::XCH, YCH = Cfg::YCH, TM = Cfg::TM, TN = Cfg::TN;
@@ -149,15 +147,11 @@ __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, co
   };
 
   gload(kt_begin);
-  if constexpr (ABL == 2) lstore();
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     __syncthreads();  // all waves finished reading the previous tile
-    if constexpr (ABL != 2) lstore();
+    lstore();
     __syncthreads();
-    if constexpr (ABL != 1) {
-      if (kt + 1 < kt_end) gload(kt + 1);  // in flight while this tile is multiplied
-    }
-    if constexpr (ABL == 4) continue;
+    if (kt + 1 < kt_end) gload(kt + 1);  // in flight while this tile is multiplied
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int chunk = ks * 2 + (lane >> 5);
@@ -188,113 +182,5 @@ __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, co
           f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], f.acc[i][j], 0, 0, 0);
         }
     }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Double-buffered variant for 8-wave (512-thread) blocks: BK = 32 (one 64-byte row per tile
-// row), two LDS stages, ONE barrier per k-tile.  Iteration kt: write the registers holding
-// tile kt+1 into stage (kt+1)&1, immediately re-issue the global loads for tile kt+2 (they
-// have the whole MFMA phase to land), multiply tile kt out of stage kt&1, barrier.
-// Waves are arranged WGM x WGN over the BM x BN tile; every wave owns 64 x 64.
-// LDS image: 16-byte chunk c of row r (4 chunks per row) at chunk position c ^ ((r >> 2) & 3):
-// conflict-free for the b128 fragment reads (16 rows distinct mod 16 -> 16 distinct 16-byte
-// slots of the 256-byte bank row) and for the staging writes.
-template <int BM_, int BN_, int NSPLIT_>
-struct GemmCfgDB {
-  static constexpr int BM = BM_, BN = BN_, NSPLIT = NSPLIT_;
-  static constexpr int BK = 32;
-  static constexpr int THREADS = 512;
-  static constexpr int WGM = BM / 64, WGN = BN / 64;
-  static_assert(WGM * WGN == 8, "8 waves of 64x64");
-  static constexpr int WM = 64, WN = 64, TM = 2, TN = 2;
-  static constexpr int NPL = (NSPLIT == 1) ? 1 : 2;
-  static constexpr int XCH = BM * 4 / THREADS, YCH = BN * 4 / THREADS;
-  static constexpr int X_BYTES = BM * 64, Y_BYTES = BN * 64;
-  static constexpr int STAGE_BYTES = NPL * (X_BYTES + Y_BYTES);
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-};
-
-__device__ __forceinline__ int lds_swz32(int row, int chunk) {
-  return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
-}
-
-// operands expose tile32(kt32) / ptr(view, plane, row, chunk) with 4 chunks of 8 bf16 per row
-template <class Cfg, class LX, class LY>
-__device__ __forceinline__ void gemm_mainloop_db(GemmFrag<Cfg>& f, const LX& lx, const LY& ly, int kt_begin,
-                                                 int kt_end, char* smem) {
-  constexpr int NPL = Cfg::NPL, XCH = Cfg::XCH, YCH = Cfg::YCH, TM = Cfg::TM, TN = Cfg::TN;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / Cfg::WGN, wc = wave % Cfg::WGN;
-  if (kt_begin >= kt_end) return;
-  u32x4_t xr[NPL * XCH], yr[NPL * YCH];
-  auto gload = [&](int kt) __attribute__((always_inline)) {
-    const TileView tx = lx.tile32(kt);
-    const TileView ty = ly.tile32(kt);
-    static_for<NPL>([&](auto P) {
-      static_for<XCH>([&](auto I) {
-        const int id = tid + I.value * Cfg::THREADS;
-        xr[P.value * XCH + I.value] = *lx.ptr(tx, P.value, id >> 2, id & 3);
-      });
-      static_for<YCH>([&](auto I) {
-        const int id = tid + I.value * Cfg::THREADS;
-        yr[P.value * YCH + I.value] = *ly.ptr(ty, P.value, id >> 2, id & 3);
-      });
-    });
-  };
-  auto lstore = [&](char* stage) __attribute__((always_inline)) {
-    static_for<NPL>([&](auto P) {
-      char* xb = stage + P.value * Cfg::X_BYTES;
-      char* yb = stage + NPL * Cfg::X_BYTES + P.value * Cfg::Y_BYTES;
-      static_for<XCH>([&](auto I) {
-        const int id = tid + I.value * Cfg::THREADS;
-        *reinterpret_cast<u32x4_t*>(xb + lds_swz32(id >> 2, id & 3)) = xr[P.value * XCH + I.value];
-      });
-      static_for<YCH>([&](auto I) {
-        const int id = tid + I.value * Cfg::THREADS;
-        *reinterpret_cast<u32x4_t*>(yb + lds_swz32(id >> 2, id & 3)) = yr[P.value * YCH + I.value];
-      });
-    });
-  };
-  gload(kt_begin);
-  lstore(smem);
-  if (kt_begin + 1 < kt_end) gload(kt_begin + 1);
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    char* cur = smem + ((kt - kt_begin) & 1) * Cfg::STAGE_BYTES;
-    char* nxt = smem + (((kt - kt_begin) & 1) ^ 1) * Cfg::STAGE_BYTES;
-    if (kt + 1 < kt_end) {
-      lstore(nxt);                              // tile kt+1 (loaded during the previous iteration)
-      if (kt + 2 < kt_end) gload(kt + 2);       // in flight during this iteration's MFMAs
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int chunk = ks * 2 + (lane >> 5);
-      bf16x8_t a[NPL][TM], b[NPL][TN];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) {
-        const char* xb = cur + p * Cfg::X_BYTES;
-        const char* yb = cur + NPL * Cfg::X_BYTES + p * Cfg::Y_BYTES;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          a[p][i] = *reinterpret_cast<const bf16x8_t*>(xb + lds_swz32(wr * 64 + i * 32 + (lane & 31), chunk));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          b[p][j] = *reinterpret_cast<const bf16x8_t*>(yb + lds_swz32(wc * 64 + j * 32 + (lane & 31), chunk));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (Cfg::NSPLIT == 3) {
-            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], f.acc[i][j], 0, 0, 0);
-            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], f.acc[i][j], 0, 0, 0);
-          }
-          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], f.acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
   }
 }
