@@ -268,6 +268,28 @@ int rmem_set_ints(int32_t *dst, const int32_t *host_vals, int32_t n, void *strea
 /* fp32 -> planes (weights at load time, fixtures in tests) */
 int rmem_split_planes(const float *x, int64_t n, rmem_bf16 *hi, rmem_bf16 *lo, void *stream);
 
+/* Clip-driver post-processing.  One decoder output per test-time
+ * augmentation: logits [C][h][w] fp32 (batch 1), flip != 0 when that augmentation ran on the
+ * horizontally flipped frame. */
+typedef struct {
+  const float *logits;
+  int32_t h, w;
+  int32_t flip;
+} rmem_label_src;
+
+/* label[y][x] = argmax_c mean_a softmax_c(unflip_a(bilinear_a(logits_a -> H0 x W0)))
+ * = F.interpolate(mode="bilinear", align_corners) of engines/aot_engine.py:457-463 followed by
+ * flip_tensor / softmax / mean / argmax of managers/evaluator.py:424-441.  With one source the
+ * softmax is skipped (monotone).  n_src <= 8, C <= 16; first maximum wins. */
+int rmem_labels_from_logits(const rmem_label_src *srcs, int32_t n_src, int32_t C,
+                            int32_t align_corners, int32_t H0, int32_t W0, uint8_t *label,
+                            void *stream);
+
+/* dst = F.interpolate(flip ? flip_x(src) : src, size=(Hd,Wd), mode="nearest") on uint8 label
+ * maps (managers/evaluator.py:506-523, utils/image.py:107-111). */
+int rmem_label_resize_nearest(const uint8_t *src, int32_t Hs, int32_t Ws, uint8_t *dst,
+                              int32_t Hd, int32_t Wd, int32_t flip, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

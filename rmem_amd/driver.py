@@ -1,16 +1,37 @@
-"""Clip-level driver pieces: static clip sharding across ranks and the one exchange step
-(gather of per-clip masks).  The reference distributes clips through an mp.Queue work queue
-and funnels statistics through a second queue (tools/eval.py:137-143,
-managers/evaluator.py:276-295,589-613); clips are independent, so here the shard is static
-(clip i -> rank i mod world) and the masks are collected with one all-gather
-(RCCL on GPUs, gloo in the CPU tests)."""
+"""Clip-level driver: the caller side of the engine API.
+
+Restates the per-clip loop of the reference evaluator (managers/evaluator.py:337-568) on top
+of ``rmem_amd.engine``: one engine per test-time augmentation, reference frame, then per frame
+match -> (un-flip, softmax, mean, argmax) -> label -> (flip, nearest resize) -> update_memory,
+mid-clip new objects, the evaluator's memory-gap rule and its CUDA-event timing window, the
+palette-PNG writer (utils/image.py:90-105) and the input-size rule of the test transform
+(dataloaders/video_transforms.py:575-621).
+
+Post-processing runs on device: when every engine has a single sub-engine (<= 10 objects) the
+decoder logits of all augmentations go through ONE kernel (``rmem_labels_from_logits``) that
+upsamples, un-flips, averages and arg-maxes straight to a uint8 label map, and one
+``rmem_label_resize_nearest`` per engine produces the map fed back to ``update_memory`` -- the
+18 MB fp32 probability volume the reference materialises per augmentation never exists.  The
+generic path (several sub-engines, whose logits are aggregated at output resolution:
+engines/aot_engine.py:650-673,704-712) uses the same torch ops as the reference.
+
+Also here: static clip sharding across ranks and the one exchange step (all-gather of masks).
+The reference distributes clips through an mp.Queue work queue and funnels statistics through
+a second queue (tools/eval.py:137-143, managers/evaluator.py:276-295,589-613); clips are
+independent, so the shard is static (clip i -> rank i mod world) and the masks are collected
+with one all-gather (RCCL on GPUs, gloo in the CPU tests)."""
 from __future__ import annotations
 
-from typing import List
+import os
+import threading
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
+import numpy as np
 import torch
+import torch.nn.functional as F
 
 
+# ------------------------------------------------------------------ sharding / exchange
 def shard_clips(n_clips: int, world: int, rank: int) -> List[int]:
     """Clip ids owned by `rank` (round-robin, as balanced as the reference's queue for
     equal-length clips)."""
@@ -38,3 +59,268 @@ def unshard_order(n_clips: int, world: int) -> List[int]:
     assuming n_clips % world == 0."""
     per = n_clips // world
     return [r + world * j for r in range(world) for j in range(per)]
+
+
+# ------------------------------------------------------------------ evaluator rules
+def memory_gap(num_frames: int, no_memory_gap: bool = False) -> int:
+    """long_term_mem_gap chosen per clip (managers/evaluator.py:327-331)."""
+    gap = max(int(round(num_frames / 30)), 5)
+    if no_memory_gap:
+        gap = int(round(gap / 4))
+    return gap
+
+
+def restrict_size(h: int, w: int, max_size: Optional[int] = 800, min_size: Optional[int] = None,
+                  scale: float = 1.0, align_corners: bool = True, max_stride: int = 16):
+    """Network input size for an h x w frame (MultiRestrictSize,
+    dataloaders/video_transforms.py:575-621): cap the long (or short) edge, apply the
+    multi-scale factor, snap to stride (+1 when align_corners)."""
+    if (min_size is not None) and (max_size is not None):
+        raise ValueError("give min_size or max_size, not both")
+    sc = None
+    if min_size is not None:
+        short = w if h > w else h
+        if short > min_size:
+            sc = float(min_size) / short
+    else:
+        long_edge = h if h > w else w
+        if long_edge > max_size:
+            sc = float(max_size) / long_edge
+    new_h, new_w = (h, w) if sc is None else (sc * h, sc * w)
+    new_h, new_w = int(new_h * scale), int(new_w * scale)
+    if align_corners:
+        if (new_h - 1) % max_stride != 0:
+            new_h = int(np.around((new_h - 1) / max_stride) * max_stride + 1)
+        if (new_w - 1) % max_stride != 0:
+            new_w = int(np.around((new_w - 1) / max_stride) * max_stride + 1)
+    else:
+        if new_h % max_stride != 0:
+            new_h = int(np.around(new_h / max_stride) * max_stride)
+        if new_w % max_stride != 0:
+            new_w = int(np.around(new_w / max_stride) * max_stride)
+    return new_h, new_w
+
+
+def mask_palette() -> List[int]:
+    """The 256-entry palette of the result PNGs (utils/image.py `_palette`): the PASCAL-VOC
+    bit-interleave colour map for ids 0..21 with 192 written as 191, a grey ramp above."""
+    pal: List[int] = []
+    for i in range(256):
+        if i >= 22:
+            pal += [i, i, i]
+            continue
+        rgb, c = [0, 0, 0], i
+        for j in range(8):
+            for ch in range(3):
+                rgb[ch] |= ((c >> ch) & 1) << (7 - j)
+            c >>= 3
+        pal += [191 if v == 192 else v for v in rgb]
+    return pal
+
+
+def _write_png(mask: np.ndarray, path: str, squeeze_idx):
+    from PIL import Image
+    if squeeze_idx is not None:                                # utils/image.py:91-97
+        un = np.zeros_like(mask)
+        for idx in range(1, len(squeeze_idx)):
+            un += ((mask == idx) * squeeze_idx[idx]).astype(np.uint8)
+        mask = un
+    im = Image.fromarray(mask).convert("P")
+    im.putpalette(mask_palette())
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    im.save(path)
+
+
+def save_mask(mask: torch.Tensor, path: str, squeeze_idx=None, background: bool = True):
+    """Palette PNG of a uint8 label map (utils/image.py:90-105; the reference also writes from
+    a background thread).  Returns the thread (or None)."""
+    m = mask.detach().cpu().numpy().astype(np.uint8)
+    if not background:
+        _write_png(m, path, squeeze_idx)
+        return None
+    th = threading.Thread(target=_write_png, args=(m, path, squeeze_idx))
+    th.start()
+    return th
+
+
+# ------------------------------------------------------------------ the clip loop
+class ClipResult:
+    """masks: uint8 [F-1, H0, W0] (frames 1..F-1) on the engines' device; frame_ms: per-frame
+    time of the reference's window (match .. update_memory); names / obj_idx as in the samples."""
+
+    def __init__(self):
+        self.masks: Optional[torch.Tensor] = None
+        self.frame_ms: List[float] = []
+        self.names: List[str] = []
+        self.obj_idx = None
+        self.gap = None
+
+    @property
+    def fps(self) -> float:
+        return 1e3 * len(self.frame_ms) / max(sum(self.frame_ms), 1e-9)
+
+
+class ClipDriver:
+    """Runs clips through one engine per augmentation (managers/evaluator.py:337-353).
+
+    `samples` for one frame is what the reference's dataloader yields: a list (one entry per
+    augmentation) of dicts with 'current_img' [1,3,H,W] float, optionally 'current_label'
+    [1,1,H0,W0], and 'meta' = {'flip', 'obj_num', 'height', 'width', 'obj_idx',
+    'current_name'} (dataloaders/eval_datasets.py).  All augmentations share the model weights
+    (the reference deep-copies the model per augmentation because its LSTT state lives in the
+    module, managers/evaluator.py:348; here the state lives in the engine)."""
+
+    def __init__(self, model, cfg=None, gpu_id: int = 0, engine_factory: Optional[Callable] = None,
+                 fused_post: Optional[bool] = None, no_memory_gap: Optional[bool] = None,
+                 fixed_gap: Optional[int] = None):
+        self.model = model
+        self.cfg = cfg if cfg is not None else model.cfg
+        self.gpu_id = gpu_id
+        self.engines: list = []
+        self._factory = engine_factory
+        self.fused_post = fused_post
+        self.no_memory_gap = bool(getattr(self.cfg, "NO_MEMORY_GAP", False)) if no_memory_gap is None \
+            else no_memory_gap
+        self.fixed_gap = fixed_gap
+        self.align_corners = bool(self.cfg.MODEL_ALIGN_CORNERS)
+
+    # -- engines
+    def _engine(self, aug_idx: int):
+        while len(self.engines) <= aug_idx:
+            if self._factory is not None:
+                eng = self._factory(self.model)
+            else:
+                from .engine import build_engine
+                eng = build_engine(self.cfg.MODEL_ENGINE, phase="eval", aot_model=self.model,
+                                   gpu_id=self.gpu_id,
+                                   long_term_mem_gap=getattr(self.cfg, "TEST_LONG_TERM_MEM_GAP", 9999))
+            eng.eval()
+            self.engines.append(eng)
+        return self.engines[aug_idx]
+
+    def _can_fuse(self, engines, sample0) -> bool:
+        """Fused device post-processing needs the un-aggregated decoder logits of every
+        augmentation: single sub-engine (<= 10 objects) engines on a GPU."""
+        if self.fused_post is False or not sample0["current_img"].is_cuda:
+            return False
+        return all(len(getattr(e, "aot_engines", ())) == 1 for e in engines)
+
+    # -- post-processing, generic path: the reference's torch ops (evaluator.py:424-441)
+    @staticmethod
+    def _labels_generic(logits: Sequence[torch.Tensor], flips: Sequence[bool]) -> torch.Tensor:
+        probs = []
+        for lg, fl in zip(logits, flips):
+            if fl:
+                lg = lg.flip(3)
+            probs.append(torch.softmax(lg, dim=1))
+        prob = torch.mean(torch.cat(probs, dim=0), dim=0, keepdim=True)
+        return torch.argmax(prob, dim=1, keepdim=True).to(torch.uint8)[0, 0].contiguous()
+
+    @staticmethod
+    def _resize_generic(label: torch.Tensor, size, flip: bool) -> torch.Tensor:
+        lab = label[None, None].float()
+        if flip:
+            lab = lab.flip(3)
+        return F.interpolate(lab, size=size, mode="nearest")
+
+    @torch.no_grad()
+    def run_clip(self, frames: Iterable[List[Dict]], num_frames: Optional[int] = None,
+                 save_dir: Optional[str] = None, on_frame: Optional[Callable] = None) -> ClipResult:
+        """One clip.  `frames` yields the per-frame sample lists; `num_frames` (len of the clip)
+        sets the memory gap (evaluator.py:327-331) -- required unless `frames` has a len().
+        `on_frame(frame_idx, label_u8, engines)` is called after each propagated frame."""
+        if num_frames is None:
+            num_frames = len(frames)        # type: ignore[arg-type]
+        gap = self.fixed_gap if self.fixed_gap is not None else memory_gap(num_frames, self.no_memory_gap)
+        res = ClipResult()
+        res.gap = gap
+        for e in self.engines:
+            e.restart_engine()
+        labels_out: List[torch.Tensor] = []
+        timers = []
+        writers = []
+        on_cuda = False
+        for frame_idx, samples in enumerate(frames):
+            engines = [self._engine(i) for i in range(len(samples))]
+            flips = [bool(s["meta"]["flip"]) for s in samples]
+            meta0 = samples[0]["meta"]
+            ori_hw = (int(meta0["height"]), int(meta0["width"]))
+            obj_nums = [int(v) for v in meta0["obj_num"]] if isinstance(meta0["obj_num"], (list, tuple)) \
+                else [int(meta0["obj_num"])]
+            on_cuda = samples[0]["current_img"].is_cuda
+            if frame_idx == 0:
+                res.obj_idx = meta0.get("obj_idx")
+                for e, s in zip(engines, samples):
+                    e.long_term_mem_gap = gap
+                    img = s["current_img"]
+                    lab = F.interpolate(s["current_label"].float(), size=img.shape[2:], mode="nearest").int()
+                    e.add_reference_frame(img, lab, frame_step=0, obj_nums=obj_nums)
+                continue
+            if on_cuda:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
+            fuse = self._can_fuse(engines, samples[0])
+            logits, new_obj_label = [], None
+            for e, s, fl in zip(engines, samples, flips):
+                lg = e.match_propogate_one_frame(s["current_img"], output_size=None if fuse else ori_hw)
+                logits.append(lg)
+                if (not fl) and s.get("current_label") is not None and new_obj_label is None:
+                    new_obj_label = s["current_label"].to(lg.device).float()
+            if fuse:
+                from . import hip
+                label = hip.labels_from_logits([lg.contiguous() for lg in logits], flips, ori_hw,
+                                               self.align_corners)
+            else:
+                label = self._labels_generic(logits, flips)
+            if new_obj_label is not None:                        # evaluator.py:484-508
+                new = new_obj_label[0, 0].to(torch.uint8)
+                label = torch.where(new == 0, label, new)
+                new_nums = [int(label.max().item())]
+                for e, s, fl in zip(engines, samples, flips):
+                    cur = self._resize_generic(label, e.input_size_2d, fl)
+                    e.add_reference_frame(s["current_img"], cur, obj_nums=new_nums, frame_step=frame_idx)
+            else:                                                # evaluator.py:509-523
+                for e, fl in zip(engines, flips):
+                    if fuse:
+                        from . import hip
+                        cur = hip.label_resize_nearest(label, e.input_size_2d, fl)[None, None]
+                    else:
+                        cur = self._resize_generic(label, e.input_size_2d, fl)
+                    e.update_memory(cur)
+            if on_cuda:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record()
+                timers.append((t0, t1))
+            labels_out.append(label)
+            if on_frame is not None:
+                on_frame(frame_idx, label, engines)
+            name = meta0.get("current_name", f"{frame_idx:05d}")
+            name = name[0] if isinstance(name, (list, tuple)) else name
+            res.names.append(str(name))
+            if save_dir is not None:
+                writers.append(save_mask(label, os.path.join(save_dir, str(name).split(".")[0] + ".png"),
+                                         res.obj_idx))
+        if on_cuda:
+            torch.cuda.synchronize()
+            res.frame_ms = [a.elapsed_time(b) for a, b in timers]
+        for th in writers:
+            if th is not None:
+                th.join()
+        res.masks = torch.stack(labels_out) if labels_out else None
+        return res
+
+
+def make_samples(img: torch.Tensor, label: Optional[torch.Tensor], ori_hw, obj_num: int, flip_aug: bool = False,
+                 name: str = "", obj_idx=None) -> List[Dict]:
+    """Sample list for one frame from a network-sized image [1,3,H,W] (and an original-sized
+    label [1,1,H0,W0] or None), with the flipped copy when `flip_aug`
+    (dataloaders/video_transforms.py:639-652)."""
+    out = []
+    for fl in ([False, True] if flip_aug else [False]):
+        s = {"current_img": img.flip(3) if fl else img,
+             "meta": {"flip": fl, "obj_num": [obj_num], "height": int(ori_hw[0]), "width": int(ori_hw[1]),
+                      "obj_idx": obj_idx, "current_name": name}}
+        if label is not None:
+            s["current_label"] = label.flip(3) if fl else label
+        out.append(s)
+    return out

@@ -102,7 +102,10 @@ class DeAOTEngine(nn.Module):
         self.lstt.assign_identity(self._label_u8(mask))
         out = self.lstt.forward(self._tokens(enc[-1]), ref_frame=True)
         self.last_mem_step = frame_step
-        self.long_memories_indexes.append(self.frame_step)
+        # A reference frame re-initialises the bank to one slot.  The reference keeps the old
+        # frame indexes (aot_engine.py:322-323) and then raises at the next long-term update
+        # (transformer.py:954, size mismatch); here the index list restarts with the bank.
+        self.long_memories_indexes = [self.frame_step]
         self.decode_current_logits(enc, out)
 
     @torch.no_grad()

@@ -91,12 +91,17 @@ class MHACombineArgs(C.Structure):
     ]
 
 
+class LabelSrc(C.Structure):
+    _fields_ = [("logits", c_p), ("h", i32), ("w", i32), ("flip", i32)]
+
+
 EXPORTS = [
     "rmem_abi_version", "rmem_linear", "rmem_attn_scores", "rmem_attn_pv", "rmem_attn_combine",
     "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
+    "rmem_labels_from_logits", "rmem_label_resize_nearest",
 ]
 
 
@@ -141,6 +146,8 @@ def load():
     lib.rmem_add_split.argtypes = [c_p, c_p, i64, c_p, c_p, c_p, c_p]
     lib.rmem_gn_gelu_tokens.argtypes = [c_p, i32, i32, i32, c_p, c_p, f32, c_p, c_p, c_p]
     lib.rmem_pe_bias_heads.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]
+    lib.rmem_labels_from_logits.argtypes = [C.POINTER(LabelSrc), i32, i32, i32, i32, i32, c_p, c_p]
+    lib.rmem_label_resize_nearest.argtypes = [c_p, i32, i32, c_p, i32, i32, i32, c_p]
     _LIB = lib
     return lib
 
@@ -264,3 +271,36 @@ def set_ints(dst: torch.Tensor, values):
     """dst[:len(values)] = values (int32 device tensor), stream-ordered, no host-blocking copy."""
     arr = (i32 * 32)(*(list(values) + [0] * (32 - len(values))))
     check(load().rmem_set_ints(dst.data_ptr(), arr, 32, stream_ptr()), "rmem_set_ints")
+
+
+def labels_from_logits(logits_list, flips, out_hw, align_corners: bool, out: torch.Tensor = None) -> torch.Tensor:
+    """uint8 label map [H0,W0] = argmax_c mean_aug softmax(unflip(bilinear(logits -> out_hw))).
+    logits_list: batch-1 fp32 [1,C,h,w] (or [C,h,w]) contiguous device tensors, one per augmentation."""
+    H0, W0 = int(out_hw[0]), int(out_hw[1])
+    srcs = (LabelSrc * len(logits_list))()
+    Cn = None
+    for i, (lg, fl) in enumerate(zip(logits_list, flips)):
+        if lg.dtype != torch.float32 or not lg.is_contiguous() or not lg.is_cuda:
+            raise RmemError("labels_from_logits needs contiguous fp32 device logits")
+        c, h, w = lg.shape[-3:]
+        if lg.numel() != c * h * w or (Cn is not None and c != Cn):
+            raise RmemError("labels_from_logits: batch 1 and equal channel counts only")
+        Cn = c
+        srcs[i].logits, srcs[i].h, srcs[i].w, srcs[i].flip = lg.data_ptr(), h, w, int(bool(fl))
+    if out is None:
+        out = torch.empty((H0, W0), dtype=torch.uint8, device=logits_list[0].device)
+    check(load().rmem_labels_from_logits(srcs, len(logits_list), Cn, int(bool(align_corners)), H0, W0,
+                                         out.data_ptr(), stream_ptr()), "rmem_labels_from_logits")
+    return out
+
+
+def label_resize_nearest(src: torch.Tensor, size, flip: bool = False, out: torch.Tensor = None) -> torch.Tensor:
+    """F.interpolate(mode="nearest") (+ horizontal flip first) on a uint8 [H,W] label map."""
+    if src.dtype != torch.uint8 or src.dim() != 2 or not src.is_contiguous():
+        raise RmemError("label_resize_nearest needs a contiguous uint8 [H,W] map")
+    Hd, Wd = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty((Hd, Wd), dtype=torch.uint8, device=src.device)
+    check(load().rmem_label_resize_nearest(src.data_ptr(), src.shape[0], src.shape[1], out.data_ptr(), Hd, Wd,
+                                           int(bool(flip)), stream_ptr()), "rmem_label_resize_nearest")
+    return out

@@ -29,6 +29,7 @@ sys.path.insert(0, HERE)
 
 import refharness as rh  # noqa: E402
 from rmem_amd.synth import synth_clip  # noqa: E402
+from make_golden_inputs import tta_new_object_label  # noqa: E402
 from inputs import (AOT_BLOCK_CASES, BLOCK_CASES, IDASSIGN_CASES, aot_block_case_name,  # noqa: E402
                     aot_block_inputs, block_case_name, block_inputs, idassign_label)
 
@@ -247,8 +248,76 @@ def gen_clips():
     print("clip 480p indexes", rec["indexes"])
 
 
+def gen_tta():
+    """Flip test-time augmentation + mid-clip new object, driven exactly as
+    managers/evaluator.py:337-527 drives its engines (one engine per augmentation, the
+    second on a deep copy of the model; probabilities un-flipped and averaged; labels
+    flipped back per engine).  The new object arrives at frame 10 of 12 with gap=2 so that
+    no long-term update follows it (the reference raises in restrict_long_memories after a
+    mid-clip re-reference: transformer.py:954 size mismatch)."""
+    import copy
+    ref = rh.import_reference()
+    H, W, frames, gap, out_hw, new_at = 97, 129, 12, 2, (90, 120), 10
+    cfg, model, eng0 = rh.build_reference("r50_deaotl", 1, 3, gap)
+    eng1 = ref["build_engine"](cfg.MODEL_ENGINE, phase="eval", aot_model=copy.deepcopy(model),
+                               gpu_id=0, long_term_mem_gap=gap)
+    eng1.eval()
+    engines, flips = [eng0, eng1], [False, True]
+    imgs, lab = synth_clip(23, frames, H, W, 3)
+    lab0 = F.interpolate(lab.float(), size=out_hw, mode="nearest")      # dataset label at original size
+    labels, indexes = [], []
+    with torch.no_grad(), rh.quiet():
+        for e in engines:
+            e.restart_engine()
+            e.long_term_mem_gap = gap
+        for t in range(frames):
+            all_preds, new_obj_label = [], None
+            cur_label = lab0 if t == 0 else (tta_new_object_label(out_hw) if t == new_at else None)
+            for e, fl in zip(engines, flips):
+                img = imgs[t].flip(3) if fl else imgs[t]
+                cl = None if cur_label is None else (cur_label.flip(3) if fl else cur_label)
+                if t == 0:
+                    _l = F.interpolate(cl, size=img.shape[2:], mode="nearest").int()
+                    e.add_reference_frame(img, _l, frame_step=0, obj_nums=[3])
+                else:
+                    logit = e.match_propogate_one_frame(img, output_size=out_hw)
+                    if fl:
+                        logit = logit.flip(3)
+                    all_preds.append(torch.softmax(logit, dim=1))
+                    if not fl and cl is not None and new_obj_label is None:
+                        new_obj_label = cl
+            if t == 0:
+                continue
+            prob = torch.mean(torch.cat(all_preds, dim=0), dim=0, keepdim=True)
+            pred = torch.argmax(prob, dim=1, keepdim=True).float()
+            if new_obj_label is not None:
+                keep = (new_obj_label == 0).float()
+                pred = pred * keep + new_obj_label * (1 - keep)
+                new_nums = [int(pred.max().item())]
+                for e, fl in zip(engines, flips):
+                    img = imgs[t].flip(3) if fl else imgs[t]
+                    cl = F.interpolate(pred.flip(3) if fl else pred, size=e.input_size_2d, mode="nearest")
+                    e.add_reference_frame(img, cl, obj_nums=new_nums, frame_step=t)
+            else:
+                for e, fl in zip(engines, flips):
+                    e.update_memory(F.interpolate(pred.flip(3) if fl else pred, size=e.input_size_2d,
+                                                  mode="nearest"))
+            labels.append(pred[0, 0].to(torch.uint8))
+            indexes.append([list(e.aot_engines[0].long_memories_indexes) for e in engines])
+    meta = dict(H=H, W=W, out_hw=list(out_hw), frames=frames, gap=gap, former=1, latter=3, seed=23,
+                flips=flips, new_at=new_at, indexes=indexes, label_sha=[sha(l) for l in labels],
+                palette_sha=hashlib.sha256(bytes(__import__("importlib").import_module("utils.image")._palette)).hexdigest())
+    with open(os.path.join(HERE, "clip_tta_k4_gap2.json"), "w") as f:
+        json.dump(meta, f)
+    np.savez_compressed(os.path.join(HERE, "clip_tta_k4_gap2.npz"), labels=torch.stack(labels).numpy())
+    print("tta clip indexes", indexes[-1], "labels max", int(torch.stack(labels).max()))
+
+
 def main():
     torch.manual_seed(0)
+    if "--tta-only" in sys.argv:
+        gen_tta()
+        return
     if "--aot-only" not in sys.argv and "--swin-only" not in sys.argv:
         cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
         gen_manifest(model)
@@ -262,6 +331,7 @@ def main():
         gen_aot_blocks(model)
         gen_aot_clips()
     gen_swin()
+    gen_tta()
     os.system(f"du -sh {HERE}")
 
 

@@ -107,7 +107,10 @@ def test_small_clip(name, golden_dir):
             print(name, "last-frame logit max abs err:", lerr)
             assert lerr < 2e-3
         else:
-            assert mism[0] == 0
+            # same tolerance as the teacher-forced run: the encoder's MIOpen convolutions are not
+            # run-to-run deterministic (1e-5 on the features, tools/determinism_probe.py), so one
+            # near-tie pixel may flip between processes
+            assert mism[0] <= 1
 
 
 @pytest.mark.parametrize("nsplit", [3, 1])
