@@ -49,6 +49,12 @@ def parse():
                     help="480p_k4 = BASELINE.json configs[1] (the headline metric); 720p_k8 = configs[2] (stress)")
     ap.add_argument("--model", choices=["r50_deaotl", "r50_aotl", "swinb_aotl"], default="r50_deaotl",
                     help="r50_deaotl = headline metric; r50_aotl = AOT block (BASELINE.json configs[0] on GPU)")
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="independent clips in flight per GPU, one engine + one HIP stream each (SURVEY.md 8f "
+                         "rank 2; BASELINE.json configs[1] is 1, configs[3] runs 8 clips per rank)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not hand the next frame to match_propogate_one_frame (its encoder pass then runs "
+                         "in line instead of on a second stream beside this frame's LSTT/decoder)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
@@ -84,38 +90,59 @@ def main():
     cpu_model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
     load_synthetic_weights(cpu_model)
     model = copy.deepcopy(cpu_model).to(dev)
-    engine = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=model, gpu_id=local_rank,
-                          long_term_mem_gap=args.gap, nsplit=args.nsplit)
-    engine.eval()
+    C = max(1, args.clips_per_gpu)
+    engines = []
+    for _ in range(C):
+        e = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=model, gpu_id=local_rank,
+                         long_term_mem_gap=args.gap, nsplit=args.nsplit)
+        e.eval()
+        engines.append(e)
+    from rmem_amd.streams import concurrent_stream
+    streams = [torch.cuda.current_stream(dev)] + [concurrent_stream(dev) for _ in range(C - 1)]
 
-    # one independent clip per rank (seed = rank); a ring of 8 distinct frames in HBM
+    # independent clips (seed = rank * C + i); a ring of 8 distinct frames per clip in HBM
     ring = 8
-    imgs, label0 = synth_clip(rank, ring, H_IN, W_IN, 3)
-    imgs = [im.to(dev) for im in imgs]
-    label0 = label0.to(dev)
+    clips = []
+    for i in range(C):
+        im, lb = synth_clip(rank * C + i, ring, H_IN, W_IN, 3)
+        clips.append(([x.to(dev) for x in im], lb.to(dev)))
 
-    def frame_step(t, masks_out=None):
-        logit = engine.match_propogate_one_frame(imgs[t % ring], output_size=(H_OUT, W_OUT))
+    PREFETCH = not args.no_prefetch
+
+    def frame_step(i, t, masks_out=None):
+        engine = engines[i]
+        logit = engine.match_propogate_one_frame(clips[i][0][t % ring], output_size=(H_OUT, W_OUT),
+                                                 next_img=clips[i][0][(t + 1) % ring] if PREFETCH else None)
         prob = torch.softmax(logit, dim=1)
         pred = torch.argmax(prob, dim=1, keepdim=True).float()
         cur = F.interpolate(pred, size=engine.input_size_2d, mode="nearest")
         engine.update_memory(cur)
         if masks_out is not None:
-            masks_out[t % masks_out.shape[0]] = pred[0, 0].to(torch.uint8)
+            masks_out[i, t % masks_out.shape[1]] = pred[0, 0].to(torch.uint8)
+
+    def all_clips(t, masks_out=None):
+        for i in range(C):
+            with torch.cuda.stream(streams[i]):
+                frame_step(i, t, masks_out)
 
     # ---- setup: reference frame + pre-roll until the bank holds K slots (steady state)
-    engine.restart_engine()
-    engine.add_reference_frame(imgs[0], label0, obj_nums=[3], frame_step=0)
+    for i, e in enumerate(engines):
+        e.restart_engine()
+        e.add_reference_frame(clips[i][0][0], clips[i][1], obj_nums=[3], frame_step=0)
     t = 1
-    sub = engine.aot_engines[0]
+    sub = engines[0].aot_engines[0]
     while len(sub.lstt.bank) < cfg.mem_cap:
-        frame_step(t)
+        all_clips(t)
         t += 1
     for _ in range(args.warmup):
-        frame_step(t)
+        all_clips(t)
         t += 1
+    torch.cuda.synchronize()
 
-    masks = torch.zeros(args.steps, H_OUT, W_OUT, dtype=torch.uint8, device=dev)
+    if os.environ.get("RMEM_BENCH_NOSYNC"):      # experiment: no long-term updates (no D2H) in the timed region
+        for e in engines:
+            e.aot_engines[0].long_term_mem_gap = 10 ** 6
+    masks = torch.zeros(C, args.steps, H_OUT, W_OUT, dtype=torch.uint8, device=dev)
     lstt = sub.lstt
     lstt.enable_kernel_timing(True)       # clears the event list
     lstt._timing = False
@@ -127,13 +154,15 @@ def main():
     for k in range(args.steps):
         # steady-state frames replay a hipGraph; every 8th frame of the timed region is issued
         # eagerly so that HIP events can bracket the dominant kernel on its launch stream
-        lstt._timing = (k % 8 == 0)
-        frame_step(t + k, masks)
+        lstt._timing = (k % 8 == 0) and not os.environ.get("RMEM_BENCH_NOSYNC")
+        all_clips(t + k, masks)
     lstt._timing = False
     host_issue = time.perf_counter() - t0     # host-side launch time (GPU work still in flight)
+    for st in streams[1:]:
+        streams[0].wait_stream(st)
     if dist is not None:                      # collect per-clip masks (the only exchange step)
         from rmem_amd.driver import gather_masks
-        gathered = gather_masks(masks[None], world)          # [world, steps, H, W] uint8 over RCCL
+        gathered = gather_masks(masks, world)          # [world*C, steps, H, W] uint8 over RCCL
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -144,7 +173,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    fps = world * args.steps / elapsed
+    fps = world * C * args.steps / elapsed
     out = {
         "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref"
         if (args.config == "480p_k4" and args.model == "r50_deaotl") else f"frames/sec/GPU ({args.config}) {args.model}+RMem"
@@ -156,10 +185,12 @@ def main():
         "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate)" if args.nsplit == 3 else "bf16 (MFMA, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"{ {'r50_deaotl': 'R50-DeAOTL', 'r50_aotl': 'R50-AOTL', 'swinb_aotl': 'SwinB-AOTL'}[args.model] } + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
-                               f"batch=1 clip per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
+                               f"batch={C} clip{'s' if C > 1 else ''} per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
                    "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
                    "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
-                   "parallelism": f"clips sharded 1-per-GPU x{world}, all-gather of masks"},
+                   "clips_per_gpu": C,
+                   "parallelism": f"clips sharded {C}-per-GPU x{world}" + (" (one engine + HIP stream per clip)" if C > 1 else "")
+                   + ", all-gather of masks"},
     }
     if rank == 0:
         out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)

@@ -240,7 +240,12 @@ class ClipDriver:
         timers = []
         writers = []
         on_cuda = False
-        for frame_idx, samples in enumerate(frames):
+        it = iter(frames)
+        nxt = next(it, None)
+        frame_idx = -1
+        while nxt is not None:
+            samples, nxt = nxt, next(it, None)          # one frame of look-ahead (encoder prefetch)
+            frame_idx += 1
             engines = [self._engine(i) for i in range(len(samples))]
             flips = [bool(s["meta"]["flip"]) for s in samples]
             meta0 = samples[0]["meta"]
@@ -261,8 +266,11 @@ class ClipDriver:
                 t0.record()
             fuse = self._can_fuse(engines, samples[0])
             logits, new_obj_label = [], None
-            for e, s, fl in zip(engines, samples, flips):
-                lg = e.match_propogate_one_frame(s["current_img"], output_size=None if fuse else ori_hw)
+            for i, (e, s, fl) in enumerate(zip(engines, samples, flips)):
+                kw = {}
+                if getattr(e, "supports_prefetch", False) and nxt is not None and len(nxt) > i:
+                    kw["next_img"] = nxt[i]["current_img"]
+                lg = e.match_propogate_one_frame(s["current_img"], output_size=None if fuse else ori_hw, **kw)
                 logits.append(lg)
                 if (not fl) and s.get("current_label") is not None and new_obj_label is None:
                     new_obj_label = s["current_label"].to(lg.device).float()

@@ -35,7 +35,12 @@ class DeAOTEngine(nn.Module):
             use_graphs = os.environ.get("RMEM_NO_GRAPHS") is None
         self.use_graphs = bool(use_graphs)
         self._fg, self._ug = {}, {}          # hipGraphs: frame graphs / update graphs by key
-        self._g_img, self._g_lab = {}, {}    # static graph inputs per shape (graphs keep their address)
+        self._eg = {}                        # encoder graphs by (img shape, parity): (graph, static img, features)
+        self._g_lab = {}                     # static graph inputs per shape (graphs keep their address)
+        self._par = 0                        # which of the two encoder feature sets holds the current frame
+        self._pref = None                    # identity of the image whose features were prefetched
+        self._enc_stream = None
+        self._enc_done = None
         self._eager_frames = 0
         if short_term_mem_skip != 1:
             raise NotImplementedError("short_term_mem_skip != 1 (reference evaluator always uses 1)")
@@ -58,6 +63,7 @@ class DeAOTEngine(nn.Module):
         self.input_size_2d = None
         self.long_memories_indexes: List[int] = []
         self.pred_id_logits = None
+        self._pref = None
         if self.lstt is not None:
             self.lstt.clear_memory()
 
@@ -70,7 +76,7 @@ class DeAOTEngine(nn.Module):
             cls = DeAOTLSTT if self.cfg.MODEL_VOS == "deaot" else AOTLSTT
             self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
             self._fg, self._ug = {}, {}      # graphs hold pointers into the old LSTT buffers
-            self._g_img, self._g_lab = {}, {}
+            self._eg, self._g_lab, self._pref = {}, {}, None
 
     def _label_u8(self, mask: torch.Tensor) -> torch.Tensor:
         """[1,1,H,W] (or [1,H,W]) label ids -> contiguous uint8 [H,W] on device."""
@@ -109,48 +115,104 @@ class DeAOTEngine(nn.Module):
         self.decode_current_logits(enc, out)
 
     @torch.no_grad()
-    def match_propogate_one_frame(self, img=None, img_embs=None, mask=None, output_size=None):
-        """aot_engine.py:398-436."""
+    def match_propogate_one_frame(self, img=None, img_embs=None, mask=None, output_size=None, next_img=None):
+        """aot_engine.py:398-436.  `next_img` (extension, optional): the frame that will be
+        passed to the NEXT call; its encoder pass then runs on a second stream concurrently
+        with this frame's LSTT / decoder (the encoder does not depend on the memory)."""
         self.frame_step += 1
         if self._graph_ok(img, img_embs):
-            return self._graphed_frame(img, output_size)
+            return self._graphed_frame(img, output_size, next_img)
         self._eager_frames += 1
-        enc = self.AOT.encode_image(img) if img_embs is None else img_embs
+        enc = img_embs
+        if enc is None:
+            enc = self._take_prefetched(img)
+        if enc is None:
+            enc = self.AOT.encode_image(img)
         out = self.lstt.forward(self._tokens(enc[-1]), ref_frame=False)
         return self.decode_current_logits(enc, out, output_size)
 
     # ------------------------------------------------------------------ hipGraph replay
     # One frame = encoder -> LSTT -> decoder -> upsample is ~270 launches; issued eagerly the host
-    # needs as long as the GPU (DESIGN.md section 6).  In steady state the whole frame is replayed
-    # from a hipGraph instead.  A graph bakes in everything that is not read from device memory:
-    # the slot the frame is written to, the bank depth T and the tensor shapes -- that tuple is the
-    # cache key (<= cap + 2 graphs per clip geometry); the logical->physical slot map stays in a
-    # device array, so appends / evictions never invalidate a graph.
+    # needs as long as the GPU (DESIGN.md section 6).  In steady state a frame is replayed from
+    # two hipGraphs: the encoder graph (depends on the image shape only; two copies with their
+    # own feature buffers, so that the next frame's encoder can run on a second stream while
+    # this frame's LSTT and decoder read the other copy) and the frame graph (LSTT + decoder +
+    # upsample).  A frame graph bakes in everything that is not read from device memory: the
+    # slot the frame is written to, the bank depth T, the tensor shapes and the feature copy --
+    # that tuple is the cache key; the logical->physical slot map stays in a device array, so
+    # appends / evictions never invalidate a graph.
     def _graph_ok(self, img, img_embs) -> bool:
         return (self.use_graphs and img_embs is None and img is not None and img.is_cuda
                 and self._eager_frames >= 2 and not self.lstt._timing)
 
-    def _graphed_frame(self, img, output_size):
+    @staticmethod
+    def _img_id(img):
+        return (img.data_ptr(), tuple(img.shape), img._version)
+
+    def _encoder_graph(self, shape, par, like):
+        ent = self._eg.get((shape, par))
+        if ent is None:
+            torch.cuda.synchronize()
+            g_img = torch.zeros_like(like)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enc = self.AOT.encode_image(g_img)
+            ent = self._eg[(shape, par)] = (g, g_img, enc)
+            if self._enc_stream is None:
+                from .streams import concurrent_stream
+                self._enc_stream = concurrent_stream(like.device)
+                self._enc_done = [torch.cuda.Event(), torch.cuda.Event()]
+        return ent
+
+    def _take_prefetched(self, img):
+        """Features of `img` if its encoder pass was prefetched by the previous call, else None."""
+        if self._pref is None:
+            return None
+        pref, self._pref = self._pref, None
+        # also when the prefetch is discarded: whatever touches that feature copy next must
+        # come after the encoder stream is done with it
+        torch.cuda.current_stream().wait_event(self._enc_done[self._par])
+        if img is None or not img.is_cuda or pref != self._img_id(img):
+            return None
+        return self._eg[(tuple(img.shape), self._par)][2]
+
+    def _prefetch(self, next_img, par):
+        """Encoder pass of `next_img` into feature copy `par` on the encoder stream.  Ordered
+        after everything already queued on the current stream (the previous reader of that
+        copy), concurrent with whatever is queued next."""
+        g, g_img, _ = self._encoder_graph(tuple(next_img.shape), par, next_img)
+        cur = torch.cuda.current_stream()
+        self._enc_stream.wait_stream(cur)
+        with torch.cuda.stream(self._enc_stream):
+            g_img.copy_(next_img, non_blocking=True)
+            g.replay()
+            self._enc_done[par].record(self._enc_stream)
+        self._pref = self._img_id(next_img)
+
+    def _graphed_frame(self, img, output_size, next_img=None):
         l = self.lstt
         l._prepare(False)
         osz = tuple(int(v) for v in output_size) if output_size is not None else None
-        key = (l.graph_key(), osz, tuple(img.shape))
-        g_img = self._g_img.get(tuple(img.shape))
-        if g_img is None:
-            g_img = self._g_img[tuple(img.shape)] = torch.empty_like(img)
-        g_img.copy_(img)
+        shape = tuple(img.shape)
+        if self._take_prefetched(img) is None:            # features not there yet: encode in line
+            g, g_img, _ = self._encoder_graph(shape, self._par, img)
+            g_img.copy_(img)
+            g.replay()
+        par = self._par
+        key = (l.graph_key(), osz, shape, par)
         ent = self._fg.get(key)
         if ent is None:
-            # capture every slot variant for this (T, shapes) at once: capture executes nothing,
-            # so the memory state is untouched, and no capture lands in a later frame
+            # capture every slot variant for this (T, shapes, feature copy) at once: capture
+            # executes nothing, so the memory state is untouched, and no capture lands in a
+            # later frame
             torch.cuda.synchronize()
+            enc = self._encoder_graph(shape, par, img)[2]
             saved = {k: getattr(l, k) for k in l.graph_variants()[0]}
             for var in l.graph_variants():
                 for k, v in var.items():
                     setattr(l, k, v)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    enc = self.AOT.encode_image(g_img)
                     l.tgt.copy_(enc[-1][0].flatten(1).t())
                     l._forward_device(False)
                     logits = self.AOT.decode_id_logits(l.out, enc)
@@ -158,10 +220,13 @@ class DeAOTEngine(nn.Module):
                         logits[batch_idx, (obj_num + 1):] = -1e10
                     up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
                                                                   align_corners=self.align_corners)
-                self._fg[(l.graph_key(), osz, tuple(img.shape))] = (g, logits, up)
+                self._fg[(l.graph_key(), osz, shape, par)] = (g, logits, up)
             for k, v in saved.items():
                 setattr(l, k, v)
             ent = self._fg[key]
+        if next_img is not None and next_img.is_cuda and tuple(next_img.shape) == shape:
+            self._prefetch(next_img, 1 - par)             # runs beside the frame graph below
+            self._par = 1 - par
         ent[0].replay()
         l._finish(False)
         self.pred_id_logits = ent[1]
@@ -229,6 +294,8 @@ class DeAOTEngine(nn.Module):
 
 class DeAOTInferEngine(nn.Module):
     """Multi-object wrapper (engines/aot_engine.py:571-725, deaot_engine.py:20-56)."""
+
+    supports_prefetch = True      # match_propogate_one_frame accepts next_img
 
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1,
                  max_aot_obj_num=None, nsplit: int = 3, fold_bn: bool = True,
@@ -300,12 +367,22 @@ class DeAOTInferEngine(nn.Module):
                                   self.short_term_mem_skip, self.nsplit, self.use_graphs)
             eng.eval()
             self.aot_engines.append(eng)
+        img_embs = self.AOT.encode_image(img) if len(self.aot_engines) > 1 else None    # shared encoder pass
         for eng, m in zip(self.aot_engines, self.separate_mask(mask)):
-            eng.add_reference_frame(img, m, obj_nums=[self.max_aot_obj_num], frame_step=frame_step)
+            eng.add_reference_frame(img, m, obj_nums=[self.max_aot_obj_num], frame_step=frame_step,
+                                    img_embs=img_embs)
         self.update_size()
 
-    def match_propogate_one_frame(self, img=None, mask=None, output_size=None):   # aot_engine.py:704-712
-        all_logits = [e.match_propogate_one_frame(img, mask=mask, output_size=output_size)
+    @torch.no_grad()
+    def match_propogate_one_frame(self, img=None, mask=None, output_size=None, next_img=None):
+        """aot_engine.py:704-712.  With several sub-engines (> 10 objects) the image is encoded
+        once and the features are shared (the reference re-encodes per sub-engine: img_embs stays
+        None at :705-709).  `next_img`: see DeAOTEngine.match_propogate_one_frame."""
+        if len(self.aot_engines) == 1:
+            return self.aot_engines[0].match_propogate_one_frame(img, mask=mask, output_size=output_size,
+                                                                 next_img=next_img)
+        img_embs = self.AOT.encode_image(img)
+        all_logits = [e.match_propogate_one_frame(img, img_embs=img_embs, mask=mask, output_size=output_size)
                       for e in self.aot_engines]
         return self.soft_logit_aggregation(all_logits)
 

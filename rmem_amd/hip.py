@@ -233,9 +233,6 @@ def linear_grouped(args):
     check(load().rmem_linear_grouped(arr, len(args), stream_ptr()), "rmem_linear_grouped")
 
 
-_GN_WS = {}
-
-
 def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool) -> torch.Tensor:
     """GroupNorm(+ReLU) of a batch-1 NCHW fp32 tensor through rmem_groupnorm_nchw."""
     x = x.contiguous()
@@ -243,9 +240,9 @@ def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool) -> torch
     if n != 1 or x.dtype != torch.float32 or ((c // gn.num_groups) * h * w) % 4:
         y = torch.nn.functional.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
         return torch.relu_(y) if relu else y
-    ws = _GN_WS.get(x.device)
-    if ws is None:
-        ws = _GN_WS[x.device] = torch.zeros(2 * 32 * 64, dtype=torch.float64, device=x.device)
+    # per-call workspace (stream-ordered caching allocator / graph pool): engines running
+    # concurrently on different streams must not share it; the stats pass overwrites all of it
+    ws = torch.empty(2 * 32 * gn.num_groups, dtype=torch.float64, device=x.device)
     y = torch.empty_like(x)
     check(load().rmem_groupnorm_nchw(x.data_ptr(), y.data_ptr(), c, h * w, gn.num_groups, gn.weight.data_ptr(),
                                      gn.bias.data_ptr(), gn.eps, int(relu), ws.data_ptr(), stream_ptr()),
