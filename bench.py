@@ -5,8 +5,10 @@ Workload (config.workload): R50-DeAOTL + RMem, 480p (481x849 -> 31x54 = 1674 tok
 K=4 memory slots (FORMER_MEM_LEN=1, LATTER_MEM_LEN=3), one synthetic clip per GPU,
 random-init (name-keyed synthetic) weights, fp32 I/O.  A "step" is one frame through the
 reference's timing window (managers/evaluator.py:399-404,525-527):
-match_propogate_one_frame -> softmax/argmax -> nearest resize -> update_memory, with the
-bank in steady state (T = K, one long-memory update + eviction every `gap` frames).
+match_propogate_one_frame -> label map (bilinear upsample + argmax; the evaluator's
+softmax/argmax torch ops with --reference-postproc) -> nearest resize -> update_memory, with
+the bank in steady state (T = K, one long-memory update + eviction every `gap` frames).
+The next frame is handed to the engine as `next_img` (encoder prefetch, as rmem_amd.driver does).
 Frames are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 40 --warmup 10
@@ -52,6 +54,9 @@ def parse():
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips in flight per GPU, one engine + one HIP stream each (SURVEY.md 8f "
                          "rank 2; BASELINE.json configs[1] is 1, configs[3] runs 8 clips per rank)")
+    ap.add_argument("--reference-postproc", action="store_true",
+                    help="softmax/argmax/nearest-resize with the evaluator's torch ops on full-size logits "
+                         "(managers/evaluator.py:424-441,518-523) instead of the driver's fused label kernels")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not hand the next frame to match_propogate_one_frame (its encoder pass then runs "
                          "in line instead of on a second stream beside this frame's LSTT/decoder)")
@@ -75,6 +80,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    from rmem_amd import hip
     from rmem_amd.config import get_config
     from rmem_amd.engine import build_engine
     from rmem_amd.model import build_vos_model
@@ -111,14 +117,23 @@ def main():
 
     def frame_step(i, t, masks_out=None):
         engine = engines[i]
-        logit = engine.match_propogate_one_frame(clips[i][0][t % ring], output_size=(H_OUT, W_OUT),
-                                                 next_img=clips[i][0][(t + 1) % ring] if PREFETCH else None)
-        prob = torch.softmax(logit, dim=1)
-        pred = torch.argmax(prob, dim=1, keepdim=True).float()
-        cur = F.interpolate(pred, size=engine.input_size_2d, mode="nearest")
-        engine.update_memory(cur)
-        if masks_out is not None:
-            masks_out[i, t % masks_out.shape[1]] = pred[0, 0].to(torch.uint8)
+        nxt = clips[i][0][(t + 1) % ring] if PREFETCH else None
+        if args.reference_postproc:
+            logit = engine.match_propogate_one_frame(clips[i][0][t % ring], output_size=(H_OUT, W_OUT), next_img=nxt)
+            prob = torch.softmax(logit, dim=1)
+            pred = torch.argmax(prob, dim=1, keepdim=True).float()
+            cur = F.interpolate(pred, size=engine.input_size_2d, mode="nearest")
+            engine.update_memory(cur)
+            if masks_out is not None:
+                masks_out[i, t % masks_out.shape[1]] = pred[0, 0].to(torch.uint8)
+            return
+        # the clip driver's path (rmem_amd/driver.py): decoder logits -> uint8 label map at the
+        # original size (bilinear upsample + argmax in one kernel, written straight into the
+        # clip's mask tensor) -> nearest resize to the input size -> update_memory
+        logit = engine.match_propogate_one_frame(clips[i][0][t % ring], output_size=None, next_img=nxt)
+        lab = masks_out[i, t % masks_out.shape[1]] if masks_out is not None else None
+        lab = hip.labels_from_logits([logit], [False], (H_OUT, W_OUT), cfg.MODEL_ALIGN_CORNERS, out=lab)
+        engine.update_memory(hip.label_resize_nearest(lab, engine.input_size_2d)[None, None])
 
     def all_clips(t, masks_out=None):
         for i in range(C):
@@ -152,9 +167,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        # steady-state frames replay a hipGraph; every 8th frame of the timed region is issued
+        # steady-state frames replay hipGraphs; every 10th frame of the timed region is issued
         # eagerly so that HIP events can bracket the dominant kernel on its launch stream
-        lstt._timing = (k % 8 == 0) and not os.environ.get("RMEM_BENCH_NOSYNC")
+        lstt._timing = (k % 10 == 0) and not os.environ.get("RMEM_BENCH_NOSYNC")
         all_clips(t + k, masks)
     lstt._timing = False
     host_issue = time.perf_counter() - t0     # host-side launch time (GPU work still in flight)

@@ -261,6 +261,12 @@ int rmem_groupnorm_nchw(const float *x, float *y, int32_t C, int64_t HW, int32_t
 int rmem_bias_act_nchw(float *x, const float *bias, const float *residual, int32_t C, int64_t HW,
                        int32_t relu, void *stream);
 
+/* Support op outside the LSTT: y = (y + bias[c]) + bilinear_upsample(x -> H x W), in place on a
+ * contiguous batch-1 NCHW map: the skip merge "adapter(shortcut) + F.interpolate(x)" of the FPN
+ * head (decoders/fpn.py:53-60) in one pass.  bias may be NULL.  C*H <= 65535. */
+int rmem_upsample_add_nchw(float *y, const float *bias, const float *x, int32_t C, int32_t H,
+                           int32_t W, int32_t h, int32_t w, int32_t align_corners, void *stream);
+
 /* dst[0..n) = host_vals[0..n) (n <= 32), stream-ordered, payload in the kernel arguments: how
  * the logical->physical slot map of the bank is published without a blocking H2D copy. */
 int rmem_set_ints(int32_t *dst, const int32_t *host_vals, int32_t n, void *stream);

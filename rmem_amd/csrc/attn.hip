@@ -3,7 +3,6 @@
 // See include/rmem_hip.h for the contract and DESIGN.md for the roofline accounting.
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
-#include <stdlib.h>
 
 // Key-tile band [t_lo, t_hi) (units of 128 keys) visible under the 15x15 window to the
 // 256-query super-tile that contains query tile `qtile` (128 queries): rows y(q_lo)-7 ..
@@ -287,173 +286,6 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   }
 }
 
-// ---- P.V, LDS-DMA variant ---------------------------------------------------------------
-// Same work decomposition and epilogue as pv_kernel, different main loop: k advances in steps
-// of 32 keys (= one block of the blocked P layout, so a 16-row group of the P tile is 1 KiB of
-// contiguous global memory), tiles go global -> LDS with global_load_lds_dwordx4 (no staging
-// VGPRs, no ds_write pass: the VGPR->LDS store path was the largest LDS cost of pv_kernel,
-// DESIGN.md section 5b), two stages so the next tile lands while the current one is
-// multiplied, ONE barrier per k-step.
-//
-// Stage image (NS = 3): [P hi | P lo | V^T hi | V^T lo], each 128 rows x 64 B.  LDS-DMA writes
-// lane-linear (base + 16 * lane), so the bank swizzle is applied on the SOURCE side: lane l of
-// a 16-row group lands at (row r = l >> 2, position p = l & 3) and fetches k-chunk
-// c = p ^ ((row >> 2) & 3); fragment reads look chunk c up at position c ^ ((row >> 2) & 3).
-// The 16 lanes of every ds_read_b128 service group then cover the 16 slots of a 256-B bank row.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
-
-template <int NS>
-__global__ __launch_bounds__(256) void pv_glds_kernel(rmem_pv_args a) {
-  constexpr int NPL = (NS == 1) ? 1 : 2;
-  constexpr int PLANE = 128 * 64;               // bytes of one operand plane tile (128 rows x 32 bf16)
-  constexpr int STAGE = 2 * NPL * PLANE;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const int nct = (a.ncols + 127) / 128;
-  const int nq = a.Npad / 128;
-  const int npairs = nq * a.ksplits;
-  const int chunk = pv_chunk(npairs);
-  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int pl = jb / nct;
-  const int ctile = jb - pl * nct;
-  const int pair = xcd * chunk + pl;
-  if (pl >= chunk || pair >= npairs) return;
-  const int z = pair / nq;
-  const int qtile = pair - z * nq;
-  const int tps = a.Npad / 64;
-  int k_lo, k_hi;
-  if (a.mode == 0) {
-    k_lo = 0;
-    k_hi = a.T * tps;
-  } else {
-    int t_lo, t_hi;
-    band_tiles(qtile, a.N, a.h, a.w, t_lo, t_hi);
-    k_lo = 2 * t_lo;
-    k_hi = 2 * t_hi;
-  }
-  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
-  int lo = k_lo + z * per, hi = lo + per;
-  if (hi > k_hi) hi = k_hi;
-  lo *= 2;   // 64-key tiles -> 32-key steps
-  hi *= 2;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int tps32 = a.Npad / 32;
-
-  // this lane's two 16-row groups (g = 2 * wave + {0, 1}) of every plane tile
-  int srow[2], schunk[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    srow[u] = (2 * wave + u) * 16 + (lane >> 2);
-    schunk[u] = (lane & 3) ^ ((srow[u] >> 2) & 3);
-  }
-  long xoff[2], yoff[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    xoff[u] = (long)(qtile * 128 + srow[u]) * 32 + schunk[u] * 8;
-    int jrow = ctile * 128 + srow[u];
-    jrow = jrow < a.ncols ? jrow : a.ncols - 1;
-    yoff[u] = (long)jrow * a.Npad + schunk[u] * 8;
-  }
-  const bf16_t* xpl[2] = {a.ph, a.pl};
-  const bf16_t* ypl[2] = {a.vh, a.vl};
-
-  auto issue = [&](int kb, int stage) __attribute__((always_inline)) {
-    const int t = kb / tps32;
-    const int phys = a.slot_map ? a.slot_map[t] : t;
-    const long xbase = (long)kb * a.Npad * 32;
-    const long ybase = (long)phys * a.v_slot_stride + (long)(kb - t * tps32) * 32;
-    char* sb = smem + stage * STAGE;
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        char* dx = sb + p * PLANE + (2 * wave + u) * 1024;
-        char* dy = sb + (NPL + p) * PLANE + (2 * wave + u) * 1024;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(xpl[p] + xbase + xoff[u]), (lds_void_t*)dx, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(ypl[p] + ybase + yoff[u]), (lds_void_t*)dy, 16, 0, 0);
-      }
-  };
-
-  GemmFrag<GemmCfg<128, 128, NS>> f;
-  f.zero();
-  // fragment read offsets (bytes within a plane tile) for the two k16 sub-steps
-  int xfo[2][2], yfo[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = ks * 2 + (lane >> 5);
-      const int rx = wr * 64 + i * 32 + (lane & 31);
-      const int ry = wc * 64 + i * 32 + (lane & 31);
-      xfo[ks][i] = rx * 64 + ((c ^ ((rx >> 2) & 3)) << 4);
-      yfo[ks][i] = ry * 64 + ((c ^ ((ry >> 2) & 3)) << 4);
-    }
-
-  if (lo < hi) issue(lo, 0);
-  for (int kb = lo; kb < hi; ++kb) {
-    const int st = (kb - lo) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // tile kb landed for every wave; every wave is done reading stage st ^ 1
-    if (kb + 1 < hi) issue(kb + 1, st ^ 1);
-    const char* sb = smem + st * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t xa[NPL][2], yb[NPL][2];
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          xa[p][i] = *reinterpret_cast<const bf16x8_t*>(sb + p * PLANE + xfo[ks][i]);
-          yb[p][i] = *reinterpret_cast<const bf16x8_t*>(sb + (NPL + p) * PLANE + yfo[ks][i]);
-        }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr (NS == 3) {
-            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][i], yb[1][j], f.acc[i][j], 0, 0, 0);
-            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1][i], yb[0][j], f.acc[i][j], 0, 0, 0);
-          }
-          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][i], yb[0][j], f.acc[i][j], 0, 0, 0);
-        }
-    }
-  }
-
-  using Cfg = GemmCfg<128, 128, NS>;
-  float* out = a.part + (long)z * a.Npad * a.ncols;
-#pragma unroll
-  for (int tn = 0; tn < Cfg::TN; ++tn) {
-    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
-    if (col >= a.ncols) continue;
-#pragma unroll
-    for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
-        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
-      }
-  }
-}
-
-template <int NS>
-static int launch_pv_glds(const rmem_pv_args& a, hipStream_t s) {
-  constexpr int LDS = 2 * 2 * ((NS == 1) ? 1 : 2) * 128 * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_glds_kernel<NS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  const int nct = (a.ncols + 127) / 128;
-  const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
-  dim3 grid(8 * chunk * nct);
-  hipLaunchKernelGGL((pv_glds_kernel<NS>), grid, dim3(256), LDS, s, a);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
-}
-
 template <int NS>
 static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
   using Cfg = GemmCfg<128, 128, NS>;
@@ -478,12 +310,11 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
   if (!a.ph || !a.vh || !a.part || a.ncols <= 0) return RMEM_ERR_INVALID;
   if (a.mode == 1 && (a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
-  static const bool legacy = getenv("RMEM_PV_LEGACY") != nullptr;   // A/B switch while the LDS-DMA loop is evaluated
   if (a.nsplit == 3) {
     if (!a.pl || !a.vl) return RMEM_ERR_INVALID;
-    return legacy ? launch_pv<3>(a, s) : launch_pv_glds<3>(a, s);
+    return launch_pv<3>(a, s);
   }
-  if (a.nsplit == 1) return legacy ? launch_pv<1>(a, s) : launch_pv_glds<1>(a, s);
+  if (a.nsplit == 1) return launch_pv<1>(a, s);
   return RMEM_ERR_INVALID;
 }
 

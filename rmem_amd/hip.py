@@ -101,7 +101,7 @@ EXPORTS = [
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
-    "rmem_labels_from_logits", "rmem_label_resize_nearest",
+    "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw",
 ]
 
 
@@ -147,6 +147,7 @@ def load():
     lib.rmem_gn_gelu_tokens.argtypes = [c_p, i32, i32, i32, c_p, c_p, f32, c_p, c_p, c_p]
     lib.rmem_pe_bias_heads.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]
     lib.rmem_labels_from_logits.argtypes = [C.POINTER(LabelSrc), i32, i32, i32, i32, i32, c_p, c_p]
+    lib.rmem_upsample_add_nchw.argtypes = [c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p]
     lib.rmem_label_resize_nearest.argtypes = [c_p, i32, i32, c_p, i32, i32, i32, c_p]
     _LIB = lib
     return lib
@@ -262,6 +263,22 @@ def bias_act_nchw_(x: torch.Tensor, bias: torch.Tensor, residual=None, relu: boo
     check(load().rmem_bias_act_nchw(x.data_ptr(), bias.data_ptr(), ptr(residual), c, h * w, int(relu),
                                     stream_ptr()), "rmem_bias_act_nchw")
     return x
+
+
+def upsample_add_nchw_(y: torch.Tensor, bias, x: torch.Tensor, align_corners: bool) -> torch.Tensor:
+    """In-place y = (y + bias[c]) + bilinear(x -> y's size) for contiguous batch-1 NCHW fp32 maps."""
+    n, c, H, W = y.shape
+    if n != 1 or x.shape[0] != 1 or x.shape[1] != c or not y.is_contiguous() or y.dtype != torch.float32 \
+            or c * H > 65535:
+        if bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        if x.shape[-2:] != y.shape[-2:]:
+            x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=align_corners)
+        return y + x
+    x = x.contiguous()
+    check(load().rmem_upsample_add_nchw(y.data_ptr(), ptr(bias), x.data_ptr(), c, H, W, x.shape[2], x.shape[3],
+                                        int(bool(align_corners)), stream_ptr()), "rmem_upsample_add_nchw")
+    return y
 
 
 def set_ints(dst: torch.Tensor, values):

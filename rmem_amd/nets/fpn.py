@@ -44,9 +44,23 @@ class FPNHead(nn.Module):
         return F.interpolate(x, size=like.shape[-2:], mode="bilinear",
                              align_corners=self.align_corners)
 
+    def _merge(self, adapter: nn.Conv2d, skip, x):
+        """adapter(skip) + upsample(x): on the GPU the adapter's bias, the bilinear upsample and the
+        sum are one HIP pass over the adapter's conv output (rmem_upsample_add_nchw)."""
+        if skip.is_cuda and not torch.is_grad_enabled():
+            from ..hip import upsample_add_nchw_
+            y = F.conv2d(skip, adapter.weight, None, adapter.stride, adapter.padding)
+            return upsample_add_nchw_(y, adapter.bias, x, self.align_corners)
+        return adapter(skip) + (x if x.shape[-2:] == skip.shape[-2:] else self._up(x, skip))
+
     def forward(self, inputs, shortcuts):
         x = torch.cat(inputs, dim=1) if self.decode_intermediate_input else inputs[-1]
         x = self.conv_in(x, relu=True)
+        if x.is_cuda and not torch.is_grad_enabled():
+            x = self.conv_16x(self._merge(self.adapter_16x, shortcuts[-2], x), relu=True)
+            x = self.conv_8x(self._merge(self.adapter_8x, shortcuts[-3], x), relu=True)
+            x = self.conv_4x(self._merge(self.adapter_4x, shortcuts[-4], x), relu=True)
+            return self.conv_out(x)
         x = self.conv_16x(self.adapter_16x(shortcuts[-2]) + x, relu=True)
         x = self.conv_8x(self.adapter_8x(shortcuts[-3]) + self._up(x, shortcuts[-3]), relu=True)
         x = self.conv_4x(self.adapter_4x(shortcuts[-4]) + self._up(x, shortcuts[-4]), relu=True)

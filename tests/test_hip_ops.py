@@ -7,6 +7,7 @@ import math
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -322,3 +323,24 @@ def test_groupnorm_nchw_relu(hip):
         y = hip.groupnorm_nchw(x.to(DEV), gn, True)
         torch.cuda.synchronize()
         assert (y.cpu().double() - ref).abs().max().item() < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(128, 121, 213, 61, 107, True), (256, 61, 107, 31, 54, True),
+                                  (256, 31, 54, 31, 54, True), (64, 30, 53, 15, 27, False), (8, 7, 9, 7, 9, False)])
+def test_upsample_add_nchw(geom):
+    """rmem_upsample_add_nchw == (y + bias) + F.interpolate(x, bilinear) (decoders/fpn.py:53-60)."""
+    from rmem_amd import hip
+    C, H, W, h, w, align = geom
+    g = torch.Generator().manual_seed(C + H)
+    y = torch.randn(1, C, H, W, generator=g).to(DEV)
+    x = torch.randn(1, C, h, w, generator=g).to(DEV)
+    b = torch.randn(C, generator=g).to(DEV)
+    want = (y + b.view(1, -1, 1, 1)) + (x if (h, w) == (H, W) else
+                                        F.interpolate(x, size=(H, W), mode="bilinear", align_corners=align))
+    got = hip.upsample_add_nchw_(y.clone(), b, x, align)
+    err = float((got - want).abs().max())
+    print("upsample_add max abs err", err)
+    assert err < 2e-6
+    got2 = hip.upsample_add_nchw_(y.clone(), None, x, align)
+    assert float((got2 - (want - b.view(1, -1, 1, 1))).abs().max()) < 4e-6
