@@ -13,6 +13,8 @@ them (LSTT, ID assignment, memory bank, RMem eviction) is rmem_amd.lstt / csrc.
 from __future__ import annotations
 
 import os
+import queue
+import threading
 from typing import List, Optional
 
 import numpy as np
@@ -22,6 +24,37 @@ import torch.nn.functional as F
 
 from .lstt import DeAOTLSTT
 from .lstt_aot import AOTLSTT
+
+
+class _GraphLauncher(threading.Thread):
+    """Host helper thread that launches a hipGraph on a given stream (see DeAOTEngine._prefetch)."""
+
+    def __init__(self, device):
+        super().__init__(daemon=True, name="rmem-graph-launcher")
+        self.device = device
+        self.jobs: "queue.Queue" = queue.Queue()
+        self.error = None
+        self.start()
+
+    def submit(self, stream, after, dst, src, graph, done_event) -> threading.Event:
+        launched = threading.Event()
+        self.jobs.put((stream, after, dst, src, graph, done_event, launched))
+        return launched
+
+    def run(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            stream, after, dst, src, graph, done_event, launched = self.jobs.get()
+            try:
+                with torch.no_grad(), torch.cuda.stream(stream):
+                    stream.wait_event(after)
+                    dst.copy_(src, non_blocking=True)
+                    graph.replay()
+                    done_event.record(stream)
+            except BaseException as e:          # surfaced by the next wait on the engine thread
+                self.error = e
+            finally:
+                launched.set()
 
 
 class DeAOTEngine(nn.Module):
@@ -41,6 +74,8 @@ class DeAOTEngine(nn.Module):
         self._pref = None                    # identity of the image whose features were prefetched
         self._enc_stream = None
         self._enc_done = None
+        self._launcher = None
+        self._pref_launched = None
         self._eager_frames = 0
         if short_term_mem_skip != 1:
             raise NotImplementedError("short_term_mem_skip != 1 (reference evaluator always uses 1)")
@@ -169,6 +204,9 @@ class DeAOTEngine(nn.Module):
         if self._pref is None:
             return None
         pref, self._pref = self._pref, None
+        self._pref_launched.wait()           # the helper thread has queued the pass and its event
+        if self._launcher.error is not None:
+            raise RuntimeError("encoder prefetch failed") from self._launcher.error
         # also when the prefetch is discarded: whatever touches that feature copy next must
         # come after the encoder stream is done with it
         torch.cuda.current_stream().wait_event(self._enc_done[self._par])
@@ -179,15 +217,18 @@ class DeAOTEngine(nn.Module):
     def _prefetch(self, next_img, par):
         """Encoder pass of `next_img` into feature copy `par` on the encoder stream.  Ordered
         after everything already queued on the current stream (the previous reader of that
-        copy), concurrent with whatever is queued next."""
-        g, g_img, _ = self._encoder_graph(tuple(next_img.shape), par, next_img)
-        cur = torch.cuda.current_stream()
-        self._enc_stream.wait_stream(cur)
-        with torch.cuda.stream(self._enc_stream):
-            g_img.copy_(next_img, non_blocking=True)
-            g.replay()
-            self._enc_done[par].record(self._enc_stream)
+        copy), concurrent with whatever is queued next.  The graph is launched from a helper
+        host thread: hipGraphLaunch enqueues node by node (~8 us of host time per kernel), so
+        launching the encoder graph and then the frame graph from one thread leaves the GPU
+        waiting for the host; replay() releases the GIL, the two launches proceed in parallel."""
+        ent = self._encoder_graph(tuple(next_img.shape), par, next_img)
+        after = torch.cuda.Event()
+        after.record(torch.cuda.current_stream())
         self._pref = self._img_id(next_img)
+        if self._launcher is None:
+            self._launcher = _GraphLauncher(next_img.device)
+        self._pref_launched = self._launcher.submit(self._enc_stream, after, ent[1], next_img, ent[0],
+                                                    self._enc_done[par])
 
     def _graphed_frame(self, img, output_size, next_img=None):
         l = self.lstt

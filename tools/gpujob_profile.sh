@@ -1,7 +1,7 @@
+# kernel trace + stats of the default bench command (steady state summarised by tools/prof_summary.py)
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python bench.py --config 720p_k8 --steps 20 --warmup 5 --gap 2 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_720p.json; cut -c1-1200 gpurun_out/bench_720p.json
-python tools/kbench.py --h 46 --w 81 --cap 8 --iters 10 2>/dev/null | tail -30 > gpurun_out/kbench_720p.json; cat gpurun_out/kbench_720p.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1c -o r1c -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-ls -la gpurun_out/prof_r1c gpurun_out/pmc_fetch gpurun_out/pmc_write
+TAG=${1:-r01_e}
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
+python tools/prof_summary.py gpurun_out/prof_$TAG/${TAG}_kernel_trace.csv 15 > gpurun_out/${TAG}_bench_x3_kernel_stats.md
+head -12 gpurun_out/${TAG}_bench_x3_kernel_stats.md
+python bench.py 2>/dev/null > gpurun_out/${TAG}_bench_x3.json; cut -c1-400 gpurun_out/${TAG}_bench_x3.json
