@@ -310,12 +310,10 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
   if (!a.ph || !a.vh || !a.part || a.ncols <= 0) return RMEM_ERR_INVALID;
   if (a.mode == 1 && (a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
-  if (a.nsplit == 3) {
-    if (!a.pl || !a.vl) return RMEM_ERR_INVALID;
-    return launch_pv<3>(a, s);
-  }
-  if (a.nsplit == 1) return launch_pv<1>(a, s);
-  return RMEM_ERR_INVALID;
+  if (a.nsplit == 3 && (!a.pl || !a.vl)) return RMEM_ERR_INVALID;
+  if (a.nsplit != 1 && a.nsplit != 3) return RMEM_ERR_INVALID;
+  if (a.nsplit == 3) return launch_pv<3>(a, s);
+  return launch_pv<1>(a, s);
 }
 
 // ------------------------------------------------------------------ combine + gate (+ mass)

@@ -141,7 +141,7 @@ def main():
     res["scores_long_pass0"] = timeit(scores(0, T, 0, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe), args.iters)
     res["scores_long_pass1"] = timeit(scores(0, T, 1, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe), args.iters)
     res["pv_long"] = timeit(pv(0, T, L.ws_main, L.bankV[1], map_bank, ksl), args.iters)
-    for ks in (1, 2, 4, 8):
+    for ks in ([int(v) for v in os.environ["RMEM_KS_LIST"].split(",")] if os.environ.get("RMEM_KS_LIST") else (1, 2, 4, 8)):
         res[f"pv_long_ks{ks}"] = timeit(pv(0, T, L.ws_main, L.bankV[1], map_bank, ks), args.iters)
     res["scores_win_pass0"] = timeit(scores(1, 1, 0, L.ws_side, L.bankK[1], map_short, curK, None), args.iters)
     res["scores_win_pass1"] = timeit(scores(1, 1, 1, L.ws_side, L.bankK[1], map_short, curK, None), args.iters)
