@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void scores_kernel(rmem_scores_args a) {
         if (PASS == 0) {
           if (valid) mx = fmaxf(mx, s);
         } else {
-          const float p = valid ? expf(s - mrow) : 0.f;
+          const float p = valid ? exp_weight(s - mrow) : 0.f;
           pv[r] = p;
           lsum += p;
         }

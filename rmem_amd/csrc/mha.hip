@@ -10,7 +10,10 @@
 // register r of lane (query j, half hi) is key (r&3) + 8(r>>2) + 4hi; k-step s, element e of
 // the B operand is register 8s+e, i.e. keys {16s+4hi+0..3, 16s+8+4hi+0..3} -- the A operand
 // (V^T) is loaded with exactly that key permutation (two 8-byte loads per k-step), so no
-// cross-lane shuffle is needed.  No LDS, no barriers: latency is hidden by occupancy.
+// cross-lane shuffle is needed.  The four waves of a block (128 queries of one head) share the
+// K / V^T tiles through LDS (64 keys per stage, coalesced 16-byte loads, register prefetch of
+// the next stage): fetching the fragments straight from global memory touched 32 cache lines
+// per load instruction and made the texture-address path the bound.
 // Key splits (flash-decoding style) write unnormalised partials + (max, sum); rmem_mha_combine
 // merges them, normalises, averages the per-slot attention mass over heads.
 #include "../../include/rmem_hip.h"
@@ -18,18 +21,28 @@
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
+// LDS image of one 64-key stage of head h (shared by the four waves = 128 queries of a block):
+//   K   [plane][64 keys][64 B]   rows of 64 B, 16-byte chunk c of row r stored at c ^ ((r >> 2) & 3)
+//   V^T [plane][32 chan][136 B]  128 B of keys + 8 B pad: the 8-byte fragment reads of the 32 lanes
+//                                of a half-wave (row = lane) then cover all 64 banks exactly once
+constexpr int MHA_KPL = 64 * 64, MHA_VROW = 136, MHA_VPL = 32 * MHA_VROW;
+
 template <int NS>
 __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   constexpr int NPL = NS == 1 ? 1 : 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) char smem[NPL * (MHA_KPL + MHA_VPL)];
+  char* ks_lds = smem;
+  char* vs_lds = smem + NPL * MHA_KPL;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, j = lane & 31;
   const int h = blockIdx.y, z = blockIdx.z;
   const int q = blockIdx.x * 128 + wave * 32 + j;   // this lane's query (column of S^T / O^T)
-  const int tps = a.Npad / 32;                       // 32-key tiles per slot
-  const int ntiles = a.T * tps;
-  const int per = (ntiles + a.ksplits - 1) / a.ksplits;
-  int lo = z * per, hi_t = lo + per;
-  if (hi_t > ntiles) hi_t = ntiles;
+  const int sps = a.Npad / 64;                       // 64-key stages per slot
+  const int nstages = a.T * sps;
+  const int per = (nstages + a.ksplits - 1) / a.ksplits;
+  int lo = z * per, hi_s = lo + per;
+  if (hi_s > nstages) hi_s = nstages;
 
   const bf16_t* qp[2] = {a.qh, a.ql};
   const bf16_t* kp[2] = {a.kh, a.kl};
@@ -41,6 +54,35 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
     for (int ks = 0; ks < 2; ++ks)
       qf[p][ks] = *reinterpret_cast<const bf16x8_t*>(qp[p] + (long)q * a.ldq + h * 32 + ks * 16 + hi * 8);
 
+  // staging: thread -> one 16-byte chunk of the K tile and one of the V^T tile, per plane
+  const int k_row = tid >> 2, k_ch = tid & 3;        // key 0..63, chunk 0..3 (8 head dims)
+  const int v_row = tid >> 3, v_ch = tid & 7;        // channel 0..31, chunk 0..7 (8 keys)
+  const int k_dst = k_row * 64 + ((k_ch ^ ((k_row >> 2) & 3)) << 4);
+  const int v_dst = v_row * MHA_VROW + v_ch * 16;
+  u32x4_t kr[NPL], vr[NPL];
+  auto gload = [&](int stage) __attribute__((always_inline)) {
+    const int t = stage / sps;
+    const int tok0 = (stage - t * sps) * 64;
+    const int phys = a.slot_map ? a.slot_map[t] : t;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      kr[p] = *reinterpret_cast<const u32x4_t*>(kp[p] + (long)phys * a.k_slot_stride + (long)(tok0 + k_row) * a.ldk +
+                                                h * 32 + k_ch * 8);
+      vr[p] = *reinterpret_cast<const u32x4_t*>(vp[p] + (long)phys * a.v_slot_stride + (long)(h * 32 + v_row) * a.ldv +
+                                                tok0 + v_ch * 8);
+    }
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      *reinterpret_cast<u32x4_t*>(ks_lds + p * MHA_KPL + k_dst) = kr[p];
+      u32x2_t w0, w1;
+      w0[0] = vr[p][0]; w0[1] = vr[p][1]; w1[0] = vr[p][2]; w1[1] = vr[p][3];
+      *reinterpret_cast<u32x2_t*>(vs_lds + p * MHA_VPL + v_dst) = w0;       // rows are 8-byte aligned only
+      *reinterpret_cast<u32x2_t*>(vs_lds + p * MHA_VPL + v_dst + 8) = w1;
+    }
+  };
+
   f32x16_t o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -49,10 +91,13 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   const bool qvalid = q < a.N;
   float* sml = a.slot_ml ? a.slot_ml + (((long)z * a.Npad + q) * a.heads + h) * a.T * 2 : nullptr;
 
-  for (int tile = lo; tile < hi_t; ++tile) {
-    const int t = tile / tps;
-    const int tok0 = (tile - t * tps) * 32;
-    const int phys = a.slot_map ? a.slot_map[t] : t;
+  if (lo < hi_s) gload(lo);
+  for (int stage = lo; stage < hi_s; ++stage) {
+    __syncthreads();            // every wave is done with the previous stage
+    lstore();
+    __syncthreads();
+    if (stage + 1 < hi_s) gload(stage + 1);          // in flight while this stage is processed
+    const int t = stage / sps;
     if (t != cur_t) {
       if (sml && cur_t >= 0 && hi == 0) {
         sml[cur_t * 2] = lslot;
@@ -62,86 +107,86 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
       cur_t = t;
       bias_t = (a.bias && qvalid) ? a.bias[((long)q * a.heads + h) * a.T + t] : 0.f;
     }
-    // ---- S^T = K . Q^T over the head dim (2 k-steps of 16)
-    f32x16_t s;
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const int tok0 = (stage - t * sps) * 64 + sub * 32;
+      // ---- fragments: K rows (keys) for S^T, V^T rows (channels) with the key permutation
+      bf16x8_t kf[NPL][2], vf[NPL][2];
+      const int krow = sub * 32 + j;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    bf16x8_t kf[NPL][2];
+      for (int p = 0; p < NPL; ++p)
 #pragma unroll
-    for (int p = 0; p < NPL; ++p)
+        for (int ks = 0; ks < 2; ++ks) {
+          kf[p][ks] = *reinterpret_cast<const bf16x8_t*>(ks_lds + p * MHA_KPL + krow * 64 +
+                                                         (((ks * 2 + hi) ^ ((krow >> 2) & 3)) << 4));
+          const char* vb = vs_lds + p * MHA_VPL + j * MHA_VROW + sub * 64 + ks * 32 + hi * 8;
+          const u32x2_t g0 = *reinterpret_cast<const u32x2_t*>(vb);
+          const u32x2_t g1 = *reinterpret_cast<const u32x2_t*>(vb + 16);
+          u32x4_t w;
+          w[0] = g0[0]; w[1] = g0[1]; w[2] = g1[0]; w[3] = g1[1];
+          vf[p][ks] = __builtin_bit_cast(bf16x8_t, w);
+        }
+      // ---- S^T = K . Q^T over the head dim (2 k-steps of 16)
+      f32x16_t s;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        kf[p][ks] = *reinterpret_cast<const bf16x8_t*>(kp[p] + (long)phys * a.k_slot_stride +
-                                                       (long)(tok0 + j) * a.ldk + h * 32 + ks * 16 + hi * 8);
-    // ---- V^T fragments (issued early; consumed after the softmax)
-    bf16x8_t vf[NPL][2];
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16_t* base = vp[p] + (long)phys * a.v_slot_stride + (long)(h * 32 + j) * a.ldv + tok0 + ks * 16 + hi * 4;
-        const u32x2_t g0 = *reinterpret_cast<const u32x2_t*>(base);
-        const u32x2_t g1 = *reinterpret_cast<const u32x2_t*>(base + 8);
-        u32x4_t w;
-        w[0] = g0[0]; w[1] = g0[1]; w[2] = g1[0]; w[3] = g1[1];
-        vf[p][ks] = __builtin_bit_cast(bf16x8_t, w);
+        if constexpr (NS == 3) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[1][ks], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks], qf[0][ks], s, 0, 0, 0);
+        }
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[0][ks], s, 0, 0, 0);
+      }
+      // ---- online softmax for this lane's query
+      float sv[16];
+      float tmax = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        sv[r] = tok < a.N ? a.scale * (s[r] + bias_t) : -3.0e38f;
+        tmax = fmaxf(tmax, sv[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m, tmax);
+      const float alpha = exp_weight(m - m_new);
+      float psum = 0.f;
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = sv[r] > -2.9e38f ? exp_weight(sv[r] - m_new) : 0.f;
+        psum += pv[r];
+      }
+      psum += __shfl_xor(psum, 32);
+      l = l * alpha + psum;
+      lslot = lslot * alpha + psum;
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      // ---- P^T as the B operand: k-step s, element e = register 8s+e
+      bf16x8_t pf[NPL][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4_t wh, wl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bf16_t h0, l0, h1, l1;
+          split_bf16(pv[8 * ks + 2 * e], h0, l0);
+          split_bf16(pv[8 * ks + 2 * e + 1], h1, l1);
+          wh[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+          wl[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+        pf[0][ks] = __builtin_bit_cast(bf16x8_t, wh);
+        if constexpr (NPL == 2) pf[1][ks] = __builtin_bit_cast(bf16x8_t, wl);
       }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if constexpr (NS == 3) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[1][ks], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks], qf[0][ks], s, 0, 0, 0);
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (NS == 3) {
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[1][ks], o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][ks], pf[0][ks], o, 0, 0, 0);
+        }
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[0][ks], o, 0, 0, 0);
       }
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[0][ks], s, 0, 0, 0);
-    }
-    // ---- online softmax for this lane's query
-    float sv[16];
-    float tmax = -3.0e38f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      sv[r] = tok < a.N ? a.scale * (s[r] + bias_t) : -3.0e38f;
-      tmax = fmaxf(tmax, sv[r]);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m, tmax);
-    const float alpha = expf(m - m_new);
-    float psum = 0.f;
-    float pv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pv[r] = sv[r] > -2.9e38f ? expf(sv[r] - m_new) : 0.f;
-      psum += pv[r];
-    }
-    psum += __shfl_xor(psum, 32);
-    l = l * alpha + psum;
-    lslot = lslot * alpha + psum;
-    m = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-    // ---- P^T as the B operand: k-step s, element e = register 8s+e
-    bf16x8_t pf[NPL][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4_t wh, wl;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bf16_t h0, l0, h1, l1;
-        split_bf16(pv[8 * ks + 2 * e], h0, l0);
-        split_bf16(pv[8 * ks + 2 * e + 1], h1, l1);
-        wh[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        wl[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
-      }
-      pf[0][ks] = __builtin_bit_cast(bf16x8_t, wh);
-      if constexpr (NPL == 2) pf[1][ks] = __builtin_bit_cast(bf16x8_t, wl);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if constexpr (NS == 3) {
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[1][ks], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][ks], pf[0][ks], o, 0, 0, 0);
-      }
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[0][ks], o, 0, 0, 0);
     }
   }
   if (sml && cur_t >= 0 && hi == 0) {
@@ -165,7 +210,7 @@ extern "C" int rmem_mha_flash(const rmem_mha_args* ap, void* stream) {
   const rmem_mha_args& a = *ap;
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) || a.T <= 0 || a.heads <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
   if (!a.qh || !a.kh || !a.vh || !a.opart || !a.ml) return RMEM_ERR_INVALID;
-  if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 4)) return RMEM_ERR_INVALID;
+  if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.k_slot_stride % 8) || (a.v_slot_stride % 8)) return RMEM_ERR_INVALID;
   dim3 grid(a.Npad / 128, a.heads, a.ksplits);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (a.nsplit == 3) {
