@@ -20,6 +20,8 @@
 #include "rmem_common.h"
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 // LDS image of one 64-key stage of head h (shared by the four waves = 128 queries of a block):
 //   K   [plane][64 keys][64 B]   rows of 64 B, 16-byte chunk c of row r stored at c ^ ((r >> 2) & 3)
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   f32x16_t o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  const float sl2e = a.scale * 1.44269504088896341f;   // scores are kept in the log2 domain
   float m = -3.0e38f, l = 0.f, lslot = 0.f, bias_t = 0.f;
   int cur_t = -1;
   const bool qvalid = q < a.N;
@@ -101,11 +104,11 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
     if (t != cur_t) {
       if (sml && cur_t >= 0 && hi == 0) {
         sml[cur_t * 2] = lslot;
-        sml[cur_t * 2 + 1] = m;
+        sml[cur_t * 2 + 1] = m * 0.693147180559945f;     // back to the natural-log domain
       }
       lslot = 0.f;
       cur_t = t;
-      bias_t = (a.bias && qvalid) ? a.bias[((long)q * a.heads + h) * a.T + t] : 0.f;
+      bias_t = (a.bias && qvalid) ? a.bias[((long)q * a.heads + h) * a.T + t] * sl2e : 0.f;
     }
 #pragma unroll 1
     for (int sub = 0; sub < 2; ++sub) {
@@ -138,31 +141,47 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
         }
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[0][ks], s, 0, 0, 0);
       }
-      // ---- online softmax for this lane's query
+      // ---- online softmax for this lane's query, in the log2 domain: y = (s + bias) * scale * log2(e),
+      // weights 2^(y - m).  The kernel is VALU-bound, so the token mask is applied only on the
+      // tile that contains padding and the accumulator rescale only when some maximum moved.
       float sv[16];
       float tmax = -3.0e38f;
+      const bool padded = tok0 + 32 > a.N;      // wave-uniform
+      if (!padded) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        sv[r] = tok < a.N ? a.scale * (s[r] + bias_t) : -3.0e38f;
-        tmax = fmaxf(tmax, sv[r]);
+        for (int r = 0; r < 16; ++r) {
+          sv[r] = fmaf(s[r], sl2e, bias_t);
+          tmax = fmaxf(tmax, sv[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          sv[r] = tok < a.N ? fmaf(s[r], sl2e, bias_t) : -3.0e38f;
+          tmax = fmaxf(tmax, sv[r]);
+        }
       }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m, tmax);
-      const float alpha = exp_weight(m - m_new);
       float psum = 0.f;
       float pv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pv[r] = sv[r] > -2.9e38f ? exp_weight(sv[r] - m_new) : 0.f;
+        pv[r] = __builtin_amdgcn_exp2f(sv[r] - m_new);
+        if (padded) pv[r] = sv[r] > -2.9e38f ? pv[r] : 0.f;   // (a split may start on an all-padding tile: m is still the sentinel)
         psum += pv[r];
       }
       psum += __shfl_xor(psum, 32);
-      l = l * alpha + psum;
-      lslot = lslot * alpha + psum;
-      m = m_new;
+      if (__any(m_new != m)) {
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        l *= alpha;
+        lslot *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        m = m_new;
+      }
+      l += psum;
+      lslot += psum;
       // ---- P^T as the B operand: k-step s, element e = register 8s+e
       bf16x8_t pf[NPL][2];
 #pragma unroll
@@ -170,11 +189,14 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
         u32x4_t wh, wl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          bf16_t h0, l0, h1, l1;
-          split_bf16(pv[8 * ks + 2 * e], h0, l0);
-          split_bf16(pv[8 * ks + 2 * e + 1], h1, l1);
-          wh[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-          wl[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+          const float p0 = pv[8 * ks + 2 * e], p1 = pv[8 * ks + 2 * e + 1];
+          const f32x2_t pp = {p0, p1};
+          const uint32_t hh = __builtin_bit_cast(uint32_t, __builtin_convertvector(pp, bf16x2_t));
+          wh[e] = hh;
+          if constexpr (NPL == 2) {
+            const f32x2_t rr = {p0 - __uint_as_float(hh << 16), p1 - __uint_as_float(hh & 0xffff0000u)};
+            wl[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr, bf16x2_t));
+          }
         }
         pf[0][ks] = __builtin_bit_cast(bf16x8_t, wh);
         if constexpr (NPL == 2) pf[1][ks] = __builtin_bit_cast(bf16x8_t, wl);
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   }
   if (sml && cur_t >= 0 && hi == 0) {
     sml[cur_t * 2] = lslot;
-    sml[cur_t * 2 + 1] = m;
+    sml[cur_t * 2 + 1] = m * 0.693147180559945f;
   }
   // ---- partial outputs: O^T rows (channels) of this lane are 4 runs of 4 consecutive channels
   float* op = a.opart + ((long)z * a.Npad + q) * (a.heads * 32) + h * 32 + 4 * hi;
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
     *reinterpret_cast<float4*>(op + 8 * g) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
   if (hi == 0) {
     float* mlp = a.ml + (((long)z * a.Npad + q) * a.heads + h) * 2;
-    mlp[0] = m;
+    mlp[0] = m * 0.693147180559945f;
     mlp[1] = l;
   }
 }
