@@ -8,7 +8,7 @@ reference's timing window (managers/evaluator.py:399-404,525-527):
 match_propogate_one_frame -> label map (bilinear upsample + argmax; the evaluator's
 softmax/argmax torch ops with --reference-postproc) -> nearest resize -> update_memory, with
 the bank in steady state (T = K, one long-memory update + eviction every `gap` frames).
-The next frame is handed to the engine as `next_img` (encoder prefetch, as rmem_amd.driver does).
+The next two frames are announced to the engine as `next_img` (encoder prefetch, as rmem_amd.driver does).
 Frames are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 40 --warmup 10
@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not hand the next frame to match_propogate_one_frame (its encoder pass then runs "
                          "in line instead of on a second stream beside this frame's LSTT/decoder)")
+    ap.add_argument("--lookahead", type=int, default=2,
+                    help="frames announced ahead to the engine for encoder prefetch (feature copies = lookahead + 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
@@ -114,10 +116,12 @@ def main():
         clips.append(([x.to(dev) for x in im], lb.to(dev)))
 
     PREFETCH = not args.no_prefetch
+    LOOKAHEAD = max(1, args.lookahead)
 
     def frame_step(i, t, masks_out=None):
         engine = engines[i]
-        nxt = clips[i][0][(t + 1) % ring] if PREFETCH else None
+        # the next two frames are announced to the engine (encoder prefetch, as rmem_amd.driver does)
+        nxt = [clips[i][0][(t + d) % ring] for d in range(1, LOOKAHEAD + 1)] if PREFETCH else None
         if args.reference_postproc:
             logit = engine.match_propogate_one_frame(clips[i][0][t % ring], output_size=(H_OUT, W_OUT), next_img=nxt)
             prob = torch.softmax(logit, dim=1)

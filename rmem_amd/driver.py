@@ -241,10 +241,13 @@ class ClipDriver:
         writers = []
         on_cuda = False
         it = iter(frames)
-        nxt = next(it, None)
+        ahead = [f for f in (next(it, None), next(it, None)) if f is not None]
         frame_idx = -1
-        while nxt is not None:
-            samples, nxt = nxt, next(it, None)          # one frame of look-ahead (encoder prefetch)
+        while ahead:
+            samples, ahead = ahead[0], ahead[1:]        # two frames of look-ahead (encoder prefetch)
+            f = next(it, None)
+            if f is not None:
+                ahead.append(f)
             frame_idx += 1
             engines = [self._engine(i) for i in range(len(samples))]
             flips = [bool(s["meta"]["flip"]) for s in samples]
@@ -268,8 +271,8 @@ class ClipDriver:
             logits, new_obj_label = [], None
             for i, (e, s, fl) in enumerate(zip(engines, samples, flips)):
                 kw = {}
-                if getattr(e, "supports_prefetch", False) and nxt is not None and len(nxt) > i:
-                    kw["next_img"] = nxt[i]["current_img"]
+                if getattr(e, "supports_prefetch", False) and ahead and all(len(a) > i for a in ahead):
+                    kw["next_img"] = [a[i]["current_img"] for a in ahead]
                 lg = e.match_propogate_one_frame(s["current_img"], output_size=None if fuse else ori_hw, **kw)
                 logits.append(lg)
                 if (not fl) and s.get("current_label") is not None and new_obj_label is None:

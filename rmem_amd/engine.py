@@ -70,13 +70,14 @@ class DeAOTEngine(nn.Module):
         self._fg, self._ug = {}, {}          # hipGraphs: frame graphs / update graphs by key
         self._eg = {}                        # encoder graphs by (img shape, parity): (graph, static img, features)
         self._g_lab = {}                     # static graph inputs per shape (graphs keep their address)
-        self._par = 0                        # which of the two encoder feature sets holds the current frame
-        self._pref = None                    # identity of the image whose features were prefetched
+        self._par = 0                        # which encoder feature copy holds the current frame
+        self._pending = []                   # prefetched, not yet consumed: [(image identity, copy, launched)]
+        self._ring = int(os.environ.get("RMEM_FEATURE_COPIES", "3"))   # copies = lookahead depth + 1
         self._enc_stream = None
         self._enc_done = None
         self._launcher = None
-        self._pref_launched = None
         self._eager_frames = 0
+        self.prefetch_at = os.environ.get("RMEM_PREFETCH_AT", "lstt")   # decoder | lstt
         if short_term_mem_skip != 1:
             raise NotImplementedError("short_term_mem_skip != 1 (reference evaluator always uses 1)")
         self.cfg = aot_model.cfg
@@ -98,7 +99,7 @@ class DeAOTEngine(nn.Module):
         self.input_size_2d = None
         self.long_memories_indexes: List[int] = []
         self.pred_id_logits = None
-        self._pref = None
+        self._drop_pending()
         if self.lstt is not None:
             self.lstt.clear_memory()
 
@@ -111,7 +112,8 @@ class DeAOTEngine(nn.Module):
             cls = DeAOTLSTT if self.cfg.MODEL_VOS == "deaot" else AOTLSTT
             self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
             self._fg, self._ug = {}, {}      # graphs hold pointers into the old LSTT buffers
-            self._eg, self._g_lab, self._pref = {}, {}, None
+            self._drop_pending()
+            self._eg, self._g_lab = {}, {}
 
     def _label_u8(self, mask: torch.Tensor) -> torch.Tensor:
         """[1,1,H,W] (or [1,H,W]) label ids -> contiguous uint8 [H,W] on device."""
@@ -151,9 +153,10 @@ class DeAOTEngine(nn.Module):
 
     @torch.no_grad()
     def match_propogate_one_frame(self, img=None, img_embs=None, mask=None, output_size=None, next_img=None):
-        """aot_engine.py:398-436.  `next_img` (extension, optional): the frame that will be
-        passed to the NEXT call; its encoder pass then runs on a second stream concurrently
-        with this frame's LSTT / decoder (the encoder does not depend on the memory)."""
+        """aot_engine.py:398-436.  `next_img` (extension, optional): the frame -- or a list of the
+        next frames, in order -- that will be passed to the NEXT call(s); their encoder passes
+        then run on a second stream concurrently with this frame's LSTT / decoder (the encoder
+        does not depend on the memory)."""
         self.frame_step += 1
         if self._graph_ok(img, img_embs):
             return self._graphed_frame(img, output_size, next_img)
@@ -196,39 +199,70 @@ class DeAOTEngine(nn.Module):
             if self._enc_stream is None:
                 from .streams import concurrent_stream
                 self._enc_stream = concurrent_stream(like.device)
-                self._enc_done = [torch.cuda.Event(), torch.cuda.Event()]
+                self._enc_done = [torch.cuda.Event() for _ in range(self._ring)]
         return ent
 
-    def _take_prefetched(self, img):
-        """Features of `img` if its encoder pass was prefetched by the previous call, else None."""
-        if self._pref is None:
-            return None
-        pref, self._pref = self._pref, None
-        self._pref_launched.wait()           # the helper thread has queued the pass and its event
-        if self._launcher.error is not None:
-            raise RuntimeError("encoder prefetch failed") from self._launcher.error
-        # also when the prefetch is discarded: whatever touches that feature copy next must
-        # come after the encoder stream is done with it
-        torch.cuda.current_stream().wait_event(self._enc_done[self._par])
-        if img is None or not img.is_cuda or pref != self._img_id(img):
-            return None
-        return self._eg[(tuple(img.shape), self._par)][2]
+    def _drop_pending(self):
+        """Forget prefetched frames (restart / resize).  Whatever touches their feature copies next
+        must still come after the encoder stream is done with them."""
+        pend, self._pending = getattr(self, "_pending", []), []
+        for _, par, launched in pend:
+            launched.wait()
+            torch.cuda.current_stream().wait_event(self._enc_done[par])
 
-    def _prefetch(self, next_img, par):
-        """Encoder pass of `next_img` into feature copy `par` on the encoder stream.  Ordered
-        after everything already queued on the current stream (the previous reader of that
-        copy), concurrent with whatever is queued next.  The graph is launched from a helper
-        host thread: hipGraphLaunch enqueues node by node (~8 us of host time per kernel), so
-        launching the encoder graph and then the frame graph from one thread leaves the GPU
-        waiting for the host; replay() releases the GIL, the two launches proceed in parallel."""
-        ent = self._encoder_graph(tuple(next_img.shape), par, next_img)
-        after = torch.cuda.Event()
-        after.record(torch.cuda.current_stream())
-        self._pref = self._img_id(next_img)
-        if self._launcher is None:
-            self._launcher = _GraphLauncher(next_img.device)
-        self._pref_launched = self._launcher.submit(self._enc_stream, after, ent[1], next_img, ent[0],
-                                                    self._enc_done[par])
+    def _take_prefetched(self, img):
+        """Features of `img` if an earlier call prefetched its encoder pass, else None.  Frames
+        are consumed in the order they were announced; older pending entries are discarded."""
+        if not self._pending:
+            return None
+        ident = self._img_id(img) if (img is not None and img.is_cuda) else None
+        hit = next((i for i, p in enumerate(self._pending) if p[0] == ident), None)
+        if hit is None:
+            self._drop_pending()
+            return None
+        drop, (_, par, launched), self._pending = self._pending[:hit], self._pending[hit], self._pending[hit + 1:]
+        for _, p, ln in drop + [(None, par, launched)]:
+            ln.wait()                            # the helper thread has queued the pass and its event
+            if self._launcher.error is not None:
+                raise RuntimeError("encoder prefetch failed") from self._launcher.error
+            torch.cuda.current_stream().wait_event(self._enc_done[p])
+        self._par = par
+        return self._eg[(tuple(img.shape), par)][2]
+
+    def _prefetch(self, next_imgs, shape):
+        """Encoder passes of the announced next frames into free feature copies on the encoder
+        stream.  Each is ordered after everything already queued on the current stream (the
+        previous reader of that copy) and after the passes queued before it, concurrent with
+        whatever is queued next.  With two frames of lookahead (three copies) the encoder stream
+        always has a pass queued, so it also fills the decoder / label / memory-update phase of
+        a frame, whose small kernels leave most of the GPU idle.  The graphs are launched from a
+        helper host thread: hipGraphLaunch enqueues node by node (~8 us of host time per
+        kernel), so launching an encoder graph and then the frame graphs from one thread leaves
+        the GPU waiting for the host; replay() releases the GIL, the launches proceed in parallel."""
+        if next_imgs is None:
+            return
+        if isinstance(next_imgs, torch.Tensor):
+            next_imgs = [next_imgs]
+        for img in list(next_imgs)[:self._ring - 1]:
+            if img is None or not img.is_cuda or tuple(img.shape) != shape:
+                break
+            ident = self._img_id(img)
+            if any(p[0] == ident for p in self._pending):
+                continue
+            busy = {self._par} | {p[1] for p in self._pending}
+            free = [c for c in range(self._ring) if c not in busy]
+            if not free:
+                break
+            # round-robin after the newest pending copy keeps a copy's reuse as far away as possible
+            last = self._pending[-1][1] if self._pending else self._par
+            par = min(free, key=lambda c: (c - last - 1) % self._ring)
+            ent = self._encoder_graph(shape, par, img)
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream())
+            if self._launcher is None:
+                self._launcher = _GraphLauncher(img.device)
+            launched = self._launcher.submit(self._enc_stream, after, ent[1], img, ent[0], self._enc_done[par])
+            self._pending.append((ident, par, launched))
 
     def _graphed_frame(self, img, output_size, next_img=None):
         l = self.lstt
@@ -239,7 +273,7 @@ class DeAOTEngine(nn.Module):
             g, g_img, _ = self._encoder_graph(shape, self._par, img)
             g_img.copy_(img)
             g.replay()
-        par = self._par
+        par = self._par                                   # the copy that holds this frame's features
         key = (l.graph_key(), osz, shape, par)
         ent = self._fg.get(key)
         if ent is None:
@@ -252,23 +286,30 @@ class DeAOTEngine(nn.Module):
             for var in l.graph_variants():
                 for k, v in var.items():
                     setattr(l, k, v)
-                g = torch.cuda.CUDAGraph()
+                g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     l.tgt.copy_(enc[-1][0].flatten(1).t())
                     l._forward_device(False)
+                with torch.cuda.graph(g2):
                     logits = self.AOT.decode_id_logits(l.out, enc)
                     for batch_idx, obj_num in enumerate(self.obj_nums):
                         logits[batch_idx, (obj_num + 1):] = -1e10
                     up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
                                                                   align_corners=self.align_corners)
-                self._fg[(l.graph_key(), osz, shape, par)] = (g, logits, up)
+                self._fg[(l.graph_key(), osz, shape, par)] = (g, logits, up, g2)
             for k, v in saved.items():
                 setattr(l, k, v)
             ent = self._fg[key]
-        if next_img is not None and next_img.is_cuda and tuple(next_img.shape) == shape:
-            self._prefetch(next_img, 1 - par)             # runs beside the frame graph below
-            self._par = 1 - par
+        # The frame is two graphs, LSTT and decoder, so that the next frame's encoder pass can be
+        # released between them: beside the LSTT it competes with latency-bound kernels for
+        # workgroup slots (every kernel of both chains ~2x slower), beside the decoder + label
+        # post-processing + memory update it fills a GPU that those small kernels leave idle.
+        if self.prefetch_at == "lstt":
+            self._prefetch(next_img, shape)               # runs beside the LSTT graph below
         ent[0].replay()
+        if self.prefetch_at != "lstt":
+            self._prefetch(next_img, shape)               # released when the LSTT is done
+        ent[3].replay()
         l._finish(False)
         self.pred_id_logits = ent[1]
         return ent[2]

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -183,6 +184,7 @@ class DeAOTLSTT:
         self.ws_main = _AttnWS(self.Tmax, N, Np, self.ksplits_max, dev)
         self.ws_side = _AttnWS(1, N, Np, self.ksplits_max, dev)
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "short_first")   # short_first | long_first | serial
         self.ev_ready = torch.cuda.Event() if dev.type == "cuda" else None
         self.ev_side = torch.cuda.Event() if dev.type == "cuda" else None
         self.Ylt = Planes.empty((Np, 1024), dev)
@@ -417,26 +419,40 @@ class DeAOTLSTT:
             hip.linear_grouped(grp)
             if ref_frame:
                 self._idv(l, cur)
-            # -- short-term windowed read on the side stream (transformer.py:1199,
-            #    attention.py:289-358); independent of the long-term chain until the projection
-            self.ev_ready.record()
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ev_ready)
+            # -- short-term windowed read (transformer.py:1199, attention.py:289-358) and long-term
+            #    memory read (transformer.py:1140-1192, attention.py:174-209): independent until
+            #    the projection.  Issue order matters under hipGraph replay: the branch whose nodes
+            #    are created first continues on the predecessor's hardware queue, the other one is
+            #    forked to a second queue and starts ~120 us late (rocprofv3 trace, profiles/r01_g).
+            def short_chain():
                 hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
                            d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
                 self._attention(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
                                 Ucat, want_mass=False, which=1)
                 self._dwconv(self.ws_side, W.dw_st, self.Yst)
-                self.ev_side.record()
-            # -- long-term memory read (transformer.py:1140-1192, attention.py:174-209)
-            st = hip.stream_ptr()
-            hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
-                                       self.mem_pe.data_ptr(), rows, T, N, 128,
-                                       self.bias_pe.data_ptr(), st), "rmem_pe_bias")
-            self._attention(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
-                            self.bias_pe, Ucat, want_mass=(l == 0), which=0)
-            self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
-            torch.cuda.current_stream().wait_event(self.ev_side)
+
+            def long_chain():
+                hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
+                                           self.mem_pe.data_ptr(), rows, T, N, 128,
+                                           self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
+                self._attention(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
+                                self.bias_pe, Ucat, want_mass=(l == 0), which=0)
+                self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
+
+            if self.branch_order == "serial":
+                short_chain()
+                long_chain()
+            else:
+                self.ev_ready.record()
+                if self.branch_order == "long_first":
+                    long_chain()
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self.ev_ready)
+                    short_chain()
+                    self.ev_side.record()
+                if self.branch_order != "long_first":
+                    long_chain()
+                torch.cuda.current_stream().wait_event(self.ev_side)
             # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
             #    adds happen in the norms that follow (rmem_layernorm_red)
             hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,

@@ -1,4 +1,6 @@
-for i in 1 2 3; do
-  echo -n "glds: "; python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['roofline']['mean_us'],1))"
-  echo -n "legacy: "; RMEM_PV_LEGACY=1 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['roofline']['mean_us'],1))"
-done
+# generic A/B: bash tools/gpujob_ab.sh "<ENV=.. ENV=..>" "<ENV=..>" ...   (each variant benched twice, interleaved)
+mkdir -p gpurun_out; export TMPDIR=/tmp
+for rep in 1 2; do
+for v in "$@"; do
+  echo -n "[$v] "; env $v python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],3), round(d['roofline']['mean_us'],1))"
+done; done

@@ -89,11 +89,26 @@ def install(plan):
     R.local_gated_propagation = local
 
 
+def install_conv(which):
+    """Emulate split-bf16 (hi+lo planes, 16 significant bits per operand) in the encoder/decoder
+    convolutions: which = 'c1' (1x1 only) or 'call' (every conv)."""
+    orig = F.conv2d
+
+    def conv2d(x, w, *a, **k):
+        if which == "call" or tuple(w.shape[2:]) == (1, 1):
+            x, w = planes(x, torch.bfloat16, 2), planes(w, torch.bfloat16, 2)
+        return orig(x, w, *a, **k)
+
+    torch.nn.functional.conv2d = conv2d
+
+
 def run(plan):
     gd = os.path.join(ROOT, "tests", "golden")
     meta = json.load(open(os.path.join(gd, "clip_480p.json")))
     gold = np.load(os.path.join(gd, "clip_480p.npz"))
-    if plan != "fp32":
+    if plan in ("c1", "call"):
+        install_conv(plan)
+    elif plan != "fp32":
         install(plan)
     torch.manual_seed(0)
     model = build_vos_model("deaot", get_config("r50_deaotl", meta["former"], meta["latter"])).eval()
