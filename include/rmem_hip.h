@@ -255,6 +255,13 @@ int rmem_groupnorm_nchw(const float *x, float *y, int32_t C, int64_t HW, int32_t
                         const float *gamma, const float *beta, float eps, int32_t relu, double *ws,
                         void *stream);
 
+/* Same, for the output x of a bias-free convolution: y = GN(x + conv_bias[c]) -- the ConvGN
+ * block's nn.Conv2d bias (layers/basic.py:60-70) applied inside the statistics and the apply
+ * pass instead of in a separate pass over the map. */
+int rmem_groupnorm_nchw_bias(const float *x, const float *conv_bias, float *y, int32_t C, int64_t HW,
+                             int32_t groups, const float *gamma, const float *beta, float eps,
+                             int32_t relu, double *ws, void *stream);
+
 /* Support op outside the LSTT: in-place conv epilogue y = act(x + bias[c] (+ residual)) on a
  * contiguous batch-1 NCHW tensor (the folded-FrozenBN bias, the bottleneck's residual add and
  * ReLU of encoders/resnet.py:47-69 in one pass). */
@@ -266,6 +273,12 @@ int rmem_bias_act_nchw(float *x, const float *bias, const float *residual, int32
  * head (decoders/fpn.py:53-60) in one pass.  bias may be NULL.  C*H <= 65535. */
 int rmem_upsample_add_nchw(float *y, const float *bias, const float *x, int32_t C, int32_t H,
                            int32_t W, int32_t h, int32_t w, int32_t align_corners, void *stream);
+
+/* Same, out of place: y_out = (y_in + bias[c]) + bilinear_upsample(x); y_in is left untouched (the
+ * adapter's convolution output computed with the encoder pass may be decoded more than once). */
+int rmem_upsample_add_nchw_out(const float *y_in, float *y_out, const float *bias, const float *x,
+                               int32_t C, int32_t H, int32_t W, int32_t h, int32_t w,
+                               int32_t align_corners, void *stream);
 
 /* dst[0..n) = host_vals[0..n) (n <= 32), stream-ordered, payload in the kernel arguments: how
  * the logical->physical slot map of the bank is published without a blocking H2D copy. */

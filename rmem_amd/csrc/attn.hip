@@ -203,16 +203,41 @@ struct PBlockedOperand {
   }
 };
 
+// Logical -> physical slot map held in two 64-bit scalars (8 bits per slot, T <= 16).  A
+// per-k-tile `slot_map[t]` read is a dependent global load followed by s_waitcnt vmcnt(0): it
+// delays the issue of the tile's staging loads by a full memory latency and drains every load in
+// flight, which also defeats any deeper prefetch (measured with tools/ubench/pv_trace).
+struct SlotLut {
+  unsigned long long w0, w1;
+  __device__ __forceinline__ void load(const int* slot_map, int T) {
+    w0 = w1 = 0;
+    if (!slot_map) {
+      w0 = 0x0706050403020100ull;
+      w1 = 0x0f0e0d0c0b0a0908ull;
+      return;
+    }
+    for (int t = 0; t < T && t < 16; ++t) {
+      const unsigned long long v = (unsigned long long)(slot_map[t] & 0xff);
+      if (t < 8) w0 |= v << (8 * t); else w1 |= v << (8 * (t - 8));
+    }
+    w0 = __builtin_amdgcn_readfirstlane((unsigned)w0) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(w0 >> 32)) << 32);
+    w1 = __builtin_amdgcn_readfirstlane((unsigned)w1) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(w1 >> 32)) << 32);
+  }
+  __device__ __forceinline__ int operator()(int t) const {
+    return (int)(((t < 8 ? w0 : w1) >> (8 * (t & 7))) & 0xff);
+  }
+};
+
 struct VtOperand {
   const bf16_t* hi;
   const bf16_t* lo;
   long slot_stride, ld;
-  const int* slot_map;
+  SlotLut lut;
   int tps;  // 64-key tiles per slot
   int row0, rows;
   __device__ __forceinline__ TileView tile(int kt) const {
     const int t = kt / tps;
-    const int phys = slot_map ? slot_map[t] : t;
+    const int phys = lut(t);
     const long off = (long)phys * slot_stride + (kt - t * tps) * 64;
     return TileView{hi + off, lo ? lo + off : nullptr, ld};
   }
@@ -263,7 +288,9 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   if (hi > k_hi) hi = k_hi;
 
   PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 128};
-  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, a.slot_map, tps, ctile * 128, a.ncols};
+  SlotLut lut;
+  lut.load(a.slot_map, a.T);
+  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, lut, tps, ctile * 128, a.ncols};
 
   GemmFrag<Cfg> f;
   f.zero();
@@ -307,7 +334,7 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   if (!ap) return RMEM_ERR_INVALID;
   const rmem_pv_args& a = *ap;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.ksplits <= 0) return RMEM_ERR_INVALID;
+  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.T > 16 || a.ksplits <= 0) return RMEM_ERR_INVALID;
   if (!a.ph || !a.vh || !a.part || a.ncols <= 0) return RMEM_ERR_INVALID;
   if (a.mode == 1 && (a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
   if (a.nsplit == 3 && (!a.pl || !a.vl)) return RMEM_ERR_INVALID;

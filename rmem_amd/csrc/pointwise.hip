@@ -425,7 +425,8 @@ extern "C" int rmem_split_planes(const float* x, int64_t n, rmem_bf16* hi, rmem_
 // workgroup per (image, group) -- 8 workgroups at batch 1 -- and costs ~100 us per call on
 // MI355X.  Here a group (a contiguous segment of (C/G)*HW floats) is reduced by `ns` blocks
 // into double partials, and the apply pass fuses the affine and the ReLU.
-__global__ __launch_bounds__(256) void gn_nchw_stats_kernel(const float* x, long seg, int ns, double* ws) {
+__global__ __launch_bounds__(256) void gn_nchw_stats_kernel(const float* x, const float* cbias, int cpg, long hw, long seg,
+                                                            int ns, double* ws) {
   __shared__ double red[2][4];
   const int g = blockIdx.y, sidx = blockIdx.x;
   const long per = ((seg / 4 + ns - 1) / ns) * 4;
@@ -433,15 +434,22 @@ __global__ __launch_bounds__(256) void gn_nchw_stats_kernel(const float* x, long
   if (hi > seg) hi = seg;
   const float* xb = x + (long)g * seg;
   double s = 0, q = 0;
+  // cbias (may be NULL): the producing convolution's per-channel bias, added here in fp32 exactly
+  // as the separate bias pass of the convolution would (x + b rounded once)
+  const float* cb = cbias ? cbias + (long)g * cpg : nullptr;
   for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
     if (i + 3 < hi) {
-      const float4 v = *reinterpret_cast<const float4*>(xb + i);
+      float4 v = *reinterpret_cast<const float4*>(xb + i);
+      if (cb) {
+        v.x += cb[i / hw]; v.y += cb[(i + 1) / hw]; v.z += cb[(i + 2) / hw]; v.w += cb[(i + 3) / hw];
+      }
       s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
       q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     } else {
       for (long j = i; j < hi; ++j) {
-        s += xb[j];
-        q += (double)xb[j] * xb[j];
+        const float v = cb ? xb[j] + cb[j / hw] : xb[j];
+        s += v;
+        q += (double)v * v;
       }
     }
   }
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(256) void gn_nchw_stats_kernel(const float* x, long
         red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
-__global__ __launch_bounds__(256) void gn_nchw_apply_kernel(const float* x, float* y, long seg, int cpg, long hw,
+__global__ __launch_bounds__(256) void gn_nchw_apply_kernel(const float* x, const float* cbias, float* y, long seg, int cpg, long hw,
                                                             int ns, const double* ws, const float* gamma,
                                                             const float* beta, float eps, int relu) {
   __shared__ float stat[2];
@@ -495,7 +503,8 @@ __global__ __launch_bounds__(256) void gn_nchw_apply_kernel(const float* x, floa
     for (int e = 0; e < 4; ++e) {
       const int c = g * cpg + (int)((i + e) / hw);
       const int cc = c < (g + 1) * cpg ? c : (g + 1) * cpg - 1;
-      float o = (v[e] - mean) * rstd * gamma[cc] + beta[cc];
+      const float xv = cbias ? v[e] + cbias[cc] : v[e];
+      float o = (xv - mean) * rstd * gamma[cc] + beta[cc];
       if (relu) o = o > 0.f ? o : 0.f;
       v[e] = o;
     }
@@ -508,22 +517,35 @@ __global__ __launch_bounds__(256) void gn_nchw_apply_kernel(const float* x, floa
   }
 }
 
-extern "C" int rmem_groupnorm_nchw(const float* x, float* y, int32_t C, int64_t HW, int32_t groups,
-                                   const float* gamma, const float* beta, float eps, int32_t relu, double* ws,
-                                   void* stream) {
+static int groupnorm_nchw_impl(const float* x, const float* cbias, float* y, int32_t C, int64_t HW, int32_t groups,
+                               const float* gamma, const float* beta, float eps, int32_t relu, double* ws,
+                               void* stream) {
   if (!x || !y || !gamma || !beta || !ws || C <= 0 || groups <= 0 || (C % groups) || HW <= 0) return RMEM_ERR_INVALID;
   const int cpg = C / groups;
   const long seg = (long)cpg * HW;
   if ((seg % 4) != 0) return RMEM_ERR_INVALID;   // keeps every group segment 16-byte aligned
   const int ns = 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_nchw_stats_kernel, dim3(ns, groups), dim3(256), 0, s, x, seg, ns, ws);
+  hipLaunchKernelGGL(gn_nchw_stats_kernel, dim3(ns, groups), dim3(256), 0, s, x, cbias, cpg, (long)HW, seg, ns, ws);
   long ab = (seg / 4 + 255) / 256;
   if (ab > 64) ab = 64;
-  hipLaunchKernelGGL(gn_nchw_apply_kernel, dim3((unsigned)ab, groups), dim3(256), 0, s, x, y, seg, cpg, (long)HW, ns,
-                     ws, gamma, beta, eps, relu);
+  hipLaunchKernelGGL(gn_nchw_apply_kernel, dim3((unsigned)ab, groups), dim3(256), 0, s, x, cbias, y, seg, cpg, (long)HW,
+                     ns, ws, gamma, beta, eps, relu);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
+}
+
+extern "C" int rmem_groupnorm_nchw(const float* x, float* y, int32_t C, int64_t HW, int32_t groups,
+                                   const float* gamma, const float* beta, float eps, int32_t relu, double* ws,
+                                   void* stream) {
+  return groupnorm_nchw_impl(x, nullptr, y, C, HW, groups, gamma, beta, eps, relu, ws, stream);
+}
+
+extern "C" int rmem_groupnorm_nchw_bias(const float* x, const float* conv_bias, float* y, int32_t C, int64_t HW,
+                                        int32_t groups, const float* gamma, const float* beta, float eps,
+                                        int32_t relu, double* ws, void* stream) {
+  if (!conv_bias) return RMEM_ERR_INVALID;
+  return groupnorm_nchw_impl(x, conv_bias, y, C, HW, groups, gamma, beta, eps, relu, ws, stream);
 }
 
 // ------------------------------------------------------------------ planes transpose
@@ -748,7 +770,7 @@ extern "C" int rmem_bias_act_nchw(float* x, const float* bias, const float* resi
 // the high-resolution map instead of bias-add, F.interpolate and add (three passes, the
 // generic upsample kernel alone runs at 0.3 TB/s).  Same interpolation arithmetic as
 // torch's upsample_bilinear2d (area_pixel_compute_source_index, fp32).
-__global__ __launch_bounds__(256) void upsample_add_kernel(float* __restrict__ y, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float* yin, float* y, const float* __restrict__ bias,
                                                           const float* __restrict__ x, int H, int W, int h, int w,
                                                           float rh, float rw, int align) {
   const int X = blockIdx.x * 256 + threadIdx.x;
@@ -768,14 +790,14 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(float* __restrict__ y
   const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
   const float* q = x + ((long)c * h + y0) * w + x0;
   const float up = ly0 * (lx0 * q[0] + lx1 * q[xp]) + ly1 * (lx0 * q[(long)yp * w] + lx1 * q[(long)yp * w + xp]);
-  float* o = y + ((long)c * H + Y) * W + X;
+  const long oi = ((long)c * H + Y) * W + X;
   const float b = bias ? bias[c] : 0.f;
-  *o = (*o + b) + up;
+  y[oi] = (yin[oi] + b) + up;
 }
 
-extern "C" int rmem_upsample_add_nchw(float* y, const float* bias, const float* x, int32_t C, int32_t H, int32_t W,
-                                      int32_t h, int32_t w, int32_t align_corners, void* stream) {
-  if (!y || !x || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return RMEM_ERR_INVALID;
+static int upsample_add_impl(const float* yin, float* y, const float* bias, const float* x, int32_t C, int32_t H,
+                             int32_t W, int32_t h, int32_t w, int32_t align_corners, void* stream) {
+  if (!y || !yin || !x || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return RMEM_ERR_INVALID;
   if ((long)C * H > 65535) return RMEM_ERR_INVALID;
   float rh, rw;
   if (align_corners) {
@@ -786,9 +808,20 @@ extern "C" int rmem_upsample_add_nchw(float* y, const float* bias, const float* 
     rw = (float)w / (float)W;
   }
   hipLaunchKernelGGL(upsample_add_kernel, dim3((W + 255) / 256, C * H), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     y, bias, x, H, W, h, w, rh, rw, align_corners);
+                     yin, y, bias, x, H, W, h, w, rh, rw, align_corners);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
+}
+
+extern "C" int rmem_upsample_add_nchw(float* y, const float* bias, const float* x, int32_t C, int32_t H, int32_t W,
+                                      int32_t h, int32_t w, int32_t align_corners, void* stream) {
+  return upsample_add_impl(y, y, bias, x, C, H, W, h, w, align_corners, stream);
+}
+
+extern "C" int rmem_upsample_add_nchw_out(const float* y_in, float* y_out, const float* bias, const float* x,
+                                          int32_t C, int32_t H, int32_t W, int32_t h, int32_t w,
+                                          int32_t align_corners, void* stream) {
+  return upsample_add_impl(y_in, y_out, bias, x, C, H, W, h, w, align_corners, stream);
 }
 
 // ------------------------------------------------------------------ slot map publish
@@ -809,4 +842,4 @@ extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 5; }
+extern "C" int rmem_abi_version(void) { return 6; }

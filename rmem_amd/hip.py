@@ -101,7 +101,8 @@ EXPORTS = [
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
-    "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw",
+    "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
+    "rmem_upsample_add_nchw_out",
 ]
 
 
@@ -138,6 +139,7 @@ def load():
     lib.rmem_attn_mass_reduce.argtypes = [c_p, i32, i32, c_p, c_p, c_p]
     lib.rmem_split_planes.argtypes = [c_p, i64, c_p, c_p, c_p]
     lib.rmem_groupnorm_nchw.argtypes = [c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]
+    lib.rmem_groupnorm_nchw_bias.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]
     lib.rmem_mha_flash.argtypes = [C.POINTER(MHAArgs), c_p]
     lib.rmem_mha_combine.argtypes = [C.POINTER(MHACombineArgs), c_p]
     lib.rmem_layernorm_ex.argtypes = [c_p, i64, c_p, i64, c_p, c_p, i32, i32, f32, c_p, i64, c_p, c_p, i64,
@@ -148,6 +150,7 @@ def load():
     lib.rmem_pe_bias_heads.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]
     lib.rmem_labels_from_logits.argtypes = [C.POINTER(LabelSrc), i32, i32, i32, i32, i32, c_p, c_p]
     lib.rmem_upsample_add_nchw.argtypes = [c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p]
+    lib.rmem_upsample_add_nchw_out.argtypes = [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p]
     lib.rmem_label_resize_nearest.argtypes = [c_p, i32, i32, c_p, i32, i32, i32, c_p]
     _LIB = lib
     return lib
@@ -234,17 +237,26 @@ def linear_grouped(args):
     check(load().rmem_linear_grouped(arr, len(args), stream_ptr()), "rmem_linear_grouped")
 
 
-def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool) -> torch.Tensor:
-    """GroupNorm(+ReLU) of a batch-1 NCHW fp32 tensor through rmem_groupnorm_nchw."""
+def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool, conv_bias=None) -> torch.Tensor:
+    """GroupNorm(+ReLU) of a batch-1 NCHW fp32 tensor through rmem_groupnorm_nchw; with
+    `conv_bias`, x is the output of a bias-free convolution and the bias is added in the kernel."""
     x = x.contiguous()
     n, c, h, w = x.shape
     if n != 1 or x.dtype != torch.float32 or ((c // gn.num_groups) * h * w) % 4:
+        if conv_bias is not None:
+            x = x + conv_bias.view(1, -1, 1, 1)
         y = torch.nn.functional.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
         return torch.relu_(y) if relu else y
     # per-call workspace (stream-ordered caching allocator / graph pool): engines running
     # concurrently on different streams must not share it; the stats pass overwrites all of it
     ws = torch.empty(2 * 32 * gn.num_groups, dtype=torch.float64, device=x.device)
     y = torch.empty_like(x)
+    if conv_bias is not None:
+        check(load().rmem_groupnorm_nchw_bias(x.data_ptr(), conv_bias.data_ptr(), y.data_ptr(), c, h * w,
+                                              gn.num_groups, gn.weight.data_ptr(), gn.bias.data_ptr(), gn.eps,
+                                              int(relu), ws.data_ptr(), stream_ptr()),
+              "rmem_groupnorm_nchw_bias")
+        return y
     check(load().rmem_groupnorm_nchw(x.data_ptr(), y.data_ptr(), c, h * w, gn.num_groups, gn.weight.data_ptr(),
                                      gn.bias.data_ptr(), gn.eps, int(relu), ws.data_ptr(), stream_ptr()),
           "rmem_groupnorm_nchw")
@@ -265,8 +277,9 @@ def bias_act_nchw_(x: torch.Tensor, bias: torch.Tensor, residual=None, relu: boo
     return x
 
 
-def upsample_add_nchw_(y: torch.Tensor, bias, x: torch.Tensor, align_corners: bool) -> torch.Tensor:
-    """In-place y = (y + bias[c]) + bilinear(x -> y's size) for contiguous batch-1 NCHW fp32 maps."""
+def upsample_add_nchw_(y: torch.Tensor, bias, x: torch.Tensor, align_corners: bool, inplace: bool = True) -> torch.Tensor:
+    """y = (y + bias[c]) + bilinear(x -> y's size) for contiguous batch-1 NCHW fp32 maps; in place,
+    or into a new tensor (inplace=False: y is left untouched)."""
     n, c, H, W = y.shape
     if n != 1 or x.shape[0] != 1 or x.shape[1] != c or not y.is_contiguous() or y.dtype != torch.float32 \
             or c * H > 65535:
@@ -276,6 +289,12 @@ def upsample_add_nchw_(y: torch.Tensor, bias, x: torch.Tensor, align_corners: bo
             x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=align_corners)
         return y + x
     x = x.contiguous()
+    if not inplace:
+        out = torch.empty_like(y)
+        check(load().rmem_upsample_add_nchw_out(y.data_ptr(), out.data_ptr(), ptr(bias), x.data_ptr(), c, H, W,
+                                                x.shape[2], x.shape[3], int(bool(align_corners)), stream_ptr()),
+              "rmem_upsample_add_nchw_out")
+        return out
     check(load().rmem_upsample_add_nchw(y.data_ptr(), ptr(bias), x.data_ptr(), c, H, W, x.shape[2], x.shape[3],
                                         int(bool(align_corners)), stream_ptr()), "rmem_upsample_add_nchw")
     return y

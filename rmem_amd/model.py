@@ -132,6 +132,10 @@ class DeAOT(nn.Module):
         enc = self.__dict__.get("_enc_infer") or self.encoder
         xs = enc(img)
         xs[-1] = self.encoder_projector(xs[-1])
+        if xs[0].is_cuda and not torch.is_grad_enabled() and hasattr(self.decoder, "adapter_convs"):
+            # the decoder's skip adapters read encoder features only: run them with the encoder pass
+            xs = FeatureList(xs)
+            xs.adapters = self.decoder.adapter_convs(xs)
         return xs
 
     def decode_id_logits(self, lstt_emb_nc, shortcuts):
@@ -139,6 +143,12 @@ class DeAOT(nn.Module):
         n, _, h, w = shortcuts[-1].shape
         emb = lstt_emb_nc.view(h, w, n, -1).permute(2, 3, 0, 1)
         return self.decoder([shortcuts[-1], emb], shortcuts)
+
+
+class FeatureList(list):
+    """Encoder pyramid [4x, 8x, 16x, projected 16x] plus, on the GPU inference path, the decoder's
+    bias-free skip-adapter convolutions of it (`adapters`, see nets/fpn.py:FPNHead.adapter_convs)."""
+    adapters = None
 
 
 class _MHA(nn.Module):

@@ -323,6 +323,14 @@ def test_groupnorm_nchw_relu(hip):
         y = hip.groupnorm_nchw(x.to(DEV), gn, True)
         torch.cuda.synchronize()
         assert (y.cpu().double() - ref).abs().max().item() < 5e-6
+        # with the producing convolution's bias folded in: GN(x + b[c]), x + b rounded once in fp32
+        cb = _rand(rs, c) * 0.5
+        xb = x + cb.view(1, -1, 1, 1)
+        ref = torch.relu(torch.nn.functional.group_norm(xb.double(), 8, gn.weight.cpu().double(),
+                                                        gn.bias.cpu().double(), gn.eps))
+        y = hip.groupnorm_nchw(x.to(DEV), gn, True, conv_bias=cb.to(DEV))
+        torch.cuda.synchronize()
+        assert (y.cpu().double() - ref).abs().max().item() < 5e-6
 
 
 @pytest.mark.gpu
@@ -344,3 +352,6 @@ def test_upsample_add_nchw(geom):
     assert err < 2e-6
     got2 = hip.upsample_add_nchw_(y.clone(), None, x, align)
     assert float((got2 - (want - b.view(1, -1, 1, 1))).abs().max()) < 4e-6
+    y0 = y.clone()
+    got3 = hip.upsample_add_nchw_(y, b, x, align, inplace=False)      # out of place: y untouched
+    assert torch.equal(got3, got) and torch.equal(y, y0)
