@@ -625,6 +625,276 @@ __global__ __launch_bounds__(512) void pv_kernel_v5(rmem_pv_args a, long long* s
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// V6: the shipped 128 x 128 / 4-wave loop, two of them per workgroup (512 threads = two groups,
+// each with its own output tile and its own 64 KB of LDS) held in ANTI-PHASE by the workgroup
+// barrier: group 1 runs one barrier behind, so one group multiplies while the other stages.
+// (Two independent 256-thread blocks per CU lock into phase: both stage, then both multiply --
+// measured with the step stamps above -- and the MFMA pipe idles a third of the time.)
+template <class Cfg, class LX, class LY>
+__device__ __forceinline__ void gemm_mainloop_grp(GemmFrag<Cfg>& f, const LX& lx, const LY& ly, int kt_begin,
+                                                  int kt_end, char* smem, int tid, int group) {
+  constexpr int NPL = Cfg::NPL, XCH = Cfg::XCH, YCH = Cfg::YCH, TM = Cfg::TM, TN = Cfg::TN;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  u32x4_t xr[NPL * XCH], yr[NPL * YCH];
+  auto gload = [&](int kt) __attribute__((always_inline)) {
+    const TileView tx = lx.tile(kt);
+    const TileView ty = ly.tile(kt);
+    static_for<NPL>([&](auto P) {
+      static_for<XCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        xr[P.value * XCH + I.value] = *lx.ptr(tx, P.value, id >> 3, id & 7);
+      });
+      static_for<YCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        yr[P.value * YCH + I.value] = *ly.ptr(ty, P.value, id >> 3, id & 7);
+      });
+    });
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+    static_for<NPL>([&](auto P) {
+      char* xb = smem + P.value * Cfg::X_BYTES;
+      char* yb = smem + NPL * Cfg::X_BYTES + P.value * Cfg::Y_BYTES;
+      static_for<XCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        *reinterpret_cast<u32x4_t*>(xb + lds_swz(id >> 3, id & 7)) = xr[P.value * XCH + I.value];
+      });
+      static_for<YCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        *reinterpret_cast<u32x4_t*>(yb + lds_swz(id >> 3, id & 7)) = yr[P.value * YCH + I.value];
+      });
+    });
+  };
+  if (kt_begin < kt_end) gload(kt_begin);
+  if (group == 1) __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    lstore();                                   // stage phase (the other group multiplies)
+    __syncthreads();
+    if (kt + 1 < kt_end) gload(kt + 1);         // multiply phase (the other group stages)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = ks * 2 + (lane >> 5);
+      bf16x8_t a[NPL][TM], b[NPL][TN];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        const char* xb = smem + p * Cfg::X_BYTES;
+        const char* yb = smem + NPL * Cfg::X_BYTES + p * Cfg::Y_BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wr * Cfg::WM + i * 32 + (lane & 31);
+          a[p][i] = *reinterpret_cast<const bf16x8_t*>(xb + lds_swz(row, chunk));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wc * Cfg::WN + j * 32 + (lane & 31);
+          b[p][j] = *reinterpret_cast<const bf16x8_t*>(yb + lds_swz(row, chunk));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (Cfg::NSPLIT == 3) {
+            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], f.acc[i][j], 0, 0, 0);
+            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], f.acc[i][j], 0, 0, 0);
+          }
+          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], f.acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  if (group == 0) __syncthreads();
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void pv_kernel_v6(rmem_pv_args a) {
+  using Cfg = GemmCfg<128, 128, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int group = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int nct = (a.ncols + 127) / 128;       // even
+  const int nq = a.Npad / 128;
+  const int npairs = nq * a.ksplits;
+  const int chunk = pv_chunk(npairs);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int nct2 = nct / 2;
+  const int pl = j / nct2;
+  const int ctile = 2 * (j - pl * nct2) + group;
+  const int pair = xcd * chunk + pl;
+  if (pl >= chunk || pair >= npairs) return;
+  const int z = pair / nq;
+  const int qtile = pair - z * nq;
+  const int tps = a.Npad / 64;
+  const int k_lo = 0, k_hi = a.T * tps;
+  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
+  int lo = k_lo + z * per, hi = lo + per;
+  if (hi > k_hi) hi = k_hi;
+  PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 128};
+  SlotLut lut;
+  lut.load(a.slot_map, a.T);
+  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, lut, tps, ctile * 128, a.ncols};
+  GemmFrag<Cfg> f;
+  f.zero();
+  gemm_mainloop_grp<Cfg>(f, lx, ly, lo, hi, smem + group * Cfg::LDS_BYTES, tid, group);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  float* out = a.part + (long)z * a.Npad * a.ncols;
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
+    if (col >= a.ncols) continue;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
+        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
+      }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V7: the shipped loop with the fragment reads of sub-step s+1 issued BEFORE the MFMAs of
+// sub-step s (two fragment register sets).  PIN: sched_barrier between read group and MFMA group.
+template <class Cfg, bool PIN, class LX, class LY>
+__device__ __forceinline__ void gemm_mainloop_v7(GemmFrag<Cfg>& f, const LX& lx, const LY& ly, int kt_begin,
+                                                 int kt_end, char* smem) {
+  constexpr int NPL = Cfg::NPL, XCH = Cfg::XCH, YCH = Cfg::YCH, TM = Cfg::TM, TN = Cfg::TN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  if (kt_begin >= kt_end) return;
+  u32x4_t xr[NPL * XCH], yr[NPL * YCH];
+  auto gload = [&](int kt) __attribute__((always_inline)) {
+    const TileView tx = lx.tile(kt);
+    const TileView ty = ly.tile(kt);
+    static_for<NPL>([&](auto P) {
+      static_for<XCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        xr[P.value * XCH + I.value] = *lx.ptr(tx, P.value, id >> 3, id & 7);
+      });
+      static_for<YCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        yr[P.value * YCH + I.value] = *ly.ptr(ty, P.value, id >> 3, id & 7);
+      });
+    });
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+    static_for<NPL>([&](auto P) {
+      char* xb = smem + P.value * Cfg::X_BYTES;
+      char* yb = smem + NPL * Cfg::X_BYTES + P.value * Cfg::Y_BYTES;
+      static_for<XCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        *reinterpret_cast<u32x4_t*>(xb + lds_swz(id >> 3, id & 7)) = xr[P.value * XCH + I.value];
+      });
+      static_for<YCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        *reinterpret_cast<u32x4_t*>(yb + lds_swz(id >> 3, id & 7)) = yr[P.value * YCH + I.value];
+      });
+    });
+  };
+  bf16x8_t fa[2][NPL][TM], fb[2][NPL][TN];
+  auto rd = [&](int ks, auto S) __attribute__((always_inline)) {
+    const int chunk = ks * 2 + (lane >> 5);
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      const char* xb = smem + p * Cfg::X_BYTES;
+      const char* yb = smem + NPL * Cfg::X_BYTES + p * Cfg::Y_BYTES;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wr * Cfg::WM + i * 32 + (lane & 31);
+        fa[S.value][p][i] = *reinterpret_cast<const bf16x8_t*>(xb + lds_swz(row, chunk));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wc * Cfg::WN + j * 32 + (lane & 31);
+        fb[S.value][p][j] = *reinterpret_cast<const bf16x8_t*>(yb + lds_swz(row, chunk));
+      }
+    }
+  };
+  auto mm = [&](auto S) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (Cfg::NSPLIT == 3) {
+          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S.value][0][i], fb[S.value][1][j], f.acc[i][j], 0, 0, 0);
+          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S.value][1][i], fb[S.value][0][j], f.acc[i][j], 0, 0, 0);
+        }
+        f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S.value][0][i], fb[S.value][0][j], f.acc[i][j], 0, 0, 0);
+      }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  gload(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    rd(0, S0{});
+    if (kt + 1 < kt_end) gload(kt + 1);
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    rd(1, S1{});
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    mm(S0{});
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    rd(2, S0{});
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    mm(S1{});
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    rd(3, S1{});
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    mm(S0{});
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    mm(S1{});
+  }
+}
+
+template <int NS, bool PIN>
+__global__ __launch_bounds__(256) void pv_kernel_v7(rmem_pv_args a) {
+  using Cfg = GemmCfg<128, 128, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nct = (a.ncols + 127) / 128;
+  const int nq = a.Npad / 128;
+  const int npairs = nq * a.ksplits;
+  const int chunk = pv_chunk(npairs);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int pl = j / nct;
+  const int ctile = j - pl * nct;
+  const int pair = xcd * chunk + pl;
+  if (pl >= chunk || pair >= npairs) return;
+  const int z = pair / nq;
+  const int qtile = pair - z * nq;
+  const int tps = a.Npad / 64;
+  const int k_lo = 0, k_hi = a.T * tps;
+  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
+  int lo = k_lo + z * per, hi = lo + per;
+  if (hi > k_hi) hi = k_hi;
+  PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 128};
+  SlotLut lut;
+  lut.load(a.slot_map, a.T);
+  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, lut, tps, ctile * 128, a.ncols};
+  GemmFrag<Cfg> f;
+  f.zero();
+  gemm_mainloop_v7<Cfg, PIN>(f, lx, ly, lo, hi, smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  float* out = a.part + (long)z * a.Npad * a.ncols;
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
+        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
+      }
+  }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main() {
@@ -778,6 +1048,58 @@ int main() {
       run5(&pv_kernel_v5<3, false>, "plain (1 barrier/step)", 8);
       run5(&pv_kernel_v5<3, true>, "staggered wave groups (2 barriers/step)", 8);
       run5(&pv_kernel_v5<3, true>, "staggered wave groups (2 barriers/step)", 4);
+    }
+    {
+      constexpr int LDS6 = 2 * Cfg::LDS_BYTES;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel_v6<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS6));
+      for (int ks6 = 4; ks6 <= 8; ks6 += 4) {
+        rmem_pv_args b = a; b.ksplits = ks6;
+        const int chunk6 = pv_chunk((Npad / 128) * ks6);
+        dim3 grid6(8 * chunk6 * (nct / 2));
+        CK(hipMemset(part, 0, (size_t)8 * Npad * ncols * 4));
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pv_kernel_v6<3>), grid6, dim3(512), LDS6, 0, b);
+        CK(hipDeviceSynchronize());
+        std::vector<float> g6((size_t)ks6 * Npad * ncols);
+        CK(hipMemcpy(g6.data(), part, g6.size() * 4, hipMemcpyDeviceToHost));
+        double maxd = 0, maxv = 0;
+        for (size_t i = 0; i < (size_t)N * ncols; ++i) {
+          double r0 = 0, r1 = 0;
+          for (int zz = 0; zz < ks; ++zz) r0 += ref[(size_t)zz * Npad * ncols + i];
+          for (int zz = 0; zz < ks6; ++zz) r1 += g6[(size_t)zz * Npad * ncols + i];
+          maxd = fmax(maxd, fabs(r0 - r1)); maxv = fmax(maxv, fabs(r0));
+        }
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+          hipEventRecord(e0);
+          for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((pv_kernel_v6<3>), grid6, dim3(512), LDS6, 0, b);
+          hipEventRecord(e1); hipEventSynchronize(e1);
+          hipEventElapsedTime(&ms, e0, e1);
+          best = fminf(best, ms);
+        }
+        printf("V6 (two anti-phased 128x128 groups per workgroup) ks=%d (grid %d): %.2f us/launch; max |diff of split sums| vs shipped %.3g (max |ref| %.3g)\n", ks6, grid6.x, best * 1e3 / 20, maxd, maxv);
+      }
+    }
+    {
+      auto run7 = [&](auto kern, const char* tag) {
+        CK(hipMemset(part, 0, ref.size() * 4));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, 0, a);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), part, got.size() * 4, hipMemcpyDeviceToHost));
+        double maxd = 0;
+        for (size_t i = 0; i < ref.size(); ++i) maxd = fmax(maxd, fabs((double)ref[i] - got[i]));
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+          hipEventRecord(e0);
+          for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, 0, a);
+          hipEventRecord(e1); hipEventSynchronize(e1);
+          hipEventElapsedTime(&ms, e0, e1);
+          best = fminf(best, ms);
+        }
+        printf("V7 %s: %.2f us/launch; max |diff| vs shipped %.3g\n", tag, best * 1e3 / 20, maxd);
+      };
+      run7(&pv_kernel_v7<3, false>, "fragment double buffer (compiler free to move)");
+      run7(&pv_kernel_v7<3, true>, "fragment double buffer (order pinned with sched_barrier)");
     }
     run3(&pv_kernel_v3<3, 0>, "var0 (compiler order)");
     run3(&pv_kernel_v3<3, 1>, "var1 (fragments read up front, then DMA issue, then MFMAs)");
