@@ -215,11 +215,11 @@ def main():
         out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
         # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
-        pmc = os.path.join(ROOT, "profiles", "r01_b_pmc_pv_long.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_pv_long.json")
         if out["roofline"] and args.config == "480p_k4" and args.nsplit == 3 and args.model == "r50_deaotl" \
                 and os.path.exists(pmc):
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/r01_b_pmc_pv_long.json)"
+            out["roofline"]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, profiles/r01_h_pmc_pv_long.json)"
         if world == 1 and not args.no_cpu_baseline and args.model == "r50_deaotl":
             out["cpu_baseline"] = cpu_baseline(cpu_model, args)
         print(json.dumps(out))

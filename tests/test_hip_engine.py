@@ -179,3 +179,48 @@ def test_multi_object_engines():
             start = idx * 10 + 1
             fg = ((cur >= start) & (cur <= start + 9)).float()
             e1.update_memory((fg * cur - start + 1) * fg)
+
+
+def test_prefetch_lookahead_ring():
+    """Encoder prefetch (rmem_amd/engine.py): announcing the next frames (`next_img` = one tensor or
+    a list, three feature copies) must not change any output -- against the same clip without
+    announcements; also an announcement that is not followed (frame skipped), a repeated frame and
+    a restart with passes still pending."""
+    from rmem_amd.synth import synth_clip
+    H, W, frames = 97, 129, 12
+    imgs, lab = synth_clip(5, frames, H, W, 3)
+    imgs = [x.to(DEV) for x in imgs]
+    _, _, _, eng = _build(1, 3, 2)
+
+    fed = []       # labels of the run without announcements, fed to every run (the closed loop is chaotic)
+
+    def run(announce):
+        eng.restart_engine()
+        eng.add_reference_frame(imgs[0], lab.to(DEV), obj_nums=[3], frame_step=0)
+        outs = []
+        for t in range(1, frames):
+            nxt = announce(t)
+            lg = eng.match_propogate_one_frame(imgs[t], output_size=(H, W), next_img=nxt)
+            outs.append(lg.clone())
+            if len(fed) < t:
+                fed.append(torch.argmax(lg, dim=1, keepdim=True).float())
+            eng.update_memory(F.interpolate(fed[t - 1], size=eng.input_size_2d, mode="nearest"))
+        return outs, list(eng.aot_engines[0].long_memories_indexes)
+
+    base, idx0 = run(lambda t: None)
+    for name, ann in [
+        ("one frame", lambda t: imgs[t + 1] if t + 1 < frames else None),
+        ("two frames", lambda t: [imgs[k] for k in (t + 1, t + 2) if k < frames] or None),
+        ("wrong announcements", lambda t: [imgs[(t + 5) % frames], imgs[(t + 1) % frames]]),   # first one is never used next
+        ("repeated frame", lambda t: [imgs[t], imgs[t + 1]] if t + 1 < frames else None),
+    ]:
+        got, idx = run(ann)
+        err = max(float((a - b).abs().max()) for a, b in zip(got, base))
+        print(f"prefetch '{name}': max |logit diff| vs no announcement {err:.2e}")
+        assert idx == idx0
+        assert err < 1e-4, (name, err)
+    sub = eng.aot_engines[0]
+    assert sub._ring == 3 and len(sub._pending) <= 2
+    eng.restart_engine()                       # with passes still pending
+    assert sub._pending == []
+    torch.cuda.synchronize()
