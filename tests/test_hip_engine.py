@@ -140,7 +140,9 @@ def test_480p_teacher_forced(nsplit, golden_dir):
     print(f"nsplit={nsplit} mismatching pixels per frame (of 409920):", mism, "logit err (fp16 gold):", lerrs)
     assert idx_hist == meta["indexes"]
     if nsplit == 3:
-        assert max(mism) <= 8, mism
+        # measured 1-7 on every box so far; the encoder's MIOpen convolutions are not bit-reproducible
+        # between processes (tools/determinism_probe.py), each flip of a near-tie pixel counts one
+        assert max(mism) <= 10, mism
     else:
         assert max(mism) <= 4000, mism        # plain bf16: ~1e-3..1e-2 logit noise near ties
     assert max(lerrs.values()) < (2e-2 if nsplit == 3 else 0.2)

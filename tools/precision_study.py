@@ -46,19 +46,22 @@ def make_q(tok):
 
 
 def install(plan):
-    where = "long,self,win"
-    if "@" in plan:
-        plan, where = plan.split("@")
-    where = where.split(",")
-    toks = plan.split("_")
+    """plan = seg[+seg...], seg = tokens[@reads]: e.g. p16_v16x2@long,self+p16x2_v16x2@win"""
     ident = lambda x: x
-    qp_ = make_q(next((t for t in toks if t.startswith("p")), None))
-    qv_ = make_q(next((t for t in toks if t.startswith("v")), None))
-    qqk_ = make_q(next((t for t in toks if t.startswith("qk")), None))
+    table = {r: (ident, ident, ident) for r in ("long", "self", "win")}
+    for seg in plan.split("+"):
+        where = "long,self,win"
+        if "@" in seg:
+            seg, where = seg.split("@")
+        toks = seg.split("_")
+        q3 = (make_q(next((t for t in toks if t.startswith("p")), None)),
+              make_q(next((t for t in toks if t.startswith("v")), None)),
+              make_q(next((t for t in toks if t.startswith("qk")), None)))
+        for r in where.split(","):
+            table[r] = q3
 
     def core(Q, K, V, U, h, w, dw_w, proj_w, proj_b, d_att=128):
-        on = ("self" if Q is K else "long") in where
-        qp, qv, qqk = (qp_, qv_, qqk_) if on else (ident, ident, ident)
+        qp, qv, qqk = table["self" if Q is K else "long"]
         logits = qqk(Q / (d_att ** 0.5)) @ qqk(K).t()
         m = logits.max(dim=-1, keepdim=True).values
         p = qp(torch.exp(logits - m))                 # the kernel stores exp(S - max), sums the stored values
@@ -70,7 +73,7 @@ def install(plan):
 
     def local(q, k, v, u, h, w, rel_w, rel_b, dw_w, proj_w, proj_b, max_dis=7):
         n, d = q.shape
-        qp, qv, qqk = (qp_, qv_, qqk_) if "win" in where else (ident, ident, ident)
+        qp, qv, qqk = table["win"]
         idx, inside = R.local_window_index(h, w, max_dis)
         rel = q @ rel_w.view(rel_w.shape[0], d).t() + rel_b
         qs = qqk(q / (d ** 0.5))
