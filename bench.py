@@ -213,6 +213,12 @@ def main():
     }
     if rank == 0:
         out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)
+        if out["roofline"] and hasattr(lstt, "time_long_pv_isolated"):
+            # information only: the same launch with the GPU to itself (in the frame it shares the
+            # CUs with the prefetched encoder pass); `achieved` / `frac` above are the in-frame figures
+            iso = lstt.time_long_pv_isolated()
+            out["roofline"]["isolated_mean_us"] = iso
+            out["roofline"]["frac_isolated"] = out["roofline"]["algorithmic_flops_per_launch"] / (iso * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
         # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
         pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_pv_long.json")

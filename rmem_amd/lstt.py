@@ -228,6 +228,30 @@ class DeAOTLSTT:
                 "traffic": None, "launches": len(ms), "mean_us": 1e3 * mean_ms,
                 "algorithmic_flops_per_launch": flops}
 
+    def time_long_pv_isolated(self, iters: int = 20) -> float:
+        """Mean duration (us) of the long-term P.V launch of the current bank state with nothing
+        else on the GPU (back-to-back launches between two HIP events): the same launch the
+        in-frame roofline entry times beside the encoder stream."""
+        T = len(self.bank)
+        pa = hip.PVArgs()
+        vpl, ws = self.bankV[0], self.ws_main
+        pa.mode, pa.ph, pa.pl = 0, ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+        pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
+        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = self.maps.data_ptr(), T, self.N, self.Npad, 1024
+        pa.h, pa.w, pa.part, pa.nsplit = self.h, self.w, ws.part.data_ptr(), self.nsplit
+        pa.ksplits = self._ksplits(T * self.Npad // 64)
+        lib, st = hip.load(), hip.stream_ptr()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
+        e1.record()
+        e1.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / iters
+
     def clear_memory(self):                                        # transformer.py:1000-1007
         self.bank: List[int] = []          # logical -> physical slot
         self.short: Optional[int] = None
