@@ -19,10 +19,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // native vector (HIP's uint4 struct keeps register arrays in scratch)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-#define RMEM_CHECK_LAUNCH()                                      \
-  do {                                                           \
-    hipError_t e__ = hipGetLastError();                          \
-    if (e__ != hipSuccess) return RMEM_ERR_LAUNCH;               \
+#include <stdio.h>
+#define RMEM_CHECK_LAUNCH()                                                                          \
+  do {                                                                                               \
+    hipError_t e__ = hipGetLastError();                                                              \
+    if (e__ != hipSuccess) {                                                                         \
+      fprintf(stderr, "rmem_hip: launch failed at %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return RMEM_ERR_LAUNCH;                                                                        \
+    }                                                                                                \
   } while (0)
 
 // round-to-nearest-even; gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
