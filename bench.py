@@ -170,10 +170,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # steady-state frames replay hipGraphs; one frame in twenty of the timed region (at least one)
+    # is issued eagerly so that HIP events can bracket the dominant kernel on its launch stream
+    n_eager = max(1, args.steps // 20)
+    eager_at = {(i * args.steps) // n_eager for i in range(n_eager)}
     for k in range(args.steps):
-        # steady-state frames replay hipGraphs; every 10th frame of the timed region is issued
-        # eagerly so that HIP events can bracket the dominant kernel on its launch stream
-        lstt._timing = (k % 10 == 0) and not os.environ.get("RMEM_BENCH_NOSYNC")
+        lstt._timing = (k in eager_at) and not os.environ.get("RMEM_BENCH_NOSYNC")
         all_clips(t + k, masks)
     lstt._timing = False
     host_issue = time.perf_counter() - t0     # host-side launch time (GPU work still in flight)
