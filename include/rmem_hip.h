@@ -204,6 +204,15 @@ int rmem_layernorm_red(float *x, int64_t ldx, const float *parts, int32_t nparts
                        float eps, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32, int64_t ldof,
                        void *stream);
 
+/* Two such problems of the same shape in one launch: norm1 / id_norm1 and norm2 / id_norm2 of a
+ * GPM layer (layers/transformer.py:1104, 1120, 1223-1224), each with its own residual stream,
+ * partials, affine parameters and output planes. */
+int rmem_layernorm_red2(float *x0, float *x1, int64_t ldx, const float *parts0, const float *parts1,
+                        int32_t nparts, int64_t part_stride, int64_t ldpart, const float *gamma0,
+                        const float *beta0, const float *gamma1, const float *beta1, int32_t N, int32_t C,
+                        float eps, rmem_bf16 *oh0, rmem_bf16 *ol0, int64_t ldo0, rmem_bf16 *oh1,
+                        rmem_bf16 *ol1, int64_t ldo1, void *stream);
+
 /* planes [N][C] (ld) -> transposed planes [C][ldo]  (AOT: V operand of the short-term attention) */
 int rmem_transpose_planes(const rmem_bf16 *ih, const rmem_bf16 *il, int64_t ld, int32_t N, int32_t C,
                           rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, void *stream);

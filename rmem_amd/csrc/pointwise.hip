@@ -120,6 +120,70 @@ extern "C" int rmem_layernorm_red(float* x, int64_t ldx, const float* parts, int
   return RMEM_OK;
 }
 
+// two independent rows-of-256 problems of the same shape in one launch (blockIdx.y selects):
+// norm1 / id_norm1 and norm2 / id_norm2 of a GPM layer (transformer.py:1104,1120,1223-1224)
+struct LnRedOne {
+  float* x;
+  const float* parts;
+  const float* gamma;
+  const float* beta;
+  bf16_t* oh;
+  bf16_t* ol;
+  long ldo;
+};
+__global__ __launch_bounds__(256) void layernorm_red2_kernel(LnRedOne p0, LnRedOne p1, long ldx, int nparts,
+                                                             long part_stride, long ldpart, int N, float eps) {
+  const LnRedOne p = blockIdx.y ? p1 : p0;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N) return;
+  float4 v = *reinterpret_cast<const float4*>(p.x + (long)row * ldx + lane * 4);
+  for (int z = 0; z < nparts; ++z) {
+    const float4 w = *reinterpret_cast<const float4*>(p.parts + (long)z * part_stride + (long)row * ldpart + lane * 4);
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
+  if (nparts > 0) *reinterpret_cast<float4*>(p.x + (long)row * ldx + lane * 4) = v;
+  float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / 256.0f);
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  float ss = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
+  const float4 g = *reinterpret_cast<const float4*>(p.gamma + lane * 4);
+  const float4 b = *reinterpret_cast<const float4*>(p.beta + lane * 4);
+  const float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
+  bf16_t hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_bf16(y[e], hi[e], lo[e]);
+  uint2 vh, vl;
+  vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+  vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+  vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+  vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+  *reinterpret_cast<uint2*>(p.oh + (long)row * p.ldo + lane * 4) = vh;
+  if (p.ol) *reinterpret_cast<uint2*>(p.ol + (long)row * p.ldo + lane * 4) = vl;
+}
+
+extern "C" int rmem_layernorm_red2(float* x0, float* x1, int64_t ldx, const float* parts0, const float* parts1,
+                                   int32_t nparts, int64_t part_stride, int64_t ldpart, const float* gamma0,
+                                   const float* beta0, const float* gamma1, const float* beta1, int32_t N,
+                                   int32_t C, float eps, rmem_bf16* oh0, rmem_bf16* ol0, int64_t ldo0,
+                                   rmem_bf16* oh1, rmem_bf16* ol1, int64_t ldo1, void* stream) {
+  if (!x0 || !x1 || !gamma0 || !beta0 || !gamma1 || !beta1 || !oh0 || !oh1 || N <= 0 || C != 256 || (ldx % 4) ||
+      (ldo0 % 4) || (ldo1 % 4) || nparts < 0 ||
+      (nparts > 0 && (!parts0 || !parts1 || (ldpart % 4) || (part_stride % 4))))
+    return RMEM_ERR_INVALID;
+  LnRedOne p0{x0, parts0, gamma0, beta0, oh0, ol0, (long)ldo0};
+  LnRedOne p1{x1, parts1, gamma1, beta1, oh1, ol1, (long)ldo1};
+  hipLaunchKernelGGL(layernorm_red2_kernel, dim3((N + 3) / 4, 2), dim3(256), 0, static_cast<hipStream_t>(stream), p0,
+                     p1, (long)ldx, nparts, (long)part_stride, (long)ldpart, N, eps);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                     int32_t N, int32_t C, float eps, rmem_bf16* oh, rmem_bf16* ol,
                                     int64_t ldo, float* of32, int64_t ldof, void* stream) {

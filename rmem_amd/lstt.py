@@ -178,7 +178,8 @@ class DeAOTLSTT:
         self.Ucat0[:, 512:] = 1.0                                 # layer 0: gate of the ID half is 1
         self.Ucat = z(N, 1024)
         self.bias_pe = z(N, self.Tmax)
-        self.rowmax = z(3, Np, dt=torch.int32)
+        self.rowmax = z(3 * self.L, Np, dt=torch.int32)          # [layer][read]: zeroed once per frame
+        self._layer = 0
         self.ksplits_max = 8
         # attention workspaces: main stream (long-term, self) and side stream (short-term window)
         self.ws_main = _AttnWS(self.Tmax, N, Np, self.ksplits_max, dev)
@@ -292,6 +293,19 @@ class DeAOTLSTT:
             out.hi.data_ptr() + col_off * 2, out.lo.data_ptr() + col_off * 2, ldo, None, 0, hip.stream_ptr())
         hip.check(rc, "rmem_layernorm_red")
 
+    def _ln2(self, gb0, out0: Planes, ldo0, off0, gb1, out1: Planes, ldo1, off1, parts: bool):
+        """LayerNorm of tgt (-> out0) and of tgt_id (-> out1) in one launch; parts: first fold the
+        split-K partials of the preceding projection (columns 0.. / 256..) into the two streams."""
+        np_ = self.KS if parts else 0
+        pp0 = self.parts.data_ptr() if parts else None
+        pp1 = self.parts.data_ptr() + 256 * 4 if parts else None
+        rc = hip.load().rmem_layernorm_red2(
+            self.tgt.data_ptr(), self.tgt_id.data_ptr(), 256, pp0, pp1, np_, self.N * 512, 512,
+            gb0[0].data_ptr(), gb0[1].data_ptr(), gb1[0].data_ptr(), gb1[1].data_ptr(), self.N, 256, 1e-5,
+            out0.hi.data_ptr() + off0 * 2, out0.lo.data_ptr() + off0 * 2, ldo0,
+            out1.hi.data_ptr() + off1 * 2, out1.lo.data_ptr() + off1 * 2, ldo1, hip.stream_ptr())
+        hip.check(rc, "rmem_layernorm_red2")
+
     def _attention(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
                    qpl: Planes, bias, U, want_mass: bool, which: int):
         """scores(pass0, pass1) + pv + combine -> ws.G."""
@@ -304,7 +318,7 @@ class DeAOTLSTT:
         sa.qh, sa.ql, sa.scale = qpl.hi.data_ptr(), qpl.lo.data_ptr(), self.scale
         sa.bias = bias.data_ptr() if bias is not None else None
         sa.R, sa.ldr, sa.h, sa.w = (self.R.data_ptr() if mode == 1 else None), self.ldr, self.h, self.w
-        sa.rowmax = self.rowmax[which].data_ptr()
+        sa.rowmax = self.rowmax[3 * self._layer + which].data_ptr()
         sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
         sa.lpart, sa.nparts, sa.nsplit = ws.lpart.data_ptr(), nparts, self.nsplit
         sa.pass_ = 0
@@ -415,18 +429,17 @@ class DeAOTLSTT:
         self.rowmax.zero_()
 
         for l in range(self.L):
+            self._layer = l
             W = self.lw[l]
             Ucat = self.Ucat0 if l == 0 else self.Ucat
-            if l > 0:
-                self.rowmax.zero_()
             curK = self.bankK[l][cur]
             curV = self.bankV[l][cur]
             # -- norms + projections (transformer.py:1104-1123); the norms first fold in the
             #    split-K partials of the previous layer's self-attention projection
-            prev = 0 if l > 0 else None
-            self._ln(self.tgt, W.ln1, self.x_pl, 256, parts_col=prev)
             if l > 0:
-                self._ln(self.tgt_id, W.lnid1, self.z_pl[l], 256, parts_col=256)
+                self._ln2(W.ln1, self.x_pl, 256, 0, W.lnid1, self.z_pl[l], 256, 0, parts=True)
+            else:
+                self._ln(self.tgt, W.ln1, self.x_pl, 256, parts_col=None)
             grp = [
                 hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
                            d0=self.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128,
@@ -483,8 +496,7 @@ class DeAOTLSTT:
                        kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=64, ksplits=self.KS, parts=self.parts,
                        part_stride=N * 512)
             # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
-            self._ln(self.tgt, W.ln2, self.s_pl, 512, 0, parts_col=0)
-            self._ln(self.tgt_id, W.lnid2, self.s_pl, 512, 256, parts_col=256)
+            self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
             sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
             sV = Planes(self.selfV.hi[0], self.selfV.lo[0])
             hip.linear_grouped([
