@@ -149,9 +149,12 @@ def _run_attention(hip, mode, T, N, Npad, K, V, slot_map, Q, bias, U, h, w, R, n
 
 
 @pytest.mark.parametrize("nsplit", [3, 1])
-@pytest.mark.parametrize("T,h,w", [(1, 9, 13), (3, 9, 13), (5, 12, 17)])
+@pytest.mark.parametrize("T,h,w", [(1, 9, 13), (3, 9, 13), (5, 12, 17), (4, 31, 54)])
 def test_attention_bank(hip, nsplit, T, h, w):
-    """Long-term / self read: softmax(scale*(Q.K^T + bias)) . V * U, attention mass per slot."""
+    """Long-term / self read: softmax(scale*(Q.K^T + bias)) . V * U, attention mass per slot.
+    (4, 31, 54) is the full BASELINE.json configs[1] size: 480p, K=4, N=1674, 6696 keys."""
+    if nsplit == 1 and h * w > 1000:
+        pytest.skip("full size is checked for the default precision only")
     rs = np.random.RandomState(T * 100 + h)
     N = h * w
     Npad = (N + 127) // 128 * 128
@@ -190,6 +193,44 @@ def test_attention_bank(hip, nsplit, T, h, w):
         big = A > 1e-6
         logit_err = (torch.log(An[big]) - torch.log(A[big])).abs().max().item()
         assert logit_err < 1e-3, logit_err
+
+
+def test_attention_bank_720p_k8_properties(hip):
+    """BASELINE.json configs[2] size (720p: 46x81 = 3726 tokens, K=8: 29808 keys), where a fp64
+    reference is too slow for a test: size-independent properties of the long-term read.
+    (a) the per-slot attention mass of every query sums to 1; (b) doubling V doubles the output
+    bit for bit (split planes, MFMA products and fp32 sums all scale exactly by 2); (c) storing
+    the bank slots in another physical order, with the slot map compensating, changes nothing."""
+    T, h, w = 8, 46, 81
+    rs = np.random.RandomState(7)
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    S = T + 2
+    Kf = torch.zeros(S, Npad, 128)
+    Vf = torch.zeros(S, 1024, Npad)
+    Kf[:, :N] = _rand(rs, S, N, 128, scale=1.5)
+    Vf[:, :, :N] = _rand(rs, S, 1024, N)
+    Qf = torch.zeros(Npad, 128)
+    Qf[:N] = _rand(rs, N, 128, scale=1.5)
+    bias = _rand(rs, N, T, scale=3.0).to(DEV)
+    U = _rand(rs, N, 1024).to(DEV)
+    Qp = _planes(hip, Qf)
+    map_a = [int(x) for x in rs.permutation(S)[:T]]
+    G, mass, *_ = _run_attention(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, Vf), map_a, Qp, bias, U,
+                                 h, w, None, 3, ksplits=2)
+    assert torch.isfinite(G).all()
+    assert (mass.sum(dim=1) - 1).abs().max().item() < 2e-6                      # (a)
+    G2, *_ = _run_attention(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, 2 * Vf), map_a, Qp, bias, U,
+                            h, w, None, 3, ksplits=2)
+    assert torch.equal(G2, 2 * G)                                               # (b)
+    perm = [int(x) for x in rs.permutation(S)]                                  # new physical position of slot s
+    Kp, Vp = torch.zeros_like(Kf), torch.zeros_like(Vf)
+    for s_old, s_new in enumerate(perm):
+        Kp[s_new], Vp[s_new] = Kf[s_old], Vf[s_old]
+    map_b = [perm[s] for s in map_a]
+    G3, mass3, *_ = _run_attention(hip, 0, T, N, Npad, _planes(hip, Kp), _planes(hip, Vp), map_b, Qp, bias, U,
+                                   h, w, None, 3, ksplits=2)
+    assert torch.equal(G3, G) and torch.equal(mass3, mass)                      # (c)
 
 
 @pytest.mark.parametrize("nsplit", [3, 1])
@@ -307,6 +348,37 @@ def test_id_assign_vs_golden(hip, deaot_model, golden_dir):
         torch.cuda.synchronize()
         assert np.abs(of.cpu().numpy() - gold["id_emb"]).max() < 2e-5
         assert np.abs(pl.float().cpu().numpy() - gold["id_emb"]).max() < 5e-5
+
+
+def test_id_assign_full_size_and_label_edge_cases(hip, deaot_model):
+    """ID assignment at the full 481x849 / 721x1281 frames against the oracle's restatement of
+    one_hot_mask + patch_wise_id_bank + id_norm (utils/image.py:69-74, aot.py:67-74,111-114,
+    deaot.py:65-69): a label map with every object id, the ignore label 255 and ids above
+    MAX_OBJ (no one-hot channel); an all-background and an all-ignore map."""
+    from oracle import lstt_ref as R
+    lib, st = hip.load(), hip.stream_ptr()
+    sd = {k: v.detach().float() for k, v in deaot_model.state_dict().items()}
+    wt = sd["patch_wise_id_bank.weight"].permute(1, 2, 3, 0).contiguous().to(DEV)
+    kb, g1, g2 = (sd["patch_wise_id_bank.bias"].to(DEV), sd["id_norm.weight"].to(DEV), sd["id_norm.bias"].to(DEV))
+    rs = np.random.RandomState(3)
+    for (H, W) in [(481, 849), (721, 1281)]:
+        eh, ew = (H - 1) // 16 + 1, (W - 1) // 16 + 1
+        coarse = rs.randint(0, 11, ((H + 23) // 24, (W + 23) // 24))
+        lab = np.kron(coarse, np.ones((24, 24), dtype=np.int64))[:H, :W].astype(np.uint8)
+        lab[H // 3:H // 3 + 40, W // 4:W // 4 + 90] = 255           # ignore region
+        lab[5:30, 10:60] = 14                                        # id above MAX_OBJ: contributes nothing
+        cases = [lab, np.zeros((H, W), np.uint8), np.full((H, W), 255, np.uint8)] if H == 481 else [lab]
+        for m in cases:
+            ref = R.id_assign(torch.from_numpy(m.astype(np.float32))[None, None], sd)
+            d = torch.from_numpy(m).to(DEV).contiguous()
+            of = torch.zeros(eh * ew, 256, device=DEV)
+            pl = hip.Planes.empty((eh * ew, 256), DEV)
+            hip.check(lib.rmem_id_assign(d.data_ptr(), H, W, wt.data_ptr(), kb.data_ptr(), 12, 17, 16, 8, eh, ew,
+                                         256, g1.data_ptr(), g2.data_ptr(), 1e-5, pl.hi.data_ptr(),
+                                         pl.lo.data_ptr(), 256, of.data_ptr(), 256, st), "id_assign")
+            torch.cuda.synchronize()
+            err = (of.cpu() - ref).abs().max().item()
+            assert err < 5e-5, (H, W, err)
 
 
 def test_groupnorm_nchw_relu(hip):
