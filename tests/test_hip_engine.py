@@ -226,3 +226,34 @@ def test_prefetch_lookahead_ring():
     eng.restart_engine()                       # with passes still pending
     assert sub._pending == []
     torch.cuda.synchronize()
+
+
+def test_720p_k8_vs_oracle():
+    """BASELINE.json configs[2] geometry (721x1281 -> 46x81 = 3726 tokens, K=8, 3 objects): the HIP
+    engine against the CPU oracle, teacher-forced with the oracle's labels, gap=1 so that the bank
+    grows past four slots (temporal positional embedding rows for T > 4) at the full size."""
+    from oracle.engine_ref import OracleDeAOTEngine
+    from rmem_amd.synth import synth_clip
+    H, W, frames = 721, 1281, 6
+    cfg, cpu_model, gpu_model, eng = _build(1, 7, 1)
+    cpu_model.cfg = cfg
+    ora = OracleDeAOTEngine(cpu_model, long_term_mem_gap=1)
+    imgs, lab = synth_clip(11, frames, H, W, 3)
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    mism, lerr = [], []
+    for t in range(1, frames):
+        lg = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(720, 1280))
+        lo = ora.match_propogate_one_frame(imgs[t], output_size=(720, 1280))
+        pg = torch.argmax(lg, dim=1, keepdim=True)
+        po = torch.argmax(lo, dim=1, keepdim=True)
+        mism.append(int((pg.cpu() != po).sum()))
+        lerr.append(float((eng.aot_engines[0].pred_id_logits.cpu() - ora.pred_id_logits).abs().max()))
+        fed = F.interpolate(po.float(), size=ora.input_size_2d, mode="nearest")
+        eng.update_memory(fed.to(DEV))
+        ora.update_memory(fed)
+        assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.long_memories_indexes)
+    print("720p K=8 mismatching pixels per frame (of 921600):", mism, "decoder-logit max abs err:", lerr)
+    assert len(ora.long_memories_indexes) == frames
+    # 2-18 measured: the same near-tie rate as at 480p (2-7 of 409,920) on 2.25x the pixels
+    assert max(mism) <= 40 and max(lerr) < 2e-3, (mism, lerr)
