@@ -4,13 +4,14 @@
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
 
-// Key-tile band [t_lo, t_hi) (units of 128 keys) visible under the 15x15 window to the
-// 256-query super-tile that contains query tile `qtile` (128 queries): rows y(q_lo)-7 ..
-// y(q_hi)+7.  The band is defined per 256 queries so that the scores kernel (128-query tiles)
-// writes -- zeros where masked -- everything the 256-row P.V tile reads.
+// Key-tile band [t_lo, t_hi) (units of 128 keys) visible under the 15x15 window to query tile
+// `qtile` (128 queries): image rows y(q_lo)-7 .. y(q_hi)+7.  Scores, P.V and combine all use this
+// function with the same 128-query tile, so what one writes (zeros where masked) is what the
+// others read.  At 31x54 tokens a band is 7-8 key tiles (the earlier 256-query granularity, kept
+// from a removed 256-row P.V kernel, made it 9-10).
 __host__ __device__ inline void band_tiles(int qtile, int N, int h, int w, int& t_lo, int& t_hi) {
-  const int q_lo = (qtile >> 1) * 256;
-  int q_hi = q_lo + 255;
+  const int q_lo = qtile * 128;
+  int q_hi = q_lo + 127;
   if (q_hi > N - 1) q_hi = N - 1;
   int y_lo = q_lo / w - 7;
   if (y_lo < 0) y_lo = 0;
