@@ -787,9 +787,13 @@ extern "C" int rmem_pe_bias_heads(const float* Q, int64_t ldq, const float* cur_
 // ------------------------------------------------------------------ conv epilogue (encoder support)
 // y = act(x + bias[c] (+ residual)) in place on a contiguous NCHW batch-1 tensor: replaces the
 // separate bias-add / residual-add / ReLU launches PyTorch-ROCm issues after every MIOpen conv.
-__global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* x, const float* bias, const float* res, long hw,
-                                                            long n, int relu) {
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+__global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* x, const float* bias, const float* res, unsigned hw,
+                                                            unsigned n, int relu) {
+  // 32-bit indices (n < 2^32 checked by the host): one division per float4 instead of four 64-bit
+  // ones -- the integer divisions were most of this kernel's instructions
+  for (unsigned i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < n; i += gridDim.x * 1024u) {
+    const unsigned c0 = i / hw;
+    const unsigned left = (c0 + 1) * hw - i;       // elements of channel c0 from i on
     if (i + 3 < n) {
       float4 v = *reinterpret_cast<const float4*>(x + i);
       float o[4] = {v.x, v.y, v.z, v.w};
@@ -798,14 +802,16 @@ __global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* x, const floa
         const float4 t = *reinterpret_cast<const float4*>(res + i);
         r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
       }
+      const float b0 = bias[c0];
+      const float b1 = left < 4 ? bias[c0 + 1] : b0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float t = o[e] + bias[(i + e) / hw] + r[e];
+        float t = o[e] + ((unsigned)e < left ? b0 : b1) + r[e];
         o[e] = relu ? fmaxf(t, 0.f) : t;
       }
       *reinterpret_cast<float4*>(x + i) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
-      for (long j = i; j < n; ++j) {
+      for (unsigned j = i; j < n; ++j) {
         float t = x[j] + bias[j / hw] + (res ? res[j] : 0.f);
         x[j] = relu ? fmaxf(t, 0.f) : t;
       }
@@ -817,13 +823,14 @@ extern "C" int rmem_bias_act_nchw(float* x, const float* bias, const float* resi
                                   int32_t relu, void* stream) {
   if (!x || !bias || C <= 0 || HW <= 0) return RMEM_ERR_INVALID;
   const long n = (long)C * HW;
+  if (n >= (1l << 32) - 4096 || HW < 4) return RMEM_ERR_INVALID;   // 32-bit indexing; a float4 spans <= 2 channels
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (residual && (reinterpret_cast<uintptr_t>(residual) & 15)))
     return RMEM_ERR_INVALID;
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(bias_act_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     bias, residual, (long)HW, n, relu);
+                     bias, residual, (unsigned)HW, (unsigned)n, relu);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }

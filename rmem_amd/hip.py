@@ -268,7 +268,7 @@ def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool, conv_bia
 def bias_act_nchw_(x: torch.Tensor, bias: torch.Tensor, residual=None, relu: bool = True) -> torch.Tensor:
     """In-place x = act(x + bias[c] (+ residual)) for a contiguous batch-1 NCHW fp32 tensor."""
     n, c, h, w = x.shape
-    if n != 1 or not x.is_contiguous() or x.dtype != torch.float32 or \
+    if n != 1 or not x.is_contiguous() or x.dtype != torch.float32 or h * w < 4 or \
             (residual is not None and not residual.is_contiguous()):
         y = x + bias.view(1, -1, 1, 1)
         if residual is not None:

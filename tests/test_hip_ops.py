@@ -427,3 +427,25 @@ def test_upsample_add_nchw(geom):
     y0 = y.clone()
     got3 = hip.upsample_add_nchw_(y, b, x, align, inplace=False)      # out of place: y untouched
     assert torch.equal(got3, got) and torch.equal(y, y0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(64, 121, 213), (256, 31, 54), (7, 5, 3), (3, 1, 5), (1024, 31, 54)])
+def test_bias_act_nchw(geom):
+    """rmem_bias_act_nchw == relu(x + bias[c] (+ residual)) bit for bit (one fp32 add per term, same
+    order as the separate PyTorch ops); H*W not a multiple of 4 makes float4 groups straddle channels."""
+    from rmem_amd import hip
+    C_, H, W = geom
+    g = torch.Generator().manual_seed(C_ * 7 + W)
+    x = torch.randn(1, C_, H, W, generator=g).to(DEV)
+    b = torch.randn(C_, generator=g).to(DEV)
+    r = torch.randn(1, C_, H, W, generator=g).to(DEV)
+    for res in (None, r):
+        for relu in (True, False):
+            want = x + b.view(1, -1, 1, 1)
+            if res is not None:
+                want = want + res
+            if relu:
+                want = torch.relu(want)
+            got = hip.bias_act_nchw_(x.clone(), b, res, relu)
+            assert torch.equal(got, want), (geom, res is not None, relu)
