@@ -250,6 +250,21 @@ struct VtOperand {
   }
 };
 
+// k-tile index over the VALID 64-key tiles of the bank (tv per slot) -> actual tile index (tps per
+// slot): the tiles of a slot that hold only padding keys (P is exactly 0 there) are never visited.
+template <class Inner>
+struct SkipPadTiles {
+  Inner in;
+  int tv, tps;
+  __device__ __forceinline__ TileView tile(int i) const {
+    const int t = i / tv;
+    return in.tile(t * tps + (i - t * tv));
+  }
+  __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
+    return in.ptr(t, plane, r, c);
+  }
+};
+
 // Work decomposition of P.V: unit = (query tile, key split, column tile).  Units are
 // laid out so that the 8 XCDs (block b runs on XCD b % 8 -- observed placement, used for
 // speed only) each own a contiguous chunk of (split, query tile) pairs, split-major, and
@@ -274,10 +289,11 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   const int z = pair / nq;
   const int qtile = pair - z * nq;
   const int tps = a.Npad / 64;
+  const int tv = a.mode == 0 ? (a.N + 63) / 64 : tps;   // bank read: skip the all-padding tiles of every slot
   int k_lo, k_hi;
   if (a.mode == 0) {
     k_lo = 0;
-    k_hi = a.T * tps;
+    k_hi = a.T * tv;
   } else {
     int t_lo, t_hi;
     band_tiles(qtile, a.N, a.h, a.w, t_lo, t_hi);
@@ -288,10 +304,11 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
   int lo = k_lo + z * per, hi = lo + per;
   if (hi > k_hi) hi = k_hi;
 
-  PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 128};
   SlotLut lut;
   lut.load(a.slot_map, a.T);
-  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, lut, tps, ctile * 128, a.ncols};
+  SkipPadTiles<PBlockedOperand> lx{PBlockedOperand{a.ph, a.pl, (long)a.Npad, qtile * 128}, tv, tps};
+  SkipPadTiles<VtOperand> ly{VtOperand{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, lut, tps, ctile * 128, a.ncols},
+                             tv, tps};
 
   GemmFrag<Cfg> f;
   f.zero();
