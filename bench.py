@@ -11,7 +11,7 @@ the bank in steady state (T = K, one long-memory update + eviction every `gap` f
 The next two frames are announced to the engine as `next_img` (encoder prefetch, as rmem_amd.driver does).
 Frames are resident in HBM before the timed region.
 
-    python bench.py --gpus 1 --steps 40 --warmup 10
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the
@@ -42,7 +42,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gap", type=int, default=5, help="long_term_mem_gap (evaluator rule gives 5 for clips <= 165 frames)")
     ap.add_argument("--nsplit", type=int, default=int(os.environ.get("RMEM_NSPLIT", "3")),
