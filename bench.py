@@ -8,7 +8,8 @@ reference's timing window (managers/evaluator.py:399-404,525-527):
 match_propogate_one_frame -> label map (bilinear upsample + argmax; the evaluator's
 softmax/argmax torch ops with --reference-postproc) -> nearest resize -> update_memory, with
 the bank in steady state (T = K, one long-memory update + eviction every `gap` frames).
-The next two frames are announced to the engine as `next_img` (encoder prefetch, as rmem_amd.driver does).
+The next frames (engine.lookahead of them) are announced to the engine as `next_img` (encoder prefetch,
+as rmem_amd.driver does).
 Frames are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
@@ -60,8 +61,9 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not hand the next frame to match_propogate_one_frame (its encoder pass then runs "
                          "in line instead of on a second stream beside this frame's LSTT/decoder)")
-    ap.add_argument("--lookahead", type=int, default=2,
-                    help="frames announced ahead to the engine for encoder prefetch (feature copies = lookahead + 1)")
+    ap.add_argument("--lookahead", type=int, default=0,
+                    help="frames announced ahead to the engine for encoder prefetch (0 = what the engine asks for: "
+                         "3 with its default encoder batch of 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
@@ -116,11 +118,11 @@ def main():
         clips.append(([x.to(dev) for x in im], lb.to(dev)))
 
     PREFETCH = not args.no_prefetch
-    LOOKAHEAD = max(1, args.lookahead)
+    LOOKAHEAD = args.lookahead if args.lookahead > 0 else engines[0].lookahead
 
     def frame_step(i, t, masks_out=None):
         engine = engines[i]
-        # the next two frames are announced to the engine (encoder prefetch, as rmem_amd.driver does)
+        # the next frames are announced to the engine (encoder prefetch, as rmem_amd.driver does)
         nxt = [clips[i][0][(t + d) % ring] for d in range(1, LOOKAHEAD + 1)] if PREFETCH else None
         if args.reference_postproc:
             logit = engine.match_propogate_one_frame(clips[i][0][t % ring], output_size=(H_OUT, W_OUT), next_img=nxt)

@@ -277,6 +277,11 @@ int rmem_groupnorm_nchw_bias(const float *x, const float *conv_bias, float *y, i
 int rmem_bias_act_nchw(float *x, const float *bias, const float *residual, int32_t C, int64_t HW,
                        int32_t relu, void *stream);
 
+/* Same for a contiguous [B][C][H][W] batch (bias indexed by channel): the encoder pass of several
+ * announced frames at once (rmem_amd/engine.py, encoder prefetch). */
+int rmem_bias_act_nchw_batched(float *x, const float *bias, const float *residual, int32_t B, int32_t C,
+                               int64_t HW, int32_t relu, void *stream);
+
 /* Support op outside the LSTT: y = (y + bias[c]) + bilinear_upsample(x -> H x W), in place on a
  * contiguous batch-1 NCHW map: the skip merge "adapter(shortcut) + F.interpolate(x)" of the FPN
  * head (decoders/fpn.py:53-60) in one pass.  bias may be NULL.  C*H <= 65535. */

@@ -788,12 +788,13 @@ extern "C" int rmem_pe_bias_heads(const float* Q, int64_t ldq, const float* cur_
 // y = act(x + bias[c] (+ residual)) in place on a contiguous NCHW batch-1 tensor: replaces the
 // separate bias-add / residual-add / ReLU launches PyTorch-ROCm issues after every MIOpen conv.
 __global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* x, const float* bias, const float* res, unsigned hw,
-                                                            unsigned n, int relu) {
+                                                            unsigned C, unsigned n, int relu) {
   // 32-bit indices (n < 2^32 checked by the host): one division per float4 instead of four 64-bit
   // ones -- the integer divisions were most of this kernel's instructions
   for (unsigned i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < n; i += gridDim.x * 1024u) {
-    const unsigned c0 = i / hw;
-    const unsigned left = (c0 + 1) * hw - i;       // elements of channel c0 from i on
+    const unsigned p0 = i / hw;                    // (image, channel) plane index
+    const unsigned left = (p0 + 1) * hw - i;       // elements of plane p0 from i on
+    const unsigned c0 = p0 % C, c1 = (p0 + 1) % C;
     if (i + 3 < n) {
       float4 v = *reinterpret_cast<const float4*>(x + i);
       float o[4] = {v.x, v.y, v.z, v.w};
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* x, const floa
         r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
       }
       const float b0 = bias[c0];
-      const float b1 = left < 4 ? bias[c0 + 1] : b0;
+      const float b1 = left < 4 ? bias[c1] : b0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = o[e] + ((unsigned)e < left ? b0 : b1) + r[e];
@@ -812,17 +813,17 @@ __global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* x, const floa
       *reinterpret_cast<float4*>(x + i) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
       for (unsigned j = i; j < n; ++j) {
-        float t = x[j] + bias[j / hw] + (res ? res[j] : 0.f);
+        float t = x[j] + bias[(j / hw) % C] + (res ? res[j] : 0.f);
         x[j] = relu ? fmaxf(t, 0.f) : t;
       }
     }
   }
 }
 
-extern "C" int rmem_bias_act_nchw(float* x, const float* bias, const float* residual, int32_t C, int64_t HW,
-                                  int32_t relu, void* stream) {
-  if (!x || !bias || C <= 0 || HW <= 0) return RMEM_ERR_INVALID;
-  const long n = (long)C * HW;
+static int bias_act_impl(float* x, const float* bias, const float* residual, int32_t B, int32_t C, int64_t HW,
+                         int32_t relu, void* stream) {
+  if (!x || !bias || B <= 0 || C <= 0 || HW <= 0) return RMEM_ERR_INVALID;
+  const long n = (long)B * C * HW;
   if (n >= (1l << 32) - 4096 || HW < 4) return RMEM_ERR_INVALID;   // 32-bit indexing; a float4 spans <= 2 channels
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (residual && (reinterpret_cast<uintptr_t>(residual) & 15)))
     return RMEM_ERR_INVALID;
@@ -830,9 +831,19 @@ extern "C" int rmem_bias_act_nchw(float* x, const float* bias, const float* resi
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(bias_act_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     bias, residual, (unsigned)HW, (unsigned)n, relu);
+                     bias, residual, (unsigned)HW, (unsigned)C, (unsigned)n, relu);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
+}
+
+extern "C" int rmem_bias_act_nchw(float* x, const float* bias, const float* residual, int32_t C, int64_t HW,
+                                  int32_t relu, void* stream) {
+  return bias_act_impl(x, bias, residual, 1, C, HW, relu, stream);
+}
+
+extern "C" int rmem_bias_act_nchw_batched(float* x, const float* bias, const float* residual, int32_t B, int32_t C,
+                                          int64_t HW, int32_t relu, void* stream) {
+  return bias_act_impl(x, bias, residual, B, C, HW, relu, stream);
 }
 
 // ------------------------------------------------------------------ FPN skip merge

@@ -241,10 +241,16 @@ class ClipDriver:
         writers = []
         on_cuda = False
         it = iter(frames)
-        ahead = [f for f in (next(it, None), next(it, None)) if f is not None]
+        from .engine import default_lookahead
+        depth = default_lookahead()                       # look-ahead (encoder prefetch)
+        ahead = []
+        for _ in range(depth):
+            f = next(it, None)
+            if f is not None:
+                ahead.append(f)
         frame_idx = -1
         while ahead:
-            samples, ahead = ahead[0], ahead[1:]        # two frames of look-ahead (encoder prefetch)
+            samples, ahead = ahead[0], ahead[1:]
             f = next(it, None)
             if f is not None:
                 ahead.append(f)

@@ -103,6 +103,7 @@ EXPORTS = [
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2",
+    "rmem_bias_act_nchw_batched",
 ]
 
 
@@ -126,6 +127,7 @@ def load():
     lib.rmem_layernorm_red.argtypes = [c_p, i64, c_p, i32, i64, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64,
                                        c_p, i64, c_p]
     lib.rmem_bias_act_nchw.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p]
+    lib.rmem_bias_act_nchw_batched.argtypes = [c_p, c_p, c_p, i32, i32, i64, i32, c_p]
     lib.rmem_layernorm_red2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i64, i64, c_p, c_p, c_p, c_p, i32, i32, f32,
                                         c_p, c_p, i64, c_p, c_p, i64, c_p]
     lib.rmem_set_ints.argtypes = [c_p, C.POINTER(i32), i32, c_p]
@@ -266,14 +268,18 @@ def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool, conv_bia
 
 
 def bias_act_nchw_(x: torch.Tensor, bias: torch.Tensor, residual=None, relu: bool = True) -> torch.Tensor:
-    """In-place x = act(x + bias[c] (+ residual)) for a contiguous batch-1 NCHW fp32 tensor."""
+    """In-place x = act(x + bias[c] (+ residual)) for a contiguous NCHW fp32 tensor."""
     n, c, h, w = x.shape
-    if n != 1 or not x.is_contiguous() or x.dtype != torch.float32 or h * w < 4 or \
+    if not x.is_contiguous() or x.dtype != torch.float32 or h * w < 4 or \
             (residual is not None and not residual.is_contiguous()):
         y = x + bias.view(1, -1, 1, 1)
         if residual is not None:
             y = y + residual
         return torch.relu_(y) if relu else y
+    if n != 1:
+        check(load().rmem_bias_act_nchw_batched(x.data_ptr(), bias.data_ptr(), ptr(residual), n, c, h * w,
+                                                int(relu), stream_ptr()), "rmem_bias_act_nchw_batched")
+        return x
     check(load().rmem_bias_act_nchw(x.data_ptr(), bias.data_ptr(), ptr(residual), c, h * w, int(relu),
                                     stream_ptr()), "rmem_bias_act_nchw")
     return x

@@ -213,6 +213,8 @@ def test_prefetch_lookahead_ring():
     for name, ann in [
         ("one frame", lambda t: imgs[t + 1] if t + 1 < frames else None),
         ("two frames", lambda t: [imgs[k] for k in (t + 1, t + 2) if k < frames] or None),
+        ("engine.lookahead frames (whole encoder batches)",
+         lambda t: [imgs[k] for k in range(t + 1, t + 1 + eng.lookahead) if k < frames] or None),
         ("wrong announcements", lambda t: [imgs[(t + 5) % frames], imgs[(t + 1) % frames]]),   # first one is never used next
         ("repeated frame", lambda t: [imgs[t], imgs[t + 1]] if t + 1 < frames else None),
     ]:
@@ -222,7 +224,7 @@ def test_prefetch_lookahead_ring():
         assert idx == idx0
         assert err < 1e-4, (name, err)
     sub = eng.aot_engines[0]
-    assert sub._ring == 3 and len(sub._pending) <= 2
+    assert len(sub._pending) <= max(2, sub.lookahead)
     eng.restart_engine()                       # with passes still pending
     assert sub._pending == []
     torch.cuda.synchronize()

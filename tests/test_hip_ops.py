@@ -430,16 +430,17 @@ def test_upsample_add_nchw(geom):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geom", [(64, 121, 213), (256, 31, 54), (7, 5, 3), (3, 1, 5), (1024, 31, 54)])
+@pytest.mark.parametrize("geom", [(64, 121, 213), (256, 31, 54), (7, 5, 3), (3, 1, 5), (1024, 31, 54),
+                                  (2, 64, 121, 213), (3, 7, 5, 3)])
 def test_bias_act_nchw(geom):
     """rmem_bias_act_nchw == relu(x + bias[c] (+ residual)) bit for bit (one fp32 add per term, same
     order as the separate PyTorch ops); H*W not a multiple of 4 makes float4 groups straddle channels."""
     from rmem_amd import hip
-    C_, H, W = geom
+    B_, C_, H, W = geom if len(geom) == 4 else (1,) + tuple(geom)        # batch > 1: several frames per encoder pass
     g = torch.Generator().manual_seed(C_ * 7 + W)
-    x = torch.randn(1, C_, H, W, generator=g).to(DEV)
+    x = torch.randn(B_, C_, H, W, generator=g).to(DEV)
     b = torch.randn(C_, generator=g).to(DEV)
-    r = torch.randn(1, C_, H, W, generator=g).to(DEV)
+    r = torch.randn(B_, C_, H, W, generator=g).to(DEV)
     for res in (None, r):
         for relu in (True, False):
             want = x + b.view(1, -1, 1, 1)
