@@ -185,7 +185,7 @@ class DeAOTLSTT:
         self.ws_main = _AttnWS(self.Tmax, N, Np, self.ksplits_max, dev)
         self.ws_side = _AttnWS(1, N, Np, self.ksplits_max, dev)
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "short_first")   # short_first | long_first | serial
+        self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "serial")   # serial | short_first | long_first (forked)
         self.ev_ready = torch.cuda.Event() if dev.type == "cuda" else None
         self.ev_side = torch.cuda.Event() if dev.type == "cuda" else None
         self.Ylt = Planes.empty((Np, 1024), dev)
@@ -458,9 +458,11 @@ class DeAOTLSTT:
                 self._idv(l, cur)
             # -- short-term windowed read (transformer.py:1199, attention.py:289-358) and long-term
             #    memory read (transformer.py:1140-1192, attention.py:174-209): independent until
-            #    the projection.  Issue order matters under hipGraph replay: the branch whose nodes
-            #    are created first continues on the predecessor's hardware queue, the other one is
-            #    forked to a second queue and starts ~120 us late (rocprofv3 trace, profiles/r01_g).
+            #    the projection.  Default: in line on one stream.  Forked onto a second stream the
+            #    frame rate is the same (417.7 vs 418.4 frames/s over four runs each) but every kernel
+            #    of the long chain shares the CUs with the short chain (long-term P.V 92 us instead
+            #    of 80 us in a frame), and under hipGraph replay the forked branch starts ~120 us
+            #    late whichever is issued first (rocprofv3 trace, profiles/r01_g).
             def short_chain():
                 hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
                            d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
