@@ -117,6 +117,10 @@ typedef struct {
 
 int rmem_attn_scores(const rmem_scores_args *a, void *stream);
 
+/* Two independent reads of one frame in ONE launch (the long-term bank read and the windowed
+ * short-term read of a GPM layer, layers/transformer.py:1183 and :1199): same pass and nsplit. */
+int rmem_attn_scores2(const rmem_scores_args *a, const rmem_scores_args *b, void *stream);
+
 typedef struct {
   int32_t mode;                            /* 0 bank, 1 window (banded k range)         */
   const rmem_bf16 *ph, *pl;                /* P planes blocked [key/32][Npad][32]       */
@@ -141,6 +145,9 @@ typedef struct {
 } rmem_combine_args;
 
 int rmem_attn_combine(const rmem_combine_args *a, void *stream);
+
+/* The combine steps of two reads in one launch (see rmem_attn_scores2). */
+int rmem_attn_combine2(const rmem_combine_args *a, const rmem_combine_args *b, void *stream);
 
 /* bias[q][t] = (Q[q] + cur_pe) . mem_pe[pe_row[t]]   (layers/transformer.py:1140-1172) */
 int rmem_pe_bias(const float *Q, int64_t ldq, const float *cur_pe, const float *mem_pe,
@@ -236,6 +243,11 @@ int rmem_pe_bias_heads(const float *Q, int64_t ldq, const float *cur_pe, const f
  * wt is [25][C] (tap-major).  Output planes. */
 int rmem_dwconv5x5_split(const float *g, int64_t ldg, const float *wt, int32_t h, int32_t w,
                          int32_t C, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, void *stream);
+
+/* Two maps of the same geometry in one launch (the gated long-term and short-term aggregates). */
+int rmem_dwconv5x5_split2(const float *g0, const float *g1, int64_t ldg, const float *wt0, const float *wt1,
+                          int32_t h, int32_t w, int32_t C, rmem_bf16 *oh0, rmem_bf16 *ol0, rmem_bf16 *oh1,
+                          rmem_bf16 *ol1, int64_t ldo, void *stream);
 
 /* Final GroupNorm1D(2 groups) over [tgt | tgt_id] (layers/transformer.py:806-808,
  * layers/basic.py:6-12): statistics over 256 channels x N tokens per group.

@@ -23,19 +23,18 @@ __host__ __device__ inline void band_tiles(int qtile, int N, int h, int w, int& 
 
 // ------------------------------------------------------------------ scores (swapped: rows = keys)
 template <int NS, int PASS>
-__global__ __launch_bounds__(256) void scores_kernel(rmem_scores_args a) {
+__device__ __forceinline__ void scores_body(const rmem_scores_args& a, int bx, int by, char* smem) {
   using Cfg = GemmCfg<128, 128, NS>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int qtile = blockIdx.y;
+  const int qtile = by;
   const int tiles_per_slot = a.Npad / 128;
   int t = 0, ktile;  // ktile: key tile inside the slot
   if (a.mode == 0) {
-    t = blockIdx.x / tiles_per_slot;
-    ktile = blockIdx.x - t * tiles_per_slot;
+    t = bx / tiles_per_slot;
+    ktile = bx - t * tiles_per_slot;
   } else {
     int t_lo, t_hi;
     band_tiles(qtile, a.N, a.h, a.w, t_lo, t_hi);
-    ktile = t_lo + blockIdx.x;
+    ktile = t_lo + bx;
     if (ktile >= t_hi) return;
   }
   const int phys = a.slot_map ? a.slot_map[t] : t;
@@ -142,6 +141,22 @@ __global__ __launch_bounds__(256) void scores_kernel(rmem_scores_args a) {
   }
 }
 
+template <int NS, int PASS>
+__global__ __launch_bounds__(256) void scores_kernel(rmem_scores_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  scores_body<NS, PASS>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// Two independent reads of the same frame (long-term bank + windowed short-term) in one launch:
+// blocks [0, na) serve problem a (x-extent gxa), the rest problem b (x-extent gxb).
+template <int NS, int PASS>
+__global__ __launch_bounds__(256) void scores2_kernel(rmem_scores_args a, rmem_scores_args b, int na, int gxa, int gxb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int i = blockIdx.x;
+  if (i < na) scores_body<NS, PASS>(a, i % gxa, i / gxa, smem);
+  else scores_body<NS, PASS>(b, (i - na) % gxb, (i - na) / gxb, smem);
+}
+
 static int max_band_tiles(int N, int Npad, int h, int w) {
   int mx = 0;
   for (int qt = 0; qt < Npad / 128; ++qt) {
@@ -166,6 +181,46 @@ static int launch_scores(const rmem_scores_args& a, hipStream_t s) {
   hipLaunchKernelGGL((scores_kernel<NS, PASS>), dim3(ktiles, qtiles), dim3(256), Cfg::LDS_BYTES, s, a);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
+}
+
+static int scores_args_ok(const rmem_scores_args& a) {
+  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0) return 0;
+  if (!a.kh || !a.qh || !a.rowmax) return 0;
+  if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1)) return 0;
+  if (a.mode != 0 && a.mode != 1) return 0;
+  if (a.pass == 1 && (!a.ph || !a.lpart)) return 0;
+  if (a.pass == 1 && a.nsplit == 3 && (!a.kl || !a.ql || !a.pl)) return 0;
+  return 1;
+}
+
+template <int NS, int PASS>
+static int launch_scores2(const rmem_scores_args& a, const rmem_scores_args& b, hipStream_t s) {
+  using Cfg = GemmCfg<128, 128, NS>;
+  const int gxa = a.mode == 0 ? a.T * (a.Npad / 128) : max_band_tiles(a.N, a.Npad, a.h, a.w);
+  const int gxb = b.mode == 0 ? b.T * (b.Npad / 128) : max_band_tiles(b.N, b.Npad, b.h, b.w);
+  const int na = gxa * (a.Npad / 128), nb = gxb * (b.Npad / 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scores2_kernel<NS, PASS>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((scores2_kernel<NS, PASS>), dim3(na + nb), dim3(256), Cfg::LDS_BYTES, s, a, b, na, gxa, gxb);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_attn_scores2(const rmem_scores_args* ap, const rmem_scores_args* bp, void* stream) {
+  if (!ap || !bp) return RMEM_ERR_INVALID;
+  const rmem_scores_args& a = *ap;
+  const rmem_scores_args& b = *bp;
+  if (!scores_args_ok(a) || !scores_args_ok(b) || a.pass != b.pass || a.nsplit != b.nsplit) return RMEM_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a.pass == 0) return launch_scores2<1, 0>(a, b, s);
+  if (a.pass != 1) return RMEM_ERR_INVALID;
+  if (a.nsplit == 3) return launch_scores2<3, 1>(a, b, s);
+  if (a.nsplit == 1) return launch_scores2<1, 1>(a, b, s);
+  return RMEM_ERR_INVALID;
 }
 
 extern "C" int rmem_attn_scores(const rmem_scores_args* ap, void* stream) {
@@ -362,9 +417,7 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
 }
 
 // ------------------------------------------------------------------ combine + gate (+ mass)
-__global__ __launch_bounds__(256) void combine_kernel(rmem_combine_args a) {
-  __shared__ float slot_sum[64];
-  const int q = blockIdx.x;
+__device__ __forceinline__ void combine_body(const rmem_combine_args& a, int q, float* slot_sum) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tps = a.Npad / 64;
   const float* lp = a.lpart + (long)q * a.nparts;
@@ -403,6 +456,30 @@ __global__ __launch_bounds__(256) void combine_kernel(rmem_combine_args a) {
     g.w = acc.w * inv_l * u.w;
     *reinterpret_cast<float4*>(a.G + (long)q * a.ldg + c) = g;
   }
+}
+
+__global__ __launch_bounds__(256) void combine_kernel(rmem_combine_args a) {
+  __shared__ float slot_sum[64];
+  combine_body(a, blockIdx.x, slot_sum);
+}
+
+__global__ __launch_bounds__(256) void combine2_kernel(rmem_combine_args a, rmem_combine_args b) {
+  __shared__ float slot_sum[64];
+  if ((int)blockIdx.x < a.N) combine_body(a, blockIdx.x, slot_sum);
+  else combine_body(b, blockIdx.x - a.N, slot_sum);
+}
+
+static int combine_args_ok(const rmem_combine_args& a) {
+  if (a.N <= 0 || a.T <= 0 || a.T > 64 || (a.ncols % 4) != 0 || !a.part || !a.lpart || !a.U || !a.G) return 0;
+  if ((a.ldu % 4) || (a.ldg % 4)) return 0;
+  return 1;
+}
+
+extern "C" int rmem_attn_combine2(const rmem_combine_args* ap, const rmem_combine_args* bp, void* stream) {
+  if (!ap || !bp || !combine_args_ok(*ap) || !combine_args_ok(*bp)) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(combine2_kernel, dim3(ap->N + bp->N), dim3(256), 0, static_cast<hipStream_t>(stream), *ap, *bp);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
 }
 
 extern "C" int rmem_attn_combine(const rmem_combine_args* ap, void* stream) {

@@ -194,11 +194,17 @@ extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* ga
 // thread = 4 channels x a run of RX output tokens along x; the 5 x (RX+4) input window is
 // loaded once (sliding-window reuse: 50 loads for 6 outputs instead of 150) and the 25
 // taps of its channels stay in registers.  block = 256 threads = 1024 channels.
+struct DwOne {
+  const float* g;
+  const float* wt;
+  bf16_t* oh;
+  bf16_t* ol;
+};
 template <int RX>
-__global__ __launch_bounds__(256) void dwconv5x5_split_kernel(const float* g, long ldg, const float* wt, int h,
-                                                              int w, int C, bf16_t* oh, bf16_t* ol, long ldo) {
+__device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const float* wt, int h, int w, int C,
+                                               bf16_t* oh, bf16_t* ol, long ldo, int bz) {
   const int x0 = blockIdx.x * RX, y = blockIdx.y;
-  const int c = (blockIdx.z * 256 + threadIdx.x) * 4;
+  const int c = (bz * 256 + threadIdx.x) * 4;
   if (c >= C) return;
   float4 k[25];
 #pragma unroll
@@ -254,6 +260,34 @@ __global__ __launch_bounds__(256) void dwconv5x5_split_kernel(const float* g, lo
     *reinterpret_cast<uint2*>(oh + p * ldo + c) = vh;
     if (ol) *reinterpret_cast<uint2*>(ol + p * ldo + c) = vl;
   }
+}
+
+template <int RX>
+__global__ __launch_bounds__(256) void dwconv5x5_split_kernel(const float* g, long ldg, const float* wt, int h,
+                                                              int w, int C, bf16_t* oh, bf16_t* ol, long ldo) {
+  dwconv5x5_body<RX>(g, ldg, wt, h, w, C, oh, ol, ldo, blockIdx.z);
+}
+
+// two maps of the same geometry (the gated long-term and short-term aggregates of a layer) in one launch
+template <int RX>
+__global__ __launch_bounds__(256) void dwconv5x5_split2_kernel(DwOne p0, DwOne p1, long ldg, int h, int w, int C,
+                                                               long ldo, int nz) {
+  const DwOne p = (int)blockIdx.z < nz ? p0 : p1;
+  dwconv5x5_body<RX>(p.g, ldg, p.wt, h, w, C, p.oh, p.ol, ldo, (int)blockIdx.z < nz ? blockIdx.z : blockIdx.z - nz);
+}
+
+extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t ldg, const float* wt0, const float* wt1,
+                                     int32_t h, int32_t w, int32_t C, rmem_bf16* oh0, rmem_bf16* ol0, rmem_bf16* oh1,
+                                     rmem_bf16* ol1, int64_t ldo, void* stream) {
+  if (!g0 || !g1 || !wt0 || !wt1 || !oh0 || !oh1 || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4))
+    return RMEM_ERR_INVALID;
+  constexpr int RX = 6;
+  const int nz = (C + 1023) / 1024;
+  DwOne p0{g0, wt0, oh0, ol0}, p1{g1, wt1, oh1, ol1};
+  hipLaunchKernelGGL(dwconv5x5_split2_kernel<RX>, dim3((w + RX - 1) / RX, h, 2 * nz), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p0, p1, (long)ldg, h, w, C, (long)ldo, nz);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
 }
 
 extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt, int32_t h, int32_t w,

@@ -103,7 +103,7 @@ EXPORTS = [
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2",
-    "rmem_bias_act_nchw_batched",
+    "rmem_bias_act_nchw_batched", "rmem_attn_scores2", "rmem_attn_combine2", "rmem_dwconv5x5_split2",
 ]
 
 
@@ -132,6 +132,9 @@ def load():
                                         c_p, c_p, i64, c_p, c_p, i64, c_p]
     lib.rmem_set_ints.argtypes = [c_p, C.POINTER(i32), i32, c_p]
     lib.rmem_attn_scores.argtypes = [C.POINTER(ScoresArgs), c_p]
+    lib.rmem_attn_scores2.argtypes = [C.POINTER(ScoresArgs), C.POINTER(ScoresArgs), c_p]
+    lib.rmem_attn_combine2.argtypes = [C.POINTER(CombineArgs), C.POINTER(CombineArgs), c_p]
+    lib.rmem_dwconv5x5_split2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p]
     lib.rmem_attn_pv.argtypes = [C.POINTER(PVArgs), c_p]
     lib.rmem_attn_combine.argtypes = [C.POINTER(CombineArgs), c_p]
     lib.rmem_pe_bias.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]

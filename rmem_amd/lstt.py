@@ -306,10 +306,9 @@ class DeAOTLSTT:
             out1.hi.data_ptr() + off1 * 2, out1.lo.data_ptr() + off1 * 2, ldo1, hip.stream_ptr())
         hip.check(rc, "rmem_layernorm_red2")
 
-    def _attention(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
+    def _attn_args(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
                    qpl: Planes, bias, U, want_mass: bool, which: int):
-        """scores(pass0, pass1) + pv + combine -> ws.G."""
-        lib, st = hip.load(), hip.stream_ptr()
+        """Argument blocks (scores, P.V, combine) of one read into workspace `ws`."""
         Np = self.Npad
         nparts = T * Np // 64
         sa = hip.ScoresArgs()
@@ -321,10 +320,6 @@ class DeAOTLSTT:
         sa.rowmax = self.rowmax[3 * self._layer + which].data_ptr()
         sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
         sa.lpart, sa.nparts, sa.nsplit = ws.lpart.data_ptr(), nparts, self.nsplit
-        sa.pass_ = 0
-        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 0)")
-        sa.pass_ = 1
-        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 1)")
         ktiles = T * Np // 64 if mode == 0 else 20
         ks = self._ksplits(ktiles)
         pa = hip.PVArgs()
@@ -332,20 +327,46 @@ class DeAOTLSTT:
         pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
         pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = slot_map_ptr, T, self.N, Np, 1024
         pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = self.h, self.w, ws.part.data_ptr(), ks, self.nsplit
-        timed = self._timing and mode == 0 and which == 0
+        ca = hip.CombineArgs()
+        ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, self.N, Np, 1024, self.h, self.w
+        ca.part, ca.ksplits, ca.lpart, ca.nparts = ws.part.data_ptr(), ks, ws.lpart.data_ptr(), nparts
+        ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, ws.G.data_ptr(), 1024
+        ca.mass = self.mass.data_ptr() if want_mass else None
+        return sa, pa, ca
+
+    def _pv(self, pa, timed: bool):
+        lib, st = hip.load(), hip.stream_ptr()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
         if timed:
             e1.record()
-            self._events.append((e0, e1, T))
-        ca = hip.CombineArgs()
-        ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, self.N, Np, 1024, self.h, self.w
-        ca.part, ca.ksplits, ca.lpart, ca.nparts = ws.part.data_ptr(), ks, ws.lpart.data_ptr(), nparts
-        ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, ws.G.data_ptr(), 1024
-        ca.mass = self.mass.data_ptr() if want_mass else None
+            self._events.append((e0, e1, pa.T))
+
+    def _attention(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
+                   qpl: Planes, bias, U, want_mass: bool, which: int):
+        """scores(pass0, pass1) + pv + combine -> ws.G."""
+        lib, st = hip.load(), hip.stream_ptr()
+        sa, pa, ca = self._attn_args(ws, mode, T, kpl, vpl, slot_map_ptr, qpl, bias, U, want_mass, which)
+        sa.pass_ = 0
+        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 0)")
+        sa.pass_ = 1
+        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 1)")
+        self._pv(pa, self._timing and mode == 0 and which == 0)
         hip.check(lib.rmem_attn_combine(C.byref(ca), st), "rmem_attn_combine")
+
+    def _attention_pair(self, A, B):
+        """Two independent reads (argument blocks from _attn_args): score passes and combine steps
+        as ONE launch each (rmem_attn_scores2 / rmem_attn_combine2), the two P.V launches apart."""
+        lib, st = hip.load(), hip.stream_ptr()
+        (sa, pa, ca), (sb, pb, cb) = A, B
+        for p in (0, 1):
+            sa.pass_ = sb.pass_ = p
+            hip.check(lib.rmem_attn_scores2(C.byref(sa), C.byref(sb), st), f"rmem_attn_scores2(pass {p})")
+        self._pv(pa, self._timing)
+        self._pv(pb, False)
+        hip.check(lib.rmem_attn_combine2(C.byref(ca), C.byref(cb), st), "rmem_attn_combine2")
 
     def _dwconv(self, ws: "_AttnWS", wt, out: Planes):
         rc = hip.load().rmem_dwconv5x5_split(ws.G.data_ptr(), 1024, wt.data_ptr(), self.h, self.w, 1024,
@@ -479,6 +500,22 @@ class DeAOTLSTT:
                 self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
 
             if self.branch_order == "serial":
+                # in line, the two reads share their score / combine / depth-wise-conv launches
+                hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
+                           d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
+                hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
+                                           self.mem_pe.data_ptr(), rows, T, N, 128,
+                                           self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
+                self._attention_pair(
+                    self._attn_args(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
+                                    self.bias_pe, Ucat, l == 0, 0),
+                    self._attn_args(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
+                                    Ucat, False, 1))
+                hip.check(lib.rmem_dwconv5x5_split2(
+                    self.ws_main.G.data_ptr(), self.ws_side.G.data_ptr(), 1024, W.dw_lt.data_ptr(),
+                    W.dw_st.data_ptr(), self.h, self.w, 1024, self.Ylt.hi.data_ptr(), self.Ylt.lo.data_ptr(),
+                    self.Yst.hi.data_ptr(), self.Yst.lo.data_ptr(), 1024, hip.stream_ptr()), "rmem_dwconv5x5_split2")
+            elif self.branch_order == "serial_unpaired":
                 short_chain()
                 long_chain()
             else:

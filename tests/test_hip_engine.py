@@ -259,3 +259,40 @@ def test_720p_k8_vs_oracle():
     assert len(ora.long_memories_indexes) == frames
     # 2-18 measured: the same near-tie rate as at 480p (2-7 of 409,920) on 2.25x the pixels
     assert max(mism) <= 40 and max(lerr) < 2e-3, (mism, lerr)
+
+
+def test_paired_launches_bit_identical():
+    """The long-term and windowed reads of a layer share their score / combine / depth-wise-conv
+    launches (rmem_attn_scores2, rmem_attn_combine2, rmem_dwconv5x5_split2): same kernels' bodies on
+    the same data, so the LSTT output, the attention mass and the bank must equal the unpaired and the
+    forked schedules bit for bit."""
+    from oracle import lstt_ref as R
+    from rmem_amd.lstt import DeAOTLSTT
+    cfg, cpu_model, gpu_model, _ = _build()
+    h, w = 12, 17
+    N = h * w
+    sd = {k: v.detach().float() for k, v in cpu_model.state_dict().items()}
+    H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
+    outs = {}
+    for order in ("serial", "serial_unpaired", "short_first"):
+        lstt = DeAOTLSTT(gpu_model, h, w, DEV, nsplit=3)
+        lstt.branch_order = order
+        rs = np.random.RandomState(0)
+        rec = []
+        for t in range(4):
+            emb = torch.from_numpy(rs.standard_normal((N, 256)).astype(np.float32)).to(DEV)
+            label = torch.from_numpy(rs.randint(0, 4, (1, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
+            lab_u8 = F.interpolate(label, size=(H, W), mode="nearest")[0, 0].to(torch.uint8).to(DEV).contiguous()
+            if t == 0:
+                lstt.assign_identity(lab_u8)
+                out = lstt.forward(emb, ref_frame=True)
+            else:
+                out = lstt.forward(emb)
+                lstt.assign_identity(lab_u8)
+                lstt.update_short_memories(t % 2 == 0)
+            torch.cuda.synchronize()
+            rec.append((out.clone(), lstt.mass.clone()))
+        outs[order] = rec
+    for order in ("serial_unpaired", "short_first"):
+        for (o0, m0), (o1, m1) in zip(outs["serial"], outs[order]):
+            assert torch.equal(o0, o1) and torch.equal(m0, m1), order
