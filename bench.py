@@ -155,6 +155,18 @@ def main():
     while len(sub.lstt.bank) < cfg.mem_cap:
         all_clips(t)
         t += 1
+    # ... and until every hipGraph of the steady state exists (one per feature copy and free slot:
+    # captures take tens of ms and must not land in the timed region, whatever --warmup is)
+    def n_graphs():
+        return sum(len(getattr(e.aot_engines[0], k)) for e in engines for k in ("_fg", "_ug", "_eg"))
+    stable, last = 0, n_graphs()
+    for _ in range(60):
+        if stable >= 2 * cfg.mem_cap + 4:
+            break
+        all_clips(t)
+        t += 1
+        cur = n_graphs()
+        stable, last = (stable + 1, last) if cur == last else (0, cur)
     for _ in range(args.warmup):
         all_clips(t)
         t += 1
