@@ -93,6 +93,10 @@ class DeAOTEngine(nn.Module):
         self._group_of = {par: g for g, pars in enumerate(self._groups) for par in pars}
         self._feats = {}                     # (shape, par) -> FeatureList view of that copy
         self._enc_warm = set()               # (shape, batch) whose convolutions MIOpen has already seen
+        self._hoist = None                   # hoisted front part of the next frame's LSTT in flight (see _try_hoist)
+        self._hoist_stream = None
+        self._gen = 0                        # bumped by whatever invalidates a hoisted front (reference frame, restart)
+        self.hoist_enabled = os.environ.get("RMEM_HOIST", "1") == "1"
         self._enc_stream = None
         self._enc_done = None
         self._launcher = None
@@ -120,6 +124,7 @@ class DeAOTEngine(nn.Module):
         self.long_memories_indexes: List[int] = []
         self.pred_id_logits = None
         self._drop_pending()
+        self._drop_hoist()
         if self.lstt is not None:
             self.lstt.clear_memory()
 
@@ -133,6 +138,7 @@ class DeAOTEngine(nn.Module):
             self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
             self._fg, self._ug = {}, {}      # graphs hold pointers into the old LSTT buffers
             self._drop_pending()
+            self._drop_hoist()
             self._eg, self._g_lab, self._feats = {}, {}, {}
 
     def _label_u8(self, mask: torch.Tensor) -> torch.Tensor:
@@ -157,6 +163,7 @@ class DeAOTEngine(nn.Module):
             frame_step = self.frame_step
         if mask is None:
             raise ValueError("No mask for reference frame!")
+        self._drop_hoist()
         enc = self.AOT.encode_image(img) if img_embs is None else img_embs
         if enc is None:
             raise ValueError("No image for reference frame!")
@@ -181,6 +188,7 @@ class DeAOTEngine(nn.Module):
         if self._graph_ok(img, img_embs):
             return self._graphed_frame(img, output_size, next_img)
         self._eager_frames += 1
+        self._drop_hoist()
         enc = img_embs
         if enc is None:
             enc = self._take_prefetched(img)
@@ -322,8 +330,54 @@ class DeAOTEngine(nn.Module):
             for im, par in zip(imgs, self._groups[group]):
                 self._pending.append((self._img_id(im), par, launched))
 
+    # -- hoisted front part of the next frame's LSTT.  Layer 0 up to and including the score passes
+    #    needs the next frame's encoder features (prefetched), the bank keys and the slot maps, not
+    #    this frame's label: on frames whose memory update will not touch the long-term bank it is
+    #    issued on a third stream right after this frame's LSTT, beside the decoder, the label
+    #    kernels and the memory update, whose small kernels leave the GPU mostly idle.
+    def _drop_hoist(self):
+        h, self._hoist = getattr(self, "_hoist", None), None
+        self._gen = getattr(self, "_gen", 0) + 1
+        if h is not None:
+            torch.cuda.current_stream().wait_event(h["event"])
+
+    def _try_hoist(self, next_img, shape, osz):
+        l = self.lstt
+        if not self.hoist_enabled or next_img is None or getattr(l, "branch_order", "") != "serial":
+            return
+        nxt = next_img if isinstance(next_img, torch.Tensor) else (next_img[0] if len(next_img) else None)
+        if nxt is None or not nxt.is_cuda or tuple(nxt.shape) != shape:
+            return
+        if (not self.cfg.NO_LONG_MEMORY) and self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            return                                        # this frame's update appends to / evicts from the bank
+        ident = self._img_id(nxt)
+        pend = next((p for p in self._pending if p[0] == ident), None)
+        if pend is None:
+            return
+        par, cur = pend[1], l.next_free_slot()
+        ent = self._fg.get(((l._T, cur), osz, shape, par))
+        if ent is None:
+            return                                        # captured when a frame first runs with that key
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())            # this frame's LSTT is done
+        if self._hoist_stream is None:
+            from .streams import concurrent_stream
+            self._hoist_stream = concurrent_stream(nxt.device)
+        pend[2].wait()                                    # the encoder pass and its event are queued
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self._hoist_stream):
+            self._hoist_stream.wait_event(ev)
+            self._hoist_stream.wait_event(self._enc_done[self._group_of[par]])
+            ent[4].replay()
+            done.record(self._hoist_stream)
+        self._hoist = dict(ident=ident, cur=cur, T=l._T, par=par, bank=tuple(l.bank), short=l.cur,
+                           gen=self._gen, event=done)
+
     def _graphed_frame(self, img, output_size, next_img=None):
         l = self.lstt
+        h, self._hoist = self._hoist, None
+        if h is not None:                                 # before _prepare rewrites the slot maps it reads
+            torch.cuda.current_stream().wait_event(h["event"])
         l._prepare(False)
         osz = tuple(int(v) for v in output_size) if output_size is not None else None
         shape = tuple(img.shape)
@@ -350,13 +404,21 @@ class DeAOTEngine(nn.Module):
                 with torch.cuda.graph(g):
                     l.tgt.copy_(enc[-1][0].flatten(1).t())
                     l._forward_device(False)
+                gf = gr = None
+                if self.hoist_enabled and getattr(l, "branch_order", "") == "serial":
+                    gf, gr = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gf):
+                        l.tgt.copy_(enc[-1][0].flatten(1).t())
+                        l._forward_device(False, "front")
+                    with torch.cuda.graph(gr):
+                        l._forward_device(False, "rest")
                 with torch.cuda.graph(g2):
                     logits = self.AOT.decode_id_logits(l.out, enc)
                     for batch_idx, obj_num in enumerate(self.obj_nums):
                         logits[batch_idx, (obj_num + 1):] = -1e10
                     up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
                                                                   align_corners=self.align_corners)
-                self._fg[(l.graph_key(), osz, shape, par)] = (g, logits, up, g2)
+                self._fg[(l.graph_key(), osz, shape, par)] = (g, logits, up, g2, gf, gr)
             for k, v in saved.items():
                 setattr(l, k, v)
             ent = self._fg[key]
@@ -364,11 +426,16 @@ class DeAOTEngine(nn.Module):
         # released between them: beside the LSTT it competes with latency-bound kernels for
         # workgroup slots (every kernel of both chains ~2x slower), beside the decoder + label
         # post-processing + memory update it fills a GPU that those small kernels leave idle.
+        hoisted = (h is not None and ent[5] is not None and h["ident"] == self._img_id(img) and h["cur"] == l.cur
+                   and h["T"] == l._T and h["par"] == par and h["bank"] == tuple(l.bank) and h["short"] == l.short
+                   and h["gen"] == self._gen)
         if self.prefetch_at == "lstt":
             self._prefetch(next_img, shape)               # runs beside the LSTT graph below
-        ent[0].replay()
+        (ent[5] if hoisted else ent[0]).replay()          # the front part ran beside the previous decoder
+        self._hoist_count = getattr(self, "_hoist_count", 0) + int(hoisted)
         if self.prefetch_at != "lstt":
             self._prefetch(next_img, shape)               # released when the LSTT is done
+        self._try_hoist(next_img, shape, osz)
         ent[3].replay()
         l._finish(False)
         self.pred_id_logits = ent[1]

@@ -356,14 +356,19 @@ class DeAOTLSTT:
         self._pv(pa, self._timing and mode == 0 and which == 0)
         hip.check(lib.rmem_attn_combine(C.byref(ca), st), "rmem_attn_combine")
 
-    def _attention_pair(self, A, B):
-        """Two independent reads (argument blocks from _attn_args): score passes and combine steps
-        as ONE launch each (rmem_attn_scores2 / rmem_attn_combine2), the two P.V launches apart."""
+    def _scores_pair(self, A, B):
+        """Both score passes of two independent reads (argument blocks from _attn_args), ONE launch
+        per pass (rmem_attn_scores2)."""
         lib, st = hip.load(), hip.stream_ptr()
-        (sa, pa, ca), (sb, pb, cb) = A, B
+        (sa, _, _), (sb, _, _) = A, B
         for p in (0, 1):
             sa.pass_ = sb.pass_ = p
             hip.check(lib.rmem_attn_scores2(C.byref(sa), C.byref(sb), st), f"rmem_attn_scores2(pass {p})")
+
+    def _pv_combine_pair(self, A, B):
+        """The two P.V launches (apart: the first is the kernel bench.py times) and ONE combine launch."""
+        lib, st = hip.load(), hip.stream_ptr()
+        (_, pa, ca), (_, pb, cb) = A, B
         self._pv(pa, self._timing)
         self._pv(pb, False)
         hip.check(lib.rmem_attn_combine2(C.byref(ca), C.byref(cb), st), "rmem_attn_combine2")
@@ -417,8 +422,16 @@ class DeAOTLSTT:
         else:
             bank_map, short = self.bank, self.short
         self._T = len(bank_map)
-        vals = list(bank_map) + [0] * (16 - self._T) + [short]
+        # [0:16] bank map, [16] short-term slot of this frame, [17] short-term slot of the NEXT frame
+        # (= this frame's slot): read by the next frame's hoisted front part, see _forward_device
+        vals = list(bank_map) + [0] * (16 - self._T) + [short, self.cur]
         hip.set_ints(self.maps, vals)
+
+    def next_free_slot(self) -> int:
+        """The slot _prepare() will pick for the next frame if this frame's update does not touch
+        the long-term bank (short := cur, bank unchanged)."""
+        used = set(self.bank) | {self.cur}
+        return next(s for s in range(self.S) if s not in used)
 
     def _finish(self, ref_frame: bool):
         self.mass_T = self._T
@@ -436,18 +449,31 @@ class DeAOTLSTT:
         all of them are captured together the first time one is needed."""
         return [{"cur": c} for c in range(self.S)]
 
-    def _forward_device(self, ref_frame: bool = False):
+    def _forward_device(self, ref_frame: bool = False, part: str = "all"):
         """Device part of a forward pass (reads self.tgt, writes self.out): kernel launches and
         device-side memsets only -- hipGraph-capturable; depends on the host only through
-        graph_key() = (T, cur)."""
+        graph_key() = (T, cur).
+
+        part = "front" / "rest" split the pass where the previous frame's label first matters: the
+        front (layer 0: norm1, Q / V / U projections, relative-bias GEMM, temporal-PE bias and both
+        score passes of the long-term and the windowed read) needs only the frame's encoder
+        features, the bank keys and the slot maps, so the engine can issue it beside the previous
+        frame's decoder (DeAOTEngine._try_hoist); "rest" starts at the first P.V, which reads the
+        ID values written by the previous frame's memory update.  Only with branch_order "serial"."""
         N, Np, ns = self.N, self.Npad, self.nsplit
         lib, st = hip.load(), hip.stream_ptr()
-        self.tgt_id.zero_()
+        do_front, do_rest = part != "rest", part != "front"
+        if part != "all" and (ref_frame or self.branch_order != "serial"):
+            raise hip.RmemError("front/rest split needs a propagation frame and the in-line schedule")
         cur, T = self.cur, self._T
         map_bank = self.maps.data_ptr()
         map_short = self.maps.data_ptr() + 16 * 4
+        # the hoisted front runs while maps[16] still belongs to the previous frame: it reads [17]
+        map_short_scores = self.maps.data_ptr() + 17 * 4 if part == "front" else map_short
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
-        self.rowmax.zero_()
+        if do_front:
+            self.tgt_id.zero_()
+            self.rowmax.zero_()
 
         for l in range(self.L):
             self._layer = l
@@ -455,6 +481,24 @@ class DeAOTLSTT:
             Ucat = self.Ucat0 if l == 0 else self.Ucat
             curK = self.bankK[l][cur]
             curV = self.bankV[l][cur]
+            seg_a = do_front if l == 0 else do_rest      # norms, projections, score passes of this layer
+            seg_b = do_rest                              # from the first P.V on
+            self._forward_layer(l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short,
+                                map_short_scores)
+        if do_rest:
+            # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
+            hip.check(lib.rmem_groupnorm2(self.tgt.data_ptr(), self.tgt_id.data_ptr(), N, 256,
+                                          self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
+                                          self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
+                      "rmem_groupnorm2")
+
+    def _forward_layer(self, l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short,
+                       map_short_scores):
+        N, Np, ns = self.N, self.Npad, self.nsplit
+        lib = hip.load()
+        cur = self.cur
+        serial = self.branch_order == "serial"
+        if seg_a:
             # -- norms + projections (transformer.py:1104-1123); the norms first fold in the
             #    split-K partials of the previous layer's self-attention projection
             if l > 0:
@@ -477,91 +521,92 @@ class DeAOTLSTT:
             hip.linear_grouped(grp)
             if ref_frame:
                 self._idv(l, cur)
-            # -- short-term windowed read (transformer.py:1199, attention.py:289-358) and long-term
-            #    memory read (transformer.py:1140-1192, attention.py:174-209): independent until
-            #    the projection.  Default: in line on one stream.  Forked onto a second stream the
-            #    frame rate is the same (417.7 vs 418.4 frames/s over four runs each) but every kernel
-            #    of the long chain shares the CUs with the short chain (long-term P.V 92 us instead
-            #    of 80 us in a frame), and under hipGraph replay the forked branch starts ~120 us
-            #    late whichever is issued first (rocprofv3 trace, profiles/r01_g).
-            def short_chain():
+
+        # -- short-term windowed read (transformer.py:1199, attention.py:289-358) and long-term
+        #    memory read (transformer.py:1140-1192, attention.py:174-209): independent until
+        #    the projection.  Default ("serial"): in line on one stream, sharing their launches where
+        #    the kernels have the same shape.  Forked onto a second stream the frame is 1.9 % slower
+        #    and every kernel of the long chain shares the CUs with the short chain (long-term P.V
+        #    94 us instead of 83 us in a frame); under hipGraph replay the forked branch starts
+        #    ~120 us late whichever is issued first (rocprofv3 trace, profiles/r01_g).
+        def short_chain():
+            hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
+                       d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
+            self._attention(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
+                            Ucat, want_mass=False, which=1)
+            self._dwconv(self.ws_side, W.dw_st, self.Yst)
+
+        def long_chain():
+            hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
+                                       self.mem_pe.data_ptr(), rows, T, N, 128,
+                                       self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
+            self._attention(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
+                            self.bias_pe, Ucat, want_mass=(l == 0), which=0)
+            self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
+
+        if serial:
+            A = self._attn_args(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
+                                self.bias_pe, Ucat, l == 0, 0)
+            B = self._attn_args(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
+                                Ucat, False, 1)
+            if seg_a:
                 hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
                            d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
-                self._attention(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
-                                Ucat, want_mass=False, which=1)
-                self._dwconv(self.ws_side, W.dw_st, self.Yst)
-
-            def long_chain():
                 hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
                                            self.mem_pe.data_ptr(), rows, T, N, 128,
                                            self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
-                self._attention(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
-                                self.bias_pe, Ucat, want_mass=(l == 0), which=0)
-                self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
-
-            if self.branch_order == "serial":
-                # in line, the two reads share their score / combine / depth-wise-conv launches
-                hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
-                           d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
-                hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
-                                           self.mem_pe.data_ptr(), rows, T, N, 128,
-                                           self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
-                self._attention_pair(
-                    self._attn_args(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
-                                    self.bias_pe, Ucat, l == 0, 0),
-                    self._attn_args(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
-                                    Ucat, False, 1))
+                B[0].slot_map = map_short_scores
+                self._scores_pair(A, B)
+            if seg_b:
+                self._pv_combine_pair(A, B)
                 hip.check(lib.rmem_dwconv5x5_split2(
                     self.ws_main.G.data_ptr(), self.ws_side.G.data_ptr(), 1024, W.dw_lt.data_ptr(),
                     W.dw_st.data_ptr(), self.h, self.w, 1024, self.Ylt.hi.data_ptr(), self.Ylt.lo.data_ptr(),
                     self.Yst.hi.data_ptr(), self.Yst.lo.data_ptr(), 1024, hip.stream_ptr()), "rmem_dwconv5x5_split2")
-            elif self.branch_order == "serial_unpaired":
-                short_chain()
+        elif self.branch_order == "serial_unpaired":
+            short_chain()
+            long_chain()
+        else:
+            self.ev_ready.record()
+            if self.branch_order == "long_first":
                 long_chain()
-            else:
-                self.ev_ready.record()
-                if self.branch_order == "long_first":
-                    long_chain()
-                with torch.cuda.stream(self.side):
-                    self.side.wait_event(self.ev_ready)
-                    short_chain()
-                    self.ev_side.record()
-                if self.branch_order != "long_first":
-                    long_chain()
-                torch.cuda.current_stream().wait_event(self.ev_side)
-            # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
-            #    adds happen in the norms that follow (rmem_layernorm_red)
-            hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
-                       kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=64, ksplits=self.KS, parts=self.parts,
-                       part_stride=N * 512)
-            # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
-            self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
-            sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
-            sV = Planes(self.selfV.hi[0], self.selfV.lo[0])
-            hip.linear_grouped([
-                hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
-                           nsplit=ns, tile=64, launch=False),
-                hip.linear(W.Wv12, self.s_pl, 512, N, 256, ldx=256, ldy=512, bias=W.bv12, bias_per_row=True,
-                           act=1, pa=sV, ldpa=Np, nbatch=2, bsx=512 * 256, bsy=256, bsbias=512,
-                           bspa=512 * Np, nsplit=ns, tile=64, launch=False),
-                hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
-                           d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
-                           bsbias=512, bsd=512, nsplit=ns, tile=64, launch=False)])
-            self._attention(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
-                            want_mass=False, which=2)
-            self._dwconv(self.ws_main, W.dw_self, self.Ylt)
-            if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
-                hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
-                           tile=64, ksplits=self.KS, parts=self.parts, part_stride=N * 512)
-            else:                  # last layer: the GroupNorm reads tgt / tgt_id directly
-                hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
-                           d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,
-                           csplit=256, accumulate=True, nsplit=ns)
-        # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
-        hip.check(lib.rmem_groupnorm2(self.tgt.data_ptr(), self.tgt_id.data_ptr(), N, 256,
-                                      self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
-                                      self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
-                  "rmem_groupnorm2")
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_ready)
+                short_chain()
+                self.ev_side.record()
+            if self.branch_order != "long_first":
+                long_chain()
+            torch.cuda.current_stream().wait_event(self.ev_side)
+        if not seg_b:
+            return
+        # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
+        #    adds happen in the norms that follow (rmem_layernorm_red)
+        hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
+                   kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=64, ksplits=self.KS, parts=self.parts,
+                   part_stride=N * 512)
+        # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
+        self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
+        sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
+        sV = Planes(self.selfV.hi[0], self.selfV.lo[0])
+        hip.linear_grouped([
+            hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
+                       nsplit=ns, tile=64, launch=False),
+            hip.linear(W.Wv12, self.s_pl, 512, N, 256, ldx=256, ldy=512, bias=W.bv12, bias_per_row=True,
+                       act=1, pa=sV, ldpa=Np, nbatch=2, bsx=512 * 256, bsy=256, bsbias=512,
+                       bspa=512 * Np, nsplit=ns, tile=64, launch=False),
+            hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
+                       d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
+                       bsbias=512, bsd=512, nsplit=ns, tile=64, launch=False)])
+        self._attention(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
+                        want_mass=False, which=2)
+        self._dwconv(self.ws_main, W.dw_self, self.Ylt)
+        if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
+            hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
+                       tile=64, ksplits=self.KS, parts=self.parts, part_stride=N * 512)
+        else:                  # last layer: the GroupNorm reads tgt / tgt_id directly
+            hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
+                       d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,
+                       csplit=256, accumulate=True, nsplit=ns)
 
     # ------------------------------------------------------------------ memory update
     def update_short_memories(self, update_long: bool):

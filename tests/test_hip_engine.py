@@ -210,6 +210,7 @@ def test_prefetch_lookahead_ring():
         return outs, list(eng.aot_engines[0].long_memories_indexes)
 
     base, idx0 = run(lambda t: None)
+    sub0 = eng.aot_engines[0]
     for name, ann in [
         ("one frame", lambda t: imgs[t + 1] if t + 1 < frames else None),
         ("two frames", lambda t: [imgs[k] for k in (t + 1, t + 2) if k < frames] or None),
@@ -217,12 +218,24 @@ def test_prefetch_lookahead_ring():
          lambda t: [imgs[k] for k in range(t + 1, t + 1 + eng.lookahead) if k < frames] or None),
         ("wrong announcements", lambda t: [imgs[(t + 5) % frames], imgs[(t + 1) % frames]]),   # first one is never used next
         ("repeated frame", lambda t: [imgs[t], imgs[t + 1]] if t + 1 < frames else None),
+        ("hoisted front part of the next frame's LSTT",
+         lambda t: [imgs[k] for k in range(t + 1, t + 1 + eng.lookahead) if k < frames] or None),
     ]:
+        hoist = name.startswith("hoisted")
+        if hoist:                                   # graphs with the front / rest split are captured from now on
+            sub0.hoist_enabled = True
+            sub0._fg.clear()
+            got, idx = run(ann)                     # first pass captures, second pass replays hoisted fronts
+            sub0._hoist_count = 0
         got, idx = run(ann)
         err = max(float((a - b).abs().max()) for a, b in zip(got, base))
         print(f"prefetch '{name}': max |logit diff| vs no announcement {err:.2e}")
         assert idx == idx0
         assert err < 1e-4, (name, err)
+        if hoist:
+            print("hoisted fronts replayed:", sub0._hoist_count)
+            assert sub0._hoist_count >= 3
+            sub0.hoist_enabled = False
     sub = eng.aot_engines[0]
     assert len(sub._pending) <= max(2, sub.lookahead)
     eng.restart_engine()                       # with passes still pending
