@@ -123,12 +123,16 @@ def test_480p_teacher_forced(nsplit, golden_dir):
     gold = np.load(os.path.join(golden_dir, "clip_480p.npz"))
     cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"], nsplit)
     imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    imgs = [x.to(DEV) for x in imgs]
     out_hw = tuple(meta["out_hw"])
     eng.restart_engine()
-    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    eng.add_reference_frame(imgs[0], lab.to(DEV), obj_nums=[3], frame_step=0)
     mism, idx_hist, lerrs = [], [], {}
     for t in range(1, meta["frames"]):
-        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=out_hw)
+        # the next frames are announced as the clip driver does: batched encoder prefetch and the
+        # hoisted front part of the next frame's LSTT are part of what is checked against the golden maps
+        nxt = imgs[t + 1:t + 1 + eng.lookahead] or None
+        logit = eng.match_propogate_one_frame(imgs[t], output_size=out_hw, next_img=nxt)
         pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True)
         mism.append(int((pred[0, 0].cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
         if f"logits_{t}" in gold:
