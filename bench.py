@@ -139,7 +139,8 @@ def main():
         logit = engine.match_propogate_one_frame(clips[i][0][t % ring], output_size=None, next_img=nxt)
         lab = masks_out[i, t % masks_out.shape[1]] if masks_out is not None else None
         lab = hip.labels_from_logits([logit], [False], (H_OUT, W_OUT), cfg.MODEL_ALIGN_CORNERS, out=lab)
-        engine.update_memory(hip.label_resize_nearest(lab, engine.input_size_2d)[None, None])
+        buf = engine.aot_engines[0].label_buffer(engine.input_size_2d, lab.device) if len(engine.aot_engines) == 1 else None
+        engine.update_memory(hip.label_resize_nearest(lab, engine.input_size_2d, out=buf)[None, None])
 
     def all_clips(t, masks_out=None):
         for i in range(C):

@@ -300,7 +300,10 @@ class ClipDriver:
                 for e, fl in zip(engines, flips):
                     if fuse:
                         from . import hip
-                        cur = hip.label_resize_nearest(label, e.input_size_2d, fl)[None, None]
+                        subs = getattr(e, "aot_engines", [])
+                        buf = subs[0].label_buffer(e.input_size_2d, label.device) \
+                            if len(subs) == 1 and hasattr(subs[0], "label_buffer") else None
+                        cur = hip.label_resize_nearest(label, e.input_size_2d, fl, out=buf)[None, None]
                     else:
                         cur = self._resize_generic(label, e.input_size_2d, fl)
                     e.update_memory(cur)

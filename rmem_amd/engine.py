@@ -451,6 +451,16 @@ class DeAOTEngine(nn.Module):
                                    align_corners=self.align_corners)
         return logits
 
+    def label_buffer(self, shape, device) -> torch.Tensor:
+        """The uint8 [H,W] buffer the memory-update graph reads its label map from.  A caller that
+        produces the label on the device (rmem_label_resize_nearest) can write it here and pass it
+        to update_memory: the copy into the graph's static input is then skipped."""
+        shape = tuple(int(v) for v in shape)
+        buf = self._g_lab.get(shape)
+        if buf is None:
+            buf = self._g_lab[shape] = torch.empty(shape, dtype=torch.uint8, device=device)
+        return buf
+
     @torch.no_grad()
     def update_short_term_memory(self, curr_mask, curr_id_emb=None, step=0):
         """aot_engine.py:327-369."""
@@ -467,7 +477,8 @@ class DeAOTEngine(nn.Module):
             g_lab = self._g_lab.get(tuple(lab.shape))
             if g_lab is None:
                 g_lab = self._g_lab[tuple(lab.shape)] = torch.empty_like(lab)
-            g_lab.copy_(lab)
+            if lab.data_ptr() != g_lab.data_ptr():        # a caller may have written into label_buffer() directly
+                g_lab.copy_(lab)
             key = (l.update_key(update_long), tuple(lab.shape))
             g = self._ug.get(key)
             if g is None:
