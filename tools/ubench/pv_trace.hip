@@ -895,6 +895,121 @@ __global__ __launch_bounds__(256) void pv_kernel_v7(rmem_pv_args a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// V8 (timing only, results are NOT those of the shipped kernel): the shipped loop with P as ONE
+// plane and V^T as two planes -- 2 MFMAs per product instead of 3, 3 staged planes instead of 4.
+// What the "P as one fp16 plane" plan of tools/precision_study.py would cost on this kernel.
+template <class Cfg, class LX, class LY>
+__device__ __forceinline__ void gemm_mainloop_p1v2(GemmFrag<Cfg>& f, const LX& lx, const LY& ly, int kt_begin,
+                                                   int kt_end, char* smem) {
+  constexpr int XCH = Cfg::XCH, YCH = Cfg::YCH, TM = Cfg::TM, TN = Cfg::TN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  if (kt_begin >= kt_end) return;
+  u32x4_t xr[XCH], yr[2 * YCH];
+  auto gload = [&](int kt) __attribute__((always_inline)) {
+    const TileView tx = lx.tile(kt);
+    const TileView ty = ly.tile(kt);
+    static_for<XCH>([&](auto I) {
+      const int id = tid + I.value * Cfg::THREADS;
+      xr[I.value] = *lx.ptr(tx, 0, id >> 3, id & 7);
+    });
+    static_for<2>([&](auto P) {
+      static_for<YCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        yr[P.value * YCH + I.value] = *ly.ptr(ty, P.value, id >> 3, id & 7);
+      });
+    });
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+    static_for<XCH>([&](auto I) {
+      const int id = tid + I.value * Cfg::THREADS;
+      *reinterpret_cast<u32x4_t*>(smem + lds_swz(id >> 3, id & 7)) = xr[I.value];
+    });
+    static_for<2>([&](auto P) {
+      char* yb = smem + Cfg::X_BYTES + P.value * Cfg::Y_BYTES;
+      static_for<YCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        *reinterpret_cast<u32x4_t*>(yb + lds_swz(id >> 3, id & 7)) = yr[P.value * YCH + I.value];
+      });
+    });
+  };
+  gload(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (kt + 1 < kt_end) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = ks * 2 + (lane >> 5);
+      bf16x8_t a[TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wr * Cfg::WM + i * 32 + (lane & 31);
+        a[i] = *reinterpret_cast<const bf16x8_t*>(smem + lds_swz(row, chunk));
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wc * Cfg::WN + j * 32 + (lane & 31);
+          b[p][j] = *reinterpret_cast<const bf16x8_t*>(smem + Cfg::X_BYTES + p * Cfg::Y_BYTES + lds_swz(row, chunk));
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1][j], f.acc[i][j], 0, 0, 0);
+          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[0][j], f.acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pv_kernel_v8(rmem_pv_args a) {
+  using Cfg = GemmCfg<128, 128, 3>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nct = (a.ncols + 127) / 128;
+  const int nq = a.Npad / 128;
+  const int npairs = nq * a.ksplits;
+  const int chunk = pv_chunk(npairs);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int pl = j / nct;
+  const int ctile = j - pl * nct;
+  const int pair = xcd * chunk + pl;
+  if (pl >= chunk || pair >= npairs) return;
+  const int z = pair / nq;
+  const int qtile = pair - z * nq;
+  const int tps = a.Npad / 64;
+  const int per = (a.T * tps + a.ksplits - 1) / a.ksplits;
+  int lo = z * per, hi = lo + per;
+  if (hi > a.T * tps) hi = a.T * tps;
+  PBlockedOperand lx{a.ph, a.pl, (long)a.Npad, qtile * 128};
+  SlotLut lut;
+  lut.load(a.slot_map, a.T);
+  VtOperand ly{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, lut, tps, ctile * 128, a.ncols};
+  GemmFrag<Cfg> f;
+  f.zero();
+  gemm_mainloop_p1v2<Cfg>(f, lx, ly, lo, hi, smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  float* out = a.part + (long)z * a.Npad * a.ncols;
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
+        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
+      }
+  }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main() {
@@ -1100,6 +1215,21 @@ int main() {
       };
       run7(&pv_kernel_v7<3, false>, "fragment double buffer (compiler free to move)");
       run7(&pv_kernel_v7<3, true>, "fragment double buffer (order pinned with sched_barrier)");
+    }
+    {
+      constexpr int LDS8 = 3 * 128 * 128;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel_v8), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8));
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(pv_kernel_v8, grid, dim3(256), LDS8, 0, a);
+      CK(hipDeviceSynchronize());
+      float best = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(pv_kernel_v8, grid, dim3(256), LDS8, 0, a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        best = fminf(best, ms);
+      }
+      printf("V8 (timing only: P one plane, V^T two planes, 2 MFMAs per product, 48 KB LDS): %.2f us/launch\n", best * 1e3 / 20);
     }
     run3(&pv_kernel_v3<3, 0>, "var0 (compiler order)");
     run3(&pv_kernel_v3<3, 1>, "var1 (fragments read up front, then DMA issue, then MFMAs)");
