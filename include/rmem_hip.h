@@ -110,7 +110,7 @@ typedef struct {
   const float *bias;                       /* mode 0: [N][T] or NULL                    */
   const float *R; int32_t ldr; int32_t h, w;  /* mode 1                                 */
   uint32_t *rowmax;                        /* [Npad] order-encoded running max (memset 0 before pass 0) */
-  rmem_bf16 *ph, *pl;                      /* pass 1: P planes                          */
+  rmem_bf16 *ph, *pl;                      /* pass 1: P planes; nsplit 3 with pl == NULL: P is ONE fp16 plane in ph */
   float *lpart; int32_t nparts;            /* pass 1: [Npad][nparts] partial row sums, part = key/64 */
   int32_t nsplit;                          /* pass 1 precision (pass 0 always runs plain bf16) */
 } rmem_scores_args;
@@ -123,7 +123,7 @@ int rmem_attn_scores2(const rmem_scores_args *a, const rmem_scores_args *b, void
 
 typedef struct {
   int32_t mode;                            /* 0 bank, 1 window (banded k range)         */
-  const rmem_bf16 *ph, *pl;                /* P planes blocked [key/32][Npad][32]       */
+  const rmem_bf16 *ph, *pl;                /* P planes blocked [key/32][Npad][32]; nsplit 3 with pl == NULL (mode 0): one fp16 plane, 2 MFMAs per product */
   const rmem_bf16 *vh, *vl; int64_t v_slot_stride;   /* V^T planes [slot][ncols][Npad]  */
   const int32_t *slot_map; int32_t T, N, Npad;
   int32_t ncols;                           /* 1024 (V | ID_V)                           */

@@ -64,6 +64,9 @@ __device__ __forceinline__ void scores_body(const rmem_scores_args& a, int bx, i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const float inv_w = a.mode == 1 ? 1.0f / (float)a.w : 0.f;
+  // split precision without a low plane: P is ONE fp16 plane (11 significant bits; P.V then takes
+  // 2 MFMAs per product and 3 staged planes instead of 3 and 4, see pv16_kernel)
+  const bool p16 = PASS == 1 && NS == 3 && a.pl == nullptr;
   // key axis of P / lpart: logical slot-major
   const long key_axis0 = (long)t * a.Npad + ktile * 128 + wr * 64;
 
@@ -105,7 +108,8 @@ __device__ __forceinline__ void scores_body(const rmem_scores_args& a, int bx, i
         if (PASS == 0) {
           if (valid) mx = fmaxf(mx, s);
         } else {
-          const float p = valid ? exp_weight(s - mrow) : 0.f;
+          float p = valid ? exp_weight(s - mrow) : 0.f;
+          if (p16) p = h_bits2f(f2h_bits(p));   // the row sum is taken over the STORED weights: the rounding of a dominant weight cancels in the normalisation
           pv[r] = p;
           lsum += p;
         }
@@ -117,8 +121,13 @@ __device__ __forceinline__ void scores_body(const rmem_scores_args& a, int bx, i
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           bf16_t hi[4], lo[4];
+          if (p16) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) split_bf16(pv[4 * g + e], hi[e], lo[e]);
+            for (int e = 0; e < 4; ++e) hi[e] = f2h_bits(pv[4 * g + e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16(pv[4 * g + e], hi[e], lo[e]);
+          }
           uint2 vh, vl;
           vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
           vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
@@ -189,7 +198,7 @@ static int scores_args_ok(const rmem_scores_args& a) {
   if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1)) return 0;
   if (a.mode != 0 && a.mode != 1) return 0;
   if (a.pass == 1 && (!a.ph || !a.lpart)) return 0;
-  if (a.pass == 1 && a.nsplit == 3 && (!a.kl || !a.ql || !a.pl)) return 0;
+  if (a.pass == 1 && a.nsplit == 3 && (!a.kl || !a.ql)) return 0;      // pl == NULL: P as one fp16 plane
   return 1;
 }
 
@@ -234,7 +243,7 @@ extern "C" int rmem_attn_scores(const rmem_scores_args* ap, void* stream) {
   if (a.pass == 0) return launch_scores<1, 0>(a, s);
   if (a.pass != 1 || !a.ph || !a.lpart) return RMEM_ERR_INVALID;
   if (a.nsplit == 3) {
-    if (!a.kl || !a.ql || !a.pl) return RMEM_ERR_INVALID;
+    if (!a.kl || !a.ql) return RMEM_ERR_INVALID;       // pl == NULL: P as one fp16 plane
     return launch_scores<3, 1>(a, s);
   }
   if (a.nsplit == 1) return launch_scores<1, 1>(a, s);
@@ -403,6 +412,139 @@ static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
   return RMEM_OK;
 }
 
+// ------------------------------------------------------------------ P . V with P as ONE fp16 plane
+// Bank read (mode 0) only.  P [fp16, one plane] x V^T [bf16 hi/lo planes, converted to fp16 while
+// they are staged -- exact inside the fp16 normal range, so every producer of V^T keeps writing
+// bf16 planes]:  O = P.Vhi + P.Vlo, 2 MFMAs (v_mfma_f32_32x32x16_f16) per product and 48 KB of
+// LDS per block instead of 3 and 64 KB.  P carries 11 significant bits; what that costs in label
+// maps is measured in tools/precision_study.py (p16@long,self) and DESIGN.md section 3.
+__global__ __launch_bounds__(256) void pv16_kernel(rmem_pv_args a) {
+  using Cfg = GemmCfg<128, 128, 3>;
+  constexpr int XCH = Cfg::XCH, YCH = Cfg::YCH, TM = Cfg::TM, TN = Cfg::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nct = (a.ncols + 127) / 128;
+  const int nq = a.Npad / 128;
+  const int npairs = nq * a.ksplits;
+  const int chunk_ = pv_chunk(npairs);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int pl = j / nct;
+  const int ctile = j - pl * nct;
+  const int pair = xcd * chunk_ + pl;
+  if (pl >= chunk_ || pair >= npairs) return;
+  const int z = pair / nq;
+  const int qtile = pair - z * nq;
+  const int tps = a.Npad / 64;
+  const int tv = (a.N + 63) / 64;
+  const int k_hi = a.T * tv;
+  const int per = (k_hi + a.ksplits - 1) / a.ksplits;
+  int lo = z * per, hi = lo + per;
+  if (hi > k_hi) hi = k_hi;
+
+  SlotLut lut;
+  lut.load(a.slot_map, a.T);
+  SkipPadTiles<PBlockedOperand> lx{PBlockedOperand{a.ph, nullptr, (long)a.Npad, qtile * 128}, tv, tps};
+  SkipPadTiles<VtOperand> ly{VtOperand{a.vh, a.vl, (long)a.v_slot_stride, (long)a.Npad, lut, tps, ctile * 128, a.ncols},
+                             tv, tps};
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  GemmFrag<Cfg> f;
+  f.zero();
+  if (lo < hi) {
+    u32x4_t xr[XCH], yr[2 * YCH];
+    auto gload = [&](int kt) __attribute__((always_inline)) {
+      const TileView tx = lx.tile(kt);
+      const TileView ty = ly.tile(kt);
+      static_for<XCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        xr[I.value] = *lx.ptr(tx, 0, id >> 3, id & 7);
+      });
+      static_for<2>([&](auto P) {
+        static_for<YCH>([&](auto I) {
+          const int id = tid + I.value * Cfg::THREADS;
+          yr[P.value * YCH + I.value] = *ly.ptr(ty, P.value, id >> 3, id & 7);
+        });
+      });
+    };
+    auto lstore = [&]() __attribute__((always_inline)) {
+      static_for<XCH>([&](auto I) {
+        const int id = tid + I.value * Cfg::THREADS;
+        *reinterpret_cast<u32x4_t*>(smem + lds_swz(id >> 3, id & 7)) = xr[I.value];
+      });
+      static_for<2>([&](auto P) {
+        char* yb = smem + Cfg::X_BYTES + P.value * Cfg::Y_BYTES;
+        static_for<YCH>([&](auto I) {
+          const int id = tid + I.value * Cfg::THREADS;
+          u32x4_t v = yr[P.value * YCH + I.value];
+          v[0] = bf16x2_to_f16x2(v[0]);
+          v[1] = bf16x2_to_f16x2(v[1]);
+          v[2] = bf16x2_to_f16x2(v[2]);
+          v[3] = bf16x2_to_f16x2(v[3]);
+          *reinterpret_cast<u32x4_t*>(yb + lds_swz(id >> 3, id & 7)) = v;
+        });
+      });
+    };
+    gload(lo);
+    for (int kt = lo; kt < hi; ++kt) {
+      __syncthreads();
+      lstore();
+      __syncthreads();
+      if (kt + 1 < hi) gload(kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = ks * 2 + (lane >> 5);
+        f16x8_t pa[TM], vb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wr * Cfg::WM + i * 32 + (lane & 31);
+          pa[i] = *reinterpret_cast<const f16x8_t*>(smem + lds_swz(row, chunk));
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj) {
+            const int row = wc * Cfg::WN + jj * 32 + (lane & 31);
+            vb[p][jj] = *reinterpret_cast<const f16x8_t*>(smem + Cfg::X_BYTES + p * Cfg::Y_BYTES + lds_swz(row, chunk));
+          }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj) {   // small term first
+            f.acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[i], vb[1][jj], f.acc[i][jj], 0, 0, 0);
+            f.acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[i], vb[0][jj], f.acc[i][jj], 0, 0, 0);
+          }
+      }
+    }
+  }
+  float* out = a.part + (long)z * a.Npad * a.ncols;
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int col = ctile * 128 + frag_col<Cfg>(wc, tn, lane);
+    if (col >= a.ncols) continue;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qtile * 128 + frag_row<Cfg>(wr, tm, r, lane);
+        out[(long)q * a.ncols + col] = f.acc[tm][tn][r];
+      }
+  }
+}
+
+static int launch_pv16(const rmem_pv_args& a, hipStream_t s) {
+  constexpr int LDS = 3 * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int nct = (a.ncols + 127) / 128;
+  const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
+  hipLaunchKernelGGL(pv16_kernel, dim3(8 * chunk * nct), dim3(256), LDS, s, a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   if (!ap) return RMEM_ERR_INVALID;
   const rmem_pv_args& a = *ap;
@@ -410,8 +552,12 @@ extern "C" int rmem_attn_pv(const rmem_pv_args* ap, void* stream) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.T > 16 || a.ksplits <= 0) return RMEM_ERR_INVALID;
   if (!a.ph || !a.vh || !a.part || a.ncols <= 0) return RMEM_ERR_INVALID;
   if (a.mode == 1 && (a.h * a.w != a.N || a.T != 1)) return RMEM_ERR_INVALID;
-  if (a.nsplit == 3 && (!a.pl || !a.vl)) return RMEM_ERR_INVALID;
+  if (a.nsplit == 3 && !a.vl) return RMEM_ERR_INVALID;
   if (a.nsplit != 1 && a.nsplit != 3) return RMEM_ERR_INVALID;
+  if (a.nsplit == 3 && !a.pl) {            // P as one fp16 plane (written by rmem_attn_scores with pl == NULL)
+    if (a.mode != 0) return RMEM_ERR_INVALID;
+    return launch_pv16(a, s);
+  }
   if (a.nsplit == 3) return launch_pv<3>(a, s);
   return launch_pv<1>(a, s);
 }

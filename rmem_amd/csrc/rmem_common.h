@@ -16,6 +16,8 @@
 typedef unsigned short bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 // native vector (HIP's uint4 struct keeps register arrays in scratch)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
@@ -32,6 +34,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 // round-to-nearest-even; gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// fp16 bits of x, round-to-nearest-even (subnormals kept)
+__device__ __forceinline__ unsigned short f2h_bits(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float h_bits2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+// two bf16 (one 32-bit word) -> two fp16 (exact inside the fp16 normal range: 8 mantissa bits fit in 11)
+__device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned w) {
+  const auto h = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+  return __builtin_bit_cast(unsigned, h);
+}
 
 __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   hi = f2bf(x);

@@ -180,6 +180,9 @@ class DeAOTLSTT:
         self.bias_pe = z(N, self.Tmax)
         self.rowmax = z(3 * self.L, Np, dt=torch.int32)          # [layer][read]: zeroed once per frame
         self._layer = 0
+        # bank reads (long-term, self) with P as ONE fp16 plane: 2 MFMAs per product instead of 3
+        # (rmem_attn_scores / rmem_attn_pv with pl = NULL); the windowed read keeps bf16 hi/lo planes
+        self.p16 = self.nsplit == 3 and os.environ.get("RMEM_P16", "1") == "1"
         self.ksplits_max = 8
         # attention workspaces: main stream (long-term, self) and side stream (short-term window)
         self.ws_main = _AttnWS(self.Tmax, N, Np, self.ksplits_max, dev)
@@ -224,7 +227,8 @@ class DeAOTLSTT:
         flops = 2.0 * self.N * (T * self.N) * 1024
         mean_ms = sum(ms) / len(ms)
         ach = flops / (mean_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": f"pv_kernel<{self.nsplit}> (long-term A.V, T={T})",
+        kern = "pv16_kernel (P one fp16 plane, V^T hi/lo: 2 MFMAs per product)" if self.p16 else f"pv_kernel<{self.nsplit}>"
+        return {"bound": "mfma", "kernel": f"{kern} (long-term A.V, T={T})",
                 "achieved": ach, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach / mfma_peak_tflops,
                 "traffic": None, "launches": len(ms), "mean_us": 1e3 * mean_ms,
                 "algorithmic_flops_per_launch": flops}
@@ -236,7 +240,7 @@ class DeAOTLSTT:
         T = len(self.bank)
         pa = hip.PVArgs()
         vpl, ws = self.bankV[0], self.ws_main
-        pa.mode, pa.ph, pa.pl = 0, ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+        pa.mode, pa.ph, pa.pl = 0, ws.P.hi.data_ptr(), (None if self.p16 else ws.P.lo.data_ptr())
         pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
         pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = self.maps.data_ptr(), T, self.N, self.Npad, 1024
         pa.h, pa.w, pa.part, pa.nsplit = self.h, self.w, ws.part.data_ptr(), self.nsplit
@@ -332,6 +336,9 @@ class DeAOTLSTT:
         ca.part, ca.ksplits, ca.lpart, ca.nparts = ws.part.data_ptr(), ks, ws.lpart.data_ptr(), nparts
         ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, ws.G.data_ptr(), 1024
         ca.mass = self.mass.data_ptr() if want_mass else None
+        if self.p16 and mode == 0:
+            sa.pl = None
+            pa.pl = None
         return sa, pa, ca
 
     def _pv(self, pa, timed: bool):

@@ -30,9 +30,12 @@ def _build(former=1, latter=3, gap=2, nsplit=3):
     return cfg, cpu_model, gpu_model, eng
 
 
-def test_lstt_forward_vs_oracle_tokens():
-    """LSTT only (no encoder/decoder): unit-variance token features, reference frame +
-    3 propagation frames with a long-memory update, compared layer by layer."""
+@pytest.mark.parametrize("p16", [True, False])
+def test_lstt_forward_vs_oracle_tokens(p16):
+    """LSTT only (no encoder/decoder): unit-variance token features (far more peaked attention than
+    encoder features give), reference frame + 3 propagation frames with a long-memory update,
+    compared layer by layer.  p16: the bank reads carry P as one fp16 plane (shipped default,
+    2^-12 per weight); False: bf16 hi/lo planes (RMEM_P16=0, 2^-17)."""
     from oracle import lstt_ref as R
     from rmem_amd.lstt import DeAOTLSTT
     cfg, cpu_model, gpu_model, _ = _build()
@@ -41,6 +44,7 @@ def test_lstt_forward_vs_oracle_tokens():
     sd = {k: v.detach().float() for k, v in cpu_model.state_dict().items()}
     ora = R.DeAOTOracle(sd, 3)
     lstt = DeAOTLSTT(gpu_model, h, w, DEV, nsplit=3)
+    lstt.p16 = p16
     rs = np.random.RandomState(0)
     H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
     worst = {}
@@ -70,8 +74,8 @@ def test_lstt_forward_vs_oracle_tokens():
             T = trace["l0.mass"].shape[1]
             merr = (lstt.mass.flatten()[:N * T].view(N, T).cpu() - trace["l0.mass"]).abs().max().item()
             worst[f"mass{t}"] = merr
-            assert merr < 1e-4, (t, merr)
-        assert err < 2e-4, (t, err, worst)
+            assert merr < (3e-4 if p16 else 1e-4), (t, merr)
+        assert err < (8e-4 if p16 else 2e-4), (t, err, worst)
     print("LSTT vs oracle max abs err:", worst)
 
 
@@ -102,7 +106,7 @@ def test_small_clip(name, golden_dir):
         print(name, "teacher-forced" if teacher else "closed-loop", "mismatching pixels per frame:", mism)
         assert idx_hist == meta["indexes"]
         if teacher:
-            assert max(mism) <= 1, mism
+            assert max(mism) <= 2, mism          # of 12.5k pixels; 0-1 with RMEM_P16=0
             lerr = np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max()
             print(name, "last-frame logit max abs err:", lerr)
             assert lerr < 2e-3
