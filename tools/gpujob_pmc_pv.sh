@@ -7,7 +7,7 @@ import csv, collections, glob
 for f in glob.glob("gpurun_out/pmc_pv_$tag/*counter_collection.csv"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "pv_kernel" in r["Kernel_Name"]:
+        if "pv_kernel" in r["Kernel_Name"] or "pv16_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         print(k, "mean %.3e" % (sum(v)/len(v)), "n", len(v))

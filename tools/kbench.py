@@ -93,14 +93,14 @@ def main():
             sa.bias = bias.data_ptr() if bias is not None else None
             sa.ldr, sa.h, sa.w = L.ldr, L.h, L.w
             sa.rowmax = L.rowmax[0].data_ptr()
-            sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+            sa.ph, sa.pl = ws.P.hi.data_ptr(), (None if (L.p16 and mode == 0) else ws.P.lo.data_ptr())
             sa.lpart, sa.nparts, sa.nsplit, sa.pass_ = ws.lpart.data_ptr(), Tn * Np // 64, L.nsplit, pass_
             hip.check(lib.rmem_attn_scores(C.byref(sa), hip.stream_ptr()), "scores")
         L.rowmax.zero_()
         scores(0, T, 0, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe)
         scores(0, T, 1, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe)
         pa = hip.PVArgs()
-        pa.mode, pa.ph, pa.pl = 0, L.ws_main.P.hi.data_ptr(), L.ws_main.P.lo.data_ptr()
+        pa.mode, pa.ph, pa.pl = 0, L.ws_main.P.hi.data_ptr(), (None if L.p16 else L.ws_main.P.lo.data_ptr())
         pa.vh, pa.vl, pa.v_slot_stride = L.bankV[1].hi.data_ptr(), L.bankV[1].lo.data_ptr(), L.v_slot_stride
         pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = map_bank, T, N, Np, 1024
         pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = L.h, L.w, L.ws_main.part.data_ptr(), ksl, L.nsplit
@@ -125,13 +125,13 @@ def main():
         sa.bias = bias.data_ptr() if bias is not None else None
         sa.R, sa.ldr, sa.h, sa.w = (L.R.data_ptr() if mode == 1 else None), L.ldr, L.h, L.w
         sa.rowmax = L.rowmax[0].data_ptr()
-        sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+        sa.ph, sa.pl = ws.P.hi.data_ptr(), (None if (L.p16 and mode == 0) else ws.P.lo.data_ptr())
         sa.lpart, sa.nparts, sa.nsplit, sa.pass_ = ws.lpart.data_ptr(), Tn * Np // 64, L.nsplit, pass_
         return lambda: hip.check(lib.rmem_attn_scores(C.byref(sa), hip.stream_ptr()), "scores")
 
     def pv(mode, Tn, ws, vpl, smap, ks):
         pa = hip.PVArgs()
-        pa.mode, pa.ph, pa.pl = mode, ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
+        pa.mode, pa.ph, pa.pl = mode, ws.P.hi.data_ptr(), (None if (L.p16 and mode == 0) else ws.P.lo.data_ptr())
         pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), L.v_slot_stride
         pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = smap, Tn, N, Np, 1024
         pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = L.h, L.w, ws.part.data_ptr(), ks, L.nsplit

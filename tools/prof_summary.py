@@ -51,7 +51,7 @@ def from_trace(path, frames):
     # the dominant kernel of bench.py's roofline entry: the long-term P.V launches are the first
     # pv_kernel launch of every layer on the long chain = the longest third of the pv_kernel dispatches
     pv = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[start:end]
-                if r["Kernel_Name"].startswith("void pv_kernel"))
+                if r["Kernel_Name"].startswith("void pv_kernel") or r["Kernel_Name"].startswith("pv16_kernel"))
     if pv:
         top = pv[-(len(pv) // 3):]
         PV_LONG = (len(top), sum(top) / len(top), min(top), max(top))
@@ -70,7 +70,8 @@ def main():
         rows = from_csv(path) if path.endswith(".csv") else from_db(path)
     rows.sort(key=lambda r: -r[2])
     tot = sum(r[2] for r in rows)
-    ours = ("linear_kernel", "linear_grouped", "pv_kernel", "scores_kernel", "combine_kernel", "dwconv5x5",
+    ours = ("linear_kernel", "linear_grouped", "pv_kernel", "pv16_kernel", "scores_kernel", "scores2_kernel",
+            "combine_kernel", "combine2_kernel", "dwconv5x5",
             "layernorm_", "gn2_", "gn_nchw", "gn_tok", "id_assign", "pe_bias", "mass_reduce", "split_planes",
             "bias_act_nchw", "upsample_add", "labels_kernel", "label_resize", "set_ints", "mha_", "transpose_planes",
             "add_split")
