@@ -105,12 +105,35 @@ def install_conv(which):
     torch.nn.functional.conv2d = conv2d
 
 
+def install_linear(which):
+    """Activations of the LSTT linears as ONE fp16 plane (weights exact): 'lin16' every linear,
+    'lin16bf' activations as bf16 hi/lo (the shipped scheme: reference point)."""
+    orig = R.linear
+
+    def linear(x, w, b):
+        if which == "lin16":
+            x = planes(x, torch.float16, 1)
+        elif which == "lin16bf":
+            x, w = planes(x, torch.bfloat16, 2), planes(w, torch.bfloat16, 2)
+        elif which == "lin16x2":
+            x, w = planes(x, torch.float16, 2), planes(w, torch.float16, 2)
+        elif which == "lin16x2a":       # activations fp16 hi/lo, weights bf16 hi/lo... (types must match on the MFMA: reference only)
+            x, w = planes(x, torch.float16, 2), planes(w, torch.bfloat16, 2)
+        elif which == "lin16w":
+            x, w = planes(x, torch.float16, 1), planes(w, torch.bfloat16, 2)
+        return orig(x, w, b)
+
+    R.linear = linear
+
+
 def run(plan):
     gd = os.path.join(ROOT, "tests", "golden")
     meta = json.load(open(os.path.join(gd, "clip_480p.json")))
     gold = np.load(os.path.join(gd, "clip_480p.npz"))
     if plan in ("c1", "call"):
         install_conv(plan)
+    elif plan.startswith("lin16"):
+        install_linear(plan)
     elif plan != "fp32":
         install(plan)
     torch.manual_seed(0)
