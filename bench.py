@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 
 H_IN, W_IN = 481, 849          # 480x854 after MultiRestrictSize (dataloaders/video_transforms.py:604-622)
 H_OUT, W_OUT = 480, 854
-MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16, MI355X_MICROARCH.md
 
 
 def parse():
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gap", type=int, default=5, help="long_term_mem_gap (evaluator rule gives 5 for clips <= 165 frames)")
     ap.add_argument("--nsplit", type=int, default=int(os.environ.get("RMEM_NSPLIT", "3")),
-                    help="3 = split-bf16 (fp32-class), 1 = plain bf16 attention/linears")
+                    help="3 = split-fp16 (hi/lo planes, fp32-class), 1 = plain fp16 attention/linears")
     ap.add_argument("--config", choices=["480p_k4", "720p_k8"], default="480p_k4",
                     help="480p_k4 = BASELINE.json configs[1] (the headline metric); 720p_k8 = configs[2] (stress)")
     ap.add_argument("--model", choices=["r50_deaotl", "r50_aotl", "swinb_aotl"], default="r50_deaotl",
@@ -218,9 +218,9 @@ def main():
         "value": fps, "unit": "frames/s (whole job)", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("split bf16/fp16 MFMA, fp32 accumulate (bf16x3; bank reads: P one fp16 plane x V^T hi/lo)"
-                  if getattr(lstt, "p16", False) else "bf16x3 (split-bf16 MFMA, fp32 accumulate)")
-        if args.nsplit == 3 else "bf16 (MFMA, fp32 accumulate)",
+        "dtype": ("fp16x3 (split-fp16 MFMA: hi/lo planes, 3 products, fp32 accumulate; bank reads: P one fp16 plane, 2 products)"
+                  if getattr(lstt, "p16", False) else "fp16x3 (split-fp16 MFMA: hi/lo planes, 3 products, fp32 accumulate)")
+        if args.nsplit == 3 else "fp16 (MFMA, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"{ {'r50_deaotl': 'R50-DeAOTL', 'r50_aotl': 'R50-AOTL', 'swinb_aotl': 'SwinB-AOTL'}[args.model] } + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
                                f"batch={C} clip{'s' if C > 1 else ''} per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",

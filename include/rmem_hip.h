@@ -12,10 +12,12 @@
  *     owns all buffers and workspaces; kernels are enqueued on `stream`
  *     (a hipStream_t passed as void*), so calls are hipGraph-capturable;
  *   - return value: 0 = enqueued, <0 = error (RMEM_ERR_*); no exceptions cross the ABI;
- *   - "planes": an fp32 tensor carried as two bf16 tensors hi = bf16(x),
- *     lo = bf16(x - hi) (rmem_bf16 = raw bf16 bits).  `nsplit` = 3 multiplies
- *     hi*lo + lo*hi + hi*hi on the bf16 MFMA pipe (fp32-class accuracy), `nsplit` = 1
- *     multiplies hi*hi only (plain bf16) and ignores the lo pointers;
+ *   - "planes": an fp32 tensor carried as two fp16 tensors hi = fp16(x),
+ *     lo = fp16(x - hi), values beyond +-65504 saturated (rmem_plane16 = raw fp16 bits;
+ *     rmem_bf16 is the name the first builds gave the same 16-bit element when the planes
+ *     were bf16).  `nsplit` = 3 multiplies hi*lo + lo*hi + hi*hi on the 16-bit MFMA pipe
+ *     (fp32-class accuracy), `nsplit` = 1 multiplies hi*hi only (plain fp16) and ignores
+ *     the lo pointers;
  *   - tokens are row-major over the feature map, p = y*w + x (layers/basic.py:73-77).
  */
 #ifndef RMEM_HIP_H
@@ -27,7 +29,8 @@
 extern "C" {
 #endif
 
-typedef uint16_t rmem_bf16;
+typedef uint16_t rmem_plane16;
+typedef rmem_plane16 rmem_bf16;
 
 #define RMEM_OK 0
 #define RMEM_ERR_INVALID (-1)

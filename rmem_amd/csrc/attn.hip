@@ -413,10 +413,8 @@ static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ P . V with P as ONE fp16 plane
-// Bank read (mode 0) only.  P [fp16, one plane] x V^T [bf16 hi/lo planes, converted to fp16 while
-// they are staged -- exact inside the fp16 normal range, so every producer of V^T keeps writing
-// bf16 planes]:  O = P.Vhi + P.Vlo, 2 MFMAs (v_mfma_f32_32x32x16_f16) per product and 48 KB of
-// LDS per block instead of 3 and 64 KB.  P carries 11 significant bits; what that costs in label
+// Bank read (mode 0) only.  P [one fp16 plane] x V^T [fp16 hi/lo planes]:  O = P.Vhi + P.Vlo,
+// 2 MFMAs (v_mfma_f32_32x32x16_f16) per product and 48 KB of LDS per block instead of 3 and 64 KB.  P carries 11 significant bits; what that costs in label
 // maps is measured in tools/precision_study.py (p16@long,self) and DESIGN.md section 3.
 __global__ __launch_bounds__(256) void pv16_kernel(rmem_pv_args a) {
   using Cfg = GemmCfg<128, 128, 3>;
@@ -475,12 +473,7 @@ __global__ __launch_bounds__(256) void pv16_kernel(rmem_pv_args a) {
         char* yb = smem + Cfg::X_BYTES + P.value * Cfg::Y_BYTES;
         static_for<YCH>([&](auto I) {
           const int id = tid + I.value * Cfg::THREADS;
-          u32x4_t v = yr[P.value * YCH + I.value];
-          v[0] = bf16x2_to_f16x2(v[0]);
-          v[1] = bf16x2_to_f16x2(v[1]);
-          v[2] = bf16x2_to_f16x2(v[2]);
-          v[3] = bf16x2_to_f16x2(v[3]);
-          *reinterpret_cast<u32x4_t*>(yb + lds_swz(id >> 3, id & 7)) = v;
+          *reinterpret_cast<u32x4_t*>(yb + lds_swz(id >> 3, id & 7)) = yr[P.value * YCH + I.value];
         });
       });
     };

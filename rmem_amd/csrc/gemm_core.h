@@ -155,7 +155,7 @@ __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, co
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int chunk = ks * 2 + (lane >> 5);
-      bf16x8_t a[NPL][TM], b[NPL][TN];
+      frag8_t a[NPL][TM], b[NPL][TN];
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
         const char* xb = smem + p * Cfg::X_BYTES;
@@ -163,12 +163,12 @@ __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, co
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int row = wr * Cfg::WM + i * 32 + (lane & 31);
-          a[p][i] = *reinterpret_cast<const bf16x8_t*>(xb + lds_swz(row, chunk));
+          a[p][i] = *reinterpret_cast<const frag8_t*>(xb + lds_swz(row, chunk));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int row = wc * Cfg::WN + j * 32 + (lane & 31);
-          b[p][j] = *reinterpret_cast<const bf16x8_t*>(yb + lds_swz(row, chunk));
+          b[p][j] = *reinterpret_cast<const frag8_t*>(yb + lds_swz(row, chunk));
         }
       }
 #pragma unroll
@@ -176,10 +176,10 @@ __device__ __forceinline__ void gemm_mainloop(GemmFrag<Cfg>& f, const LX& lx, co
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if constexpr (Cfg::NSPLIT == 3) {  // small terms first
-            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], f.acc[i][j], 0, 0, 0);
-            f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], f.acc[i][j], 0, 0, 0);
+            f.acc[i][j] = RMEM_MFMA(a[0][i], b[1][j], f.acc[i][j]);
+            f.acc[i][j] = RMEM_MFMA(a[1][i], b[0][j], f.acc[i][j]);
           }
-          f.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], f.acc[i][j], 0, 0, 0);
+          f.acc[i][j] = RMEM_MFMA(a[0][i], b[0][j], f.acc[i][j]);
         }
     }
   }

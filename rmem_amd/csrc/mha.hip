@@ -21,7 +21,6 @@
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 // LDS image of one 64-key stage of head h (shared by the four waves = 128 queries of a block):
 //   K   [plane][64 keys][64 B]   rows of 64 B, 16-byte chunk c of row r stored at c ^ ((r >> 2) & 3)
@@ -49,12 +48,12 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   const bf16_t* qp[2] = {a.qh, a.ql};
   const bf16_t* kp[2] = {a.kh, a.kl};
   const bf16_t* vp[2] = {a.vh, a.vl};
-  bf16x8_t qf[NPL][2];
+  frag8_t qf[NPL][2];
 #pragma unroll
   for (int p = 0; p < NPL; ++p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-      qf[p][ks] = *reinterpret_cast<const bf16x8_t*>(qp[p] + (long)q * a.ldq + h * 32 + ks * 16 + hi * 8);
+      qf[p][ks] = *reinterpret_cast<const frag8_t*>(qp[p] + (long)q * a.ldq + h * 32 + ks * 16 + hi * 8);
 
   // staging: thread -> one 16-byte chunk of the K tile and one of the V^T tile, per plane
   const int k_row = tid >> 2, k_ch = tid & 3;        // key 0..63, chunk 0..3 (8 head dims)
@@ -114,20 +113,20 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
     for (int sub = 0; sub < 2; ++sub) {
       const int tok0 = (stage - t * sps) * 64 + sub * 32;
       // ---- fragments: K rows (keys) for S^T, V^T rows (channels) with the key permutation
-      bf16x8_t kf[NPL][2], vf[NPL][2];
+      frag8_t kf[NPL][2], vf[NPL][2];
       const int krow = sub * 32 + j;
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          kf[p][ks] = *reinterpret_cast<const bf16x8_t*>(ks_lds + p * MHA_KPL + krow * 64 +
+          kf[p][ks] = *reinterpret_cast<const frag8_t*>(ks_lds + p * MHA_KPL + krow * 64 +
                                                          (((ks * 2 + hi) ^ ((krow >> 2) & 3)) << 4));
           const char* vb = vs_lds + p * MHA_VPL + j * MHA_VROW + sub * 64 + ks * 32 + hi * 8;
           const u32x2_t g0 = *reinterpret_cast<const u32x2_t*>(vb);
           const u32x2_t g1 = *reinterpret_cast<const u32x2_t*>(vb + 16);
           u32x4_t w;
           w[0] = g0[0]; w[1] = g0[1]; w[2] = g1[0]; w[3] = g1[1];
-          vf[p][ks] = __builtin_bit_cast(bf16x8_t, w);
+          vf[p][ks] = __builtin_bit_cast(frag8_t, w);
         }
       // ---- S^T = K . Q^T over the head dim (2 k-steps of 16)
       f32x16_t s;
@@ -136,10 +135,10 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if constexpr (NS == 3) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[1][ks], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][ks], qf[0][ks], s, 0, 0, 0);
+          s = RMEM_MFMA(kf[0][ks], qf[1][ks], s);
+          s = RMEM_MFMA(kf[1][ks], qf[0][ks], s);
         }
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][ks], qf[0][ks], s, 0, 0, 0);
+        s = RMEM_MFMA(kf[0][ks], qf[0][ks], s);
       }
       // ---- online softmax for this lane's query, in the log2 domain: y = (s + bias) * scale * log2(e),
       // weights 2^(y - m).  The kernel is VALU-bound, so the token mask is applied only on the
@@ -183,31 +182,28 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
       l += psum;
       lslot += psum;
       // ---- P^T as the B operand: k-step s, element e = register 8s+e
-      bf16x8_t pf[NPL][2];
+      frag8_t pf[NPL][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4_t wh, wl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float p0 = pv[8 * ks + 2 * e], p1 = pv[8 * ks + 2 * e + 1];
-          const f32x2_t pp = {p0, p1};
-          const uint32_t hh = __builtin_bit_cast(uint32_t, __builtin_convertvector(pp, bf16x2_t));
-          wh[e] = hh;
-          if constexpr (NPL == 2) {
-            const f32x2_t rr = {p0 - __uint_as_float(hh << 16), p1 - __uint_as_float(hh & 0xffff0000u)};
-            wl[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr, bf16x2_t));
-          }
+          const unsigned short h0 = f2h_bits(p0), h1 = f2h_bits(p1);   // softmax weights <= 1: no saturation needed
+          wh[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+          if constexpr (NPL == 2)
+            wl[e] = (uint32_t)f2h_bits(p0 - h_bits2f(h0)) | ((uint32_t)f2h_bits(p1 - h_bits2f(h1)) << 16);
         }
-        pf[0][ks] = __builtin_bit_cast(bf16x8_t, wh);
-        if constexpr (NPL == 2) pf[1][ks] = __builtin_bit_cast(bf16x8_t, wl);
+        pf[0][ks] = __builtin_bit_cast(frag8_t, wh);
+        if constexpr (NPL == 2) pf[1][ks] = __builtin_bit_cast(frag8_t, wl);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if constexpr (NS == 3) {
-          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[1][ks], o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][ks], pf[0][ks], o, 0, 0, 0);
+          o = RMEM_MFMA(vf[0][ks], pf[1][ks], o);
+          o = RMEM_MFMA(vf[1][ks], pf[0][ks], o);
         }
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][ks], pf[0][ks], o, 0, 0, 0);
+        o = RMEM_MFMA(vf[0][ks], pf[0][ks], o);
       }
     }
   }

@@ -958,4 +958,4 @@ extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 6; }
+extern "C" int rmem_abi_version(void) { return 7; }   // 7: planes are fp16 hi/lo

@@ -1,10 +1,15 @@
 // rmem_common.h -- shared device helpers for the RMem gfx950 kernels.
 //
-// Numeric convention ("split-bf16"): an fp32 value x is carried as two bf16 planes
-// hi = bf16(x), lo = bf16(x - hi).  A product of two such values evaluated on the
-// bf16 MFMA pipe as  hi*lo' + lo*hi' + hi*hi'  (NSPLIT = 3) has a relative error of
-// ~2^-17 per product, i.e. fp32-class, at 3 MFMA issues; NSPLIT = 1 uses hi*hi' only
-// (plain bf16).  All accumulation is fp32 in the MFMA accumulators.
+// Numeric convention ("split-fp16"): an fp32 value x is carried as two fp16 planes
+// hi = fp16(x), lo = fp16(x - hi): 22 significant bits (fp16 subnormals are kept by the
+// conversions and by the MFMA, tools/ubench/f16_denorm.hip).  A product of two such values
+// evaluated on the 16-bit MFMA pipe as  hi*lo' + lo*hi' + hi*hi'  (NSPLIT = 3) has a relative
+// error of ~2^-21 per product, i.e. fp32-class, at 3 MFMA issues; NSPLIT = 1 uses hi*hi' only
+// (plain fp16).  All accumulation is fp32 in the MFMA accumulators.  The first builds carried
+// bf16 planes (16 bits, 2^-17): measured on the golden 480p clip that rounding alone moved 31
+// label pixels over 9 frames, fp16 planes move 3 (tools/precision_study.py lin16bf / lin16x2) at
+// the same MFMA rate.  Values beyond +-65504 saturate (the reference itself evaluates under fp16
+// autocast with --amp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,7 +18,8 @@
 #define RMEM_ERR_INVALID (-1)
 #define RMEM_ERR_LAUNCH (-2)
 
-typedef unsigned short bf16_t;  // raw bf16 bits
+typedef unsigned short bf16_t;  // raw 16 bits of a plane element (fp16 since the split-fp16 switch; the name is historical)
+typedef __attribute__((ext_vector_type(8))) _Float16 frag8_t;   // MFMA operand fragment: 8 consecutive k of one row
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
@@ -44,10 +50,12 @@ __device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned w) {
   return __builtin_bit_cast(unsigned, h);
 }
 
-__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-  hi = f2bf(x);
-  lo = f2bf(x - bf2f(hi));
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {   // -> fp16 hi/lo planes
+  const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  hi = f2h_bits(xc);
+  lo = f2h_bits(__builtin_amdgcn_fmed3f(xc - h_bits2f(hi), -65504.f, 65504.f));
 }
+#define RMEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 // Monotone float <-> uint encoding so that atomicMax on the uint orders like the
 // float; 0 encodes "below every float" (lets a plain memset(0) reset the buffer).

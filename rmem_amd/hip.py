@@ -180,7 +180,8 @@ def check(rc: int, what: str):
 
 
 class Planes:
-    """An fp32 tensor carried as two bf16 planes (hi, lo)."""
+    """An fp32 tensor carried as two fp16 planes (hi, lo): 22 significant bits, values beyond
+    +-65504 saturate (rmem_common.h: split-fp16)."""
 
     __slots__ = ("hi", "lo")
 
@@ -189,13 +190,14 @@ class Planes:
 
     @staticmethod
     def empty(shape, device):
-        return Planes(torch.zeros(shape, dtype=torch.bfloat16, device=device),
-                      torch.zeros(shape, dtype=torch.bfloat16, device=device))
+        return Planes(torch.zeros(shape, dtype=torch.float16, device=device),
+                      torch.zeros(shape, dtype=torch.float16, device=device))
 
     @staticmethod
     def from_f32(x: torch.Tensor):
-        hi = x.to(torch.bfloat16)
-        lo = (x - hi.float()).to(torch.bfloat16)
+        x = x.float().clamp(-65504.0, 65504.0)
+        hi = x.to(torch.float16)
+        lo = (x - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
         return Planes(hi.contiguous(), lo.contiguous())
 
     def float(self):
@@ -215,7 +217,7 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
     """x_off / y_off: element offsets into the plane tensors (column windows).
     launch=False returns the filled argument struct (for linear_grouped)."""
     a = LinearArgs()
-    eb = 2  # bytes per bf16
+    eb = 2  # bytes per plane element
     a.xh, a.xl, a.ldx = x.hi.data_ptr() + x_off * eb, x.lo.data_ptr() + x_off * eb, ldx
     if x2 is not None:
         a.xh2, a.xl2, a.ldx2, a.kx_split = x2.hi.data_ptr(), x2.lo.data_ptr(), ldx2, kx_split

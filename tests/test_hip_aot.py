@@ -241,7 +241,7 @@ def test_aot_480p_clip_teacher_forced(golden_dir):
         idx_hist.append(list(eng.aot_engines[0].long_memories_indexes))
     print("AOT 480p mismatching pixels per frame (of 409920):", mism, "logit err:", lerrs)
     assert idx_hist == meta["indexes"]
-    assert max(mism) <= 12, mism
+    assert max(mism) <= 8, mism           # measured 0-3 (0-6 when the planes were bf16)
     assert max(lerrs.values()) < 2e-2
 
 

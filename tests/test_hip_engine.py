@@ -75,7 +75,7 @@ def test_lstt_forward_vs_oracle_tokens(p16):
             merr = (lstt.mass.flatten()[:N * T].view(N, T).cpu() - trace["l0.mass"]).abs().max().item()
             worst[f"mass{t}"] = merr
             assert merr < (3e-4 if p16 else 1e-4), (t, merr)
-        assert err < (8e-4 if p16 else 2e-4), (t, err, worst)
+        assert err < (8e-4 if p16 else 6e-5), (t, err, worst)      # measured 5.2e-4 / 1.8e-5 (fp16 hi/lo planes)
     print("LSTT vs oracle max abs err:", worst)
 
 
@@ -106,7 +106,7 @@ def test_small_clip(name, golden_dir):
         print(name, "teacher-forced" if teacher else "closed-loop", "mismatching pixels per frame:", mism)
         assert idx_hist == meta["indexes"]
         if teacher:
-            assert max(mism) <= 2, mism          # of 12.5k pixels; 0-1 with RMEM_P16=0
+            assert max(mism) <= 2, mism          # of 12.5k pixels; measured 0-2 (0 with RMEM_P16=0)
             lerr = np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max()
             print(name, "last-frame logit max abs err:", lerr)
             assert lerr < 2e-3
@@ -150,9 +150,9 @@ def test_480p_teacher_forced(nsplit, golden_dir):
     if nsplit == 3:
         # measured 1-7 on every box so far; the encoder's MIOpen convolutions are not bit-reproducible
         # between processes (tools/determinism_probe.py), each flip of a near-tie pixel counts one
-        assert max(mism) <= 10, mism
+        assert max(mism) <= 8, mism           # measured 0-4 (0-3 with RMEM_P16=0; 2-8 when the planes were bf16)
     else:
-        assert max(mism) <= 4000, mism        # plain bf16: ~1e-3..1e-2 logit noise near ties
+        assert max(mism) <= 600, mism         # plain fp16 (one plane per operand): measured 69-197
     assert max(lerrs.values()) < (2e-2 if nsplit == 3 else 0.2)
 
 
@@ -278,8 +278,8 @@ def test_720p_k8_vs_oracle():
         assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.long_memories_indexes)
     print("720p K=8 mismatching pixels per frame (of 921600):", mism, "decoder-logit max abs err:", lerr)
     assert len(ora.long_memories_indexes) == frames
-    # 2-18 measured: the same near-tie rate as at 480p (2-7 of 409,920) on 2.25x the pixels
-    assert max(mism) <= 40 and max(lerr) < 2e-3, (mism, lerr)
+    # 1-3 measured (decoder logits within 2e-5); 2-18 when the planes were bf16
+    assert max(mism) <= 12 and max(lerr) < 2e-4, (mism, lerr)
 
 
 def test_paired_launches_bit_identical():

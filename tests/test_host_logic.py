@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rmem_hip.h but not exported"
     assert declared == set(hip.EXPORTS)
-    assert lib.rmem_abi_version() == 6
+    assert lib.rmem_abi_version() == 7
 
 
 def test_ctypes_struct_sizes_match_header_layout():
