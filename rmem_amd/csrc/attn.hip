@@ -1,5 +1,5 @@
 // attn.hip -- memory-read attention (long-term bank / windowed short-term / self) as
-// three MFMA launches over a materialised split-bf16 probability matrix.
+// three MFMA launches over a materialised split-fp16 probability matrix.
 // See include/rmem_hip.h for the contract and DESIGN.md for the roofline accounting.
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"

@@ -1,10 +1,10 @@
-// gemm_core.h -- LDS-tiled split-bf16 MFMA main loop for gfx950 (wave64).
+// gemm_core.h -- LDS-tiled split-fp16 MFMA main loop for gfx950 (wave64).
 //
 //   D[i][j] = sum_k X[i][k] * Y[j][k]        (both operands reduction-contiguous)
 //
 // Block = 256 threads = 4 waves arranged 2x2 over a BM x BN tile; every wave owns a
-// (BM/2) x (BN/2) sub-tile made of 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, fp32
-// accumulate).  K is consumed in steps of BK = 64 bf16 (one 128-byte row per tile row).
+// (BM/2) x (BN/2) sub-tile made of 32x32 MFMA tiles (v_mfma_f32_32x32x16_f16, fp32
+// accumulate).  K is consumed in steps of BK = 64 fp16 (one 128-byte row per tile row).
 //
 // LDS image of one operand plane: row r occupies bytes [128 r, 128 r + 128); the eight
 // 16-byte chunks of a row are stored at chunk position  c ^ ((r >> 1) & 7).  With
@@ -58,7 +58,7 @@ struct TileView {
   long ld;
 };
 
-// Row-major operand [rows][ld] (bf16 planes), optionally continued by a second source
+// Row-major operand [rows][ld] (fp16 hi/lo planes), optionally continued by a second source
 // for k-tiles >= kt_split (used to concatenate two activations along K).
 struct RowMajorOperand {
   const bf16_t* hi;

@@ -1,5 +1,5 @@
 // linear.hip -- rmem_linear: D = act(X . Y^T + bias) with fused multi-destination
-// epilogue (fp32 / split-bf16 planes / residual accumulate).  See include/rmem_hip.h.
+// epilogue (fp32 / split-fp16 planes / residual accumulate).  See include/rmem_hip.h.
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
 

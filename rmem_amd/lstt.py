@@ -181,7 +181,7 @@ class DeAOTLSTT:
         self.rowmax = z(3 * self.L, Np, dt=torch.int32)          # [layer][read]: zeroed once per frame
         self._layer = 0
         # bank reads (long-term, self) with P as ONE fp16 plane: 2 MFMAs per product instead of 3
-        # (rmem_attn_scores / rmem_attn_pv with pl = NULL); the windowed read keeps bf16 hi/lo planes
+        # (rmem_attn_scores / rmem_attn_pv with pl = NULL); the windowed read keeps hi/lo planes
         self.p16 = self.nsplit == 3 and os.environ.get("RMEM_P16", "1") == "1"
         self.ksplits_max = 8
         # attention workspaces: main stream (long-term, self) and side stream (short-term window)

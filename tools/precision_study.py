@@ -48,7 +48,7 @@ def make_q(tok):
 def install(plan):
     """plan = seg[+seg...], seg = tokens[@reads]: e.g. p16_v16x2@long,self+p16x2_v16x2@win"""
     ident = lambda x: x
-    table = {r: (ident, ident, ident) for r in ("long", "self", "win")}
+    table = {r: (ident, ident, ident, ident) for r in ("long", "self", "win")}
     for seg in plan.split("+"):
         where = "long,self,win"
         if "@" in seg:
@@ -56,13 +56,14 @@ def install(plan):
         toks = seg.split("_")
         q3 = (make_q(next((t for t in toks if t.startswith("p")), None)),
               make_q(next((t for t in toks if t.startswith("v")), None)),
-              make_q(next((t for t in toks if t.startswith("qk")), None)))
+              make_q(next((t for t in toks if t.startswith("qk")), None)),
+              make_q(next((t for t in toks if t.startswith("qonly")), None)))
         for r in where.split(","):
             table[r] = q3
 
     def core(Q, K, V, U, h, w, dw_w, proj_w, proj_b, d_att=128):
-        qp, qv, qqk = table["self" if Q is K else "long"]
-        logits = qqk(Q / (d_att ** 0.5)) @ qqk(K).t()
+        qp, qv, qqk, qq = table["self" if Q is K else "long"]
+        logits = qq(qqk(Q / (d_att ** 0.5))) @ qqk(K).t()
         m = logits.max(dim=-1, keepdim=True).values
         p = qp(torch.exp(logits - m))                 # the kernel stores exp(S - max), sums the stored values
         attn = p / p.sum(dim=-1, keepdim=True)
@@ -73,10 +74,10 @@ def install(plan):
 
     def local(q, k, v, u, h, w, rel_w, rel_b, dw_w, proj_w, proj_b, max_dis=7):
         n, d = q.shape
-        qp, qv, qqk = table["win"]
+        qp, qv, qqk, qq = table["win"]
         idx, inside = R.local_window_index(h, w, max_dis)
         rel = q @ rel_w.view(rel_w.shape[0], d).t() + rel_b
-        qs = qqk(q / (d ** 0.5))
+        qs = qq(qqk(q / (d ** 0.5)))
         kg = qqk(k)[idx.clamp(min=0)] * inside.unsqueeze(-1)
         qk = torch.einsum("nc,noc->no", qs, kg) + rel
         qk = qk - (~inside).float() * 1e8
