@@ -185,9 +185,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # steady-state frames replay hipGraphs; one frame in twenty of the timed region (at least one)
-    # is issued eagerly so that HIP events can bracket the dominant kernel on its launch stream
-    n_eager = max(1, args.steps // 20)
+    # steady-state frames replay hipGraphs; one frame in fifty of the timed region (at least one) is
+    # issued eagerly (~0.9 ms slower than a replayed frame) so that HIP events can bracket the
+    # dominant kernel on its launch stream
+    n_eager = max(1, args.steps // 50)
     eager_at = {(i * args.steps) // n_eager for i in range(n_eager)}
     for k in range(args.steps):
         lstt._timing = (k in eager_at) and not os.environ.get("RMEM_BENCH_NOSYNC")
