@@ -13,9 +13,8 @@
  *     (a hipStream_t passed as void*), so calls are hipGraph-capturable;
  *   - return value: 0 = enqueued, <0 = error (RMEM_ERR_*); no exceptions cross the ABI;
  *   - "planes": an fp32 tensor carried as two fp16 tensors hi = fp16(x),
- *     lo = fp16(x - hi), values beyond +-65504 saturated (rmem_plane16 = raw fp16 bits;
- *     rmem_bf16 is the name the first builds gave the same 16-bit element when the planes
- *     were bf16).  `nsplit` = 3 multiplies hi*lo + lo*hi + hi*hi on the 16-bit MFMA pipe
+ *     lo = fp16(x - hi), values beyond +-65504 saturated (rmem_f16 = raw IEEE fp16 bits).
+ *     `nsplit` = 3 multiplies hi*lo + lo*hi + hi*hi on the 16-bit MFMA pipe
  *     (fp32-class accuracy), `nsplit` = 1 multiplies hi*hi only (plain fp16) and ignores
  *     the lo pointers;
  *   - tokens are row-major over the feature map, p = y*w + x (layers/basic.py:73-77).
@@ -29,8 +28,7 @@
 extern "C" {
 #endif
 
-typedef uint16_t rmem_plane16;
-typedef rmem_plane16 rmem_bf16;
+typedef uint16_t rmem_f16;
 
 #define RMEM_OK 0
 #define RMEM_ERR_INVALID (-1)
@@ -40,7 +38,7 @@ typedef rmem_plane16 rmem_bf16;
 int rmem_abi_version(void);
 
 /* ------------------------------------------------------------------ linear layers
- * D = act(X . Y^T + bias) on the bf16 MFMA pipe.  X is [M][K], Y is [N][K] (both
+ * D = act(X . Y^T + bias) on the fp16 MFMA pipe (v_mfma_f32_32x32x16_f16).  X is [M][K], Y is [N][K] (both
  * K-contiguous planes), D is [M][N].  Either operand may be continued along K by a
  * second source (x2/y2) after k_split elements (concatenated inputs).  With
  * bias_per_row the roles are swapped (X = weight, Y = activation) and D is the
@@ -50,11 +48,11 @@ int rmem_abi_version(void);
  * (layers/attention.py:151-172,209) and relative_emb_k (layers/attention.py:314).
  */
 typedef struct {
-  const rmem_bf16 *xh, *xl; int64_t ldx;   /* X planes, first K segment              */
-  const rmem_bf16 *xh2, *xl2; int64_t ldx2; /* second K segment (or NULL)             */
+  const rmem_f16 *xh, *xl; int64_t ldx;   /* X planes, first K segment              */
+  const rmem_f16 *xh2, *xl2; int64_t ldx2; /* second K segment (or NULL)             */
   int32_t kx_split;                        /* elements of K served by the first X source */
-  const rmem_bf16 *yh, *yl; int64_t ldy;
-  const rmem_bf16 *yh2, *yl2; int64_t ldy2;
+  const rmem_f16 *yh, *yl; int64_t ldy;
+  const rmem_f16 *yh2, *yl2; int64_t ldy2;
   int32_t ky_split;
   int32_t M, N, K;                         /* K, k*_split multiples of 64            */
   const float *bias; int32_t bias_per_row; /* bias[N] (or bias[M] when per row), may be NULL */
@@ -63,8 +61,8 @@ typedef struct {
   float *d1; int64_t ldd1;                 /* fp32 out for columns [csplit, N)       */
   int32_t csplit;                          /* = N when there is one destination       */
   int32_t accumulate;                      /* D += result (fused residual add)       */
-  rmem_bf16 *pah, *pal; int64_t ldpa;      /* planes of the result (may be NULL)      */
-  rmem_bf16 *pbh, *pbl; int64_t ldpb;      /* planes of result + addvec[col] (may be NULL) */
+  rmem_f16 *pah, *pal; int64_t ldpa;      /* planes of the result (may be NULL)      */
+  rmem_f16 *pbh, *pbl; int64_t ldpb;      /* planes of result + addvec[col] (may be NULL) */
   const float *addvec;
   int32_t nbatch;                          /* gridDim.z; strides below in elements    */
   int64_t bsx, bsy, bsd, bsbias, bspa;
@@ -84,8 +82,8 @@ int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
 
 /* ------------------------------------------------------------------ attention
  * Memory-read attention of GatedPropagation.forward (layers/attention.py:174-206) in
- * three launches over a materialised bf16 probability matrix:
- *   rmem_attn_scores(pass=0)  running row max of S = scale*(Q.K^T + bias)   (plain bf16)
+ * three launches over a materialised split-fp16 probability matrix:
+ *   rmem_attn_scores(pass=0)  running row max of S = scale*(Q.K^T + bias)   (plain fp16) 
  *   rmem_attn_scores(pass=1)  P = exp(S - max) -> planes, partial row sums   (nsplit)
  *   rmem_attn_pv              partial O = P . V per key split                 (nsplit)
  *   rmem_attn_combine         G = (sum_splits O) / rowsum * U, per-slot attention mass
@@ -105,17 +103,17 @@ int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
 typedef struct {
   int32_t mode;                            /* 0 bank, 1 window                         */
   int32_t pass;                            /* 0 row max, 1 probabilities               */
-  const rmem_bf16 *kh, *kl; int64_t k_slot_stride;   /* K planes base, elements per slot */
+  const rmem_f16 *kh, *kl; int64_t k_slot_stride;   /* K planes base, elements per slot */
   const int32_t *slot_map;                 /* device [T] logical -> physical slot       */
   int32_t T, N, Npad;
-  const rmem_bf16 *qh, *ql;                /* Q planes [Npad][128]                      */
+  const rmem_f16 *qh, *ql;                /* Q planes [Npad][128]                      */
   float scale;                             /* 1/sqrt(d_att)                             */
   const float *bias;                       /* mode 0: [N][T] or NULL                    */
   const float *R; int32_t ldr; int32_t h, w;  /* mode 1                                 */
   uint32_t *rowmax;                        /* [Npad] order-encoded running max (memset 0 before pass 0) */
-  rmem_bf16 *ph, *pl;                      /* pass 1: P planes; nsplit 3 with pl == NULL: P is ONE fp16 plane in ph */
+  rmem_f16 *ph, *pl;                      /* pass 1: P planes; nsplit 3 with pl == NULL: P is ONE fp16 plane in ph */
   float *lpart; int32_t nparts;            /* pass 1: [Npad][nparts] partial row sums, part = key/64 */
-  int32_t nsplit;                          /* pass 1 precision (pass 0 always runs plain bf16) */
+  int32_t nsplit;                          /* pass 1 precision (pass 0 always runs plain fp16) */
 } rmem_scores_args;
 
 int rmem_attn_scores(const rmem_scores_args *a, void *stream);
@@ -126,8 +124,8 @@ int rmem_attn_scores2(const rmem_scores_args *a, const rmem_scores_args *b, void
 
 typedef struct {
   int32_t mode;                            /* 0 bank, 1 window (banded k range)         */
-  const rmem_bf16 *ph, *pl;                /* P planes blocked [key/32][Npad][32]; nsplit 3 with pl == NULL (mode 0): one fp16 plane, 2 MFMAs per product */
-  const rmem_bf16 *vh, *vl; int64_t v_slot_stride;   /* V^T planes [slot][ncols][Npad]  */
+  const rmem_f16 *ph, *pl;                /* P planes blocked [key/32][Npad][32]; nsplit 3 with pl == NULL (mode 0): one fp16 plane, 2 MFMAs per product */
+  const rmem_f16 *vh, *vl; int64_t v_slot_stride;   /* V^T planes [slot][ncols][Npad]  */
   const int32_t *slot_map; int32_t T, N, Npad;
   int32_t ncols;                           /* 1024 (V | ID_V)                           */
   int32_t h, w;                            /* mode 1                                    */
@@ -168,9 +166,9 @@ int rmem_pe_bias(const float *Q, int64_t ldq, const float *cur_pe, const float *
  * slot_ml: [ksplits][Npad][heads][T][2] zero-filled by the caller (or NULL when no mass is needed).
  */
 typedef struct {
-  const rmem_bf16 *qh, *ql; int64_t ldq;
-  const rmem_bf16 *kh, *kl; int64_t k_slot_stride, ldk;
-  const rmem_bf16 *vh, *vl; int64_t v_slot_stride, ldv;
+  const rmem_f16 *qh, *ql; int64_t ldq;
+  const rmem_f16 *kh, *kl; int64_t k_slot_stride, ldk;
+  const rmem_f16 *vh, *vl; int64_t v_slot_stride, ldv;
   const int32_t *slot_map; int32_t T, N, Npad, heads;
   float scale;                              /* 1/sqrt(32)                               */
   const float *bias;
@@ -184,7 +182,7 @@ int rmem_mha_flash(const rmem_mha_args *a, void *stream);
 typedef struct {
   int32_t N, Npad, heads, T, ksplits;
   const float *opart; const float *ml; const float *slot_ml;
-  rmem_bf16 *oh, *ol; float *of32; int64_t ldo;   /* out [N][heads*32]: planes (+ optional fp32) */
+  rmem_f16 *oh, *ol; float *of32; int64_t ldo;   /* out [N][heads*32]: planes (+ optional fp32) */
   float *mass;                                     /* [N][T] or NULL                            */
 } rmem_mha_combine_args;
 
@@ -194,7 +192,7 @@ int rmem_mha_combine(const rmem_mha_combine_args *a, void *stream);
 /* LayerNorm over C=256 channels -> planes (+ optional fp32); nn.LayerNorm of
  * layers/transformer.py:1104,1120,1223-1224 and models/deaot.py:41. */
 int rmem_layernorm_split(const float *x, int64_t ldx, const float *gamma, const float *beta,
-                         int32_t N, int32_t C, float eps, rmem_bf16 *oh, rmem_bf16 *ol,
+                         int32_t N, int32_t C, float eps, rmem_f16 *oh, rmem_f16 *ol,
                          int64_t ldo, float *of32, int64_t ldof, void *stream);
 
 /* LayerNorm with fused adds: y = LN(x + x2) * gamma + beta + post  (x2 / post may be NULL).
@@ -202,7 +200,7 @@ int rmem_layernorm_split(const float *x, int64_t ldx, const float *gamma, const 
  * norm2(tgt) + id_emb as the input of linear_V (:586, :277-280). */
 int rmem_layernorm_ex(const float *x, int64_t ldx, const float *x2, int64_t ldx2, const float *gamma,
                       const float *beta, int32_t N, int32_t C, float eps, const float *post,
-                      int64_t ldpost, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32,
+                      int64_t ldpost, rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, float *of32,
                       int64_t ldof, void *stream);
 
 /* Residual reduce + LayerNorm: x[row][:] += sum_z parts[z][row][:]  (z in split order, written
@@ -211,7 +209,7 @@ int rmem_layernorm_ex(const float *x, int64_t ldx, const float *x2, int64_t ldx2
  * (layers/transformer.py:1212-1224, 1231-1232).  nparts = 0 is a plain LayerNorm. */
 int rmem_layernorm_red(float *x, int64_t ldx, const float *parts, int32_t nparts, int64_t part_stride,
                        int64_t ldpart, const float *gamma, const float *beta, int32_t N, int32_t C,
-                       float eps, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32, int64_t ldof,
+                       float eps, rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, float *of32, int64_t ldof,
                        void *stream);
 
 /* Two such problems of the same shape in one launch: norm1 / id_norm1 and norm2 / id_norm2 of a
@@ -220,16 +218,16 @@ int rmem_layernorm_red(float *x, int64_t ldx, const float *parts, int32_t nparts
 int rmem_layernorm_red2(float *x0, float *x1, int64_t ldx, const float *parts0, const float *parts1,
                         int32_t nparts, int64_t part_stride, int64_t ldpart, const float *gamma0,
                         const float *beta0, const float *gamma1, const float *beta1, int32_t N, int32_t C,
-                        float eps, rmem_bf16 *oh0, rmem_bf16 *ol0, int64_t ldo0, rmem_bf16 *oh1,
-                        rmem_bf16 *ol1, int64_t ldo1, void *stream);
+                        float eps, rmem_f16 *oh0, rmem_f16 *ol0, int64_t ldo0, rmem_f16 *oh1,
+                        rmem_f16 *ol1, int64_t ldo1, void *stream);
 
 /* planes [N][C] (ld) -> transposed planes [C][ldo]  (AOT: V operand of the short-term attention) */
-int rmem_transpose_planes(const rmem_bf16 *ih, const rmem_bf16 *il, int64_t ld, int32_t N, int32_t C,
-                          rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, void *stream);
+int rmem_transpose_planes(const rmem_f16 *ih, const rmem_f16 *il, int64_t ld, int32_t N, int32_t C,
+                          rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, void *stream);
 
 /* dst (fp32, optional, may alias a) = a + b ; planes of the sum (optional).  n elements. */
-int rmem_add_split(const float *a, const float *b, int64_t n, float *dst, rmem_bf16 *oh,
-                   rmem_bf16 *ol, void *stream);
+int rmem_add_split(const float *a, const float *b, int64_t n, float *dst, rmem_f16 *oh,
+                   rmem_f16 *ol, void *stream);
 
 /* GNActDWConv2d front half (layers/basic.py:27-32): GroupNorm(groups) over token-major
  * [N][C] (statistics over C/groups channels x N tokens) followed by exact GELU -> fp32.
@@ -245,12 +243,12 @@ int rmem_pe_bias_heads(const float *Q, int64_t ldq, const float *cur_pe, const f
 /* Depth-wise 5x5, pad 2, no bias, on token-major [h*w][C] (layers/basic.py:38-57);
  * wt is [25][C] (tap-major).  Output planes. */
 int rmem_dwconv5x5_split(const float *g, int64_t ldg, const float *wt, int32_t h, int32_t w,
-                         int32_t C, rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, void *stream);
+                         int32_t C, rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, void *stream);
 
 /* Two maps of the same geometry in one launch (the gated long-term and short-term aggregates). */
 int rmem_dwconv5x5_split2(const float *g0, const float *g1, int64_t ldg, const float *wt0, const float *wt1,
-                          int32_t h, int32_t w, int32_t C, rmem_bf16 *oh0, rmem_bf16 *ol0, rmem_bf16 *oh1,
-                          rmem_bf16 *ol1, int64_t ldo, void *stream);
+                          int32_t h, int32_t w, int32_t C, rmem_f16 *oh0, rmem_f16 *ol0, rmem_f16 *oh1,
+                          rmem_f16 *ol1, int64_t ldo, void *stream);
 
 /* Final GroupNorm1D(2 groups) over [tgt | tgt_id] (layers/transformer.py:806-808,
  * layers/basic.py:6-12): statistics over 256 channels x N tokens per group.
@@ -261,12 +259,16 @@ int rmem_groupnorm2(const float *tgt, const float *tgt_id, int32_t N, int32_t C,
 
 /* ID assignment: label map -> one-hot(+ignore) -> Conv2d(k,stride,pad) -> LayerNorm_C
  * (utils/image.py:69-74, engines/aot_engine.py:208-232, models/aot.py:67-74,
- * models/deaot.py:65-69).  wt is [ncls][k][k][C]; gamma NULL skips the LayerNorm (AOT). */
+ * models/deaot.py:65-69).  wt is [ncls][k][k][C]; gamma NULL skips the LayerNorm (AOT).
+ * ignore_channel != 0: label 255 selects the ignore channel ncls-1 (update_short_term_memory,
+ * aot_engine.py:330-336, passes the real ignore mask); ignore_channel == 0: label 255 contributes
+ * nothing (add_reference_frame, aot_engine.py:304, calls assign_identity without an ignore mask,
+ * which :209-213 turn into all zeros). */
 int rmem_id_assign(const uint8_t *label, int32_t H, int32_t W, const float *wt, const float *bias,
                    int32_t ncls, int32_t ksize, int32_t stride, int32_t pad, int32_t eh, int32_t ew,
                    int32_t C, const float *gamma, const float *beta, float eps,
-                   rmem_bf16 *oh, rmem_bf16 *ol, int64_t ldo, float *of32, int64_t ldof,
-                   void *stream);
+                   rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, float *of32, int64_t ldof,
+                   int32_t ignore_channel, void *stream);
 
 /* RMem relevance: out[t] = sum_q mass[q][t] * fg[q]   (layers/transformer.py:900-904) */
 int rmem_attn_mass_reduce(const float *mass, int32_t N, int32_t T, const float *fg, float *out,
@@ -314,7 +316,7 @@ int rmem_upsample_add_nchw_out(const float *y_in, float *y_out, const float *bia
 int rmem_set_ints(int32_t *dst, const int32_t *host_vals, int32_t n, void *stream);
 
 /* fp32 -> planes (weights at load time, fixtures in tests) */
-int rmem_split_planes(const float *x, int64_t n, rmem_bf16 *hi, rmem_bf16 *lo, void *stream);
+int rmem_split_planes(const float *x, int64_t n, rmem_f16 *hi, rmem_f16 *lo, void *stream);
 
 /* Clip-driver post-processing.  One decoder output per test-time
  * augmentation: logits [C][h][w] fp32 (batch 1), flip != 0 when that augmentation ran on the

@@ -201,7 +201,7 @@ class AOTOracle:
         return drop
 
 
-def aot_id_assign(label: Tensor, sd: SD, max_obj: int = 10) -> Tensor:
+def aot_id_assign(label: Tensor, sd: SD, max_obj: int = 10, use_ignore: bool = True) -> Tensor:
     """AOT.get_id_emb has no LayerNorm (models/aot.py:111-114)."""
     from .lstt_ref import id_assign
-    return id_assign(label, sd, max_obj, deaot=False)
+    return id_assign(label, sd, max_obj, deaot=False, use_ignore=use_ignore)

@@ -63,7 +63,8 @@ class OracleDeAOTEngine:
             self.enc_size_2d = tuple(enc[-1].shape[2:])
             self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
         h, w = self.enc_size_2d
-        id_emb = R.id_assign(mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM)
+        # the reference frame's assign_identity gets no ignore mask (aot_engine.py:304, :209-213)
+        id_emb = R.id_assign(mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM, use_ignore=False)
         emb = enc[-1][0].permute(1, 2, 0).reshape(h * w, -1)    # bchw_2_lbc (utils/tensor.py:3-6)
         out = self.lstt.forward(emb, h, w, curr_id_emb=id_emb, trace=self.trace)
         self.last_mem_step = frame_step
@@ -134,7 +135,7 @@ class OracleAOTEngine(OracleDeAOTEngine):
         h, w = self.enc_size_2d
         if self.pos is None:
             self.pos = self.A.sine_pos_emb(h, w)
-        id_emb = self.A.aot_id_assign(mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM)
+        id_emb = self.A.aot_id_assign(mask.float(), self.sd, self.cfg.MODEL_MAX_OBJ_NUM, use_ignore=False)
         outs = self.lstt.forward(self._tokens(enc), h, w, self.pos, curr_id_emb=id_emb, trace=self.trace)
         self.last_mem_step = frame_step
         self.lstt.init_memory()

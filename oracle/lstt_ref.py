@@ -357,16 +357,20 @@ def rmem_policy_step(w: List[float], indexes: List[int], ema_prev: Dict[int, flo
 
 # ----------------------------------------------------------------------------- B5
 def id_assign(label: Tensor, sd: SD, max_obj: int = 10, deaot: bool = True,
-              stride: int = 16, ksize: int = 0, pad: int = -1) -> Tensor:
+              stride: int = 16, ksize: int = 0, pad: int = -1, use_ignore: bool = True) -> Tensor:
     """one_hot_mask + assign_identity + get_id_emb
     (utils/image.py:69-74, engines/aot_engine.py:208-232, models/deaot.py:65-69,
-    models/aot.py:67-74,111-114).  label [1,1,H,W] float ids (255 = ignore) -> [N,256]."""
+    models/aot.py:67-74,111-114).  label [1,1,H,W] float ids (255 = ignore) -> [N,256].
+    use_ignore=True is update_short_term_memory (aot_engine.py:330-336: the (mask == 255) map
+    is the ignore channel); use_ignore=False is add_reference_frame (:304), which calls
+    assign_identity without an ignore mask, i.e. with zeros (:209-213): a 255 pixel then has
+    neither a one-hot nor an ignore channel."""
     if ksize == 0:      # k17/p8 with MODEL_ALIGN_CORNERS, k16/p0 without (models/aot.py:67-84)
         ksize = sd["patch_wise_id_bank.weight"].shape[-1]
         pad = 8 if ksize == 17 else 0
     ids = torch.arange(0, max_obj + 1).view(1, -1, 1, 1).to(label.dtype)
     onehot = (label == ids).float()
-    ign = (label == 255).float()
+    ign = (label == 255).float() if use_ignore else torch.zeros_like(label)
     onehot[:, 0] = onehot[:, 0] * (ign[:, 0] == 0).float()
     x = torch.cat([onehot, ign], dim=1)
     e = F.conv2d(x, sd["patch_wise_id_bank.weight"], sd["patch_wise_id_bank.bias"],

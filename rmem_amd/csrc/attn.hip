@@ -120,13 +120,13 @@ __device__ __forceinline__ void scores_body(const rmem_scores_args& a, int bx, i
         const long base = (kb * a.Npad + q) * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          bf16_t hi[4], lo[4];
+          h16_t hi[4], lo[4];
           if (p16) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) hi[e] = f2h_bits(pv[4 * g + e]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split_bf16(pv[4 * g + e], hi[e], lo[e]);
+            for (int e = 0; e < 4; ++e) split_f16(pv[4 * g + e], hi[e], lo[e]);
           }
           uint2 vh, vl;
           vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
@@ -252,8 +252,8 @@ extern "C" int rmem_attn_scores(const rmem_scores_args* ap, void* stream) {
 
 // ------------------------------------------------------------------ P . V
 struct PBlockedOperand {
-  const bf16_t* hi;
-  const bf16_t* lo;
+  const h16_t* hi;
+  const h16_t* lo;
   long npad;
   int row0;
   __device__ __forceinline__ TileView tile(int kt) const {
@@ -261,7 +261,7 @@ struct PBlockedOperand {
     return TileView{hi + off, lo ? lo + off : nullptr, npad * 32};   // ld = one 32-key block
   }
   __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
-    const bf16_t* b = plane ? t.lo : t.hi;
+    const h16_t* b = plane ? t.lo : t.hi;
     long q = row0 + r;
     q = q < npad ? q : npad - 1;
     return reinterpret_cast<const u32x4_t*>(b + (c >> 2) * t.ld + q * 32 + (c & 3) * 8);
@@ -294,8 +294,8 @@ struct SlotLut {
 };
 
 struct VtOperand {
-  const bf16_t* hi;
-  const bf16_t* lo;
+  const h16_t* hi;
+  const h16_t* lo;
   long slot_stride, ld;
   SlotLut lut;
   int tps;  // 64-key tiles per slot
@@ -309,7 +309,7 @@ struct VtOperand {
   __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
     int j = row0 + r;
     j = j < rows ? j : rows - 1;
-    const bf16_t* b = plane ? t.lo : t.hi;
+    const h16_t* b = plane ? t.lo : t.hi;
     return reinterpret_cast<const u32x4_t*>(b + (long)j * t.ld + c * 8);
   }
 };

@@ -53,19 +53,19 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) {
 // choice, slot lookup, divisions) is resolved ONCE per k-tile in tile(); ptr() is then
 // pure per-lane address arithmetic, so the 8-16 staging loads of a tile issue back to back.
 struct TileView {
-  const bf16_t* hi;
-  const bf16_t* lo;
+  const h16_t* hi;
+  const h16_t* lo;
   long ld;
 };
 
 // Row-major operand [rows][ld] (fp16 hi/lo planes), optionally continued by a second source
 // for k-tiles >= kt_split (used to concatenate two activations along K).
 struct RowMajorOperand {
-  const bf16_t* hi;
-  const bf16_t* lo;
+  const h16_t* hi;
+  const h16_t* lo;
   long ld;
-  const bf16_t* hi2;
-  const bf16_t* lo2;
+  const h16_t* hi2;
+  const h16_t* lo2;
   long ld2;
   int kt_split;   // number of k-tiles served by the first source
   int row0;       // first row of this block's tile
@@ -77,7 +77,7 @@ struct RowMajorOperand {
   __device__ __forceinline__ const u32x4_t* ptr(const TileView& t, int plane, int r, int c) const {
     int gr = row0 + r;
     gr = gr < rows ? gr : rows - 1;
-    const bf16_t* b = plane ? t.lo : t.hi;
+    const h16_t* b = plane ? t.lo : t.hi;
     return reinterpret_cast<const u32x4_t*>(b + (long)gr * t.ld + c * 8);
   }
 };

@@ -65,10 +65,10 @@ __device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, i
   const float* bias = a.bias ? a.bias + bz * a.bsbias : nullptr;
   float* d0 = a.d0 ? a.d0 + bz * a.bsd : nullptr;
   float* d1 = a.d1 ? a.d1 + bz * a.bsd : nullptr;
-  bf16_t* pah = a.pah ? a.pah + bz * a.bspa : nullptr;
-  bf16_t* pal = a.pal ? a.pal + bz * a.bspa : nullptr;
-  bf16_t* pbh = a.pbh ? a.pbh + bz * a.bspa : nullptr;
-  bf16_t* pbl = a.pbl ? a.pbl + bz * a.bspa : nullptr;
+  h16_t* pah = a.pah ? a.pah + bz * a.bspa : nullptr;
+  h16_t* pal = a.pal ? a.pal + bz * a.bspa : nullptr;
+  h16_t* pbh = a.pbh ? a.pbh + bz * a.bspa : nullptr;
+  h16_t* pbl = a.pbl ? a.pbl + bz * a.bspa : nullptr;
 
 #pragma unroll
   for (int tn = 0; tn < Cfg::TN; ++tn) {
@@ -95,14 +95,14 @@ __device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, i
           *p = a.accumulate ? (*p + v) : v;
         }
         if (pah) {
-          bf16_t hi, lo;
-          split_bf16(v, hi, lo);
+          h16_t hi, lo;
+          split_f16(v, hi, lo);
           pah[(long)row * a.ldpa + col] = hi;
           if (pal) pal[(long)row * a.ldpa + col] = lo;
         }
         if (pbh) {
-          bf16_t hi, lo;
-          split_bf16(v + addv, hi, lo);
+          h16_t hi, lo;
+          split_f16(v + addv, hi, lo);
           pbh[(long)row * a.ldpb + col] = hi;
           if (pbl) pbl[(long)row * a.ldpb + col] = lo;
         }

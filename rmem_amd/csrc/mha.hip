@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   int lo = z * per, hi_s = lo + per;
   if (hi_s > nstages) hi_s = nstages;
 
-  const bf16_t* qp[2] = {a.qh, a.ql};
-  const bf16_t* kp[2] = {a.kh, a.kl};
-  const bf16_t* vp[2] = {a.vh, a.vl};
+  const h16_t* qp[2] = {a.qh, a.ql};
+  const h16_t* kp[2] = {a.kh, a.kl};
+  const h16_t* vp[2] = {a.vh, a.vl};
   frag8_t qf[NPL][2];
 #pragma unroll
   for (int p = 0; p < NPL; ++p)
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void mha_combine_kernel(rmem_mha_combine_args 
   }
   const float y = O / L;
   if (a.of32) a.of32[(long)q * a.ldo + c] = y;
-  bf16_t hi, lo;
-  split_bf16(y, hi, lo);
+  h16_t hi, lo;
+  split_f16(y, hi, lo);
   a.oh[(long)q * a.ldo + c] = hi;
   if (a.ol) a.ol[(long)q * a.ldo + c] = lo;
   if (a.mass) {

@@ -10,7 +10,7 @@
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, long ldx, const float* x2, long ldx2,
                                                               const float* gamma, const float* beta, int N,
                                                               float eps, const float* post, long ldpost,
-                                                              bf16_t* oh, bf16_t* ol, long ldo, float* of32,
+                                                              h16_t* oh, h16_t* ol, long ldo, float* of32,
                                                               long ldof) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -38,9 +38,9 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, lo
   }
   if (of32) *reinterpret_cast<float4*>(of32 + (long)row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
   if (oh) {
-    bf16_t hi[4], lo[4];
+    h16_t hi[4], lo[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split_bf16(y[e], hi[e], lo[e]);
+    for (int e = 0; e < 4; ++e) split_f16(y[e], hi[e], lo[e]);
     uint2 vh, vl;
     vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
     vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, lo
 
 extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, int64_t ldx2, const float* gamma,
                                  const float* beta, int32_t N, int32_t C, float eps, const float* post,
-                                 int64_t ldpost, rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, float* of32,
+                                 int64_t ldpost, rmem_f16* oh, rmem_f16* ol, int64_t ldo, float* of32,
                                  int64_t ldof, void* stream) {
   if (!x || !gamma || !beta || N <= 0 || C != 256 || (ldx % 4) || (ldo % 4) || (ldof % 4) || (ldx2 % 4) ||
       (ldpost % 4))
@@ -68,8 +68,8 @@ extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, i
 // residual reduce (split-K partials, fixed order) + LayerNorm
 __global__ __launch_bounds__(256) void layernorm_red_kernel(float* x, long ldx, const float* parts, int nparts,
                                                             long part_stride, long ldpart, const float* gamma,
-                                                            const float* beta, int N, float eps, bf16_t* oh,
-                                                            bf16_t* ol, long ldo, float* of32, long ldof) {
+                                                            const float* beta, int N, float eps, h16_t* oh,
+                                                            h16_t* ol, long ldo, float* of32, long ldof) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void layernorm_red_kernel(float* x, long ldx, 
   const float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
   if (of32) *reinterpret_cast<float4*>(of32 + (long)row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
   if (oh) {
-    bf16_t hi[4], lo[4];
+    h16_t hi[4], lo[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split_bf16(y[e], hi[e], lo[e]);
+    for (int e = 0; e < 4; ++e) split_f16(y[e], hi[e], lo[e]);
     uint2 vh, vl;
     vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
     vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_red_kernel(float* x, long ldx, 
 
 extern "C" int rmem_layernorm_red(float* x, int64_t ldx, const float* parts, int32_t nparts, int64_t part_stride,
                                   int64_t ldpart, const float* gamma, const float* beta, int32_t N, int32_t C,
-                                  float eps, rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, float* of32, int64_t ldof,
+                                  float eps, rmem_f16* oh, rmem_f16* ol, int64_t ldo, float* of32, int64_t ldof,
                                   void* stream) {
   if (!x || !gamma || !beta || N <= 0 || C != 256 || (ldx % 4) || (ldo % 4) || (ldof % 4) || nparts < 0 ||
       (nparts > 0 && (!parts || (ldpart % 4) || (part_stride % 4))))
@@ -127,8 +127,8 @@ struct LnRedOne {
   const float* parts;
   const float* gamma;
   const float* beta;
-  bf16_t* oh;
-  bf16_t* ol;
+  h16_t* oh;
+  h16_t* ol;
   long ldo;
 };
 __global__ __launch_bounds__(256) void layernorm_red2_kernel(LnRedOne p0, LnRedOne p1, long ldx, int nparts,
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256) void layernorm_red2_kernel(LnRedOne p0, LnRedO
   const float4 g = *reinterpret_cast<const float4*>(p.gamma + lane * 4);
   const float4 b = *reinterpret_cast<const float4*>(p.beta + lane * 4);
   const float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
-  bf16_t hi[4], lo[4];
+  h16_t hi[4], lo[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split_bf16(y[e], hi[e], lo[e]);
+  for (int e = 0; e < 4; ++e) split_f16(y[e], hi[e], lo[e]);
   uint2 vh, vl;
   vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
   vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void layernorm_red2_kernel(LnRedOne p0, LnRedO
 extern "C" int rmem_layernorm_red2(float* x0, float* x1, int64_t ldx, const float* parts0, const float* parts1,
                                    int32_t nparts, int64_t part_stride, int64_t ldpart, const float* gamma0,
                                    const float* beta0, const float* gamma1, const float* beta1, int32_t N,
-                                   int32_t C, float eps, rmem_bf16* oh0, rmem_bf16* ol0, int64_t ldo0,
-                                   rmem_bf16* oh1, rmem_bf16* ol1, int64_t ldo1, void* stream) {
+                                   int32_t C, float eps, rmem_f16* oh0, rmem_f16* ol0, int64_t ldo0,
+                                   rmem_f16* oh1, rmem_f16* ol1, int64_t ldo1, void* stream) {
   if (!x0 || !x1 || !gamma0 || !beta0 || !gamma1 || !beta1 || !oh0 || !oh1 || N <= 0 || C != 256 || (ldx % 4) ||
       (ldo0 % 4) || (ldo1 % 4) || nparts < 0 ||
       (nparts > 0 && (!parts0 || !parts1 || (ldpart % 4) || (part_stride % 4))))
@@ -185,7 +185,7 @@ extern "C" int rmem_layernorm_red2(float* x0, float* x1, int64_t ldx, const floa
 }
 
 extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta,
-                                    int32_t N, int32_t C, float eps, rmem_bf16* oh, rmem_bf16* ol,
+                                    int32_t N, int32_t C, float eps, rmem_f16* oh, rmem_f16* ol,
                                     int64_t ldo, float* of32, int64_t ldof, void* stream) {
   return rmem_layernorm_ex(x, ldx, nullptr, 0, gamma, beta, N, C, eps, nullptr, 0, oh, ol, ldo, of32, ldof, stream);
 }
@@ -197,12 +197,12 @@ extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* ga
 struct DwOne {
   const float* g;
   const float* wt;
-  bf16_t* oh;
-  bf16_t* ol;
+  h16_t* oh;
+  h16_t* ol;
 };
 template <int RX>
 __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const float* wt, int h, int w, int C,
-                                               bf16_t* oh, bf16_t* ol, long ldo, int bz) {
+                                               h16_t* oh, h16_t* ol, long ldo, int bz) {
   const int x0 = blockIdx.x * RX, y = blockIdx.y;
   const int c = (bz * 256 + threadIdx.x) * 4;
   if (c >= C) return;
@@ -249,9 +249,9 @@ __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const f
     if (x >= w) continue;
     const long p = (long)y * w + x;
     const float yv[4] = {acc[o].x, acc[o].y, acc[o].z, acc[o].w};
-    bf16_t hi[4], lo[4];
+    h16_t hi[4], lo[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split_bf16(yv[e], hi[e], lo[e]);
+    for (int e = 0; e < 4; ++e) split_f16(yv[e], hi[e], lo[e]);
     uint2 vh, vl;
     vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
     vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
@@ -264,7 +264,7 @@ __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const f
 
 template <int RX>
 __global__ __launch_bounds__(256) void dwconv5x5_split_kernel(const float* g, long ldg, const float* wt, int h,
-                                                              int w, int C, bf16_t* oh, bf16_t* ol, long ldo) {
+                                                              int w, int C, h16_t* oh, h16_t* ol, long ldo) {
   dwconv5x5_body<RX>(g, ldg, wt, h, w, C, oh, ol, ldo, blockIdx.z);
 }
 
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void dwconv5x5_split2_kernel(DwOne p0, DwOne p
 }
 
 extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t ldg, const float* wt0, const float* wt1,
-                                     int32_t h, int32_t w, int32_t C, rmem_bf16* oh0, rmem_bf16* ol0, rmem_bf16* oh1,
-                                     rmem_bf16* ol1, int64_t ldo, void* stream) {
+                                     int32_t h, int32_t w, int32_t C, rmem_f16* oh0, rmem_f16* ol0, rmem_f16* oh1,
+                                     rmem_f16* ol1, int64_t ldo, void* stream) {
   if (!g0 || !g1 || !wt0 || !wt1 || !oh0 || !oh1 || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4))
     return RMEM_ERR_INVALID;
   constexpr int RX = 6;
@@ -291,7 +291,7 @@ extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t l
 }
 
 extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt, int32_t h, int32_t w,
-                                    int32_t C, rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, void* stream) {
+                                    int32_t C, rmem_f16* oh, rmem_f16* ol, int64_t ldo, void* stream) {
   if (!g || !wt || !oh || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
   constexpr int RX = 6;
   hipLaunchKernelGGL(dwconv5x5_split_kernel<RX>, dim3((w + RX - 1) / RX, h, (C + 1023) / 1024), dim3(256), 0,
@@ -397,8 +397,8 @@ extern "C" int rmem_groupnorm2(const float* tgt, const float* tgt_id, int32_t N,
 __global__ __launch_bounds__(256) void id_assign_kernel(const uint8_t* label, int H, int W, const float* wt,
                                                         const float* bias, int ncls, int ksize, int stride,
                                                         int pad, int ew, const float* gamma, const float* beta,
-                                                        float eps, bf16_t* oh, bf16_t* ol, long ldo, float* of32,
-                                                        long ldof) {
+                                                        float eps, h16_t* oh, h16_t* ol, long ldo, float* of32,
+                                                        long ldof, int ignore_channel) {
   __shared__ float red[4];
   __shared__ float red2[4];
   __shared__ int cls_s[1024];          // class per tap of the receptive field (-1 = no channel)
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void id_assign_kernel(const uint8_t* label, in
     int cls = -1;
     if (y >= 0 && y < H && x >= 0 && x < W) {
       cls = label[(long)y * W + x];
-      if (cls == 255) cls = ncls - 1;      // ignore channel is the last one
+      if (cls == 255) cls = ignore_channel ? ncls - 1 : -1;   // ignore channel is the last one; reference frames carry none
       else if (cls >= ncls - 1) cls = -1;  // ids above max_obj have no one-hot channel
     }
     cls_s[t] = cls;
@@ -447,8 +447,8 @@ __global__ __launch_bounds__(256) void id_assign_kernel(const uint8_t* label, in
   }
   if (of32) of32[(long)tok * ldof + c] = yv;
   if (oh) {
-    bf16_t hi, lo;
-    split_bf16(yv, hi, lo);
+    h16_t hi, lo;
+    split_f16(yv, hi, lo);
     oh[(long)tok * ldo + c] = hi;
     if (ol) ol[(long)tok * ldo + c] = lo;
   }
@@ -456,13 +456,14 @@ __global__ __launch_bounds__(256) void id_assign_kernel(const uint8_t* label, in
 
 extern "C" int rmem_id_assign(const uint8_t* label, int32_t H, int32_t W, const float* wt, const float* bias,
                               int32_t ncls, int32_t ksize, int32_t stride, int32_t pad, int32_t eh, int32_t ew,
-                              int32_t C, const float* gamma, const float* beta, float eps, rmem_bf16* oh,
-                              rmem_bf16* ol, int64_t ldo, float* of32, int64_t ldof, void* stream) {
+                              int32_t C, const float* gamma, const float* beta, float eps, rmem_f16* oh,
+                              rmem_f16* ol, int64_t ldo, float* of32, int64_t ldof, int32_t ignore_channel,
+                              void* stream) {
   if (!label || !wt || !bias || C != 256 || eh <= 0 || ew <= 0 || ncls < 2 || ksize <= 0 || ksize > 32)
     return RMEM_ERR_INVALID;
   hipLaunchKernelGGL(id_assign_kernel, dim3(eh * ew), dim3(256), 0, static_cast<hipStream_t>(stream), label, H, W,
                      wt, bias, ncls, ksize, stride, pad, ew, gamma, beta, eps, oh, ol, (long)ldo, of32,
-                     (long)ldof);
+                     (long)ldof, ignore_channel);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }
@@ -498,16 +499,16 @@ extern "C" int rmem_attn_mass_reduce(const float* mass, int32_t N, int32_t T, co
 }
 
 // ------------------------------------------------------------------ fp32 -> planes
-__global__ void split_planes_kernel(const float* x, long n, bf16_t* hi, bf16_t* lo) {
+__global__ void split_planes_kernel(const float* x, long n, h16_t* hi, h16_t* lo) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    bf16_t h, l;
-    split_bf16(x[i], h, l);
+    h16_t h, l;
+    split_f16(x[i], h, l);
     hi[i] = h;
     if (lo) lo[i] = l;
   }
 }
 
-extern "C" int rmem_split_planes(const float* x, int64_t n, rmem_bf16* hi, rmem_bf16* lo, void* stream) {
+extern "C" int rmem_split_planes(const float* x, int64_t n, rmem_f16* hi, rmem_f16* lo, void* stream) {
   if (!x || !hi || n <= 0) return RMEM_ERR_INVALID;
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -647,16 +648,16 @@ extern "C" int rmem_groupnorm_nchw_bias(const float* x, const float* conv_bias, 
 }
 
 // ------------------------------------------------------------------ planes transpose
-__global__ __launch_bounds__(256) void transpose_planes_kernel(const bf16_t* ih, const bf16_t* il, long ld, int N,
-                                                               int C, bf16_t* oh, bf16_t* ol, long ldo) {
-  __shared__ bf16_t th[64][66];
-  __shared__ bf16_t tl[64][66];
+__global__ __launch_bounds__(256) void transpose_planes_kernel(const h16_t* ih, const h16_t* il, long ld, int N,
+                                                               int C, h16_t* oh, h16_t* ol, long ldo) {
+  __shared__ h16_t th[64][66];
+  __shared__ h16_t tl[64][66];
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     const bool ok = n0 + r < N && c0 + c < C;
-    th[r][c] = ok ? ih[(long)(n0 + r) * ld + c0 + c] : (bf16_t)0;
-    if (il) tl[r][c] = ok ? il[(long)(n0 + r) * ld + c0 + c] : (bf16_t)0;
+    th[r][c] = ok ? ih[(long)(n0 + r) * ld + c0 + c] : (h16_t)0;
+    if (il) tl[r][c] = ok ? il[(long)(n0 + r) * ld + c0 + c] : (h16_t)0;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -668,8 +669,8 @@ __global__ __launch_bounds__(256) void transpose_planes_kernel(const bf16_t* ih,
   }
 }
 
-extern "C" int rmem_transpose_planes(const rmem_bf16* ih, const rmem_bf16* il, int64_t ld, int32_t N, int32_t C,
-                                     rmem_bf16* oh, rmem_bf16* ol, int64_t ldo, void* stream) {
+extern "C" int rmem_transpose_planes(const rmem_f16* ih, const rmem_f16* il, int64_t ld, int32_t N, int32_t C,
+                                     rmem_f16* oh, rmem_f16* ol, int64_t ldo, void* stream) {
   if (!ih || !oh || N <= 0 || C <= 0) return RMEM_ERR_INVALID;
   hipLaunchKernelGGL(transpose_planes_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0,
                      static_cast<hipStream_t>(stream), ih, il, (long)ld, N, C, oh, ol, (long)ldo);
@@ -678,20 +679,20 @@ extern "C" int rmem_transpose_planes(const rmem_bf16* ih, const rmem_bf16* il, i
 }
 
 // ------------------------------------------------------------------ a + b -> fp32 / planes
-__global__ void add_split_kernel(const float* a, const float* b, long n, float* dst, bf16_t* oh, bf16_t* ol) {
+__global__ void add_split_kernel(const float* a, const float* b, long n, float* dst, h16_t* oh, h16_t* ol) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = a[i] + (b ? b[i] : 0.f);
     if (dst) dst[i] = v;
     if (oh) {
-      bf16_t h, l;
-      split_bf16(v, h, l);
+      h16_t h, l;
+      split_f16(v, h, l);
       oh[i] = h;
       if (ol) ol[i] = l;
     }
   }
 }
 
-extern "C" int rmem_add_split(const float* a, const float* b, int64_t n, float* dst, rmem_bf16* oh, rmem_bf16* ol,
+extern "C" int rmem_add_split(const float* a, const float* b, int64_t n, float* dst, rmem_f16* oh, rmem_f16* ol,
                               void* stream) {
   if (!a || n <= 0 || (!dst && !oh)) return RMEM_ERR_INVALID;
   long blocks = (n + 255) / 256;
@@ -958,4 +959,4 @@ extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 7; }   // 7: planes are fp16 hi/lo
+extern "C" int rmem_abi_version(void) { return 8; }   // 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

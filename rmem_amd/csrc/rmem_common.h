@@ -5,10 +5,10 @@
 // conversions and by the MFMA, tools/ubench/f16_denorm.hip).  A product of two such values
 // evaluated on the 16-bit MFMA pipe as  hi*lo' + lo*hi' + hi*hi'  (NSPLIT = 3) has a relative
 // error of ~2^-21 per product, i.e. fp32-class, at 3 MFMA issues; NSPLIT = 1 uses hi*hi' only
-// (plain fp16).  All accumulation is fp32 in the MFMA accumulators.  The first builds carried
-// bf16 planes (16 bits, 2^-17): measured on the golden 480p clip that rounding alone moved 31
-// label pixels over 9 frames, fp16 planes move 3 (tools/precision_study.py lin16bf / lin16x2) at
-// the same MFMA rate.  Values beyond +-65504 saturate (the reference itself evaluates under fp16
+// (plain fp16).  All accumulation is fp32 in the MFMA accumulators.  (bf16 hi/lo planes carry 16
+// bits, 2^-17 per product: measured on the golden 480p clip that rounding alone moved 31 label
+// pixels over 9 frames, fp16 planes move 3 -- tools/precision_study.py lin16bf / lin16x2 -- at the
+// same MFMA rate.)  Values beyond +-65504 saturate (the reference itself evaluates under fp16
 // autocast with --amp).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,9 +18,8 @@
 #define RMEM_ERR_INVALID (-1)
 #define RMEM_ERR_LAUNCH (-2)
 
-typedef unsigned short bf16_t;  // raw 16 bits of a plane element (fp16 since the split-fp16 switch; the name is historical)
+typedef unsigned short h16_t;  // raw 16 bits of a plane element (IEEE fp16)
 typedef __attribute__((ext_vector_type(8))) _Float16 frag8_t;   // MFMA operand fragment: 8 consecutive k of one row
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
@@ -37,20 +36,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     }                                                                                                \
   } while (0)
 
-// round-to-nearest-even; gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-
 // fp16 bits of x, round-to-nearest-even (subnormals kept)
 __device__ __forceinline__ unsigned short f2h_bits(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
 __device__ __forceinline__ float h_bits2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
-// two bf16 (one 32-bit word) -> two fp16 (exact inside the fp16 normal range: 8 mantissa bits fit in 11)
-__device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned w) {
-  const auto h = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
-  return __builtin_bit_cast(unsigned, h);
-}
 
-__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {   // -> fp16 hi/lo planes
+__device__ __forceinline__ void split_f16(float x, h16_t& hi, h16_t& lo) {   // -> fp16 hi/lo planes
   const float xc = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
   hi = f2h_bits(xc);
   lo = f2h_bits(__builtin_amdgcn_fmed3f(xc - h_bits2f(hi), -65504.f, 65504.f));
@@ -70,7 +60,7 @@ __device__ __forceinline__ float dec_ordered(uint32_t u) {
 // exp for softmax weights exp(s - max), s - max <= 0: v_exp_f32(x * log2(e)), 2 instructions
 // instead of the 13 of the correctly rounded expf (the flash MHA kernel is VALU-bound: 91 vs
 // 125 us).  Relative error ~ |x| * 6e-8 + 1 ulp: below 1e-6 for every weight that matters
-// (x > -15), an order of magnitude inside the split-bf16 product error (2^-17); carrying the
+// (x > -15), an order of magnitude inside the split-fp16 product error (2^-21 relative per product); carrying the
 // rounding error of the product as a correction term (6 instructions) changed nothing measurable.
 // -3e38 sentinels overflow to -inf and give exactly 0.
 __device__ __forceinline__ float exp_weight(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }

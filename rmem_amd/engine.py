@@ -58,7 +58,9 @@ class _GraphLauncher(threading.Thread):
                 with torch.no_grad(), torch.cuda.stream(stream):
                     stream.wait_event(after)
                     for i in range(dst.shape[0]):
-                        dst[i:i + 1].copy_(srcs[min(i, len(srcs) - 1)], non_blocking=True)
+                        src = srcs[min(i, len(srcs) - 1)]
+                        dst[i:i + 1].copy_(src, non_blocking=True)
+                        src.record_stream(stream)     # the caller may free it before this copy has run
                     graph.replay()
                     done_event.record(stream)
             except BaseException as e:          # surfaced by the next wait on the engine thread
@@ -169,7 +171,9 @@ class DeAOTEngine(nn.Module):
             raise ValueError("No image for reference frame!")
         if self.input_size_2d is None:
             self.update_size(img.shape[2:], enc[-1].shape[2:])
-        self.lstt.assign_identity(self._label_u8(mask))
+        # no ignore channel on reference frames: the reference calls assign_identity without an
+        # ignore mask here (aot_engine.py:304 -> :209-213), so a 255 pixel contributes nothing
+        self.lstt.assign_identity(self._label_u8(mask), ignore=False)
         out = self.lstt.forward(self._tokens(enc[-1]), ref_frame=True)
         self.last_mem_step = frame_step
         # A reference frame re-initialises the bank to one slot.  The reference keeps the old
@@ -211,9 +215,24 @@ class DeAOTEngine(nn.Module):
         return (self.use_graphs and img_embs is None and img is not None and img.is_cuda
                 and self._eager_frames >= 2 and not self.lstt._timing)
 
-    @staticmethod
-    def _img_id(img):
-        return (img.data_ptr(), tuple(img.shape), img._version)
+    class _ImgId:
+        """Identity of an announced frame: the tensor OBJECT (a strong reference, so its address
+        cannot be recycled for another frame while the entry is pending) and its version counter.
+        Callers must pass to match_propogate_one_frame the same tensor objects they announced."""
+        __slots__ = ("img", "version")
+
+        def __init__(self, img):
+            self.img, self.version = img, img._version
+
+        def __eq__(self, other):
+            return isinstance(other, DeAOTEngine._ImgId) and self.img is other.img and self.version == other.version
+
+        def __hash__(self):
+            return hash((id(self.img), self.version))
+
+    @classmethod
+    def _img_id(cls, img):
+        return cls._ImgId(img)
 
     @property
     def lookahead(self) -> int:

@@ -142,7 +142,7 @@ def load():
     lib.rmem_dwconv5x5_split.argtypes = [c_p, i64, c_p, i32, i32, i32, c_p, c_p, i64, c_p]
     lib.rmem_groupnorm2.argtypes = [c_p, c_p, i32, i32, c_p, c_p, f32, c_p, c_p, i64, c_p]
     lib.rmem_id_assign.argtypes = [c_p, i32, i32, c_p, c_p, i32, i32, i32, i32, i32, i32, i32,
-                                   c_p, c_p, f32, c_p, c_p, i64, c_p, i64, c_p]
+                                   c_p, c_p, f32, c_p, c_p, i64, c_p, i64, i32, c_p]
     lib.rmem_attn_mass_reduce.argtypes = [c_p, i32, i32, c_p, c_p, c_p]
     lib.rmem_split_planes.argtypes = [c_p, i64, c_p, c_p, c_p]
     lib.rmem_groupnorm_nchw.argtypes = [c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]

@@ -182,7 +182,7 @@ class DeAOTLSTT:
         self._layer = 0
         # bank reads (long-term, self) with P as ONE fp16 plane: 2 MFMAs per product instead of 3
         # (rmem_attn_scores / rmem_attn_pv with pl = NULL); the windowed read keeps hi/lo planes
-        self.p16 = self.nsplit == 3 and os.environ.get("RMEM_P16", "1") == "1"
+        self.p16 = self.nsplit == 3 and os.environ.get("RMEM_P16", "0") == "1"
         self.ksplits_max = 8
         # attention workspaces: main stream (long-term, self) and side stream (short-term window)
         self.ws_main = _AttnWS(self.Tmax, N, Np, self.ksplits_max, dev)
@@ -400,14 +400,16 @@ class DeAOTLSTT:
                           nsplit=self.nsplit, tile=64, launch=launch)
 
     # ------------------------------------------------------------------ ID assignment
-    def assign_identity(self, label_u8: torch.Tensor):
-        """label [H][W] uint8 on device -> id_emb planes (aot_engine.py:208-232, deaot.py:65-69)."""
+    def assign_identity(self, label_u8: torch.Tensor, ignore: bool = True):
+        """label [H][W] uint8 on device -> id_emb planes (aot_engine.py:208-232, deaot.py:65-69).
+        ignore=True: label 255 selects the ignore channel (update_short_term_memory, :330-336);
+        ignore=False: label 255 contributes nothing (add_reference_frame, :304 -> :209-213)."""
         H, Wd = label_u8.shape
         rc = hip.load().rmem_id_assign(
             label_u8.data_ptr(), H, Wd, self.id_wt.data_ptr(), self.id_bias.data_ptr(), self.id_ncls,
             self.id_ksize, self.id_stride, self.id_pad, self.h, self.w, 256, self.id_gamma.data_ptr(),
             self.id_beta.data_ptr(), 1e-5, self.idemb_pl.hi.data_ptr(), self.idemb_pl.lo.data_ptr(), 256,
-            None, 0, hip.stream_ptr())
+            None, 0, int(bool(ignore)), hip.stream_ptr())
         hip.check(rc, "rmem_id_assign")
 
     # ------------------------------------------------------------------ forward

@@ -227,13 +227,14 @@ class AOTLSTT:
         c.mass = self.mass.data_ptr() if want_mass else None
         hip.check(lib.rmem_mha_combine(C.byref(c), st), "rmem_mha_combine")
 
-    def assign_identity(self, label_u8: torch.Tensor):
-        """label [H][W] uint8 -> id_emb fp32 [N][256]; AOT has no id LayerNorm (aot.py:111-114)."""
+    def assign_identity(self, label_u8: torch.Tensor, ignore: bool = True):
+        """label [H][W] uint8 -> id_emb fp32 [N][256]; AOT has no id LayerNorm (aot.py:111-114).
+        ignore: see DeAOTLSTT.assign_identity (False for reference frames)."""
         H, Wd = label_u8.shape
         rc = hip.load().rmem_id_assign(
             label_u8.data_ptr(), H, Wd, self.id_wt.data_ptr(), self.id_bias.data_ptr(), self.id_ncls,
             self.id_ksize, self.id_stride, self.id_pad, self.h, self.w, 256, None, None, 1e-5, None, None, 256,
-            self.idemb.data_ptr(), 256, hip.stream_ptr())
+            self.idemb.data_ptr(), 256, int(bool(ignore)), hip.stream_ptr())
         hip.check(rc, "rmem_id_assign")
 
     # ------------------------------------------------------------------ forward

@@ -29,7 +29,7 @@ sys.path.insert(0, HERE)
 
 import refharness as rh  # noqa: E402
 from rmem_amd.synth import synth_clip  # noqa: E402
-from make_golden_inputs import tta_new_object_label  # noqa: E402
+from make_golden_inputs import ignore_region_label, tta_new_object_label  # noqa: E402
 from inputs import (AOT_BLOCK_CASES, BLOCK_CASES, IDASSIGN_CASES, aot_block_case_name,  # noqa: E402
                     aot_block_inputs, block_case_name, block_inputs, idassign_label)
 
@@ -248,6 +248,34 @@ def gen_clips():
     print("clip 480p indexes", rec["indexes"])
 
 
+def gen_ignore_clip():
+    """A clip whose reference mask holds 255 pixels, through the reference's own
+    add_reference_frame (no ignore mask there) and update_memory (argmax labels, no 255)."""
+    name, H, W, frames, gap, former, latter = "ign255_k4_gap2", 97, 129, 10, 2, 1, 3
+    cfg, model, engine = rh.build_reference("r50_deaotl", former, latter, gap)
+    imgs, lab = synth_clip(11, frames, H, W, 3)
+    lab = ignore_region_label(lab)
+    rec = dict(indexes=[], labels=[], logits={})
+    with torch.no_grad(), rh.quiet():
+        engine.restart_engine()
+        engine.add_reference_frame(imgs[0], lab.int(), obj_nums=[3], frame_step=0)
+        sub = engine.aot_engines[0]
+        rec["ref_logits"] = sub.pred_id_logits.clone()
+        for t in range(1, frames):
+            logit = engine.match_propogate_one_frame(imgs[t], output_size=(H, W))
+            pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float()
+            engine.update_memory(F.interpolate(pred, size=engine.input_size_2d, mode="nearest"))
+            rec["indexes"].append(list(sub.long_memories_indexes))
+            rec["labels"].append(pred[0, 0].to(torch.uint8))
+        rec["last_logits"] = sub.pred_id_logits.clone()
+    meta = dict(H=H, W=W, frames=frames, gap=gap, former=former, latter=latter, seed=11,
+                indexes=rec["indexes"], label_sha=[sha(l) for l in rec["labels"]])
+    json.dump(meta, open(os.path.join(HERE, f"clip_small_{name}.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, f"clip_small_{name}.npz"), labels=torch.stack(rec["labels"]).numpy(),
+                        ref_logits=rec["ref_logits"].numpy(), last_logits=rec["last_logits"].numpy())
+    print("ignore clip indexes", rec["indexes"][-1])
+
+
 def gen_tta():
     """Flip test-time augmentation + mid-clip new object, driven exactly as
     managers/evaluator.py:337-527 drives its engines (one engine per augmentation, the
@@ -318,6 +346,9 @@ def main():
     if "--tta-only" in sys.argv:
         gen_tta()
         return
+    if "--ignore-only" in sys.argv:
+        gen_ignore_clip()
+        return
     if "--aot-only" not in sys.argv and "--swin-only" not in sys.argv:
         cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
         gen_manifest(model)
@@ -332,6 +363,7 @@ def main():
         gen_aot_clips()
     gen_swin()
     gen_tta()
+    gen_ignore_clip()
     os.system(f"du -sh {HERE}")
 
 

@@ -7,3 +7,13 @@ def tta_new_object_label(out_hw):
     lab = torch.zeros(1, 1, *out_hw)
     lab[:, :, out_hw[0] // 8: out_hw[0] // 3, out_hw[1] // 2: out_hw[1] * 3 // 4] = 4
     return lab
+
+
+def ignore_region_label(label0):
+    """Reference-frame label with an ignore (255) rectangle that overlaps object 1 and the
+    background: exercises the rule that add_reference_frame passes NO ignore mask to
+    assign_identity (aot_engine.py:304 -> :209-213), so 255 pixels carry no channel at all."""
+    lab = label0.clone()
+    H, W = lab.shape[-2:]
+    lab[:, :, H // 8: H // 3, W // 5: W // 2] = 255
+    return lab

@@ -117,6 +117,33 @@ def test_small_clip(name, golden_dir):
             assert mism[0] <= 1
 
 
+def test_reference_mask_with_ignore_label(golden_dir):
+    """Reference mask with 255 pixels (golden clip from the reference's own add_reference_frame,
+    which passes no ignore mask: aot_engine.py:304 -> :209-213): reference-frame decoder logits,
+    teacher-forced label maps and the eviction sequence."""
+    from make_golden_inputs import ignore_region_label
+    from rmem_amd.synth import synth_clip
+    meta = json.load(open(os.path.join(golden_dir, "clip_small_ign255_k4_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_small_ign255_k4_gap2.npz"))
+    cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"])
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    lab = ignore_region_label(lab)
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    rerr = np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["ref_logits"]).max()
+    print("reference-frame logit max abs err:", rerr)
+    assert rerr < 2e-3                      # the ignore-channel rule is off by > 0.1 here
+    mism, idx = [], []
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(meta["H"], meta["W"]))
+        pred = torch.argmax(logit, dim=1, keepdim=True)
+        mism.append(int((pred[0, 0].cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        idx.append(list(eng.aot_engines[0].long_memories_indexes))
+    print("ign255 clip mismatching pixels per frame:", mism)
+    assert idx == meta["indexes"] and max(mism) <= 2, (idx, mism)
+
+
 @pytest.mark.parametrize("nsplit", [3, 1])
 def test_480p_teacher_forced(nsplit, golden_dir):
     """481x849 (N=1674, K=4, gap=2, one eviction): update_memory is fed the reference's

@@ -355,7 +355,7 @@ def test_id_assign_vs_golden(hip, deaot_model, golden_dir):
                                      kb.data_ptr(), 12, 17, 16, 8, eh, ew,
                                      256, g1.data_ptr(),
                                      g2.data_ptr(), 1e-5, pl.hi.data_ptr(),
-                                     pl.lo.data_ptr(), 256, of.data_ptr(), 256, st), "id_assign")
+                                     pl.lo.data_ptr(), 256, of.data_ptr(), 256, 1, st), "id_assign")
         torch.cuda.synchronize()
         assert np.abs(of.cpu().numpy() - gold["id_emb"]).max() < 2e-5
         assert np.abs(pl.float().cpu().numpy() - gold["id_emb"]).max() < 5e-5
@@ -380,16 +380,17 @@ def test_id_assign_full_size_and_label_edge_cases(hip, deaot_model):
         lab[5:30, 10:60] = 14                                        # id above MAX_OBJ: contributes nothing
         cases = [lab, np.zeros((H, W), np.uint8), np.full((H, W), 255, np.uint8)] if H == 481 else [lab]
         for m in cases:
-            ref = R.id_assign(torch.from_numpy(m.astype(np.float32))[None, None], sd)
-            d = torch.from_numpy(m).to(DEV).contiguous()
-            of = torch.zeros(eh * ew, 256, device=DEV)
-            pl = hip.Planes.empty((eh * ew, 256), DEV)
-            hip.check(lib.rmem_id_assign(d.data_ptr(), H, W, wt.data_ptr(), kb.data_ptr(), 12, 17, 16, 8, eh, ew,
-                                         256, g1.data_ptr(), g2.data_ptr(), 1e-5, pl.hi.data_ptr(),
-                                         pl.lo.data_ptr(), 256, of.data_ptr(), 256, st), "id_assign")
-            torch.cuda.synchronize()
-            err = (of.cpu() - ref).abs().max().item()
-            assert err < 5e-5, (H, W, err)
+            for ign in (True, False):     # False: reference-frame rule, label 255 contributes nothing
+                ref = R.id_assign(torch.from_numpy(m.astype(np.float32))[None, None], sd, use_ignore=ign)
+                d = torch.from_numpy(m).to(DEV).contiguous()
+                of = torch.zeros(eh * ew, 256, device=DEV)
+                pl = hip.Planes.empty((eh * ew, 256), DEV)
+                hip.check(lib.rmem_id_assign(d.data_ptr(), H, W, wt.data_ptr(), kb.data_ptr(), 12, 17, 16, 8, eh, ew,
+                                             256, g1.data_ptr(), g2.data_ptr(), 1e-5, pl.hi.data_ptr(),
+                                             pl.lo.data_ptr(), 256, of.data_ptr(), 256, int(ign), st), "id_assign")
+                torch.cuda.synchronize()
+                err = (of.cpu() - ref).abs().max().item()
+                assert err < 5e-5, (H, W, ign, err)
 
 
 def test_groupnorm_nchw_relu(hip):

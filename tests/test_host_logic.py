@@ -175,5 +175,5 @@ def test_c_abi_rejects_invalid_arguments():
     assert lib.rmem_pe_bias(None, 0, None, None, None, 0, 0, 0, None, None) == -1
     assert lib.rmem_layernorm_split(None, 0, None, None, 0, 256, 1e-5, None, None, 0, None, 0, None) == -1
     assert lib.rmem_id_assign(None, 0, 0, None, None, 12, 17, 16, 8, 1, 1, 256, None, None, 1e-5,
-                              None, None, 0, None, 0, None) == -1
+                              None, None, 0, None, 0, 1, None) == -1
     assert lib.rmem_set_ints(None, None, 0, None) == -1

@@ -119,6 +119,38 @@ def test_small_clip_state_machine(name, golden_dir):
     assert np.abs(rec["logits"][last].numpy() - gold["last_logits"]).max() < 1e-4
 
 
+def test_reference_mask_with_ignore_label(golden_dir):
+    """Reference mask holding 255 pixels (golden clip produced by the reference's own
+    add_reference_frame): the reference frame's ID assignment has NO ignore channel
+    (aot_engine.py:304 -> :209-213).  Decoder logits of the reference frame, every label map
+    and the eviction sequence; and the ignore-channel variant must NOT reproduce them."""
+    from make_golden_inputs import ignore_region_label
+    meta = json.load(open(os.path.join(golden_dir, "clip_small_ign255_k4_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_small_ign255_k4_gap2.npz"))
+    torch.manual_seed(0)
+    model = build_vos_model("deaot", get_config("r50_deaotl")).eval()
+    load_synthetic_weights(model)
+    model.cfg = get_config("r50_deaotl", meta["former"], meta["latter"])
+    eng = OracleDeAOTEngine(model, long_term_mem_gap=meta["gap"])
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    lab = ignore_region_label(lab)
+    assert int((lab == 255).sum()) > 0
+    eng.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    assert np.abs(eng.pred_id_logits.numpy() - gold["ref_logits"]).max() < 1e-4
+    wrong = R.id_assign(lab, eng.sd, use_ignore=True) - R.id_assign(lab, eng.sd, use_ignore=False)
+    assert wrong.abs().max() > 1e-2          # the two rules differ on this mask
+    idx, labels = [], []
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t], output_size=(meta["H"], meta["W"]))
+        pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float()
+        eng.update_memory(F.interpolate(pred, size=eng.input_size_2d, mode="nearest"))
+        idx.append(list(eng.long_memories_indexes))
+        labels.append(pred[0, 0].to(torch.uint8))
+    assert idx == meta["indexes"]
+    assert int((torch.stack(labels).numpy() != gold["labels"]).sum()) == 0
+    assert np.abs(eng.pred_id_logits.numpy() - gold["last_logits"]).max() < 1e-4
+
+
 @pytest.mark.slow
 def test_480p_clip(golden_dir):
     """481x849 (N=1674), K=4, gap=2, 10 frames with one eviction: label hashes + logits."""
