@@ -219,9 +219,8 @@ def main():
         "value": fps, "unit": "frames/s (whole job)", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("fp16x3 (split-fp16 MFMA: hi/lo planes, 3 products, fp32 accumulate; bank reads: P one fp16 plane, 2 products)"
-                  if getattr(lstt, "p16", False) else "fp16x3 (split-fp16 MFMA: hi/lo planes, 3 products, fp32 accumulate)")
-        if args.nsplit == 3 else "fp16 (MFMA, fp32 accumulate)",
+        "dtype": "fp16x3 (split-fp16 MFMA: hi/lo planes, 3 products, fp32 accumulate)"
+        if args.nsplit == 3 else "fp16 linears (MFMA, fp32 accumulate), fp16x3 memory reads",
         "data": "synthetic",
         "config": {"workload": f"{ {'r50_deaotl': 'R50-DeAOTL', 'r50_aotl': 'R50-AOTL', 'swinb_aotl': 'SwinB-AOTL'}[args.model] } + RMem, {H_OUT}p ({H_IN}x{W_IN}, {lstt.N} tokens), K={mem_k} memory, "
                                f"batch={C} clip{'s' if C > 1 else ''} per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
@@ -233,19 +232,17 @@ def main():
     }
     if rank == 0:
         out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)
-        if out["roofline"] and hasattr(lstt, "time_long_pv_isolated"):
+        if out["roofline"] and hasattr(lstt, "time_read_isolated"):
             # information only: the same launch with the GPU to itself (in the frame it shares the
             # CUs with the prefetched encoder pass); `achieved` / `frac` above are the in-frame figures
-            iso = lstt.time_long_pv_isolated()
+            iso = lstt.time_read_isolated()
             out["roofline"]["isolated_mean_us"] = iso
             out["roofline"]["frac_isolated"] = out["roofline"]["algorithmic_flops_per_launch"] / (iso * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
         # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
-        p16 = bool(getattr(lstt, "p16", False))
-        pmc_name = "r01_n_pmc_pv_long.json" if p16 else "r01_h_pmc_pv_long.json"     # pv16_kernel / pv_kernel<3>
+        pmc_name = "r02_pmc_read2.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
-        if out["roofline"] and args.config == "480p_k4" and args.nsplit == 3 and args.model == "r50_deaotl" \
-                and os.path.exists(pmc):
+        if out["roofline"] and args.config == "480p_k4" and args.model == "r50_deaotl" and os.path.exists(pmc):
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = f"bytes/launch (rocprofv3 PMC, profiles/{pmc_name})"
         if world == 1 and not args.no_cpu_baseline and args.model == "r50_deaotl":

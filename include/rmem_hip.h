@@ -72,6 +72,10 @@ typedef struct {
                                               parts[split][M][N] instead of the outputs above; the
                                               consumer sums them in split order (rmem_layernorm_red) */
   float *parts; int64_t part_stride;       /* elements between splits (>= M*N)          */
+  int32_t pa_blocked;                      /* != 0: pah/pal are written "blocked-16" over rows: element (row, col)
+                                              at ((row/16)*ldpa + col)*16 + row%16 (ldpa = columns of the blocked
+                                              tensor; a column window is selected by offsetting pah/pal by 16*col0
+                                              elements); the V operand layout of rmem_attn_read; only output allowed */
 } rmem_linear_args;
 
 int rmem_linear(const rmem_linear_args *a, void *stream);
@@ -149,6 +153,50 @@ int rmem_attn_combine(const rmem_combine_args *a, void *stream);
 
 /* The combine steps of two reads in one launch (see rmem_attn_scores2). */
 int rmem_attn_combine2(const rmem_combine_args *a, const rmem_combine_args *b, void *stream);
+
+/* ------------------------------------------------------------------ fused memory read
+ * The same read (GatedPropagation.forward / LocalGatedPropagation.forward, layers/attention.py:
+ * 174-209 and 289-358, call sites layers/transformer.py:1183, 1199, 1227) as ONE flash-style
+ * launch: S = scale*(Q.K^T + bias), online softmax, O = P.V per key split, the probability matrix
+ * stays in LDS.  rmem_attn_read_combine merges the splits, normalises, gates with U and emits the
+ * per-slot attention mass (record_attn_weight, transformer.py:1186-1192).
+ * Modes and the K / Q layouts are those of rmem_attn_scores.  V is "blocked-16":
+ * planes [slot][Npad/16][ncols][16] (element (key k, column c) at ((k/16)*ncols + c)*16 + k%16),
+ * written by rmem_linear with pa_blocked = 1, so that an MFMA B fragment of 32 columns is one
+ * contiguous KiB.  ncols must be a multiple of 512.  Split precision (hi/lo planes, 3 products) only.
+ * Requires rmem_init() on the device (dynamic LDS above 64 KiB).
+ */
+typedef struct {
+  int32_t mode;                            /* 0 bank, 1 window                         */
+  const rmem_f16 *qh, *ql;                 /* Q planes [Npad][128]                      */
+  const rmem_f16 *kh, *kl; int64_t k_slot_stride;   /* K planes [slot][Npad][128]       */
+  const rmem_f16 *vh, *vl; int64_t v_slot_stride;   /* V planes, blocked-16             */
+  const int32_t *slot_map;                 /* device [T] logical -> physical slot, or NULL */
+  int32_t T, N, Npad, ncols;
+  float scale;
+  const float *bias;                       /* mode 0: [N][T] or NULL                    */
+  const float *R; int32_t ldr; int32_t h, w;  /* mode 1                                 */
+  int32_t ksplits;                         /* <= 32                                     */
+  float *part;                             /* [ksplits][Npad][ncols] un-normalised partial O */
+  float *ml;                               /* [ksplits][Npad][2]  (running max, row sum) */
+  float *lslot;                            /* [ksplits][Npad][T][2] per-slot (sum, max at that time) or NULL */
+} rmem_read_args;
+
+int rmem_attn_read(const rmem_read_args *a, void *stream);
+/* the bank read (a: mode 0) and the windowed read (b: mode 1) of one GPM layer in one launch */
+int rmem_attn_read2(const rmem_read_args *a, const rmem_read_args *b, void *stream);
+
+typedef struct {
+  int32_t T, N, Npad, ncols, ksplits;
+  const float *part; const float *ml; const float *lslot;
+  const float *U; int64_t ldu;             /* gate [N][ncols] (attention.py:206)        */
+  float *G; int64_t ldg;                   /* out: gated aggregate [N][ncols] fp32      */
+  float *mass;                             /* out (may be NULL): [N][T]                 */
+} rmem_read_combine_args;
+
+int rmem_attn_read_combine(const rmem_read_combine_args *a, void *stream);
+/* two reads of one layer in one launch (long-term bank + windowed short-term) */
+int rmem_attn_read_combine2(const rmem_read_combine_args *a, const rmem_read_combine_args *b, void *stream);
 
 /* bias[q][t] = (Q[q] + cur_pe) . mem_pe[pe_row[t]]   (layers/transformer.py:1140-1172) */
 int rmem_pe_bias(const float *Q, int64_t ldq, const float *cur_pe, const float *mem_pe,

@@ -78,6 +78,41 @@ __device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, i
     const float addv = a.addvec ? a.addvec[col] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm) {
+      if (a.pa_blocked) {
+        // plane output in the "blocked-16" layout of the fused memory read (fused.hip): element
+        // (row, col) at ((row / 16) * ldpa + col) * 16 + row % 16.  Accumulator registers 4g..4g+3
+        // are 4 consecutive rows of one 16-row block: one 8-byte store per plane.
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row0 = m0 + frag_row<Cfg>(wr, tm, 4 * g, lane);
+          h16_t hh[4], ll[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = f.acc[tm][tn][4 * g + e] + bcol;
+            if (bias && a.bias_per_row && row0 + e < a.M) v += bias[row0 + e];
+            if (a.act == 1) v = silu_f(v);
+            split_f16(v, hh[e], ll[e]);
+          }
+          const long off = ((long)(row0 >> 4) * a.ldpa + col) * 16 + (row0 & 15);
+          if (row0 + 3 < a.M) {
+            uint2 wh, wl;
+            wh.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+            wh.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+            wl.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
+            wl.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+            *reinterpret_cast<uint2*>(pah + off) = wh;
+            if (pal) *reinterpret_cast<uint2*>(pal + off) = wl;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (row0 + e < a.M) {
+                pah[off + e] = hh[e];
+                if (pal) pal[off + e] = ll[e];
+              }
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + frag_row<Cfg>(wr, tm, r, lane);
@@ -166,6 +201,7 @@ static int validate_linear(rmem_linear_args& a) {
   if (a.csplit <= 0 || a.csplit > a.N) a.csplit = a.N;
   if (a.ksplits > 1 && (!a.parts || a.nbatch > 1 || a.act != 0 || a.bias_per_row || a.ksplits > a.K / 64))
     return RMEM_ERR_INVALID;
+  if (a.pa_blocked && (!a.pah || a.d0 || a.d1 || a.pbh || a.ksplits > 1)) return RMEM_ERR_INVALID;   // blocked planes are the only output
   return RMEM_OK;
 }
 

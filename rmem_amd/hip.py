@@ -39,6 +39,27 @@ class LinearArgs(C.Structure):
         ("nbatch", i32), ("bsx", i64), ("bsy", i64), ("bsd", i64), ("bsbias", i64), ("bspa", i64),
         ("nsplit", i32), ("tile", i32),
         ("ksplits", i32), ("parts", c_p), ("part_stride", i64),
+        ("pa_blocked", i32),
+    ]
+
+
+class ReadArgs(C.Structure):
+    _fields_ = [
+        ("mode", i32),
+        ("qh", c_p), ("ql", c_p),
+        ("kh", c_p), ("kl", c_p), ("k_slot_stride", i64),
+        ("vh", c_p), ("vl", c_p), ("v_slot_stride", i64),
+        ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32), ("ncols", i32),
+        ("scale", f32), ("bias", c_p), ("R", c_p), ("ldr", i32), ("h", i32), ("w", i32),
+        ("ksplits", i32), ("part", c_p), ("ml", c_p), ("lslot", c_p),
+    ]
+
+
+class ReadCombineArgs(C.Structure):
+    _fields_ = [
+        ("T", i32), ("N", i32), ("Npad", i32), ("ncols", i32), ("ksplits", i32),
+        ("part", c_p), ("ml", c_p), ("lslot", c_p),
+        ("U", c_p), ("ldu", i64), ("G", c_p), ("ldg", i64), ("mass", c_p),
     ]
 
 
@@ -104,6 +125,7 @@ EXPORTS = [
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2",
     "rmem_bias_act_nchw_batched", "rmem_attn_scores2", "rmem_attn_combine2", "rmem_dwconv5x5_split2",
+    "rmem_attn_read", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
 ]
 
 
@@ -136,6 +158,10 @@ def load():
     lib.rmem_attn_combine2.argtypes = [C.POINTER(CombineArgs), C.POINTER(CombineArgs), c_p]
     lib.rmem_dwconv5x5_split2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p]
     lib.rmem_attn_pv.argtypes = [C.POINTER(PVArgs), c_p]
+    lib.rmem_attn_read.argtypes = [C.POINTER(ReadArgs), c_p]
+    lib.rmem_attn_read2.argtypes = [C.POINTER(ReadArgs), C.POINTER(ReadArgs), c_p]
+    lib.rmem_attn_read_combine.argtypes = [C.POINTER(ReadCombineArgs), c_p]
+    lib.rmem_attn_read_combine2.argtypes = [C.POINTER(ReadCombineArgs), C.POINTER(ReadCombineArgs), c_p]
     lib.rmem_attn_combine.argtypes = [C.POINTER(CombineArgs), c_p]
     lib.rmem_pe_bias.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]
     lib.rmem_layernorm_split.argtypes = [c_p, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64, c_p, i64, c_p]
@@ -213,7 +239,8 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
            pa: Planes = None, ldpa=0, pb: Planes = None, ldpb=0, addvec=None,
            x2: Planes = None, ldx2=0, kx_split=0, y2: Planes = None, ldy2=0, ky_split=0,
            nbatch=1, bsx=0, bsy=0, bsd=0, bsbias=0, bspa=0, nsplit=3, tile=0,
-           x_off=0, y_off=0, ksplits=1, parts=None, part_stride=0, launch=True):
+           x_off=0, y_off=0, ksplits=1, parts=None, part_stride=0, launch=True, pa_blocked=False,
+           pa_off=0):
     """x_off / y_off: element offsets into the plane tensors (column windows).
     launch=False returns the filled argument struct (for linear_grouped)."""
     a = LinearArgs()
@@ -229,7 +256,8 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
     a.d0, a.ldd0, a.d1, a.ldd1 = d0, ldd0, d1, ldd1
     a.csplit, a.accumulate = csplit, int(accumulate)
     if pa is not None:
-        a.pah, a.pal, a.ldpa = pa.hi.data_ptr(), pa.lo.data_ptr(), ldpa
+        a.pah, a.pal, a.ldpa = pa.hi.data_ptr() + pa_off * eb, pa.lo.data_ptr() + pa_off * eb, ldpa
+        a.pa_blocked = int(bool(pa_blocked))
     if pb is not None:
         a.pbh, a.pbl, a.ldpb, a.addvec = pb.hi.data_ptr(), pb.lo.data_ptr(), ldpb, ptr(addvec)
     a.nbatch, a.bsx, a.bsy, a.bsd, a.bsbias, a.bspa = nbatch, bsx, bsy, bsd, bsbias, bspa

@@ -5,9 +5,11 @@ Host-side mirror of the reference's ``DualBranchGPM`` / ``GatedPropagationModule
 same state (long-term bank, short-term frame, EMA / visit dictionaries), but
 
   * the memory bank is a pre-allocated ring of ``cap + 2`` physical slots per layer
-    (K planes [slot][Npad][128], V^T planes [slot][1024][Npad]); append / evict only
-    edit a logical->physical map, no ``torch.cat`` re-allocation (transformer.py:859-878,
-    :967-989);
+    (K planes [slot][Npad][128], V planes "blocked-16" [slot][Npad/16][1024][16], the
+    operand layout of the fused read, csrc/fused.hip); append / evict only edit a
+    logical->physical map, no ``torch.cat`` re-allocation (transformer.py:859-878, :967-989);
+  * every memory read (long-term bank, windowed short-term, self) is ONE flash-style launch
+    (rmem_attn_read / rmem_attn_read2) + one combine: no probability matrix in HBM;
   * stored keys are PE-free, the temporal positional embedding enters the logits as a
     per-(query, slot) bias (transformer.py:1140-1172);
   * there is no D2H sync inside a frame; the RMem relevance vector (<= 16 floats) is
@@ -70,12 +72,12 @@ class _LayerWeights:
 
 
 class _AttnWS:
-    """Per-stream attention workspace: P planes (blocked), partial row sums, split partials, G."""
+    """Workspace of one fused read: split partials, (max, sum) statistics, per-slot sums, G."""
 
     def __init__(self, T, N, Np, ksplits, dev):
-        self.P = Planes.empty((T * Np // 32, Np, 32), dev)
-        self.lpart = torch.zeros(Np, T * Np // 64, device=dev)
         self.part = torch.zeros(ksplits, Np, 1024, device=dev)
+        self.ml = torch.zeros(ksplits, Np, 2, device=dev)
+        self.lslot = torch.zeros(ksplits, Np, T, 2, device=dev)
         self.G = torch.zeros(N, 1024, device=dev)
 
 
@@ -173,24 +175,30 @@ class DeAOTLSTT:
         self.Qf32 = z(N, 128)
         self.Qpe = Planes.empty((Np, 128), dev)
         self.bankK = [Planes.empty((self.S, Np, 128), dev) for _ in range(self.L)]
-        self.bankV = [Planes.empty((self.S, 1024, Np), dev) for _ in range(self.L)]
+        self.bankV = [Planes.empty((self.S, Np // 16, 1024, 16), dev) for _ in range(self.L)]   # blocked-16
         self.Ucat0 = z(N, 1024)
         self.Ucat0[:, 512:] = 1.0                                 # layer 0: gate of the ID half is 1
         self.Ucat = z(N, 1024)
         self.bias_pe = z(N, self.Tmax)
-        self.rowmax = z(3 * self.L, Np, dt=torch.int32)          # [layer][read]: zeroed once per frame
         self._layer = 0
-        # bank reads (long-term, self) with P as ONE fp16 plane: 2 MFMAs per product instead of 3
-        # (rmem_attn_scores / rmem_attn_pv with pl = NULL); the windowed read keeps hi/lo planes
-        self.p16 = self.nsplit == 3 and os.environ.get("RMEM_P16", "0") == "1"
-        self.ksplits_max = 8
-        # attention workspaces: main stream (long-term, self) and side stream (short-term window)
-        self.ws_main = _AttnWS(self.Tmax, N, Np, self.ksplits_max, dev)
-        self.ws_side = _AttnWS(1, N, Np, self.ksplits_max, dev)
-        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "serial")   # serial | short_first | long_first (forked)
-        self.ev_ready = torch.cuda.Event() if dev.type == "cuda" else None
-        self.ev_side = torch.cuda.Event() if dev.type == "cuda" else None
+        # Key splits of the fused reads.  A unit = (128-query tile, 512-column half, split) fills a
+        # CU's accumulator file, so one resident wave of workgroups = 256 units: the long-term and
+        # the windowed read of a layer share ONE launch (ks_long + ks_win splits), the self read
+        # gets all of them.
+        nq = Np // 128
+        total = max(2, min(32, 256 // (2 * nq)))
+        tv = (N + 63) // 64
+        # measured at 480p K=4 (bench.py, frames/s for ks_long, ks_win, ks_self): 7,2,9 382.6 / 6,3,9 397.7 /
+        # 6,3,6 403.1 / 5,4,6 407.2 / 6,3,4 397.6 -- a windowed tile costs ~2.5 long-term tiles (relative-bias gather)
+        self.ks_win = max(1, min(8, int(round(total * 0.4 * min(1.0, 4.0 / max(self.cap, 1))))))
+        self.ks_long = max(1, min(total - self.ks_win, 32))
+        self.ks_self = max(1, min(total, tv, 6))
+        if os.environ.get("RMEM_KS"):                             # tuning override: "long,win,self"
+            self.ks_long, self.ks_win, self.ks_self = (int(x) for x in os.environ["RMEM_KS"].split(","))
+        self.ksplits_max = max(self.ks_long, self.ks_win, self.ks_self)
+        self.ws_main = _AttnWS(self.Tmax, N, Np, max(self.ks_long, self.ks_self), dev)
+        self.ws_side = _AttnWS(1, N, Np, self.ks_win, dev)
+        self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "serial")   # serial (paired launches) | serial_unpaired
         self.Ylt = Planes.empty((Np, 1024), dev)
         self.Yst = Planes.empty((Np, 1024), dev)
         self.KS = 4                                                # split-K of the projection GEMMs
@@ -199,7 +207,7 @@ class DeAOTLSTT:
         self.R = z(N, self.ldr)
         self.s_pl = Planes.empty((Np, 512), dev)
         self.selfQK = Planes.empty((1, Np, 128), dev)
-        self.selfV = Planes.empty((1, 1024, Np), dev)
+        self.selfV = Planes.empty((1, Np // 16, 1024, 16), dev)
         self.Uself = z(N, 1024)
         self.out = z(N, 512)
         self.gn_ws = z(4 * ((N + 63) // 64), dt=torch.float64)
@@ -211,48 +219,49 @@ class DeAOTLSTT:
 
     # ------------------------------------------------------------------ measurement
     def enable_kernel_timing(self, on: bool):
-        """HIP-event pairs around the dominant kernel (long-term P.V) on the launch stream."""
+        """HIP-event pairs around the dominant kernel (the fused long-term + windowed read of a
+        layer, read2_kernel) on the launch stream."""
         self._timing = bool(on)
         if on:
             self._events = []
 
+    def read_flops(self, T: int) -> float:
+        """Algorithmic FLOPs of one read2 launch: Q.K^T and P.V of the
+        long-term read over T*N keys plus the 225-key windowed read, unpadded, one product each."""
+        return 2.0 * self.N * (T * self.N + self.WIN) * (1024 + 128)
+
     def roofline_report(self, mfma_peak_tflops: float):
-        """Roofline entry for the long-term P.V kernel: algorithmic FLOPs per launch
-        = 2 * N * (T*N) * 1024 over the mean HIP-event duration."""
         if not self._events:
             return None
         torch.cuda.synchronize()
         ms = [a.elapsed_time(b) for a, b, _ in self._events]
         T = self._events[0][2]
-        flops = 2.0 * self.N * (T * self.N) * 1024
+        flops = self.read_flops(T)
         mean_ms = sum(ms) / len(ms)
         ach = flops / (mean_ms * 1e-3) / 1e12
-        kern = "pv16_kernel (P one fp16 plane, V^T hi/lo: 2 MFMAs per product)" if self.p16 else f"pv_kernel<{self.nsplit}>"
-        return {"bound": "mfma", "kernel": f"{kern} (long-term A.V, T={T})",
+        return {"bound": "mfma", "kernel": f"read2_kernel (fused long-term T={T} + windowed memory read: Q.K^T, softmax, P.V)",
                 "achieved": ach, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach / mfma_peak_tflops,
                 "traffic": None, "launches": len(ms), "mean_us": 1e3 * mean_ms,
                 "algorithmic_flops_per_launch": flops}
 
-    def time_long_pv_isolated(self, iters: int = 20) -> float:
-        """Mean duration (us) of the long-term P.V launch of the current bank state with nothing
-        else on the GPU (back-to-back launches between two HIP events): the same launch the
-        in-frame roofline entry times beside the encoder stream."""
+    def time_read_isolated(self, iters: int = 20) -> float:
+        """Mean duration (us) of the read2 launch of the current bank state with nothing else on
+        the GPU (back-to-back launches between two HIP events)."""
         T = len(self.bank)
-        pa = hip.PVArgs()
-        vpl, ws = self.bankV[0], self.ws_main
-        pa.mode, pa.ph, pa.pl = 0, ws.P.hi.data_ptr(), (None if self.p16 else ws.P.lo.data_ptr())
-        pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
-        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = self.maps.data_ptr(), T, self.N, self.Npad, 1024
-        pa.h, pa.w, pa.part, pa.nsplit = self.h, self.w, ws.part.data_ptr(), self.nsplit
-        pa.ksplits = self._ksplits(T * self.Npad // 64)
+        self._layer = 0
+        A = self._read_args(self.ws_main, 0, T, self.bankK[0], self.bankV[0], self.maps.data_ptr(), self.Qpe,
+                            self.bias_pe, self.Ucat0, True, self.ks_long)
+        B = self._read_args(self.ws_side, 1, 1, self.bankK[0], self.bankV[0], self.maps.data_ptr() + 64,
+                            Planes(self.bankK[0].hi[self.cur], self.bankK[0].lo[self.cur]), None, self.Ucat0, False,
+                            self.ks_win)
         lib, st = hip.load(), hip.stream_ptr()
         torch.cuda.synchronize()
         for _ in range(3):
-            hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
+            hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
+            hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
         e1.record()
         e1.synchronize()
         return 1e3 * e0.elapsed_time(e1) / iters
@@ -282,12 +291,6 @@ class DeAOTLSTT:
                 return s
         raise hip.RmemError("no free bank slot (internal error)")
 
-    def _ksplits(self, ktiles: int) -> int:
-        """Key splits of P.V: ~56 (query tile, split) pairs = 7 per XCD x 8 column tiles
-        = one resident wave of 448 blocks (2 per CU); see pv_kernel's work mapping."""
-        nq = self.Npad // 128
-        return max(1, min(self.ksplits_max, int(round(56.0 / nq)), ktiles))
-
     def _ln(self, x, gb, out: Planes, ldo, col_off=0, parts_col=None):
         """LayerNorm -> planes; parts_col = column offset into the split-K partials of the
         preceding projection GEMM, which are first summed into x (fixed order)."""
@@ -310,75 +313,47 @@ class DeAOTLSTT:
             out1.hi.data_ptr() + off1 * 2, out1.lo.data_ptr() + off1 * 2, ldo1, hip.stream_ptr())
         hip.check(rc, "rmem_layernorm_red2")
 
-    def _attn_args(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
-                   qpl: Planes, bias, U, want_mass: bool, which: int):
-        """Argument blocks (scores, P.V, combine) of one read into workspace `ws`."""
+    def _read_args(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
+                   qpl: Planes, bias, U, want_mass: bool, ksplits: int):
+        """Argument blocks (fused read, combine) of one read into workspace `ws`."""
         Np = self.Npad
-        nparts = T * Np // 64
-        sa = hip.ScoresArgs()
-        sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, kpl.hi.data_ptr(), kpl.lo.data_ptr(), self.k_slot_stride
-        sa.slot_map, sa.T, sa.N, sa.Npad = slot_map_ptr, T, self.N, Np
-        sa.qh, sa.ql, sa.scale = qpl.hi.data_ptr(), qpl.lo.data_ptr(), self.scale
-        sa.bias = bias.data_ptr() if bias is not None else None
-        sa.R, sa.ldr, sa.h, sa.w = (self.R.data_ptr() if mode == 1 else None), self.ldr, self.h, self.w
-        sa.rowmax = self.rowmax[3 * self._layer + which].data_ptr()
-        sa.ph, sa.pl = ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
-        sa.lpart, sa.nparts, sa.nsplit = ws.lpart.data_ptr(), nparts, self.nsplit
-        ktiles = T * Np // 64 if mode == 0 else 20
-        ks = self._ksplits(ktiles)
-        pa = hip.PVArgs()
-        pa.mode, pa.ph, pa.pl = mode, ws.P.hi.data_ptr(), ws.P.lo.data_ptr()
-        pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
-        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = slot_map_ptr, T, self.N, Np, 1024
-        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = self.h, self.w, ws.part.data_ptr(), ks, self.nsplit
-        ca = hip.CombineArgs()
-        ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, self.N, Np, 1024, self.h, self.w
-        ca.part, ca.ksplits, ca.lpart, ca.nparts = ws.part.data_ptr(), ks, ws.lpart.data_ptr(), nparts
+        ra = hip.ReadArgs()
+        ra.mode, ra.qh, ra.ql = mode, qpl.hi.data_ptr(), qpl.lo.data_ptr()
+        ra.kh, ra.kl, ra.k_slot_stride = kpl.hi.data_ptr(), kpl.lo.data_ptr(), self.k_slot_stride
+        ra.vh, ra.vl, ra.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), self.v_slot_stride
+        ra.slot_map, ra.T, ra.N, ra.Npad, ra.ncols = slot_map_ptr, T, self.N, Np, 1024
+        ra.scale = self.scale
+        ra.bias = bias.data_ptr() if bias is not None else None
+        ra.R, ra.ldr, ra.h, ra.w = (self.R.data_ptr() if mode == 1 else None), self.ldr, self.h, self.w
+        tiles = T * ((self.N + 63) // 64)
+        ks = max(1, min(ksplits, tiles))
+        ra.ksplits = ks
+        ra.part, ra.ml = ws.part.data_ptr(), ws.ml.data_ptr()
+        ra.lslot = ws.lslot.data_ptr() if want_mass else None
+        ca = hip.ReadCombineArgs()
+        ca.T, ca.N, ca.Npad, ca.ncols, ca.ksplits = T, self.N, Np, 1024, ks
+        ca.part, ca.ml, ca.lslot = ws.part.data_ptr(), ws.ml.data_ptr(), (ws.lslot.data_ptr() if want_mass else None)
         ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, ws.G.data_ptr(), 1024
         ca.mass = self.mass.data_ptr() if want_mass else None
-        if self.p16 and mode == 0:
-            sa.pl = None
-            pa.pl = None
-        return sa, pa, ca
+        return ra, ca
 
-    def _pv(self, pa, timed: bool):
+    def _read(self, A):
+        """One fused read + its combine -> ws.G."""
         lib, st = hip.load(), hip.stream_ptr()
-        if timed:
+        hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "rmem_attn_read")
+        hip.check(lib.rmem_attn_read_combine(C.byref(A[1]), st), "rmem_attn_read_combine")
+
+    def _read_pair(self, A, B):
+        """The long-term (A) and windowed (B) reads of a layer: ONE read launch, ONE combine launch."""
+        lib, st = hip.load(), hip.stream_ptr()
+        if self._timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(lib.rmem_attn_pv(C.byref(pa), st), "rmem_attn_pv")
-        if timed:
+        hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
+        if self._timing:
             e1.record()
-            self._events.append((e0, e1, pa.T))
-
-    def _attention(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
-                   qpl: Planes, bias, U, want_mass: bool, which: int):
-        """scores(pass0, pass1) + pv + combine -> ws.G."""
-        lib, st = hip.load(), hip.stream_ptr()
-        sa, pa, ca = self._attn_args(ws, mode, T, kpl, vpl, slot_map_ptr, qpl, bias, U, want_mass, which)
-        sa.pass_ = 0
-        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 0)")
-        sa.pass_ = 1
-        hip.check(lib.rmem_attn_scores(C.byref(sa), st), "rmem_attn_scores(pass 1)")
-        self._pv(pa, self._timing and mode == 0 and which == 0)
-        hip.check(lib.rmem_attn_combine(C.byref(ca), st), "rmem_attn_combine")
-
-    def _scores_pair(self, A, B):
-        """Both score passes of two independent reads (argument blocks from _attn_args), ONE launch
-        per pass (rmem_attn_scores2)."""
-        lib, st = hip.load(), hip.stream_ptr()
-        (sa, _, _), (sb, _, _) = A, B
-        for p in (0, 1):
-            sa.pass_ = sb.pass_ = p
-            hip.check(lib.rmem_attn_scores2(C.byref(sa), C.byref(sb), st), f"rmem_attn_scores2(pass {p})")
-
-    def _pv_combine_pair(self, A, B):
-        """The two P.V launches (apart: the first is the kernel bench.py times) and ONE combine launch."""
-        lib, st = hip.load(), hip.stream_ptr()
-        (_, pa, ca), (_, pb, cb) = A, B
-        self._pv(pa, self._timing)
-        self._pv(pb, False)
-        hip.check(lib.rmem_attn_combine2(C.byref(ca), C.byref(cb), st), "rmem_attn_combine2")
+            self._events.append((e0, e1, A[0].T))
+        hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
 
     def _dwconv(self, ws: "_AttnWS", wt, out: Planes):
         rc = hip.load().rmem_dwconv5x5_split(ws.G.data_ptr(), 1024, wt.data_ptr(), self.h, self.w, 1024,
@@ -386,17 +361,16 @@ class DeAOTLSTT:
         hip.check(rc, "rmem_dwconv5x5_split")
 
     def _idv(self, l: int, slot: int, launch: bool = True):
-        """ID_V = silu(linear_ID_V([z | id_emb])) -> V^T rows 512.. of `slot`
+        """ID_V = silu(linear_ID_V([z | id_emb])) -> columns 512.. of the V planes of `slot`
         (fuse_key_value_id, transformer.py:1238-1244)."""
-        W, N, Np = self.lw[l], self.N, self.Npad
+        W, N = self.lw[l], self.N
         dst = self.bankV[l][slot]
-        pa = Planes(dst.hi[512:], dst.lo[512:])
         if l == 0:
-            return hip.linear(W.Widv, self.idemb_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bidv,
-                              bias_per_row=True, act=1, pa=pa, ldpa=Np, nsplit=self.nsplit, tile=64,
+            return hip.linear(self.idemb_pl, W.Widv, N, 512, 256, ldx=256, ldy=256, bias=W.bidv, act=1,
+                              pa=dst, ldpa=1024, pa_blocked=True, pa_off=512 * 16, nsplit=self.nsplit, tile=64,
                               launch=launch)
-        return hip.linear(W.Widv, self.z_pl[l], 512, N, 512, ldx=512, ldy=256, y2=self.idemb_pl, ldy2=256,
-                          ky_split=256, bias=W.bidv, bias_per_row=True, act=1, pa=pa, ldpa=Np,
+        return hip.linear(self.z_pl[l], W.Widv, N, 512, 512, ldx=256, ldy=512, x2=self.idemb_pl, ldx2=256,
+                          kx_split=256, bias=W.bidv, act=1, pa=dst, ldpa=1024, pa_blocked=True, pa_off=512 * 16,
                           nsplit=self.nsplit, tile=64, launch=launch)
 
     # ------------------------------------------------------------------ ID assignment
@@ -464,25 +438,21 @@ class DeAOTLSTT:
         graph_key() = (T, cur).
 
         part = "front" / "rest" split the pass where the previous frame's label first matters: the
-        front (layer 0: norm1, Q / V / U projections, relative-bias GEMM, temporal-PE bias and both
-        score passes of the long-term and the windowed read) needs only the frame's encoder
-        features, the bank keys and the slot maps, so the engine can issue it beside the previous
-        frame's decoder (DeAOTEngine._try_hoist); "rest" starts at the first P.V, which reads the
-        ID values written by the previous frame's memory update.  Only with branch_order "serial"."""
+        front (layer 0: norm1, Q / V / U projections, relative-bias GEMM, temporal-PE bias) needs
+        only the frame's encoder features, so the engine can issue it beside the previous frame's
+        decoder (DeAOTEngine._try_hoist); "rest" starts at the fused memory reads, which read the
+        ID values written by the previous frame's memory update and the slot maps."""
         N, Np, ns = self.N, self.Npad, self.nsplit
         lib, st = hip.load(), hip.stream_ptr()
         do_front, do_rest = part != "rest", part != "front"
         if part != "all" and (ref_frame or self.branch_order != "serial"):
-            raise hip.RmemError("front/rest split needs a propagation frame and the in-line schedule")
+            raise hip.RmemError("front/rest split needs a propagation frame and the paired schedule")
         cur, T = self.cur, self._T
         map_bank = self.maps.data_ptr()
         map_short = self.maps.data_ptr() + 16 * 4
-        # the hoisted front runs while maps[16] still belongs to the previous frame: it reads [17]
-        map_short_scores = self.maps.data_ptr() + 17 * 4 if part == "front" else map_short
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
         if do_front:
             self.tgt_id.zero_()
-            self.rowmax.zero_()
 
         for l in range(self.L):
             self._layer = l
@@ -490,10 +460,9 @@ class DeAOTLSTT:
             Ucat = self.Ucat0 if l == 0 else self.Ucat
             curK = self.bankK[l][cur]
             curV = self.bankV[l][cur]
-            seg_a = do_front if l == 0 else do_rest      # norms, projections, score passes of this layer
-            seg_b = do_rest                              # from the first P.V on
-            self._forward_layer(l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short,
-                                map_short_scores)
+            seg_a = do_front if l == 0 else do_rest      # norms, projections of this layer
+            seg_b = do_rest                              # from the memory reads on
+            self._forward_layer(l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short)
         if do_rest:
             # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
             hip.check(lib.rmem_groupnorm2(self.tgt.data_ptr(), self.tgt_id.data_ptr(), N, 256,
@@ -501,12 +470,10 @@ class DeAOTLSTT:
                                           self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
                       "rmem_groupnorm2")
 
-    def _forward_layer(self, l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short,
-                       map_short_scores):
+    def _forward_layer(self, l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short):
         N, Np, ns = self.N, self.Npad, self.nsplit
         lib = hip.load()
         cur = self.cur
-        serial = self.branch_order == "serial"
         if seg_a:
             # -- norms + projections (transformer.py:1104-1123); the norms first fold in the
             #    split-K partials of the previous layer's self-attention projection
@@ -518,9 +485,9 @@ class DeAOTLSTT:
                 hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
                            d0=self.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128,
                            pb=self.Qpe, ldpb=128, addvec=self.cur_pe, nsplit=ns, tile=64, launch=False),
-                hip.linear(W.Wv, self.x_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True,
-                           act=1, pa=Planes(curV.hi[:512], curV.lo[:512]), ldpa=Np, nsplit=ns, tile=64,
-                           launch=False),
+                # V = silu(linear_V(x)) -> columns 0..511 of the current slot's blocked-16 V planes
+                hip.linear(self.x_pl, W.Wv, N, 512, 256, ldx=256, ldy=256, bias=W.bv, act=1,
+                           pa=curV, ldpa=1024, pa_blocked=True, nsplit=ns, tile=64, launch=False),
                 hip.linear(self.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1,
                            d0=Ucat.data_ptr(), ldd0=1024, nsplit=ns, tile=64, launch=False)]
             if l > 0:
@@ -530,64 +497,34 @@ class DeAOTLSTT:
             hip.linear_grouped(grp)
             if ref_frame:
                 self._idv(l, cur)
-
-        # -- short-term windowed read (transformer.py:1199, attention.py:289-358) and long-term
-        #    memory read (transformer.py:1140-1192, attention.py:174-209): independent until
-        #    the projection.  Default ("serial"): in line on one stream, sharing their launches where
-        #    the kernels have the same shape.  Forked onto a second stream the frame is 1.9 % slower
-        #    and every kernel of the long chain shares the CUs with the short chain (long-term P.V
-        #    94 us instead of 83 us in a frame); under hipGraph replay the forked branch starts
-        #    ~120 us late whichever is issued first (rocprofv3 trace, profiles/r01_g).
-        def short_chain():
+            # relative-position bias of the windowed read (attention.py:314) and temporal-PE bias of
+            # the long-term read (transformer.py:1140-1172)
             hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
                        d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
-            self._attention(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
-                            Ucat, want_mass=False, which=1)
-            self._dwconv(self.ws_side, W.dw_st, self.Yst)
-
-        def long_chain():
             hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
                                        self.mem_pe.data_ptr(), rows, T, N, 128,
                                        self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
-            self._attention(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
-                            self.bias_pe, Ucat, want_mass=(l == 0), which=0)
-            self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
-
-        if serial:
-            A = self._attn_args(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
-                                self.bias_pe, Ucat, l == 0, 0)
-            B = self._attn_args(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
-                                Ucat, False, 1)
-            if seg_a:
-                hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
-                           d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
-                hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
-                                           self.mem_pe.data_ptr(), rows, T, N, 128,
-                                           self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
-                B[0].slot_map = map_short_scores
-                self._scores_pair(A, B)
-            if seg_b:
-                self._pv_combine_pair(A, B)
-                hip.check(lib.rmem_dwconv5x5_split2(
-                    self.ws_main.G.data_ptr(), self.ws_side.G.data_ptr(), 1024, W.dw_lt.data_ptr(),
-                    W.dw_st.data_ptr(), self.h, self.w, 1024, self.Ylt.hi.data_ptr(), self.Ylt.lo.data_ptr(),
-                    self.Yst.hi.data_ptr(), self.Yst.lo.data_ptr(), 1024, hip.stream_ptr()), "rmem_dwconv5x5_split2")
-        elif self.branch_order == "serial_unpaired":
-            short_chain()
-            long_chain()
-        else:
-            self.ev_ready.record()
-            if self.branch_order == "long_first":
-                long_chain()
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ev_ready)
-                short_chain()
-                self.ev_side.record()
-            if self.branch_order != "long_first":
-                long_chain()
-            torch.cuda.current_stream().wait_event(self.ev_side)
         if not seg_b:
             return
+        # -- long-term memory read (transformer.py:1140-1192, attention.py:174-209) and short-term
+        #    windowed read (transformer.py:1199, attention.py:289-358): independent until the
+        #    projection; ONE fused-read launch, one combine and one depth-wise-conv launch for both
+        #    ("serial_unpaired": one launch each, bit-identical, kept for the equivalence test)
+        A = self._read_args(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
+                            self.bias_pe, Ucat, l == 0, self.ks_long)
+        B = self._read_args(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
+                            Ucat, False, self.ks_win)
+        if self.branch_order == "serial":
+            self._read_pair(A, B)
+            hip.check(lib.rmem_dwconv5x5_split2(
+                self.ws_main.G.data_ptr(), self.ws_side.G.data_ptr(), 1024, W.dw_lt.data_ptr(),
+                W.dw_st.data_ptr(), self.h, self.w, 1024, self.Ylt.hi.data_ptr(), self.Ylt.lo.data_ptr(),
+                self.Yst.hi.data_ptr(), self.Yst.lo.data_ptr(), 1024, hip.stream_ptr()), "rmem_dwconv5x5_split2")
+        else:
+            self._read(B)
+            self._dwconv(self.ws_side, W.dw_st, self.Yst)
+            self._read(A)
+            self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
         # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
         #    adds happen in the norms that follow (rmem_layernorm_red)
         hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
@@ -596,18 +533,18 @@ class DeAOTLSTT:
         # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
         self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
         sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
-        sV = Planes(self.selfV.hi[0], self.selfV.lo[0])
         hip.linear_grouped([
             hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
                        nsplit=ns, tile=64, launch=False),
-            hip.linear(W.Wv12, self.s_pl, 512, N, 256, ldx=256, ldy=512, bias=W.bv12, bias_per_row=True,
-                       act=1, pa=sV, ldpa=Np, nbatch=2, bsx=512 * 256, bsy=256, bsbias=512,
-                       bspa=512 * Np, nsplit=ns, tile=64, launch=False),
+            # V = silu([V1(s[:256]) | V2(s[256:])]) -> blocked-16 planes (two diagonal blocks)
+            hip.linear(self.s_pl, W.Wv12, N, 512, 256, ldx=512, ldy=256, bias=W.bv12, act=1,
+                       pa=self.selfV, ldpa=1024, pa_blocked=True, nbatch=2, bsx=256, bsy=512 * 256, bsbias=512,
+                       bspa=512 * 16, nsplit=ns, tile=64, launch=False),
             hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
                        d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
                        bsbias=512, bsd=512, nsplit=ns, tile=64, launch=False)])
-        self._attention(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
-                        want_mass=False, which=2)
+        self._read(self._read_args(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
+                                   False, self.ks_self))
         self._dwconv(self.ws_main, W.dw_self, self.Ylt)
         if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,

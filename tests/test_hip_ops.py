@@ -462,3 +462,173 @@ def test_bias_act_nchw(geom):
                 want = torch.relu(want)
             got = hip.bias_act_nchw_(x.clone(), b, res, relu)
             assert torch.equal(got, want), (geom, res is not None, relu)
+
+
+# ------------------------------------------------------------------ fused memory read (fused.hip)
+def _block16(Vf):
+    """channel-major V^T [S][C][Npad] -> blocked-16 [S][Npad/16][C][16] (the layout rmem_attn_read reads)."""
+    S, Cn, Np = Vf.shape
+    return Vf.permute(0, 2, 1).reshape(S, Np // 16, 16, Cn).permute(0, 1, 3, 2).contiguous()
+
+
+def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, ksplits, want_mass=True):
+    """K: [S][Npad][128] planes, Vb: blocked-16 planes [S][Npad/16][1024][16], Q planes [Npad][128]."""
+    lib, st = hip.load(), hip.stream_ptr()
+    part = torch.full((ksplits, Npad, 1024), float("nan"), device=DEV)     # every valid row must be written
+    ml = torch.full((ksplits, Npad, 2), float("nan"), device=DEV)
+    lslot = torch.full((ksplits, Npad, T, 2), float("nan"), device=DEV) if want_mass else None
+    G = torch.zeros(N, 1024, device=DEV)
+    mass = torch.zeros(N, T, device=DEV)
+    sm = torch.tensor(slot_map, dtype=torch.int32, device=DEV) if slot_map is not None else None
+    ra = hip.ReadArgs()
+    ra.mode, ra.qh, ra.ql = mode, Q.hi.data_ptr(), Q.lo.data_ptr()
+    ra.kh, ra.kl, ra.k_slot_stride = K.hi.data_ptr(), K.lo.data_ptr(), Npad * 128
+    ra.vh, ra.vl, ra.v_slot_stride = Vb.hi.data_ptr(), Vb.lo.data_ptr(), 1024 * Npad
+    ra.slot_map = sm.data_ptr() if sm is not None else None
+    ra.T, ra.N, ra.Npad, ra.ncols, ra.scale = T, N, Npad, 1024, 1.0 / math.sqrt(128)
+    ra.bias = bias.data_ptr() if bias is not None else None
+    if R is not None:
+        ra.R, ra.ldr = R.data_ptr(), R.shape[1]
+    ra.h, ra.w, ra.ksplits = h, w, ksplits
+    ra.part, ra.ml = part.data_ptr(), ml.data_ptr()
+    ra.lslot = lslot.data_ptr() if want_mass else None
+    hip.check(lib.rmem_attn_read(C.byref(ra), st), "read")
+    ca = hip.ReadCombineArgs()
+    ca.T, ca.N, ca.Npad, ca.ncols, ca.ksplits = T, N, Npad, 1024, ksplits
+    ca.part, ca.ml, ca.lslot = part.data_ptr(), ml.data_ptr(), (lslot.data_ptr() if want_mass else None)
+    ca.U, ca.ldu, ca.G, ca.ldg = U.data_ptr(), 1024, G.data_ptr(), 1024
+    ca.mass = mass.data_ptr() if want_mass else None
+    hip.check(lib.rmem_attn_read_combine(C.byref(ca), st), "read_combine")
+    torch.cuda.synchronize()
+    return G, mass, part, ml
+
+
+def _bank_case(rs, T, h, w, spike=False):
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    S = T + 2
+    slot_map = [int(x) for x in rs.permutation(S)[:T]]
+    Kf = torch.zeros(S, Npad, 128)
+    Vf = torch.zeros(S, 1024, Npad)
+    Kf[:, :N] = _rand(rs, S, N, 128, scale=1.5)
+    Vf[:, :, :N] = _rand(rs, S, 1024, N)
+    Kf[:, N:] = 37.0      # padding rows must be ignored (masked), not merely zero
+    Vf[:, :, N:] = -53.0
+    Qf = torch.zeros(Npad, 128)
+    Qf[:N] = _rand(rs, N, 128, scale=1.5)
+    if spike:
+        # force the deferred-rescale path: a few keys late in the bank score far above everything
+        # a query has seen before (row maximum jumps by much more than RD_THR = 10 mid-split)
+        for qq in (0, 5, N // 2, N - 1):
+            for (tt, kk) in ((T - 1, N - 3), (T // 2, N // 2 + 1)):
+                Kf[slot_map[tt], kk] = Qf[qq] * (1.0 + 0.5 * (tt + 1))
+    bias = _rand(rs, N, T, scale=3.0)
+    U = _rand(rs, N, 1024)
+    Kl = torch.stack([Kf[s, :N] for s in slot_map]).double()            # [T][N][128]
+    Vl = torch.stack([Vf[s, :, :N].t() for s in slot_map]).double()     # [T][N][1024]
+    S_ = torch.einsum("qc,tkc->qtk", Qf[:N].double(), Kl) + bias.double()[:, :, None]
+    S_ = S_ / math.sqrt(128)
+    A = torch.softmax(S_.reshape(N, T * N), dim=1).reshape(N, T, N)
+    ref = torch.einsum("qtk,tkc->qc", A, Vl) * U.double()
+    return N, Npad, slot_map, Kf, Vf, Qf, bias, U, A, ref, S_
+
+
+@pytest.mark.parametrize("ksplits", [1, 3, 9])
+@pytest.mark.parametrize("T,h,w", [(1, 9, 13), (3, 9, 13), (5, 12, 17), (4, 31, 54)])
+def test_read_bank(hip, ksplits, T, h, w):
+    """Fused long-term / self read against fp64: softmax(scale*(Q.K^T + bias)) . V * U and the per-slot
+    attention mass, with slot-map permutation and poisoned padding.  (4, 31, 54) is the full
+    BASELINE.json configs[1] size (N=1674, 6696 keys)."""
+    if h * w > 1000 and ksplits == 1:
+        pytest.skip("one split at full size only repeats the small cases")
+    rs = np.random.RandomState(T * 100 + h)
+    N, Npad, slot_map, Kf, Vf, Qf, bias, U, A, ref, _ = _bank_case(rs, T, h, w)
+    G, mass, part, ml = _run_read(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, _block16(Vf)), slot_map,
+                                  _planes(hip, Qf), bias.to(DEV), U.to(DEV), h, w, None, ksplits)
+    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    merr = (mass.cpu().double() - A.sum(dim=2)).abs().max().item()
+    print(f"fused bank read T={T} {h}x{w} ksplits={ksplits}: G rel err {err:.2e}, mass err {merr:.2e}")
+    assert err < 5e-5 and merr < 1e-5, (err, merr)
+    assert torch.isfinite(ml[:, :N]).all()
+    live = ml[:, :N, 1] > 0                      # splits without a key tile leave their partial unwritten
+    assert torch.isfinite(part[:, :N][live]).all()
+
+
+def test_read_bank_logits_and_rescale(hip):
+    """(a) the statistics the kernel writes ARE the logits' log-sum-exp: m + log(l) within 1e-3 of fp64
+    (north star: attention logits within 1e-3); (b) keys whose score jumps far above the running
+    maximum in the middle of a split force the deferred rescale (segment flush through the partial
+    buffer): outputs and mass must still match fp64."""
+    rs = np.random.RandomState(77)
+    for spike in (False, True):
+        T, h, w = 4, 20, 23
+        N, Npad, slot_map, Kf, Vf, Qf, bias, U, A, ref, S_ = _bank_case(rs, T, h, w, spike=spike)
+        for ksplits in (1, 2):
+            G, mass, part, ml = _run_read(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, _block16(Vf)), slot_map,
+                                          _planes(hip, Qf), bias.to(DEV), U.to(DEV), h, w, None, ksplits)
+            err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+            merr = (mass.cpu().double() - A.sum(dim=2)).abs().max().item()
+            mlc = ml[:, :N].cpu().double()
+            lse = torch.logsumexp(mlc[..., 0] + torch.log(mlc[..., 1]), dim=0)
+            lse_ref = torch.logsumexp(S_.reshape(N, -1), dim=1)
+            lerr = (lse - lse_ref).abs().max().item()
+            print(f"spike={spike} ksplits={ksplits}: G rel err {err:.2e} mass {merr:.2e} logsumexp err {lerr:.2e}")
+            assert err < 5e-5 and merr < 1e-5 and lerr < 1e-3, (spike, ksplits, err, merr, lerr)
+
+
+@pytest.mark.parametrize("ksplits", [1, 4])
+@pytest.mark.parametrize("h,w", [(9, 13), (20, 23), (31, 54)])
+def test_read_window(hip, ksplits, h, w):
+    """Fused short-term 15x15 windowed read against the oracle's LocalGatedPropagation core."""
+    from oracle import lstt_ref as R
+    rs = np.random.RandomState(h * 10 + w)
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    q, k = _rand(rs, N, 128, scale=1.5), _rand(rs, N, 128, scale=1.5)
+    v, u = _rand(rs, N, 1024), _rand(rs, N, 1024)
+    rel_w, rel_b = _rand(rs, 225, 128, scale=0.15), _rand(rs, 225, scale=0.1)
+    idx, inside = R.local_window_index(h, w)
+    rel = q.double() @ rel_w.double().t() + rel_b.double()
+    kg = k.double()[idx.clamp(min=0)] * inside.unsqueeze(-1)
+    qk = torch.einsum("nc,noc->no", q.double() / math.sqrt(128), kg) + rel
+    qk = qk.masked_fill(~inside, -1e8)
+    attn = torch.softmax(qk, dim=1)
+    vg = v.double()[idx.clamp(min=0)] * inside.unsqueeze(-1)
+    ref = torch.einsum("no,noc->nc", attn, vg) * u.double()
+    Kf, Vf, Qf = torch.zeros(2, Npad, 128), torch.zeros(2, 1024, Npad), torch.zeros(Npad, 128)
+    Kf[1, :N], Vf[1, :, :N], Qf[:N] = k, v.t(), q
+    Kf[0] = 99.0
+    Rm = torch.zeros(N, 232)
+    Rm[:, :225] = rel.float()
+    G, _, _, _ = _run_read(hip, 1, 1, N, Npad, _planes(hip, Kf), _planes(hip, _block16(Vf)), [1], _planes(hip, Qf),
+                           None, u.to(DEV), h, w, Rm.to(DEV), ksplits, want_mass=False)
+    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"fused window read {h}x{w} ksplits={ksplits}: G rel err {err:.2e}")
+    assert err < 5e-5, err
+
+
+def test_linear_blocked_output(hip):
+    """rmem_linear with pa_blocked: silu(X.W^T + b) written as blocked-16 planes at a column window of
+    a [Npad/16][1024][16] tensor (how V | ID_V of the bank are produced), nbatch = 2 included."""
+    rs = np.random.RandomState(11)
+    ntok, Np = 150, 256
+    X, W, b = _rand(rs, ntok, 256), _rand(rs, 512, 256, scale=0.1), _rand(rs, 512)
+    dst = hip.Planes.empty((Np // 16, 1024, 16), DEV)
+    hip.linear(_planes(hip, X), _planes(hip, W), ntok, 512, 256, ldx=256, ldy=256, bias=b.to(DEV), act=1,
+               pa=dst, ldpa=1024, pa_blocked=True, pa_off=512 * 16, tile=64)
+    torch.cuda.synchronize()
+    ref = _silu(X.double() @ W.double().t() + b.double())                  # [ntok][512]
+    got = dst.float().cpu().permute(0, 2, 1).reshape(Np, 1024)             # [token][col]
+    assert (got[:ntok, 512:].double() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
+    assert torch.all(got[:, :512] == 0) and torch.all(got[ntok:] == 0)
+    # two blocks of the weight on two halves of the input (self-attention V1 | V2)
+    S, W2, b2 = _rand(rs, ntok, 512), _rand(rs, 1024, 256, scale=0.1), _rand(rs, 1024)
+    dst = hip.Planes.empty((Np // 16, 1024, 16), DEV)
+    hip.linear(_planes(hip, S), _planes(hip, W2), ntok, 512, 256, ldx=512, ldy=256, bias=b2.to(DEV), act=1,
+               pa=dst, ldpa=1024, pa_blocked=True, nbatch=2, bsx=256, bsy=512 * 256, bsbias=512, bspa=512 * 16,
+               tile=64)
+    torch.cuda.synchronize()
+    ref = torch.cat([_silu(S[:, :256].double() @ W2[:512].double().t() + b2[:512].double()),
+                     _silu(S[:, 256:].double() @ W2[512:].double().t() + b2[512:].double())], 1)
+    got = dst.float().cpu().permute(0, 2, 1).reshape(Np, 1024)
+    assert (got[:ntok].double() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()

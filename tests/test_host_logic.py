@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/rmem_hip.h but not exported"
     assert declared == set(hip.EXPORTS)
-    assert lib.rmem_abi_version() == 7
+    assert lib.rmem_abi_version() == 8
 
 
 def test_ctypes_struct_sizes_match_header_layout():
@@ -32,9 +32,9 @@ def test_ctypes_struct_sizes_match_header_layout():
     src = r'''
     #include "rmem_hip.h"
     #include <stdio.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_scores_args),
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_scores_args),
                        sizeof(rmem_pv_args), sizeof(rmem_combine_args), sizeof(rmem_mha_args),
-                       sizeof(rmem_mha_combine_args)); return 0; }'''
+                       sizeof(rmem_mha_combine_args), sizeof(rmem_read_args), sizeof(rmem_read_combine_args)); return 0; }'''
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
@@ -43,7 +43,7 @@ def test_ctypes_struct_sizes_match_header_layout():
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     assert sizes == [ctypes.sizeof(hip.LinearArgs), ctypes.sizeof(hip.ScoresArgs),
                      ctypes.sizeof(hip.PVArgs), ctypes.sizeof(hip.CombineArgs), ctypes.sizeof(hip.MHAArgs),
-                     ctypes.sizeof(hip.MHACombineArgs)]
+                     ctypes.sizeof(hip.MHACombineArgs), ctypes.sizeof(hip.ReadArgs), ctypes.sizeof(hip.ReadCombineArgs)]
 
 
 def test_product_path_never_imports_oracle():
