@@ -48,8 +48,12 @@ def parse():
     ap.add_argument("--gap", type=int, default=5, help="long_term_mem_gap (evaluator rule gives 5 for clips <= 165 frames)")
     ap.add_argument("--nsplit", type=int, default=int(os.environ.get("RMEM_NSPLIT", "3")),
                     help="3 = split-fp16 (hi/lo planes, fp32-class), 1 = plain fp16 attention/linears")
-    ap.add_argument("--config", choices=["480p_k4", "720p_k8"], default="480p_k4",
-                    help="480p_k4 = BASELINE.json configs[1] (the headline metric); 720p_k8 = configs[2] (stress)")
+    ap.add_argument("--config", choices=["480p_k4", "720p_k8", "clips64"], default="480p_k4",
+                    help="480p_k4 = BASELINE.json configs[1] (the headline metric); 720p_k8 = configs[2] (stress); "
+                         "clips64 = configs[3]: 8 clips per rank x 16 frames through the clip driver (reference frame "
+                         "and bank fill inside the timed window), static shard + all-gather of masks, sha256 per clip")
+    ap.add_argument("--clips-per-rank", type=int, default=8, help="clips64 mode: clips per rank (64 clips at 8 GPUs)")
+    ap.add_argument("--clip-frames", type=int, default=16, help="clips64 mode: frames per clip")
     ap.add_argument("--model", choices=["r50_deaotl", "r50_aotl", "swinb_aotl"], default="r50_deaotl",
                     help="r50_deaotl = headline metric; r50_aotl = AOT block (BASELINE.json configs[0] on GPU)")
     ap.add_argument("--clips-per-gpu", type=int, default=1,
@@ -65,6 +69,7 @@ def parse():
                     help="frames announced ahead to the engine for encoder prefetch (0 = what the engine asks for: "
                          "3 with its default encoder batch of 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the second timed leg (drop-in flags)")
     ap.add_argument("--cpu-frames", type=int, default=4)
     return ap.parse_args()
 
@@ -91,6 +96,8 @@ def main():
     from rmem_amd.synth import load_synthetic_weights, synth_clip
 
     global H_IN, W_IN, H_OUT, W_OUT
+    if args.config == "clips64":
+        return clips64(args, world, rank, local_rank, dev, dist)
     mem_k = 4
     if args.config == "720p_k8":      # 720x1280 -> 721x1281 -> 46x81 tokens, K=8, 3 objects
         H_IN, W_IN, H_OUT, W_OUT, mem_k = 721, 1281, 720, 1280, 8
@@ -211,6 +218,26 @@ def main():
         elapsed = float(tt.item())
 
     fps = world * C * args.steps / elapsed
+
+    # ---- the two-import drop-in of INTEGRATION.md section 1: the reference evaluator announces no
+    # frames and does its own softmax / argmax / nearest resize (managers/evaluator.py:424-441,
+    # 518-523).  Same engines, same steady state, a shorter timed run; reported beside the headline.
+    dropin = None
+    if rank == 0 and world == 1 and C == 1 and not args.no_dropin and not (args.no_prefetch and args.reference_postproc):
+        PREFETCH_SAVE, POST_SAVE = PREFETCH, args.reference_postproc
+        PREFETCH, args.reference_postproc = False, True
+        n_d = max(10, args.steps // 2)
+        for k in range(8):
+            all_clips(t + args.steps + k)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        for k in range(n_d):
+            all_clips(t + args.steps + 8 + k)
+        torch.cuda.synchronize()
+        dropin = {"value": n_d / (time.perf_counter() - td), "unit": "frames/s", "steps": n_d,
+                  "flags": "--no-prefetch --reference-postproc (match_propogate_one_frame(img, output_size) -> torch "
+                           "softmax/argmax/nearest -> update_memory, nothing announced ahead)"}
+        PREFETCH, args.reference_postproc = PREFETCH_SAVE, POST_SAVE
     out = {
         "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref"
         if (args.config == "480p_k4" and args.model == "r50_deaotl") else f"frames/sec/GPU ({args.config}) {args.model}+RMem"
@@ -245,42 +272,151 @@ def main():
         if out["roofline"] and args.config == "480p_k4" and args.model == "r50_deaotl" and os.path.exists(pmc):
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = f"bytes/launch (rocprofv3 PMC, profiles/{pmc_name})"
+        if dropin is not None:
+            out["dropin"] = dropin
         if world == 1 and not args.no_cpu_baseline and args.model == "r50_deaotl":
-            out["cpu_baseline"] = cpu_baseline(cpu_model, args)
+            cb, par = cpu_baseline_and_parity(cpu_model, model, cfg, args, dev)
+            out["cpu_baseline"] = cb
+            out.update(par)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(cpu_model, args):
-    """Oracle (CPU restatement of the reference path, fp32 PyTorch-CPU) on a bounded
-    sample of the same workload: same clip generator, geometry and K; the bank is
-    pre-filled to T=K with gap=1, then `cpu_frames` steady-state frames are timed with
-    the reference's timing window."""
+def clips64(args, world, rank, local_rank, dev, dist):
+    """BASELINE.json configs[3]: R50-DeAOTL + RMem, 480p, K=4, `clips_per_rank` x world independent
+    synthetic clips of `clip_frames` frames, clip i on rank i mod world, every clip through
+    rmem_amd.driver.ClipDriver (the evaluator's per-clip protocol: gap rule, reference frame, bank
+    fill, fused label post-processing), one RCCL all-gather of the uint8 masks.  The timed window
+    covers everything from the first reference frame to the gathered masks."""
+    import hashlib
+    from rmem_amd import driver as D
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+    cfg = get_config("r50_deaotl", 1, 3)
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    load_synthetic_weights(model)
+    model = model.to(dev)
+    n_clips, F_ = args.clips_per_rank * world, args.clip_frames
+    drv = D.ClipDriver(model, cfg, gpu_id=local_rank)
+
+    def frames_of(cid):          # frames are resident in HBM before they are consumed; generated per clip
+        imgs, lab = synth_clip(cid, F_, H_IN, W_IN, 3)
+        lab0 = F.interpolate(lab, size=(H_OUT, W_OUT), mode="nearest").to(dev)
+        return [D.make_samples(imgs[t].to(dev), lab0 if t == 0 else None, (H_OUT, W_OUT), 3, name=f"{t:05d}.jpg")
+                for t in range(F_)]
+
+    # warm-up clip (MIOpen solver search, hipGraph captures of the first geometry): not timed
+    drv.run_clip(frames_of(10 ** 6), num_frames=F_)
+    # all clips of this rank are materialised first so that the timed window holds no host-side synthesis
+    mine = D.shard_clips(n_clips, world, rank)
+    cache = {c: frames_of(c) for c in mine}
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hashes, allm, frames_run = D.run_sharded_clips(drv, n_clips, world, rank, lambda c: cache[c], F_)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_frames = n_clips * (F_ - 1)               # propagated frames (the reference frame is not a "frame/s" frame in evaluator.py:571-587)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec (480p, K=4) R50-DeAOTL+RMem, independent clips sharded across GPUs, masks all-gathered",
+            "value": total_frames / elapsed, "unit": "frames/s (whole job)", "n_gpus": world, "steps": total_frames // world,
+            "warmup": 1, "ms_per_step": 1e3 * elapsed / max(1, total_frames // world), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp16x3 (split-fp16 MFMA)", "data": "synthetic",
+            "config": {"workload": f"R50-DeAOTL + RMem, 480p, K=4, {n_clips} clips x {F_} frames, {args.clips_per_rank} per rank "
+                                   f"(clip i -> rank i mod {world}), evaluator gap rule (gap {D.memory_gap(F_)}), reference frame + bank fill timed",
+                       "clips": n_clips, "frames_per_clip": F_, "frames_per_sec_per_gpu": total_frames / elapsed / world,
+                       "parallelism": f"clips sharded {args.clips_per_rank}-per-GPU x{world}, one all-gather of uint8 masks "
+                                      f"({allm.numel() / 1e6:.1f} MB)"},
+            "clip_sha256": [h[:16] for h in hashes],
+            "masks_sha256": hashlib.sha256(allm.cpu().numpy().tobytes()).hexdigest()}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def db_eval_iou(annotation, segmentation):
+    """Jaccard index of two binary maps, 1 when both are empty (restates
+    evaluation/source/metrics.py:6-37 of the reference without its cv2 import)."""
+    inter = float((annotation & segmentation).sum())
+    union = float((annotation | segmentation).sum())
+    return 1.0 if union == 0 else inter / union
+
+
+def cpu_baseline_and_parity(cpu_model, gpu_model, cfg, args, dev):
+    """(a) cpu_baseline: the oracle (CPU restatement of the reference path, fp32 PyTorch-CPU) timed
+    on a bounded sample of the same workload: same clip generator, geometry and K; the bank is
+    pre-filled to T=K with gap=1, then `cpu_frames` steady-state frames are timed with the reference's
+    timing window.  (b) parity, outside every timed region: a fresh HIP engine runs the same frames
+    teacher-forced (both engines are fed the ORACLE's label, so the count is per frame, not the growth
+    of a chaotic closed loop): mismatching label pixels and mean object IoU against the oracle."""
+    import numpy as np
     from oracle.engine_ref import OracleDeAOTEngine
+    from rmem_amd.engine import build_engine
     from rmem_amd.synth import synth_clip
     # all cores is slower than a few dozen on many-core hosts for these op sizes (measured:
     # 256 threads -> 112 s/frame); use at most 32 and report the count actually used.
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     ora = OracleDeAOTEngine(cpu_model, long_term_mem_gap=1)
+    eng = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=gpu_model, gpu_id=dev.index or 0,
+                       long_term_mem_gap=1, nsplit=args.nsplit)
+    eng.eval()
     n = args.cpu_frames
     imgs, lab = synth_clip(0, 4 + n, H_IN, W_IN, 3)
+    gimgs = [x.to(dev) for x in imgs]
     ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    eng.add_reference_frame(gimgs[0], lab.to(dev), obj_nums=[3], frame_step=0)
+    mism, ious, lerr = [], [], []
 
-    def step(t):
+    def step(t, timed):
         logit = ora.match_propogate_one_frame(imgs[t], output_size=(H_OUT, W_OUT))
         pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True).float()
-        ora.update_memory(F.interpolate(pred, size=ora.input_size_2d, mode="nearest"))
+        cur = F.interpolate(pred, size=ora.input_size_2d, mode="nearest")
+        ora.update_memory(cur)
+        return pred, cur, ora.pred_id_logits.clone()
 
+    def hip_step(t, pred, cur, ologits):
+        lg = eng.match_propogate_one_frame(gimgs[t], output_size=(H_OUT, W_OUT))
+        mine = torch.argmax(lg, dim=1, keepdim=True).cpu()
+        a, b = pred.long().numpy()[0, 0], mine.numpy()[0, 0]
+        mism.append(int((a != b).sum()))
+        ious.append(float(np.mean([db_eval_iou(a == o, b == o) for o in range(1, 4)])))
+        lerr.append(float((eng.aot_engines[0].pred_id_logits.cpu() - ologits).abs().max()))
+        eng.update_memory(cur.to(dev))
+
+    fed = []
     for t in range(1, 4):
-        step(t)
+        fed.append((t,) + step(t, False))
     ora.long_term_mem_gap = args.gap
     t0 = time.perf_counter()
     for t in range(4, 4 + n):
-        step(t)
+        fed.append((t,) + step(t, True))
     el = time.perf_counter() - t0
-    return {"value": n / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} steady-state frames (T=4) of the same 480p K=4 workload, oracle/ on PyTorch-CPU fp32"}
+    for t, pred, cur, ologits in fed:               # the HIP engine replays the same protocol
+        if t == 4:
+            eng.long_term_mem_gap = args.gap
+            for e in eng.aot_engines:
+                e.long_term_mem_gap = args.gap
+        hip_step(t, pred, cur, ologits)
+    idx_ok = list(eng.aot_engines[0].long_memories_indexes) == list(ora.long_memories_indexes)
+    cb = {"value": n / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+          "sample": f"{n} steady-state frames (T=4) of the same 480p K=4 workload, oracle/ on PyTorch-CPU fp32"}
+    par = {"mask_mismatch_px": mism, "mask_pixels_per_frame": int(H_OUT * W_OUT),
+           "iou_vs_oracle": float(np.mean(ious)), "iou_vs_oracle_min": float(np.min(ious)),
+           "logit_max_abs_err_vs_oracle": float(np.max(lerr)), "eviction_sequence_equal": bool(idx_ok),
+           "parity_note": f"{len(mism)} teacher-forced frames (oracle labels fed to both), HIP engine vs CPU oracle, "
+                          "outside the timed regions; IoU = mean over 3 objects of evaluation/source/metrics.py:db_eval_iou"}
+    return cb, par
 
 
 if __name__ == "__main__":

@@ -76,6 +76,10 @@ typedef struct {
                                               at ((row/16)*ldpa + col)*16 + row%16 (ldpa = columns of the blocked
                                               tensor; a column window is selected by offsetting pah/pal by 16*col0
                                               elements); the V operand layout of rmem_attn_read; only output allowed */
+  int32_t d0_cs;                           /* column stride of d0 in elements (0 or 1 = contiguous).  With ldd0 = 225 and
+                                              d0_cs = 226 element (q, o) lands at 225*(q+o) + o: the relative-bias matrix
+                                              stored by anti-diagonals, which is what makes its gather in the windowed
+                                              read coalesced (rmem_read_args.rcs) */
 } rmem_linear_args;
 
 int rmem_linear(const rmem_linear_args *a, void *stream);
@@ -163,8 +167,9 @@ int rmem_attn_combine2(const rmem_combine_args *a, const rmem_combine_args *b, v
  * Modes and the K / Q layouts are those of rmem_attn_scores.  V is "blocked-16":
  * planes [slot][Npad/16][ncols][16] (element (key k, column c) at ((k/16)*ncols + c)*16 + k%16),
  * written by rmem_linear with pa_blocked = 1, so that an MFMA B fragment of 32 columns is one
- * contiguous KiB.  ncols must be a multiple of 512.  Split precision (hi/lo planes, 3 products) only.
- * Requires rmem_init() on the device (dynamic LDS above 64 KiB).
+ * contiguous KiB.  ncols must be a multiple of 512.
+ * Split precision (hi/lo planes, 3 products) only.
+
  */
 typedef struct {
   int32_t mode;                            /* 0 bank, 1 window                         */
@@ -175,7 +180,10 @@ typedef struct {
   int32_t T, N, Npad, ncols;
   float scale;
   const float *bias;                       /* mode 0: [N][T] or NULL                    */
-  const float *R; int32_t ldr; int32_t h, w;  /* mode 1                                 */
+  const float *R; int32_t ldr; int32_t h, w;  /* mode 1: relative bias, element (q, o) at R[q*ldr + o*rcs] */
+  int32_t rcs;                             /* column stride of R (0 = 1).  ldr = 225, rcs = 226 = stored by anti-diagonals:
+                                              the 32 queries of a wave (consecutive x) then read 32 CONSECUTIVE floats for a
+                                              given key instead of 32 different cache lines */
   int32_t ksplits;                         /* <= 32                                     */
   float *part;                             /* [ksplits][Npad][ncols] un-normalised partial O */
   float *ml;                               /* [ksplits][Npad][2]  (running max, row sum) */

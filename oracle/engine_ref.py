@@ -168,6 +168,63 @@ class OracleAOTEngine(OracleDeAOTEngine):
                                              self.long_memories_indexes, fg)
 
 
+class OracleDeAOTInferEngine:
+    """AOTInferEngine / DeAOTInferEngine for more than MODEL_MAX_OBJ_NUM objects
+    (engines/aot_engine.py:571-725, deaot_engine.py:20-56): one OracleDeAOTEngine per group of
+    `max_obj` object ids, each with its OWN memory state, masks separated per engine
+    (aot_engine.py:604-628) and decoder logits merged by soft aggregation (:650-673).
+
+    The reference itself cannot run this case: its sub-engines share one model and therefore one
+    LSTT memory (layers/transformer.py:1000-1007 lives on the shared module), so the second
+    engine re-fuses already fused memories and raises (tests/golden/make_golden.py note).  This
+    class restates what the wrapper computes when every sub-engine keeps its own state, which is
+    also what rmem_amd.engine.DeAOTInferEngine does."""
+
+    def __init__(self, model, long_term_mem_gap: int = 5):
+        self.model, self.cfg = model, model.cfg
+        self.long_term_mem_gap = long_term_mem_gap
+        self.max_obj = self.cfg.MODEL_MAX_OBJ_NUM
+        self.engines: List[OracleDeAOTEngine] = []
+
+    def restart_engine(self):                                   # aot_engine.py:598-602
+        self.engines = []
+
+    def separate_mask(self, mask):                              # aot_engine.py:604-618 (label masks)
+        if len(self.engines) == 1:
+            return [mask]
+        out = []
+        for idx in range(len(self.engines)):
+            start_id, end_id = idx * self.max_obj + 1, (idx + 1) * self.max_obj
+            fg = ((mask >= start_id) & (mask <= end_id)).float()
+            out.append((fg * mask - start_id + 1) * fg)
+        return out
+
+    def soft_logit_aggregation(self, all_logits):               # aot_engine.py:650-673
+        if len(all_logits) == 1:
+            return all_logits[0]
+        probs = [torch.softmax(lg, dim=1) for lg in all_logits]
+        bg = torch.prod(torch.cat([p[:, 0:1] for p in probs], dim=1), dim=1, keepdim=True)
+        merged = torch.cat([bg] + [p[:, 1:1 + self.max_obj] for p in probs], dim=1).clamp(1e-5, 1 - 1e-5)
+        return torch.logit(merged)
+
+    def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):      # :675-702
+        n = obj_nums[0] if isinstance(obj_nums, list) else obj_nums
+        need = max(-(-int(n) // self.max_obj), 1)
+        while len(self.engines) < need:
+            self.engines.append(OracleDeAOTEngine(self.model, self.long_term_mem_gap))
+        for e, m in zip(self.engines, self.separate_mask(mask)):
+            e.add_reference_frame(img, m, obj_nums=[self.max_obj], frame_step=frame_step)
+        self.input_size_2d = self.engines[0].input_size_2d
+
+    def match_propogate_one_frame(self, img, mask=None, output_size=None):  # :704-712
+        return self.soft_logit_aggregation([e.match_propogate_one_frame(img, output_size=output_size)
+                                            for e in self.engines])
+
+    def update_memory(self, curr_mask):                         # :714-720
+        for e, m in zip(self.engines, self.separate_mask(curr_mask)):
+            e.update_memory(m)
+
+
 def run_clip(engine, imgs, label0, out_hw=None):
     """The evaluator's per-frame protocol (networks/managers/evaluator.py:384-441,
     518-523): reference frame, then per frame match -> softmax -> argmax -> nearest

@@ -165,12 +165,10 @@ static int launch_scores(const rmem_scores_args& a, hipStream_t s) {
   using Cfg = GemmCfg<128, 128, NS>;
   const int qtiles = a.Npad / 128;
   const int ktiles = a.mode == 0 ? a.T * (a.Npad / 128) : max_band_tiles(a.N, a.Npad, a.h, a.w);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scores_kernel<NS, PASS>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    attr_set = true;
-  }
+  // per launch: the attribute belongs to the (device, function) pair, and a cached "already set"
+  // flag would be process-wide state shared by every device and host thread
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scores_kernel<NS, PASS>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
   hipLaunchKernelGGL((scores_kernel<NS, PASS>), dim3(ktiles, qtiles), dim3(256), Cfg::LDS_BYTES, s, a);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
@@ -192,12 +190,10 @@ static int launch_scores2(const rmem_scores_args& a, const rmem_scores_args& b, 
   const int gxa = a.mode == 0 ? a.T * (a.Npad / 128) : max_band_tiles(a.N, a.Npad, a.h, a.w);
   const int gxb = b.mode == 0 ? b.T * (b.Npad / 128) : max_band_tiles(b.N, b.Npad, b.h, b.w);
   const int na = gxa * (a.Npad / 128), nb = gxb * (b.Npad / 128);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scores2_kernel<NS, PASS>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    attr_set = true;
-  }
+  // per launch: the attribute belongs to the (device, function) pair, and a cached "already set"
+  // flag would be process-wide state shared by every device and host thread
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scores2_kernel<NS, PASS>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
   hipLaunchKernelGGL((scores2_kernel<NS, PASS>), dim3(na + nb), dim3(256), Cfg::LDS_BYTES, s, a, b, na, gxa, gxb);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
@@ -357,12 +353,10 @@ __global__ __launch_bounds__(256) void pv_kernel(rmem_pv_args a) {
 template <int NS>
 static int launch_pv(const rmem_pv_args& a, hipStream_t s) {
   using Cfg = GemmCfg<128, 128, NS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel<NS>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    attr_set = true;
-  }
+  // per launch: the attribute belongs to the (device, function) pair, and a cached "already set"
+  // flag would be process-wide state shared by every device and host thread
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_kernel<NS>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
   const int nct = (a.ncols + 127) / 128;
   const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
   dim3 grid(8 * chunk * nct);
@@ -485,11 +479,9 @@ __global__ __launch_bounds__(256) void pv16_kernel(rmem_pv_args a) {
 
 static int launch_pv16(const rmem_pv_args& a, hipStream_t s) {
   constexpr int LDS = 3 * 128 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  // per launch: the attribute belongs to the (device, function) pair, and a cached "already set"
+  // flag would be process-wide state shared by every device and host thread
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   const int nct = (a.ncols + 127) / 128;
   const int chunk = pv_chunk((a.Npad / 128) * a.ksplits);
   hipLaunchKernelGGL(pv16_kernel, dim3(8 * chunk * nct), dim3(256), LDS, s, a);

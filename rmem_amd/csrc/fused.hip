@@ -209,6 +209,7 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
   int qy = 0, qx = 0;
   const float inv_w = MODE == 1 ? 1.0f / (float)a.w : 0.f;   // (a.w >= 1 is validated for mode 1)
   const float* Rq = nullptr;
+  const int rcs = a.rcs > 0 ? a.rcs : 1;
   if (MODE == 1) {
     qy = fast_div(qvalid ? q : 0, inv_w);
     qx = (qvalid ? q : 0) - qy * a.w;
@@ -216,7 +217,10 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
   }
 
   // ---- reference pass: m = (approximate) row maximum of the scores over the whole split, from the hi
-  // planes only (one product instead of three; |error| ~ 2^-10 of |q||k| scale, a few hundredths).
+  // planes only (one product instead of three; |error| ~ 2^-10 of |q||k| scale, a few hundredths;
+  // the relative bias of the windowed read is added exactly: a reference ABOVE the maximum by D bits
+  // pushes the lo plane of every weight D bits into the fp16 subnormals -- 1.7e-4 on the LSTT output
+  // when the bias was simply dropped -- and one far below it ends the segment early).
   // The weights of the main pass are exp2(y - m) against this FIXED reference, so they stay within a
   // few per cent of 1 at the row maximum and the accumulators never need a rescale.  (A reference
   // taken from the first tile alone made the deferred-rescale path below data dependent: peaked
@@ -278,10 +282,7 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
               const int kx = tok - ky * a.w;
               const int dy = ky - qy, dx = kx - qx;
               valid = valid && qvalid && dy >= -7 && dy <= 7 && dx >= -7 && dx <= 7;
-              // the relative bias is left out of the reference (its gather costs as much as the whole
-              // tile: 64 cache lines per load instruction); it moves the maximum by a few units, the
-              // weights tolerate 2^14 and the segment mechanism below catches anything beyond
-              rb2 = 0.f;
+              rb2 = valid ? Rq[((dy + 7) * 15 + dx + 7) * rcs] * 1.44269504088896341f : 0.f;
             }
             const float sv = fmaf(sub ? s1[r] : s0[r], sl2e, rb2);
             mest = fmaxf(mest, valid ? sv : RD_NEG);
@@ -407,7 +408,7 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
             const int kx = tok - ky * a.w;
             const int dy = ky - qy, dx = kx - qx;
             valid = valid && qvalid && dy >= -7 && dy <= 7 && dx >= -7 && dx <= 7;
-            const float rb = valid ? Rq[(dy + 7) * 15 + dx + 7] : 0.f;
+            const float rb = valid ? Rq[((dy + 7) * 15 + dx + 7) * rcs] : 0.f;
             sv = fmaf(s[sub][r], sl2e, rb * 1.44269504088896341f);
           }
           sv = valid ? sv : RD_NEG;
@@ -599,7 +600,7 @@ static int read_args_ok(const rmem_read_args& a) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.T > 16 || a.ksplits <= 0 || a.ksplits > 32) return 0;
   if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.part || !a.ml) return 0;
   if (a.ncols <= 0 || (a.ncols % 512) != 0) return 0;
-  if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1)) return 0;
+  if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1 || a.w < 1 || a.ldr < 1)) return 0;
   if (a.mode != 0 && a.mode != 1) return 0;
   return 1;
 }
@@ -611,13 +612,8 @@ static int read_chunk(const rmem_read_args& a) {
 extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* bp, void* stream) {
   if (!ap || !bp || !read_args_ok(*ap) || !read_args_ok(*bp) || ap->mode != 0 || bp->mode != 1) return RMEM_ERR_INVALID;
   const int cha = read_chunk(*ap), chb = read_chunk(*bp);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  static bool attr_set[64] = {};
-  if (dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS);
-    attr_set[dev] = true;
-  }
+  // per launch: the attribute belongs to the (device, function) pair; no process-wide "already set" flag
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS);
   Read2Args g;
   g.p[0] = *ap;
   g.p[1] = *bp;
@@ -633,15 +629,9 @@ extern "C" int rmem_attn_read(const rmem_read_args* ap, void* stream) {
   const rmem_read_args& a = *ap;
   const int chunk = read_chunk(a);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  static bool attr_set[2][64] = {};
   const int var = (a.mode == 0 && a.R) ? 1 : 0;       // bank mode with R != NULL: the tracing build (debug aid)
   const void* fn = var == 0 ? reinterpret_cast<const void*>(&read_kernel<0>) : reinterpret_cast<const void*>(&read_kernel<1>);
-  if (dev < 64 && !attr_set[var][dev]) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS);
-    attr_set[var][dev] = true;
-  }
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS);
   if (var == 0) hipLaunchKernelGGL((read_kernel<0>), dim3(8 * chunk), dim3(256), RD_LDS, s, a);
   else hipLaunchKernelGGL((read_kernel<1>), dim3(8 * chunk), dim3(256), RD_LDS, s, a);
   RMEM_CHECK_LAUNCH();

@@ -122,7 +122,7 @@ __device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, i
         if (a.act == 1) v = silu_f(v);
         if (col < a.csplit) {
           if (d0) {
-            float* p = d0 + (long)row * a.ldd0 + col;
+            float* p = d0 + (long)row * a.ldd0 + (long)col * (a.d0_cs > 0 ? a.d0_cs : 1);
             *p = a.accumulate ? (*p + v) : v;
           }
         } else if (d1) {
@@ -179,12 +179,10 @@ template <int BM, int BN, int NS>
 static int launch_linear(const rmem_linear_args& a, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, NS>;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, NS>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    attr_set = true;
-  }
+  // per launch: the attribute belongs to the (device, function) pair, and a cached "already set"
+  // flag would be process-wide state shared by every device and host thread
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, NS>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
   hipLaunchKernelGGL((linear_kernel<BM, BN, NS>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;

@@ -48,10 +48,37 @@ def gather_masks(local_masks: torch.Tensor, world: int, group=None) -> torch.Ten
     import torch.distributed as dist
     if local_masks.dtype != torch.uint8:
         raise TypeError("masks are exchanged as uint8 label maps")
-    out = torch.empty((world * local_masks.shape[0],) + tuple(local_masks.shape[1:]),
-                      dtype=torch.uint8, device=local_masks.device)
-    dist.all_gather_into_tensor(out, local_masks.contiguous(), group=group)
-    return out
+    src = local_masks.contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":      # (tests: two processes sharing one GPU)
+        src = src.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=torch.uint8, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.to(local_masks.device)
+
+
+def run_sharded_clips(driver, n_clips: int, world: int, rank: int, frames_of: Callable[[int], list],
+                      num_frames: int, group=None):
+    """BASELINE.json configs[3]: `n_clips` independent clips, clip i on rank i mod world
+    (tools/eval.py:137-143 and managers/evaluator.py:276-295 hand clips to processes through a queue;
+    equal-length clips make the static shard as balanced), each through `driver.run_clip` (reference
+    frame and bank fill included), then ONE all-gather of the uint8 masks
+    (evaluator.py:589-613 funnels results through a queue instead).  Returns (sha256 per clip in
+    clip-id order, gathered masks [n_clips, F-1, H0, W0] in gather order, frames run on this rank).
+    The hashes do not depend on `world`: what rank a clip runs on changes nothing it computes."""
+    import hashlib
+    if n_clips % world:
+        raise ValueError("n_clips must be a multiple of the world size (pad the clip list)")
+    local, frames_run = [], 0
+    for cid in shard_clips(n_clips, world, rank):
+        res = driver.run_clip(frames_of(cid), num_frames=num_frames)
+        local.append(res.masks)
+        frames_run += int(res.masks.shape[0])
+    allm = gather_masks(torch.stack(local), world, group)
+    hashes: List[Optional[str]] = [None] * n_clips
+    host = allm.cpu().numpy()
+    for pos, cid in enumerate(unshard_order(n_clips, world)):
+        hashes[cid] = hashlib.sha256(host[pos].tobytes()).hexdigest()
+    return hashes, allm, frames_run
 
 
 def unshard_order(n_clips: int, world: int) -> List[int]:

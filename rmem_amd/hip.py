@@ -39,7 +39,7 @@ class LinearArgs(C.Structure):
         ("nbatch", i32), ("bsx", i64), ("bsy", i64), ("bsd", i64), ("bsbias", i64), ("bspa", i64),
         ("nsplit", i32), ("tile", i32),
         ("ksplits", i32), ("parts", c_p), ("part_stride", i64),
-        ("pa_blocked", i32),
+        ("pa_blocked", i32), ("d0_cs", i32),
     ]
 
 
@@ -50,7 +50,7 @@ class ReadArgs(C.Structure):
         ("kh", c_p), ("kl", c_p), ("k_slot_stride", i64),
         ("vh", c_p), ("vl", c_p), ("v_slot_stride", i64),
         ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32), ("ncols", i32),
-        ("scale", f32), ("bias", c_p), ("R", c_p), ("ldr", i32), ("h", i32), ("w", i32),
+        ("scale", f32), ("bias", c_p), ("R", c_p), ("ldr", i32), ("h", i32), ("w", i32), ("rcs", i32),
         ("ksplits", i32), ("part", c_p), ("ml", c_p), ("lslot", c_p),
     ]
 
@@ -240,7 +240,7 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
            x2: Planes = None, ldx2=0, kx_split=0, y2: Planes = None, ldy2=0, ky_split=0,
            nbatch=1, bsx=0, bsy=0, bsd=0, bsbias=0, bspa=0, nsplit=3, tile=0,
            x_off=0, y_off=0, ksplits=1, parts=None, part_stride=0, launch=True, pa_blocked=False,
-           pa_off=0):
+           pa_off=0, d0_cs=0):
     """x_off / y_off: element offsets into the plane tensors (column windows).
     launch=False returns the filled argument struct (for linear_grouped)."""
     a = LinearArgs()
@@ -254,6 +254,7 @@ def linear(x: Planes, y: Planes, M, N, K, *, ldx, ldy, bias=None, bias_per_row=F
     a.M, a.N, a.K = M, N, K
     a.bias, a.bias_per_row, a.act = ptr(bias), int(bias_per_row), act
     a.d0, a.ldd0, a.d1, a.ldd1 = d0, ldd0, d1, ldd1
+    a.d0_cs = d0_cs
     a.csplit, a.accumulate = csplit, int(accumulate)
     if pa is not None:
         a.pah, a.pal, a.ldpa = pa.hi.data_ptr() + pa_off * eb, pa.lo.data_ptr() + pa_off * eb, ldpa

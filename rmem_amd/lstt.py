@@ -188,9 +188,10 @@ class DeAOTLSTT:
         nq = Np // 128
         total = max(2, min(32, 256 // (2 * nq)))
         tv = (N + 63) // 64
-        # measured at 480p K=4 (bench.py, frames/s for ks_long, ks_win, ks_self): 7,2,9 382.6 / 6,3,9 397.7 /
-        # 6,3,6 403.1 / 5,4,6 407.2 / 6,3,4 397.6 -- a windowed tile costs ~2.5 long-term tiles (relative-bias gather)
-        self.ks_win = max(1, min(8, int(round(total * 0.4 * min(1.0, 4.0 / max(self.cap, 1))))))
+        # measured at 480p K=4 (bench.py frames/s / read2 us isolated, for ks_long, ks_win, ks_self):
+        # 7,2,6 385.9 / 242;  6,3,6 397.7 / 197;  5,4,6 388.5 / 207 -- a windowed tile costs more than a
+        # long-term one (mask arithmetic + relative-bias gather), so it gets a third of the splits at K = 4
+        self.ks_win = max(1, min(8, int(round(total * 0.33 * min(1.0, 4.0 / max(self.cap, 1))))))
         self.ks_long = max(1, min(total - self.ks_win, 32))
         self.ks_self = max(1, min(total, tv, 6))
         if os.environ.get("RMEM_KS"):                             # tuning override: "long,win,self"
@@ -203,8 +204,10 @@ class DeAOTLSTT:
         self.Yst = Planes.empty((Np, 1024), dev)
         self.KS = 4                                                # split-K of the projection GEMMs
         self.parts = z(self.KS, N, 512)
-        self.ldr = 232
-        self.R = z(N, self.ldr)
+        # relative bias of the windowed read, stored by anti-diagonals: element (q, o) at 225*(q+o) + o
+        # = q*ldr + o*rcs with ldr = 225, rcs = 226 (rmem_read_args.rcs: coalesced gathers)
+        self.ldr, self.rcs = 225, 226
+        self.R = z(N * 225 + 225 * 226)
         self.s_pl = Planes.empty((Np, 512), dev)
         self.selfQK = Planes.empty((1, Np, 128), dev)
         self.selfV = Planes.empty((1, Np // 16, 1024, 16), dev)
@@ -325,6 +328,7 @@ class DeAOTLSTT:
         ra.scale = self.scale
         ra.bias = bias.data_ptr() if bias is not None else None
         ra.R, ra.ldr, ra.h, ra.w = (self.R.data_ptr() if mode == 1 else None), self.ldr, self.h, self.w
+        ra.rcs = self.rcs
         tiles = T * ((self.N + 63) // 64)
         ks = max(1, min(ksplits, tiles))
         ra.ksplits = ks
@@ -500,7 +504,7 @@ class DeAOTLSTT:
             # relative-position bias of the windowed read (attention.py:314) and temporal-PE bias of
             # the long-term read (transformer.py:1140-1172)
             hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
-                       d0=self.R.data_ptr(), ldd0=self.ldr, nsplit=ns)
+                       d0=self.R.data_ptr(), ldd0=self.ldr, d0_cs=self.rcs, nsplit=ns)
             hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
                                        self.mem_pe.data_ptr(), rows, T, N, 128,
                                        self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")

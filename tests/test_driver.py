@@ -171,3 +171,54 @@ def test_driver_hip_vs_reference_golden(fused, golden_dir):
     assert idx[:new_at - 1] == meta["indexes"][:new_at - 1]
     assert idx[new_at - 1:] == [[[new_at], [new_at]]] * (meta["frames"] - new_at)
     assert len(res.frame_ms) == meta["frames"] - 1
+
+
+def _sharded_hip_worker(rank, world, port, q, n_clips, frames, H, W):
+    import torch.distributed as dist
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = get_config("r50_deaotl", 1, 3)
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    load_synthetic_weights(model)
+    model = model.to(DEV)
+    drv = D.ClipDriver(model, cfg, fixed_gap=2)
+
+    def frames_of(cid):
+        imgs, lab = synth_clip(100 + cid, frames, H, W, 3)
+        return [D.make_samples(imgs[t].to(DEV), lab.to(DEV) if t == 0 else None, (H, W), 3, name=f"{t:05d}.jpg")
+                for t in range(frames)]
+
+    hashes, allm, _ = D.run_sharded_clips(drv, n_clips, world, rank, frames_of, frames)
+    if rank == 0:
+        q.put(hashes)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_clips_world_invariance_hip():
+    """BASELINE.json configs[3] in miniature on the HIP engines: 4 clips x 8 frames as one process
+    and as two processes sharing cuda:0 (gloo; masks all-gathered) -- identical sha256 per clip.
+    (The MIOpen encoder is deterministic for a fixed process configuration; each clip is computed
+    by the same code whatever rank it lands on.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 33500 + os.getpid() % 2000 + world
+        procs = [ctx.Process(target=_sharded_hip_worker, args=(r, world, port, q, 4, 8, 97, 129)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out[world] = q.get(timeout=900)
+        for p in procs:
+            p.join(timeout=900)
+            assert p.exitcode == 0
+    same = [a == b for a, b in zip(out[1], out[2])]
+    print("per-clip hash equality world=1 vs world=2:", same)
+    assert all(same) and len(set(out[1])) == 4

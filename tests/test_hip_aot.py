@@ -273,3 +273,39 @@ def test_swin_aot_clip_teacher_forced(golden_dir):
     assert idx == meta["indexes"]
     assert max(mism) <= 3, mism
     assert np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max() < 3e-3
+
+
+def test_swin_aot_480x848_vs_oracle():
+    """BASELINE.json configs[4] at its full geometry: SwinB-AOTL + RMem, 480x848 (30x53 = 1590
+    tokens), K=4, gap 1 -- the HIP engine against the CPU oracle (oracle/aot_ref.py, pinned by the
+    Swin golden clip at 128x160), teacher-forced with the oracle's labels for 3 frames."""
+    import copy
+    from oracle.engine_ref import OracleAOTEngine
+    from rmem_amd.config import get_config
+    from rmem_amd.engine import build_engine
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+    H, W, frames = 480, 848, 4
+    cfg = get_config("swinb_aotl", 1, 3)
+    model = build_vos_model("aot", cfg).eval()
+    load_synthetic_weights(model)
+    model.cfg = cfg
+    eng = build_engine("aotengine", phase="eval", aot_model=copy.deepcopy(model).to(DEV), gpu_id=0, long_term_mem_gap=1)
+    ora = OracleAOTEngine(model, long_term_mem_gap=1)
+    imgs, lab = synth_clip(5, frames, H, W, 3)
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    assert eng.aot_engines[0].lstt.N == 30 * 53
+    mism, lerr = [], []
+    for t in range(1, frames):
+        lg = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(480, 854))
+        lo = ora.match_propogate_one_frame(imgs[t], output_size=(480, 854))
+        po = torch.argmax(lo, dim=1, keepdim=True)
+        mism.append(int((torch.argmax(lg, dim=1, keepdim=True).cpu() != po).sum()))
+        lerr.append(float((eng.aot_engines[0].pred_id_logits.cpu() - ora.pred_id_logits).abs().max()))
+        fed = F.interpolate(po.float(), size=ora.input_size_2d, mode="nearest")
+        eng.update_memory(fed.to(DEV))
+        ora.update_memory(fed)
+        assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.long_memories_indexes)
+    print("SwinB-AOTL 480x848 mismatching pixels per frame (of 409920):", mism, "decoder-logit max abs err:", lerr)
+    assert max(mism) <= 12 and max(lerr) < 2e-3, (mism, lerr)

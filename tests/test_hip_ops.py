@@ -471,7 +471,7 @@ def _block16(Vf):
     return Vf.permute(0, 2, 1).reshape(S, Np // 16, 16, Cn).permute(0, 1, 3, 2).contiguous()
 
 
-def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, ksplits, want_mass=True):
+def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, ksplits, want_mass=True, ldr=None, rcs=0):
     """K: [S][Npad][128] planes, Vb: blocked-16 planes [S][Npad/16][1024][16], Q planes [Npad][128]."""
     lib, st = hip.load(), hip.stream_ptr()
     part = torch.full((ksplits, Npad, 1024), float("nan"), device=DEV)     # every valid row must be written
@@ -488,7 +488,7 @@ def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, kspli
     ra.T, ra.N, ra.Npad, ra.ncols, ra.scale = T, N, Npad, 1024, 1.0 / math.sqrt(128)
     ra.bias = bias.data_ptr() if bias is not None else None
     if R is not None:
-        ra.R, ra.ldr = R.data_ptr(), R.shape[1]
+        ra.R, ra.ldr, ra.rcs = R.data_ptr(), (ldr if ldr is not None else R.shape[1]), rcs
     ra.h, ra.w, ra.ksplits = h, w, ksplits
     ra.part, ra.ml = part.data_ptr(), ml.data_ptr()
     ra.lslot = lslot.data_ptr() if want_mass else None
@@ -605,6 +605,14 @@ def test_read_window(hip, ksplits, h, w):
     err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     print(f"fused window read {h}x{w} ksplits={ksplits}: G rel err {err:.2e}")
     assert err < 5e-5, err
+    # the same bias stored by anti-diagonals (element (q, o) at 225*(q+o) + o: ldr = 225, rcs = 226), the layout
+    # the LSTT uses: coalesced gathers, bit-identical result
+    Rd = torch.zeros(N * 225 + 225 * 226)
+    qi, oi = torch.meshgrid(torch.arange(N), torch.arange(225), indexing="ij")
+    Rd[(qi * 225 + oi * 226).flatten()] = rel.float().flatten()
+    G2, _, _, _ = _run_read(hip, 1, 1, N, Npad, _planes(hip, Kf), _planes(hip, _block16(Vf)), [1], _planes(hip, Qf),
+                            None, u.to(DEV), h, w, Rd.to(DEV), ksplits, want_mass=False, ldr=225, rcs=226)
+    assert torch.equal(G2, G)
 
 
 def test_linear_blocked_output(hip):

@@ -177,3 +177,55 @@ def test_c_abi_rejects_invalid_arguments():
     assert lib.rmem_id_assign(None, 0, 0, None, None, 12, 17, 16, 8, 1, 1, 256, None, None, 1e-5,
                               None, None, 0, None, 0, 1, None) == -1
     assert lib.rmem_set_ints(None, None, 0, None) == -1
+
+
+# ------------------------------------------------------------------ config 4: rank-count invariance
+def _clip_frames(cid, frames, H, W, device="cpu"):
+    from rmem_amd import driver as D
+    from rmem_amd.synth import synth_clip
+    imgs, lab = synth_clip(100 + cid, frames, H, W, 3)
+    return [D.make_samples(imgs[t].to(device), lab.to(device) if t == 0 else None, (H, W), 3, name=f"{t:05d}.jpg")
+            for t in range(frames)]
+
+
+def _sharded_oracle_worker(rank, world, port, q, n_clips, frames, H, W):
+    import torch.distributed as dist
+    from oracle.engine_ref import OracleDeAOTEngine
+    from rmem_amd import driver as D
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = get_config("r50_deaotl", 1, 3)
+    model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(model)
+    model.cfg = cfg
+    drv = D.ClipDriver(model, cfg, engine_factory=lambda m: OracleDeAOTEngine(m), fixed_gap=2)
+    hashes, allm, _ = D.run_sharded_clips(drv, n_clips, world, rank, lambda c: _clip_frames(c, frames, H, W), frames)
+    if rank == 0:
+        q.put(hashes)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_clips_hashes_do_not_depend_on_world_size():
+    """BASELINE.json configs[3] (64 clips over 8 ranks) in miniature, oracle engines injected into
+    the clip driver: 4 clips x 6 frames as world = 1 and as two gloo processes give the same sha256
+    per clip (static shard clip i -> rank i mod world, one all-gather of uint8 masks)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 31500 + os.getpid() % 2000 + world
+        procs = [ctx.Process(target=_sharded_oracle_worker, args=(r, world, port, q, 4, 6, 49, 65)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out[world] = q.get(timeout=600)
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0
+    assert out[1] == out[2] and len(set(out[1])) == 4      # same per clip, and the clips differ

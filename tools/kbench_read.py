@@ -44,8 +44,6 @@ def main():
     args = ap.parse_args()
     from rmem_amd import hip
     lib = hip.load()
-    if hasattr(lib, "rmem_init"):
-        lib.rmem_init()
     dev = torch.device("cuda:0")
     h, w, T = args.h, args.w, args.T
     N = h * w
