@@ -12,16 +12,17 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${TAG}_$i -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-dropin > gpurun_out/pmc_${TAG}_$i.log 2>&1
 done
-python - <<PY
-import csv, glob, json, collections
+TAG=$TAG python - <<'PY'
+import csv, glob, json, collections, os
+TAG = os.environ["TAG"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_${TAG}_*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(f"gpurun_out/pmc_{TAG}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         name = "read2_kernel" if k.startswith("read2_kernel") else ("read_kernel" if "read_kernel" in k else None)
         if name:
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-res = {"note": "rocprofv3 --kernel-trace --pmc <set> in separate passes of `python bench.py --steps 6 --warmup 2`; mean per dispatch "
+res = {"note": "rocprofv3 --kernel-trace --pmc <set> in separate passes of python bench.py --steps 6 --warmup 2; mean per dispatch "
                "over every dispatch of the kernel in the run (pre-roll included); FETCH_SIZE / WRITE_SIZE in KB as reported; "
                "hbm_bytes_per_launch = 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; "
                "SQ_* cycle counters are quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles, = 32 per 32x32x16 MFMA)"}
@@ -34,6 +35,6 @@ for name, cs in agg.items():
     res[name] = d
 if "read2_kernel" in res and "hbm_bytes_per_launch" in res["read2_kernel"]:
     res["hbm_bytes_per_launch"] = res["read2_kernel"]["hbm_bytes_per_launch"]
-json.dump(res, open("gpurun_out/${TAG}_pmc_read.json", "w"), indent=1)
+json.dump(res, open(f"gpurun_out/{TAG}_pmc_read.json", "w"), indent=1)
 print(json.dumps(res)[:1500])
 PY

@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--cap", type=int, default=4)
     ap.add_argument("--nsplit", type=int, default=3)
     ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--only", default="", help="pv: run only the long-term scores + P.V kernels (for --pmc runs)")
+    ap.add_argument("--only", default="", help="pv: run only the fused memory-read launches (for --pmc runs)")
     args = ap.parse_args()
     from rmem_amd import hip
     from rmem_amd.config import get_config
@@ -73,82 +73,27 @@ def main():
     rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
     map_bank, map_short = L.maps.data_ptr(), L.maps.data_ptr() + 64
     curK = L.bankK[1][T]
-    # --- attention pieces (long-term): build args once via the executor's own path
-    import types
-    calls = {}
-
-    def attention(ws, mode, Tn, kpl, vpl, smap, qpl, bias, U, which):
-        L.rowmax.zero_()
-        L._attention(ws, mode, Tn, kpl, vpl, smap, qpl, bias, U, False, which)
-
-    if args.only == "pv":
-        ksl = L._ksplits(T * Np // 64)
-        f0 = None
-
-        def scores(mode, Tn, pass_, ws, kpl, smap, qpl, bias):
-            sa = hip.ScoresArgs()
-            sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, kpl.hi.data_ptr(), kpl.lo.data_ptr(), L.k_slot_stride
-            sa.slot_map, sa.T, sa.N, sa.Npad = smap, Tn, N, Np
-            sa.qh, sa.ql, sa.scale = qpl.hi.data_ptr(), qpl.lo.data_ptr(), L.scale
-            sa.bias = bias.data_ptr() if bias is not None else None
-            sa.ldr, sa.h, sa.w = L.ldr, L.h, L.w
-            sa.rowmax = L.rowmax[0].data_ptr()
-            sa.ph, sa.pl = ws.P.hi.data_ptr(), (None if (L.p16 and mode == 0) else ws.P.lo.data_ptr())
-            sa.lpart, sa.nparts, sa.nsplit, sa.pass_ = ws.lpart.data_ptr(), Tn * Np // 64, L.nsplit, pass_
-            hip.check(lib.rmem_attn_scores(C.byref(sa), hip.stream_ptr()), "scores")
-        L.rowmax.zero_()
-        scores(0, T, 0, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe)
-        scores(0, T, 1, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe)
-        pa = hip.PVArgs()
-        pa.mode, pa.ph, pa.pl = 0, L.ws_main.P.hi.data_ptr(), (None if L.p16 else L.ws_main.P.lo.data_ptr())
-        pa.vh, pa.vl, pa.v_slot_stride = L.bankV[1].hi.data_ptr(), L.bankV[1].lo.data_ptr(), L.v_slot_stride
-        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = map_bank, T, N, Np, 1024
-        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = L.h, L.w, L.ws_main.part.data_ptr(), ksl, L.nsplit
+    # --- the three memory reads of a layer through the executor's own argument builders
+    L._layer = 1
+    sQK = hip.Planes(L.selfQK.hi[0], L.selfQK.lo[0])
+    A = L._read_args(L.ws_main, 0, T, L.bankK[1], L.bankV[1], map_bank, L.Qpe, L.bias_pe, L.Ucat, True, L.ks_long)
+    B = L._read_args(L.ws_side, 1, 1, L.bankK[1], L.bankV[1], map_short, curK, None, L.Ucat, False, L.ks_win)
+    S = L._read_args(L.ws_main, 0, 1, L.selfQK, L.selfV, None, sQK, None, L.Uself, False, L.ks_self)
+    st = hip.stream_ptr()
+    if args.only == "pv":       # for --pmc runs: only the fused read launches
         for _ in range(args.iters):
-            hip.check(lib.rmem_attn_pv(C.byref(pa), hip.stream_ptr()), "pv")
+            hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "read2")
+            hip.check(lib.rmem_attn_read(C.byref(S[0]), st), "read")
         torch.cuda.synchronize()
         return
-    res["attn_long_total"] = timeit(lambda: attention(L.ws_main, 0, T, L.bankK[1], L.bankV[1], map_bank, L.Qpe,
-                                                      L.bias_pe, L.Ucat, 0), args.iters)
-    res["attn_window_total"] = timeit(lambda: attention(L.ws_side, 1, 1, L.bankK[1], L.bankV[1], map_short, curK,
-                                                        None, L.Ucat, 1), args.iters)
-    res["attn_self_total"] = timeit(lambda: attention(L.ws_main, 0, 1, L.selfQK, L.selfV, None,
-                                                      hip.Planes(L.selfQK.hi[0], L.selfQK.lo[0]), None, L.Uself, 2),
-                                    args.iters)
-
-    # individual kernels through the C ABI
-    def scores(mode, Tn, pass_, ws, kpl, smap, qpl, bias):
-        sa = hip.ScoresArgs()
-        sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, kpl.hi.data_ptr(), kpl.lo.data_ptr(), L.k_slot_stride
-        sa.slot_map, sa.T, sa.N, sa.Npad = smap, Tn, N, Np
-        sa.qh, sa.ql, sa.scale = qpl.hi.data_ptr(), qpl.lo.data_ptr(), L.scale
-        sa.bias = bias.data_ptr() if bias is not None else None
-        sa.R, sa.ldr, sa.h, sa.w = (L.R.data_ptr() if mode == 1 else None), L.ldr, L.h, L.w
-        sa.rowmax = L.rowmax[0].data_ptr()
-        sa.ph, sa.pl = ws.P.hi.data_ptr(), (None if (L.p16 and mode == 0) else ws.P.lo.data_ptr())
-        sa.lpart, sa.nparts, sa.nsplit, sa.pass_ = ws.lpart.data_ptr(), Tn * Np // 64, L.nsplit, pass_
-        return lambda: hip.check(lib.rmem_attn_scores(C.byref(sa), hip.stream_ptr()), "scores")
-
-    def pv(mode, Tn, ws, vpl, smap, ks):
-        pa = hip.PVArgs()
-        pa.mode, pa.ph, pa.pl = mode, ws.P.hi.data_ptr(), (None if (L.p16 and mode == 0) else ws.P.lo.data_ptr())
-        pa.vh, pa.vl, pa.v_slot_stride = vpl.hi.data_ptr(), vpl.lo.data_ptr(), L.v_slot_stride
-        pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = smap, Tn, N, Np, 1024
-        pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = L.h, L.w, ws.part.data_ptr(), ks, L.nsplit
-        return lambda: hip.check(lib.rmem_attn_pv(C.byref(pa), hip.stream_ptr()), "pv")
-
-    ksl = L._ksplits(T * Np // 64)
-    res["scores_long_pass0"] = timeit(scores(0, T, 0, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe), args.iters)
-    res["scores_long_pass1"] = timeit(scores(0, T, 1, L.ws_main, L.bankK[1], map_bank, L.Qpe, L.bias_pe), args.iters)
-    res["pv_long"] = timeit(pv(0, T, L.ws_main, L.bankV[1], map_bank, ksl), args.iters)
-    for ks in ([int(v) for v in os.environ["RMEM_KS_LIST"].split(",")] if os.environ.get("RMEM_KS_LIST") else (1, 2, 4, 8)):
-        res[f"pv_long_ks{ks}"] = timeit(pv(0, T, L.ws_main, L.bankV[1], map_bank, ks), args.iters)
-    res["scores_win_pass0"] = timeit(scores(1, 1, 0, L.ws_side, L.bankK[1], map_short, curK, None), args.iters)
-    res["scores_win_pass1"] = timeit(scores(1, 1, 1, L.ws_side, L.bankK[1], map_short, curK, None), args.iters)
-    res["pv_win"] = timeit(pv(1, 1, L.ws_side, L.bankV[1], map_short, L._ksplits(16)), args.iters)
-    res["pv_self"] = timeit(pv(0, 1, L.ws_main, L.selfV, None, L._ksplits(Np // 64)), args.iters)
-    flops = 2.0 * N * T * N * 1024
-    res["pv_long_TFLOPs_algorithmic"] = flops / res["pv_long"] / 1e6
+    res["splits_long_win_self"] = float(f"{L.ks_long}.{L.ks_win}{L.ks_self}")
+    res["read2_long+window"] = timeit(lambda: hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "r2"), args.iters)
+    res["read_combine2"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "c2"), args.iters)
+    res["read_long_alone"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "r"), args.iters)
+    res["read_window_alone"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(B[0]), st), "r"), args.iters)
+    res["read_self"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(S[0]), st), "r"), args.iters)
+    res["read_combine_self"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine(C.byref(S[1]), st), "c"), args.iters)
+    res["read2_TFLOPs_algorithmic"] = L.read_flops(T) / res["read2_long+window"] / 1e6
     res["dwconv"] = timeit(lambda: L._dwconv(L.ws_main, W.dw_lt, L.Ylt), args.iters)
     ns = L.nsplit
     res["ln"] = timeit(lambda: L._ln(L.tgt, W.ln1, L.x_pl, 256), args.iters)
@@ -156,9 +101,9 @@ def main():
                                                        d0=L.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128, pb=L.Qpe,
                                                        ldpb=128, addvec=L.cur_pe, nsplit=ns), args.iters)
     curV = L.bankV[1][T]
-    res["gemm_Vt(512x256,swapped)"] = timeit(lambda: hip.linear(
-        W.Wv, L.x_pl, 512, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True, act=1,
-        pa=hip.Planes(curV.hi[:512], curV.lo[:512]), ldpa=Np, nsplit=ns), args.iters)
+    res["gemm_V(512x256,blocked-16 out)"] = timeit(lambda: hip.linear(
+        L.x_pl, W.Wv, N, 512, 256, ldx=256, ldy=256, bias=W.bv, act=1, pa=curV, ldpa=1024, pa_blocked=True,
+        nsplit=ns), args.iters)
     res["gemm_U(512x256)"] = timeit(lambda: hip.linear(L.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1,
                                                        d0=L.Ucat.data_ptr(), ldd0=1024, nsplit=ns), args.iters)
     res["gemm_proj_ls(512x2048)"] = timeit(lambda: hip.linear(
@@ -169,7 +114,7 @@ def main():
         L.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, d0=L.tgt.data_ptr(), ldd0=256,
         d1=L.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns), args.iters)
     res["gemm_R(225x128)"] = timeit(lambda: hip.linear(curK, W.Wrel, N, 225, 128, ldx=128, ldy=128, bias=W.brel,
-                                                       d0=L.R.data_ptr(), ldd0=L.ldr, nsplit=ns), args.iters)
+                                                       d0=L.R.data_ptr(), ldd0=L.ldr, d0_cs=L.rcs, nsplit=ns), args.iters)
     lab = torch.randint(0, 11, (481, 849), dtype=torch.uint8, device=dev) if (args.h, args.w) == (31, 54) else \
         torch.randint(0, 11, ((args.h - 1) * 16 + 1, (args.w - 1) * 16 + 1), dtype=torch.uint8, device=dev)
     res["id_assign"] = timeit(lambda: L.assign_identity(lab), args.iters)
