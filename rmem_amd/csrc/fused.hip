@@ -554,33 +554,41 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
     // as [64 rows][128 columns] per wave, two rounds, the tile leaves as 16-byte stores of whole
     // 512-byte rows (the 4-byte form was store-issue-bound: ~25 us of a 113 us launch).
     char* stg = smem + wave * 32768;
+    int lrow = hi, lcol = j;                          // opaque here: keeps this block's 64 row pointers out of the prologue
+    RD_OPAQUE(lrow);
+    RD_OPAQUE(lcol);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = q2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int row = q2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
 #pragma unroll
           for (int ci = 0; ci < 4; ++ci)
-            *reinterpret_cast<float*>(stg + row * 512 + (ci * 32 + j) * 4) = o[half * 2 + q2][ci][r];
+            *reinterpret_cast<float*>(stg + row * 512 + (ci * 32 + lcol) * 4) = o[half * 2 + q2][ci][r];
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS operations complete in order
       float* orow = a.part + ((long)z * a.Npad + qtile * 128 + half * 64) * a.ncols + (long)cp * 512 + wave * 128;
 #pragma unroll
       for (int it = 0; it < 32; ++it) {
-        const int row = it * 2 + hi;
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + j * 16);
-        *reinterpret_cast<f32x4_t*>(orow + (long)row * a.ncols + j * 4) = v;
+        const int row = it * 2 + lrow;
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + lcol * 16);
+        *reinterpret_cast<f32x4_t*>(orow + (long)row * a.ncols + lcol * 4) = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
     }
   } else {
+    // (the lane term is made opaque HERE: otherwise the compiler computes the 64 factor addresses and
+    // the 256 row offsets of this rare block before the tile loop and spills them -- 237 registers x
+    // 65536 threads = 62 MB of scratch writes per launch, measured as WRITE_SIZE 162 MB vs 66 MB of partials)
+    int hi4 = 4 * hi;
+    RD_OPAQUE(hi4);
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int qq = qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int qq = qi * 32 + (r & 3) + 8 * (r >> 2) + hi4;
         const float f = fac[qq];
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
