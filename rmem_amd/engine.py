@@ -114,6 +114,7 @@ class DeAOTEngine(nn.Module):
         self.long_term_mem_gap = long_term_mem_gap
         self.nsplit = nsplit
         self.lstt: Optional[DeAOTLSTT] = None
+        self._lstt_wv = 0
         self.restart_engine()
 
     def restart_engine(self):                                   # aot_engine.py:533-563
@@ -127,6 +128,9 @@ class DeAOTEngine(nn.Module):
         self.pred_id_logits = None
         self._drop_pending()
         self._drop_hoist()
+        if self.lstt is not None and self._lstt_wv != self.AOT.__dict__.get("_weights_version", 0):
+            self.lstt = None                 # weights were (re)loaded: re-pack at the next reference frame
+            self._fg, self._ug = {}, {}
         if self.lstt is not None:
             self.lstt.clear_memory()
 
@@ -134,7 +138,9 @@ class DeAOTEngine(nn.Module):
         self.input_size_2d = tuple(int(v) for v in input_size)
         self.enc_size_2d = tuple(int(v) for v in enc_size)
         self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
-        if self.lstt is None or (self.lstt.h, self.lstt.w) != self.enc_size_2d:
+        wv = self.AOT.__dict__.get("_weights_version", 0)
+        if self.lstt is None or (self.lstt.h, self.lstt.w) != self.enc_size_2d or self._lstt_wv != wv:
+            self._lstt_wv = wv          # load_network() after this engine was built: packed weights are stale
             dev = next(self.AOT.parameters()).device
             cls = DeAOTLSTT if self.cfg.MODEL_VOS == "deaot" else AOTLSTT
             self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
@@ -374,7 +380,7 @@ class DeAOTEngine(nn.Module):
         if pend is None:
             return
         par, cur = pend[1], l.next_free_slot()
-        ent = self._fg.get(((l._T, cur), osz, shape, par))
+        ent = self._fg.get(((l._T, cur), osz, shape, par, tuple(self.obj_nums)))
         if ent is None:
             return                                        # captured when a frame first runs with that key
         ev = torch.cuda.Event()
@@ -407,7 +413,7 @@ class DeAOTEngine(nn.Module):
             g_img.copy_(img)
             g.replay()
         par = self._par                                   # the copy that holds this frame's features
-        key = (l.graph_key(), osz, shape, par)
+        key = (l.graph_key(), osz, shape, par, tuple(self.obj_nums))     # obj_nums is baked into the decoder graph
         ent = self._fg.get(key)
         if ent is None:
             # capture every slot variant for this (T, shapes, feature copy) at once: capture
@@ -437,7 +443,7 @@ class DeAOTEngine(nn.Module):
                         logits[batch_idx, (obj_num + 1):] = -1e10
                     up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
                                                                   align_corners=self.align_corners)
-                self._fg[(l.graph_key(), osz, shape, par)] = (g, logits, up, g2, gf, gr)
+                self._fg[(l.graph_key(), osz, shape, par, tuple(self.obj_nums))] = (g, logits, up, g2, gf, gr)
             for k, v in saved.items():
                 setattr(l, k, v)
             ent = self._fg[key]

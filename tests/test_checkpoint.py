@@ -38,3 +38,16 @@ def test_remap_rules():
     assert removed2 == []
     assert torch.equal(out["patch_wise_id_bank.weight"][:, :11], sd["patch_wise_id_bank.weight"][:, :11] * 2)
     assert torch.equal(out["patch_wise_id_bank.weight"][:, 11], before_last)
+
+
+def test_load_network_bumps_the_weights_version():
+    """Engines pack the LSTT weights when they are built; load_network() afterwards must make them
+    re-pack (rmem_amd/engine.py: update_size / restart_engine compare `_weights_version`)."""
+    from rmem_amd.checkpoint import load_network
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    m = build_vos_model("deaot", get_config("r50_deaotl")).eval()
+    v0 = m.__dict__.get("_weights_version", 0)
+    m, _ = load_network(m, {k: v.clone() for k, v in m.state_dict().items()})
+    assert m.__dict__["_weights_version"] == v0 + 1
+    assert "_weights_version" not in m.state_dict()
