@@ -256,18 +256,33 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
   // few per cent of 1 at the row maximum and the accumulators never need a rescale.  (A reference
   // taken from the first tile alone made the deferred-rescale path below data dependent: peaked
   // attention, whose maximum sits in a late tile, broke every unit into 2-3 segments -- 2.3x slower
-  // in the engine than on random data.)  Costs 16 MFMAs + one K staging per tile, ~10 %.
+  // in the engine than on random data.)  Costs 16 MFMAs + one hi-plane K staging per tile.
   {
     float mest = RD_NEG;
     int pt = -1;
     float pb2 = 0.f;
-    kload(lo);
-    kstore();
+    // hi plane only, two tiles resident in the K region of the LDS (buffer b at +16 KB * b): the next
+    // tile is requested before this one is multiplied and stored after it -- one barrier per tile
+    u32x4_t hr[4];
+    auto hload = [&](int i) __attribute__((always_inline)) {
+      int key0;
+      const int t = tile_slot(i, key0);
+      const h16_t* b0 = a.kh + (long)lut(t) * a.k_slot_stride + (long)key0 * 128;
+      static_for<4>([&](auto P) { hr[P.value] = *reinterpret_cast<const u32x4_t*>(b0 + P.value * 16 * 128 + goff); });
+    };
+    auto hstore = [&](int b) __attribute__((always_inline)) {
+      static_for<4>([&](auto P) {
+        *reinterpret_cast<u32x4_t*>(smem + ast + st_half * 8192 + b * 16384 + (KS_OFF + P.value * 2048)) = hr[P.value];
+      });
+    };
+    hload(lo);
+    hstore(0);
     __syncthreads();
     for (int i = lo; i < hi_t; ++i) {
       int key0;
       const int t = tile_slot(i, key0);
-      if (i + 1 < hi_t) kload(i + 1);
+      const int boff = ((i - lo) & 1) * 16384;
+      if (i + 1 < hi_t) hload(i + 1);
       if (MODE == 0 && t != pt) {
         pt = t;
         pb2 = ((a.bias && qvalid) ? a.bias[(long)q * a.T + t] : 0.f) * sl2e;
@@ -280,8 +295,8 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
         constexpr int ks = KS.value;
         constexpr int kh = ks >> 2, k4 = ks & 3;
         g[0] = *reinterpret_cast<const frag8_t*>(smem + aq[k4] + kh * 16384);
-        g[1] = *reinterpret_cast<const frag8_t*>(smem + ak[k4] + kh * 8192);
-        g[2] = *reinterpret_cast<const frag8_t*>(smem + ak[k4] + (kh * 8192 + 4096));
+        g[1] = *reinterpret_cast<const frag8_t*>(smem + ak[k4] + boff + kh * 8192);
+        g[2] = *reinterpret_cast<const frag8_t*>(smem + ak[k4] + boff + (kh * 8192 + 4096));
       };
       gload(g0, std::integral_constant<int, 0>{});
       static_for<8>([&](auto KS) {
@@ -321,11 +336,8 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
             mest = fmaxf(mest, rbv > -2.9e38f ? sv : RD_NEG);
           }
       }
-      __syncthreads();                                // everyone is done with this K tile
-      if (i + 1 < hi_t) {
-        kstore();
-        __syncthreads();
-      }
+      if (i + 1 < hi_t) hstore(((i - lo) + 1) & 1);    // the other buffer: its readers passed the last barrier
+      __syncthreads();
     }
     mest = fmaxf(mest, __shfl_xor(mest, 32));
     if (mest > -2.9e38f) m = mest;
