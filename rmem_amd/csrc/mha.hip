@@ -188,11 +188,16 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
         u32x4_t wh, wl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p0 = pv[8 * ks + 2 * e], p1 = pv[8 * ks + 2 * e + 1];
-          const unsigned short h0 = f2h_bits(p0), h1 = f2h_bits(p1);   // softmax weights <= 1: no saturation needed
-          wh[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-          if constexpr (NPL == 2)
-            wl[e] = (uint32_t)f2h_bits(p0 - h_bits2f(h0)) | ((uint32_t)f2h_bits(p1 - h_bits2f(h1)) << 16);
+          // packed conversions (v_cvt_pk_f16_f32, round to nearest even): softmax weights <= 1, no saturation needed
+          f32x2_t pp;
+          pp[0] = pv[8 * ks + 2 * e];
+          pp[1] = pv[8 * ks + 2 * e + 1];
+          const f16x2_t hh = __builtin_convertvector(pp, f16x2_t);
+          wh[e] = __builtin_bit_cast(uint32_t, hh);
+          if constexpr (NPL == 2) {
+            const f32x2_t rr = pp - __builtin_convertvector(hh, f32x2_t);
+            wl[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr, f16x2_t));
+          }
         }
         pf[0][ks] = __builtin_bit_cast(frag8_t, wh);
         if constexpr (NPL == 2) pf[1][ks] = __builtin_bit_cast(frag8_t, wl);
