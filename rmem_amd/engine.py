@@ -80,6 +80,7 @@ class DeAOTEngine(nn.Module):
             use_graphs = os.environ.get("RMEM_NO_GRAPHS") is None
         self.use_graphs = bool(use_graphs)
         self._fg, self._ug = {}, {}          # hipGraphs: frame graphs / update graphs by key
+        self._dg = {}                        # decoder (+ upsample) graphs by (output size, shape, feature copy, obj_nums)
         self._eg = {}                        # encoder graphs by (img shape, parity): (graph, static img, features)
         self._g_lab = {}                     # static graph inputs per shape (graphs keep their address)
         # Encoder feature copies.  A copy `par` belongs to a group = one encoder hipGraph: three
@@ -130,7 +131,7 @@ class DeAOTEngine(nn.Module):
         self._drop_hoist()
         if self.lstt is not None and self._lstt_wv != self.AOT.__dict__.get("_weights_version", 0):
             self.lstt = None                 # weights were (re)loaded: re-pack at the next reference frame
-            self._fg, self._ug = {}, {}
+            self._fg, self._ug, self._dg = {}, {}, {}
         if self.lstt is not None:
             self.lstt.clear_memory()
 
@@ -144,7 +145,7 @@ class DeAOTEngine(nn.Module):
             dev = next(self.AOT.parameters()).device
             cls = DeAOTLSTT if self.cfg.MODEL_VOS == "deaot" else AOTLSTT
             self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
-            self._fg, self._ug = {}, {}      # graphs hold pointers into the old LSTT buffers
+            self._fg, self._ug, self._dg = {}, {}, {}      # graphs hold pointers into the old LSTT buffers
             self._drop_pending()
             self._drop_hoist()
             self._eg, self._g_lab, self._feats = {}, {}, {}
@@ -437,12 +438,21 @@ class DeAOTEngine(nn.Module):
                         l._forward_device(False, "front")
                     with torch.cuda.graph(gr):
                         l._forward_device(False, "rest")
-                with torch.cuda.graph(g2):
-                    logits = self.AOT.decode_id_logits(l.out, enc)
-                    for batch_idx, obj_num in enumerate(self.obj_nums):
-                        logits[batch_idx, (obj_num + 1):] = -1e10
-                    up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
-                                                                  align_corners=self.align_corners)
+                # the decoder (+ upsample) graph reads the LSTT's static output buffer and this feature
+                # copy only: ONE capture per (output size, shape, copy, obj_nums), shared by every
+                # (T, slot) variant (a private copy per variant was ~200 activation pools per geometry)
+                dkey = (osz, shape, par, tuple(self.obj_nums))
+                dent = self._dg.get(dkey)
+                if dent is None:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2):
+                        logits = self.AOT.decode_id_logits(l.out, enc)
+                        for batch_idx, obj_num in enumerate(self.obj_nums):
+                            logits[batch_idx, (obj_num + 1):] = -1e10
+                        up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
+                                                                      align_corners=self.align_corners)
+                    dent = self._dg[dkey] = (g2, logits, up)
+                g2, logits, up = dent
                 self._fg[(l.graph_key(), osz, shape, par, tuple(self.obj_nums))] = (g, logits, up, g2, gf, gr)
             for k, v in saved.items():
                 setattr(l, k, v)
