@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips in flight per GPU, one engine + one HIP stream each (SURVEY.md 8f "
                          "rank 2; BASELINE.json configs[1] is 1, configs[3] runs 8 clips per rank)")
+    ap.add_argument("--batched", action="store_true",
+                    help="--clips-per-gpu B clips in lockstep through rmem_amd.batched: ONE launch per kernel for all "
+                         "clips (encoder / decoder at batch B), instead of one engine + HIP stream per clip")
     ap.add_argument("--reference-postproc", action="store_true",
                     help="softmax/argmax/nearest-resize with the evaluator's torch ops on full-size logits "
                          "(managers/evaluator.py:424-441,518-523) instead of the driver's fused label kernels")
@@ -108,6 +111,8 @@ def main():
     load_synthetic_weights(cpu_model)
     model = copy.deepcopy(cpu_model).to(dev)
     C = max(1, args.clips_per_gpu)
+    if args.batched:
+        return batched_steady(args, world, rank, dev, dist, cfg, model, mem_k)
     engines = []
     for _ in range(C):
         e = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=model, gpu_id=local_rank,
@@ -278,6 +283,80 @@ def main():
             cb, par = cpu_baseline_and_parity(cpu_model, model, cfg, args, dev)
             out["cpu_baseline"] = cb
             out.update(par)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
+    """Steady-state frames of B = --clips-per-gpu clips per GPU served by shared launches
+    (rmem_amd.batched.BatchedDeAOTEngine): same protocol as the default mode (reference frame,
+    pre-roll until the bank holds K slots, timed steps), a step = one frame of every clip."""
+    from rmem_amd import hip
+    from rmem_amd.batched import BatchedDeAOTEngine
+    from rmem_amd.synth import synth_clip
+    B = max(1, args.clips_per_gpu)
+    eng = BatchedDeAOTEngine(model, B, long_term_mem_gap=args.gap, nsplit=args.nsplit)
+    ring = 8
+    per = [synth_clip(rank * B + i, ring, H_IN, W_IN, 3) for i in range(B)]
+    imgs = [torch.cat([per[i][0][t] for i in range(B)]).to(dev) for t in range(ring)]
+    labs = torch.cat([per[i][1] for i in range(B)]).to(dev)
+    eng.add_reference_frame(imgs[0], labs, obj_nums=[3] * B, frame_step=0)
+    lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
+
+    def step(t, masks_out=None):
+        logit = eng.match_propogate_one_frame(imgs[t % ring], output_size=None,
+                                              next_imgs=None if args.no_prefetch else imgs[(t + 1) % ring])
+        for i in range(B):
+            out = masks_out[i, t % masks_out.shape[1]] if masks_out is not None else None
+            lab = hip.labels_from_logits([logit[i:i + 1]], [False], (H_OUT, W_OUT), cfg.MODEL_ALIGN_CORNERS, out=out)
+            hip.label_resize_nearest(lab, eng.input_size_2d, out=lab_in[i])
+        eng.update_memory(lab_in)
+
+    t = 1
+    while len(eng.lstt.clips[0].bank) < cfg.mem_cap:
+        step(t)
+        t += 1
+    for _ in range(2 * cfg.mem_cap + 6 + args.warmup):       # every (clip, slot) argument block recorded
+        step(t)
+        t += 1
+    masks = torch.zeros(B, args.steps, H_OUT, W_OUT, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    launches0 = eng.lstt.launches
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(t + k, masks)
+    host_issue = time.perf_counter() - t0
+    if dist is not None:
+        from rmem_amd.driver import gather_masks
+        gather_masks(masks, world)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    fps = world * B * args.steps / elapsed
+    c0 = eng.lstt.clips[0]
+    out = {"metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref" if args.config == "480p_k4"
+           else "frames/sec/GPU (720p, K=8 memory, 3 objects) R50-DeAOTL+RMem",
+           "value": fps, "unit": "frames/s (whole job)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "fp16x3 (split-fp16 MFMA: hi/lo planes, 3 products, fp32 accumulate)", "data": "synthetic",
+           "config": {"workload": f"R50-DeAOTL + RMem, {H_OUT}p ({H_IN}x{W_IN}, {c0.N} tokens), K={mem_k} memory, {B} clips per GPU "
+                                  f"in lockstep, ONE launch per kernel for all clips, long_term_mem_gap={args.gap}, steady-state bank",
+                      "frames_per_sec_per_gpu": fps / world, "clips_per_gpu": B, "batched": True,
+                      "memory_path_launches_per_step": (eng.lstt.launches - launches0) / args.steps,
+                      "key_splits_long_win_self": [c0.ks_long, c0.ks_win, c0.ks_self],
+                      "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
+                      "parallelism": f"clips sharded {B}-per-GPU x{world}, batched launches, all-gather of masks"}}
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -396,6 +396,37 @@ int rmem_labels_from_logits(const rmem_label_src *srcs, int32_t n_src, int32_t C
 int rmem_label_resize_nearest(const uint8_t *src, int32_t Hs, int32_t Ws, uint8_t *dst,
                               int32_t Hd, int32_t Wd, int32_t flip, void *stream);
 
+/* ---- several clips' memory banks in one launch -------------------------------
+ * The reference serves one clip per call: its attention asserts batch 1
+ * (aot_plus/networks/layers/transformer.py:641,1190) and the evaluator walks clips one after the
+ * other per process (managers/evaluator.py:344-523).  Here B clips of one geometry that advance in
+ * lockstep share every launch of the memory path:
+ *
+ *   h = rmem_rec_begin();  ...any sequence of the calls below...;  rmem_rec_end(h);
+ *
+ * While a host thread is recording, rmem_linear / rmem_linear_grouped / rmem_layernorm_red[2] /
+ * rmem_pe_bias / rmem_attn_read[2] / rmem_attn_read_combine[2] / rmem_dwconv5x5_split[2] /
+ * rmem_groupnorm2 / rmem_id_assign / rmem_attn_mass_reduce on that thread validate their arguments
+ * as usual but launch nothing: the argument block and launch geometry are appended to the
+ * recording (other entry points are not recordable and launch immediately).  Recording the same
+ * host code once per clip (different buffers) gives B argument blobs (rmem_rec_data/_size) with the
+ * same rmem_rec_signature.  The caller places blob i at dev_args + i * clip_stride in device memory
+ * (16-byte aligned, clip_stride >= blob size, multiple of 16) and
+ *
+ *   rmem_launch_recorded(h_of_any_clip, dev_args, clip_stride, B, stream)
+ *
+ * issues each recorded op ONCE for all B clips (grid z extent x B; a block reads its clip's
+ * argument block from dev_args).  Per clip the arithmetic is the single-clip kernel's, bit for bit.
+ * dev_args must stay unchanged until the launches have executed. */
+void *rmem_rec_begin(void);                 /* NULL if this thread is already recording */
+int rmem_rec_end(void *rec);
+void rmem_rec_free(void *rec);
+int32_t rmem_rec_count(const void *rec);    /* recorded ops */
+int64_t rmem_rec_size(const void *rec);     /* bytes of the argument blob */
+const void *rmem_rec_data(const void *rec);
+uint64_t rmem_rec_signature(const void *rec);
+int rmem_launch_recorded(const void *rec, const void *dev_args, int64_t clip_stride, int32_t B, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,359 @@
+"""Several clips per GPU in ONE launch per kernel.
+
+The reference serves one clip per process: its attention asserts batch 1
+(/root/reference/aot_plus/networks/layers/transformer.py:641,1190) and the evaluator walks the clips
+one after the other (managers/evaluator.py:344-523).  Here B clips of one geometry advance in
+lockstep (same frame index, same memory schedule -- config 4 of BASELINE.json: equal-length clips,
+one gap rule) and share every launch of the memory path:
+
+  * each clip keeps its own ``DeAOTLSTT`` state (bank ring, slot map, EMA / visit dictionaries);
+    their packed weights are shared;
+  * the host code of a pass is RECORDED once per (clip, slot, bank depth) -- librmem_hip's launch
+    recorder (include/rmem_hip.h, csrc/launch.h) turns every entry point into "append the
+    argument block" -- and the B argument blobs are uploaded (one pinned-memory copy) and replayed
+    by ``rmem_launch_recorded``: per kernel ONE launch whose grid covers all clips, each block
+    reading its clip's arguments from device memory.  Per clip the arithmetic is the single-clip
+    kernel's, bit for bit (tests/test_hip_batched.py);
+  * encoder and decoder run through MIOpen at batch B (hipGraphs keyed by the shapes only: nothing
+    clip-specific is baked in, the per-clip state lives in the uploaded argument blocks);
+  * the RMem eviction needs ONE device-to-host copy per long-term update for all clips.
+
+``BatchedDeAOTEngine`` mirrors the engine API of engines/aot_engine.py with a leading clip axis:
+``add_reference_frame(imgs [B,3,H,W], masks [B,1,H,W], obj_nums=[n_0..n_B-1])``,
+``match_propogate_one_frame(imgs)`` -> logits [B,C,H,W], ``update_memory(masks)``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .lstt import DeAOTLSTT
+
+
+class _Upload:
+    """Stream-ordered host -> device upload of a small byte block through a ring of pinned buffers
+    (the device buffer keeps its address: it is baked into recorded argument blocks)."""
+
+    RING = 6
+
+    def __init__(self, nbytes: int, device):
+        self.nbytes = int(nbytes)
+        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.pin = [torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self.np = [p.numpy() for p in self.pin]
+        self.done: List[Optional[torch.cuda.Event]] = [None] * self.RING
+        self.k = 0
+
+    def stage(self) -> np.ndarray:
+        """The pinned buffer to fill next (waits until the copy that last read it has run)."""
+        self.k = (self.k + 1) % self.RING
+        if self.done[self.k] is not None:
+            self.done[self.k].synchronize()
+        return self.np[self.k]
+
+    def send(self):
+        self.dev.copy_(self.pin[self.k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.done[self.k] = ev
+
+
+class BatchedLSTT:
+    """B ``DeAOTLSTT`` states of one geometry served by shared launches."""
+
+    def __init__(self, model, h: int, w: int, device, B: int, nsplit: int = 3):
+        self.B = int(B)
+        first = DeAOTLSTT(model, h, w, device, nsplit, clips_per_launch=self.B)
+        self.clips: List[DeAOTLSTT] = [first] + [
+            DeAOTLSTT(model, h, w, device, nsplit, clips_per_launch=self.B, weights_from=first)
+            for _ in range(self.B - 1)]
+        self.dev = first.dev
+        self.N, self.h, self.w = first.N, first.h, first.w
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)
+        self.tgt, self.tgt_id = z(self.B, self.N, 256), z(self.B, self.N, 256)
+        self.out = z(self.B, self.N, 512)
+        self.w_out = z(self.B, first.Tmax)
+        self.fg = z(self.B, self.N)
+        self.maps_up = _Upload(self.B * 128, self.dev)
+        maps_i32 = self.maps_up.dev.view(torch.int32).view(self.B, 32)
+        for i, c in enumerate(self.clips):
+            c.tgt, c.tgt_id, c.out, c.w_out = self.tgt[i], self.tgt_id[i], self.out[i], self.w_out[i]
+            c.maps = maps_i32[i]
+            c._batched = True
+        self._labels: Dict[tuple, torch.Tensor] = {}
+        self._recs: Dict[tuple, hip.Recording] = {}
+        self._chan: Dict[tuple, _Upload] = {}
+        self.launches = 0            # recorded ops issued (each ONE launch for all clips)
+
+    # ------------------------------------------------------------------ recorder plumbing
+    def _record(self, kind: str, i: int, key: tuple, fn) -> hip.Recording:
+        k = (kind, i) + key
+        r = self._recs.get(k)
+        if r is None:
+            with hip.Recording() as r:
+                fn(self.clips[i])
+            self._recs[k] = r
+        return r
+
+    def _run(self, kind: str, keys: List[tuple], fn):
+        """Record (or look up) `fn(clip)` for every clip, upload the B argument blobs, launch."""
+        recs = [self._record(kind, i, keys[i], fn) for i in range(self.B)]
+        sig, n = recs[0].signature, len(recs[0].blob)
+        if any(r.signature != sig or len(r.blob) != n for r in recs):
+            raise hip.RmemError(f"batched '{kind}': the clips recorded different launch sequences "
+                                "(clips of one batch must share geometry and bank depth)")
+        stride = (n + 255) // 256 * 256
+        ch = self._chan.get((kind, n))
+        if ch is None:
+            ch = self._chan[(kind, n)] = _Upload(self.B * stride, self.dev)
+        buf = ch.stage()
+        for i, r in enumerate(recs):
+            buf[i * stride:i * stride + n] = np.frombuffer(r.blob, dtype=np.uint8)
+        ch.send()
+        recs[0].launch(ch.dev, stride, self.B)
+        self.launches += recs[0].count
+
+    # ------------------------------------------------------------------ passes
+    def label_buffer(self, H: int, W: int) -> torch.Tensor:
+        """Static uint8 [B,H,W] buffer the ID assignment reads the clips' label maps from."""
+        buf = self._labels.get((H, W))
+        if buf is None:
+            buf = self._labels[(H, W)] = torch.zeros(self.B, H, W, dtype=torch.uint8, device=self.dev)
+        return buf
+
+    def clear_memory(self):
+        for c in self.clips:
+            c.clear_memory()
+
+    def assign_identity(self, labels_u8: torch.Tensor, ignore: bool = True):
+        """labels_u8: the label_buffer() of its shape (or a tensor copied into it)."""
+        B, H, W = labels_u8.shape
+        lab = self.label_buffer(H, W)
+        if labels_u8.data_ptr() != lab.data_ptr():
+            lab.copy_(labels_u8)
+        self._run("id", [(H, W, bool(ignore))] * self.B,
+                  lambda c: c.assign_identity(lab[self.clips.index(c)], ignore=ignore))
+
+    def forward(self, emb_bnc: torch.Tensor, ref_frame: bool = False) -> torch.Tensor:
+        """DualBranchGPM.forward for every clip.  emb_bnc: [B,N,256] fp32 -> [B,N,512]."""
+        self.tgt.copy_(emb_bnc)
+        self.tgt_id.zero_()
+        stage = self.maps_up.stage().view(np.int32).reshape(self.B, 32)
+        for i, c in enumerate(self.clips):
+            c._prepare(ref_frame)
+            stage[i, :18] = c._map_vals
+        self.maps_up.send()
+        T = self.clips[0]._T
+        if any(c._T != T for c in self.clips):
+            raise hip.RmemError("batched clips must hold banks of the same depth (lockstep schedule)")
+        self._run("fwd", [(c.cur, c._T, bool(ref_frame)) for c in self.clips],
+                  lambda c: c._forward_device(ref_frame))
+        for c in self.clips:
+            c._finish(ref_frame)
+        return self.out
+
+    def update_short_memories(self, update_long: bool):
+        self._run("upd", [(c.cur,) for c in self.clips], lambda c: c._update_device(update_long))
+        for c in self.clips:
+            c._update_host(update_long)
+
+    def restrict_long_memories(self, indexes: List[List[int]], fg_bn: torch.Tensor):
+        """restrict_long_memories (transformer.py:880-991) for every clip: one reduce launch, ONE
+        device-to-host copy, the EMA + UCB rule per clip on the host."""
+        self.fg.copy_(fg_bn)
+        T = self.clips[0].mass_T
+        self._run("mass", [(c.mass_T,) for c in self.clips],
+                  lambda c: c._mass_reduce_device(self.fg[self.clips.index(c)]))
+        w = self.w_out[:, :T].cpu().numpy().astype(np.float32)
+        return [c._restrict_host(indexes[i], w[i]) for i, c in enumerate(self.clips)]
+
+
+class BatchedDeAOTEngine:
+    """B clips (one engine each in the reference, engines/aot_engine.py:18-568) in lockstep."""
+
+    def __init__(self, aot_model, B: int, gpu_id: int = 0, long_term_mem_gap: int = 9999, nsplit: int = 3,
+                 fold_bn: bool = True, use_graphs: Optional[bool] = None):
+        if aot_model.cfg.MODEL_VOS != "deaot":
+            raise NotImplementedError("batched clips are built for the DeAOT + RMem path")
+        self.AOT = aot_model
+        self.cfg = aot_model.cfg
+        self.B = int(B)
+        self.gpu_id = gpu_id
+        self.long_term_mem_gap = long_term_mem_gap
+        self.nsplit = nsplit
+        self.align_corners = self.cfg.MODEL_ALIGN_CORNERS
+        if use_graphs is None:
+            use_graphs = os.environ.get("RMEM_NO_GRAPHS") is None
+        self.use_graphs = bool(use_graphs)
+        if fold_bn and next(aot_model.parameters()).is_cuda:
+            aot_model.optimize_for_inference(True)
+        self.lstt: Optional[BatchedLSTT] = None
+        self._eg, self._dg = {}, {}
+        self._par = 0                        # encoder feature copy (of two) that holds the current frame
+        self._pending = None                 # (images, copy, done event) of the announced next frame
+        self._enc_stream = None
+        self.restart_engine()
+
+    def restart_engine(self):                                   # aot_engine.py:533-563
+        self.frame_step = 0
+        self.last_mem_step = -1
+        self.obj_nums = None
+        self.input_size_2d = self.enc_size_2d = self.enc_hw = None
+        self.long_memories_indexes: List[List[int]] = [[] for _ in range(self.B)]
+        self.pred_id_logits = None
+        self._drop_pending()
+        if self.lstt is not None:
+            self.lstt.clear_memory()
+
+    def update_size(self, input_size, enc_size):                # aot_engine.py:565-568
+        self.input_size_2d = tuple(int(v) for v in input_size)
+        self.enc_size_2d = tuple(int(v) for v in enc_size)
+        self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
+        if self.lstt is None or (self.lstt.h, self.lstt.w) != self.enc_size_2d:
+            dev = next(self.AOT.parameters()).device
+            self.lstt = BatchedLSTT(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.B, self.nsplit)
+            self._eg, self._dg = {}, {}
+
+    # ------------------------------------------------------------------ encoder / decoder at batch B
+    def _encoder_graph(self, imgs: torch.Tensor, par: int):
+        key = (tuple(imgs.shape), par)
+        ent = self._eg.get(key)
+        if ent is None:
+            g_img = torch.zeros_like(imgs)
+            self.AOT.encode_image(g_img)                  # MIOpen picks its solvers outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enc = self.AOT.encode_image(g_img)
+            ent = self._eg[key] = (g, g_img, enc)
+        return ent
+
+    def _drop_pending(self):
+        p, self._pending = getattr(self, "_pending", None), None
+        if p is not None:
+            torch.cuda.current_stream().wait_event(p[2])
+
+    def _encode(self, imgs: torch.Tensor):
+        """Encoder pyramid of the B frames.  With hipGraphs there are two feature copies: the pass of
+        an announced next frame (`_prefetch`) runs on a second stream into the other copy while
+        this frame's LSTT and decoder read theirs."""
+        if not (self.use_graphs and imgs.is_cuda):
+            return self.AOT.encode_image(imgs)
+        p, self._pending = self._pending, None
+        if p is not None:
+            torch.cuda.current_stream().wait_event(p[2])
+            if p[0] is imgs:
+                self._par = p[1]
+                return self._eg[(tuple(imgs.shape), self._par)][2]
+        ent = self._encoder_graph(imgs, self._par)
+        ent[1].copy_(imgs)
+        ent[0].replay()
+        return ent[2]
+
+    def _prefetch(self, next_imgs):
+        if next_imgs is None or not (self.use_graphs and next_imgs.is_cuda) or self._pending is not None:
+            return
+        par = 1 - self._par
+        ent = self._encoder_graph(next_imgs, par)
+        if self._enc_stream is None:
+            from .streams import concurrent_stream
+            self._enc_stream = concurrent_stream(next_imgs.device)
+        after, done = torch.cuda.Event(), torch.cuda.Event()
+        after.record(torch.cuda.current_stream())     # the previous reader of that copy is queued before this point
+        with torch.cuda.stream(self._enc_stream):
+            self._enc_stream.wait_event(after)
+            ent[1].copy_(next_imgs, non_blocking=True)
+            next_imgs.record_stream(self._enc_stream)
+            ent[0].replay()
+            done.record(self._enc_stream)
+        self._pending = (next_imgs, par, done)
+
+    def _decode_eager(self, enc, osz):
+        h, w = self.enc_size_2d
+        emb = self.lstt.out.view(self.B, h, w, 512).permute(0, 3, 1, 2)
+        logits = self.AOT.decoder([enc[-1], emb], enc)
+        for b, obj_num in enumerate(self.obj_nums):
+            logits[b, (obj_num + 1):] = -1e10
+        up = logits if osz is None else F.interpolate(logits, size=osz, mode="bilinear",
+                                                      align_corners=self.align_corners)
+        return logits, up
+
+    def _decode(self, enc, output_size, graph_ok: bool):
+        osz = tuple(int(v) for v in output_size) if output_size is not None else None
+        if not (self.use_graphs and graph_ok):
+            return self._decode_eager(enc, osz)
+        key = (osz, id(enc), tuple(self.obj_nums))
+        ent = self._dg.get(key)
+        if ent is None:
+            self._decode_eager(enc, osz)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logits, up = self._decode_eager(enc, osz)
+            ent = self._dg[key] = (g, logits, up, enc)
+        ent[0].replay()
+        return ent[1], ent[2]
+
+    def _labels_u8(self, masks: torch.Tensor) -> torch.Tensor:
+        m = masks
+        if m.dim() == 4:
+            if m.shape[1] != 1:
+                raise NotImplementedError("probability masks are a training-only input (aot_engine.py:333-334)")
+            m = m[:, 0]
+        if m.dim() != 3 or m.shape[0] != self.B:
+            raise ValueError(f"masks must be [B,1,H,W] or [B,H,W] with B = {self.B}")
+        return m.to(torch.uint8).contiguous()
+
+    # ------------------------------------------------------------------ engine API
+    @torch.no_grad()
+    def add_reference_frame(self, imgs, masks, obj_nums, frame_step: int = -1):
+        """aot_engine.py:241-325 for B clips.  obj_nums: one object count per clip."""
+        if len(obj_nums) != self.B or imgs.shape[0] != self.B:
+            raise ValueError("one image, mask and object count per clip")
+        self.obj_nums = [int(n) for n in obj_nums]
+        if frame_step == -1:
+            frame_step = self.frame_step
+        self._drop_pending()
+        enc = self._encode(imgs)
+        if self.input_size_2d is None:
+            self.update_size(imgs.shape[2:], enc[-1].shape[2:])
+        # no ignore channel on reference frames (aot_engine.py:304 -> :209-213)
+        self.lstt.assign_identity(self._labels_u8(masks), ignore=False)
+        self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=True)
+        self.last_mem_step = frame_step
+        self.long_memories_indexes = [[self.frame_step] for _ in range(self.B)]
+        self.pred_id_logits, _ = self._decode(enc, None, imgs.is_cuda)
+
+    @torch.no_grad()
+    def match_propogate_one_frame(self, imgs, output_size=None, next_imgs=None):
+        """aot_engine.py:398-436 for B clips -> logits [B,C,H,W].  `next_imgs` (extension, optional):
+        the tensor that will be passed to the NEXT call; its encoder pass then runs on a second
+        stream beside this frame's LSTT and decoder (the encoder does not depend on the memory)."""
+        self.frame_step += 1
+        enc = self._encode(imgs)
+        self._prefetch(next_imgs)
+        self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=False)
+        self.pred_id_logits, up = self._decode(enc, output_size, imgs.is_cuda)
+        return up
+
+    @torch.no_grad()
+    def update_memory(self, masks):
+        """update_short_term_memory (aot_engine.py:327-369) for B clips; the long-term update and the
+        RMem eviction follow the shared gap schedule."""
+        update_long = False
+        if (not self.cfg.NO_LONG_MEMORY) and self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
+            update_long = True
+            self.last_mem_step = self.frame_step
+        self.lstt.assign_identity(self._labels_u8(masks), ignore=True)
+        self.lstt.update_short_memories(update_long)
+        if update_long:
+            for idx in self.long_memories_indexes:
+                idx.append(self.frame_step)
+            lg = F.interpolate(self.pred_id_logits, size=self.enc_size_2d, mode="bilinear", align_corners=True)
+            fg = (1 - torch.softmax(lg, dim=1)[:, 0]).reshape(self.B, -1).contiguous()
+            self.lstt.restrict_long_memories(self.long_memories_indexes, fg)

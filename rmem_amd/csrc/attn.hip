@@ -3,6 +3,7 @@
 // See include/rmem_hip.h for the contract and DESIGN.md for the roofline accounting.
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
+#include "launch.h"
 #include "attn_common.h"
 
 // ------------------------------------------------------------------ scores (swapped: rows = keys)
@@ -586,8 +587,12 @@ extern "C" int rmem_attn_combine(const rmem_combine_args* ap, void* stream) {
 // ------------------------------------------------------------------ temporal-PE bias
 struct PeRows { int row[16]; };
 
-__global__ void pe_bias_kernel(const float* Q, long ldq, const float* cur_pe, const float* mem_pe,
-                               PeRows rows, int T, int N, int d, float* bias) {
+struct PeBiasArgs {
+  const float* Q; long ldq; const float* cur_pe; const float* mem_pe; PeRows rows; int T, N, d; float* bias;
+};
+__device__ void pe_bias_kernel(const PeBiasArgs& a, int) {
+  const float* Q = a.Q; const long ldq = a.ldq; const float* cur_pe = a.cur_pe; const float* mem_pe = a.mem_pe;
+  const PeRows& rows = a.rows; const int T = a.T, N = a.N, d = a.d; float* bias = a.bias;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= N) return;
@@ -605,10 +610,8 @@ extern "C" int rmem_pe_bias(const float* Q, int64_t ldq, const float* cur_pe, co
                             const int32_t* pe_row_host, int32_t T, int32_t N, int32_t d, float* bias,
                             void* stream) {
   if (!Q || !cur_pe || !mem_pe || !pe_row_host || !bias || T <= 0 || T > 16 || N <= 0) return RMEM_ERR_INVALID;
-  PeRows rows;
-  for (int t = 0; t < 16; ++t) rows.row[t] = t < T ? pe_row_host[t] : 0;
-  hipLaunchKernelGGL(pe_bias_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), Q,
-                     (long)ldq, cur_pe, mem_pe, rows, T, N, d, bias);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  PeBiasArgs a{Q, (long)ldq, cur_pe, mem_pe, {}, T, N, d, bias};
+  for (int t = 0; t < 16; ++t) a.rows.row[t] = t < T ? pe_row_host[t] : 0;
+  return rmem::launch<PeBiasArgs, pe_bias_kernel, 256>(a, dim3((N + 3) / 4), dim3(256), 0,
+                                                        static_cast<hipStream_t>(stream));
 }

@@ -28,6 +28,7 @@
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
 #include "attn_common.h"
+#include "launch.h"
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -650,6 +651,37 @@ __global__ __launch_bounds__(256, 1) void read2_kernel(Read2Args g) {
   read_body<0>(g.p[which], (which ? jj - g.cha : jj) * 8 + xcd, smem);
 }
 
+// the same two kernels for several clips in one launch (launch.h): block z = clip, whose argument
+// block is read from device memory
+__global__ __launch_bounds__(256, 1) void read_many_kernel(const char* __restrict__ argv, long stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const rmem_read_args a = *reinterpret_cast<const rmem_read_args*>(argv + (long)blockIdx.z * stride);
+  read_body<0>(a, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(256, 1) void read2_many_kernel(const char* __restrict__ argv, long stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Read2Args& g = *reinterpret_cast<const Read2Args*>(argv + (long)blockIdx.z * stride);
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int which = jj < g.cha ? 0 : 1;
+  const rmem_read_args a = g.p[which];
+  read_body<0>(a, (which ? jj - g.cha : jj) * 8 + xcd, smem);
+}
+
+template <class K>
+static int read_many_thunk(K kernel, const rmem::RecOp& op, const char* dev_args, long stride, int B, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS);
+  hipLaunchKernelGGL(kernel, dim3(op.grid.x, 1, B), dim3(256), RD_LDS, s, dev_args + op.off, stride);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+static int read_many(const rmem::RecOp& op, const char* d, long st, int B, hipStream_t s) {
+  return read_many_thunk(&read_many_kernel, op, d, st, B, s);
+}
+static int read2_many(const rmem::RecOp& op, const char* d, long st, int B, hipStream_t s) {
+  return read_many_thunk(&read2_many_kernel, op, d, st, B, s);
+}
+
 static int read_args_ok(const rmem_read_args& a) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.T > 16 || a.ksplits <= 0 || a.ksplits > 32) return 0;
   if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.part || !a.ml) return 0;
@@ -673,6 +705,10 @@ extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* b
   g.p[1] = *bp;
   g.cha = cha;
   g.chb = chb;
+  if (rmem::Recorder* r = rmem::current_recorder()) {
+    rmem::rec_push(r, &read2_many, dim3(8 * (cha + chb)), dim3(256), RD_LDS, &g, (unsigned)sizeof(g));
+    return RMEM_OK;
+  }
   hipLaunchKernelGGL(read2_kernel, dim3(8 * (cha + chb)), dim3(256), RD_LDS, static_cast<hipStream_t>(stream), g);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
@@ -684,6 +720,11 @@ extern "C" int rmem_attn_read(const rmem_read_args* ap, void* stream) {
   const int chunk = read_chunk(a);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int var = (a.mode == 0 && a.R) ? 1 : 0;       // bank mode with R != NULL: the tracing build (debug aid)
+  if (rmem::Recorder* r = rmem::current_recorder()) {
+    if (var) return RMEM_ERR_INVALID;
+    rmem::rec_push(r, &read_many, dim3(8 * chunk), dim3(256), RD_LDS, &a, (unsigned)sizeof(a));
+    return RMEM_OK;
+  }
   const void* fn = var == 0 ? reinterpret_cast<const void*>(&read_kernel<0>) : reinterpret_cast<const void*>(&read_kernel<1>);
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS);
   if (var == 0) hipLaunchKernelGGL((read_kernel<0>), dim3(8 * chunk), dim3(256), RD_LDS, s, a);
@@ -749,15 +790,18 @@ __device__ __forceinline__ void read_combine_body(const rmem_read_combine_args& 
   }
 }
 
-__global__ __launch_bounds__(256) void read_combine_kernel(rmem_read_combine_args a) {
+__device__ void read_combine_kernel(const rmem_read_combine_args& a, int) {
   __shared__ float sh[40];
   read_combine_body(a, blockIdx.x, sh);
 }
 
-__global__ __launch_bounds__(256) void read_combine2_kernel(rmem_read_combine_args a, rmem_read_combine_args b) {
+struct Combine2Args {
+  rmem_read_combine_args a, b;
+};
+__device__ void read_combine2_kernel(const Combine2Args& g, int) {
   __shared__ float sh[40];
-  if ((int)blockIdx.x < a.N) read_combine_body(a, blockIdx.x, sh);
-  else read_combine_body(b, blockIdx.x - a.N, sh);
+  if ((int)blockIdx.x < g.a.N) read_combine_body(g.a, blockIdx.x, sh);
+  else read_combine_body(g.b, blockIdx.x - g.a.N, sh);
 }
 
 static int read_combine_ok(const rmem_read_combine_args& a) {
@@ -769,14 +813,13 @@ static int read_combine_ok(const rmem_read_combine_args& a) {
 
 extern "C" int rmem_attn_read_combine(const rmem_read_combine_args* ap, void* stream) {
   if (!ap || !read_combine_ok(*ap)) return RMEM_ERR_INVALID;
-  hipLaunchKernelGGL(read_combine_kernel, dim3(ap->N), dim3(256), 0, static_cast<hipStream_t>(stream), *ap);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  return rmem::launch<rmem_read_combine_args, read_combine_kernel, 256>(*ap, dim3(ap->N), dim3(256), 0,
+                                                                        static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rmem_attn_read_combine2(const rmem_read_combine_args* ap, const rmem_read_combine_args* bp, void* stream) {
   if (!ap || !bp || !read_combine_ok(*ap) || !read_combine_ok(*bp)) return RMEM_ERR_INVALID;
-  hipLaunchKernelGGL(read_combine2_kernel, dim3(ap->N + bp->N), dim3(256), 0, static_cast<hipStream_t>(stream), *ap, *bp);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  Combine2Args g{*ap, *bp};
+  return rmem::launch<Combine2Args, read_combine2_kernel, 256>(g, dim3(ap->N + bp->N), dim3(256), 0,
+                                                               static_cast<hipStream_t>(stream));
 }

@@ -2,6 +2,7 @@
 // epilogue (fp32 / split-fp16 planes / residual accumulate).  See include/rmem_hip.h.
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
+#include "launch.h"
 
 // One BM x BN output tile of problem `a`.  bz = batch index (nbatch > 1) or K-split index
 // (ksplits > 1, raw partial sums to a.parts, bias added by split 0 only).
@@ -147,9 +148,9 @@ __device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, i
 }
 
 template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void linear_kernel(rmem_linear_args a) {
+__device__ void linear_kernel(const rmem_linear_args& a, int bz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  linear_body<BM, BN, NS>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  linear_body<BM, BN, NS>(a, blockIdx.x, blockIdx.y, bz, smem);
 }
 
 // Several independent small problems in one launch (the projections of one LSTT stage share
@@ -162,7 +163,7 @@ struct GroupedLinear {
 };
 
 template <int NS>
-__global__ __launch_bounds__(256) void linear_grouped_kernel(GroupedLinear g) {
+__device__ void linear_grouped_kernel(const GroupedLinear& g, int) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.tile_start[i + 1]) ++i;
@@ -179,13 +180,7 @@ template <int BM, int BN, int NS>
 static int launch_linear(const rmem_linear_args& a, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, NS>;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
-  // per launch: the attribute belongs to the (device, function) pair, and a cached "already set"
-  // flag would be process-wide state shared by every device and host thread
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel<BM, BN, NS>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-  hipLaunchKernelGGL((linear_kernel<BM, BN, NS>), grid, dim3(256), Cfg::LDS_BYTES, s, a);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  return rmem::launch<rmem_linear_args, linear_kernel<BM, BN, NS>, 256>(a, grid, dim3(256), Cfg::LDS_BYTES, s);
 }
 
 static int validate_linear(rmem_linear_args& a) {
@@ -217,15 +212,11 @@ extern "C" int rmem_linear_grouped(const rmem_linear_args* args, int32_t n, void
   }
   g.tile_start[n] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (args[0].nsplit == 3) {
-    using Cfg = GemmCfg<64, 64, 3>;
-    hipLaunchKernelGGL(linear_grouped_kernel<3>, dim3(total), dim3(256), Cfg::LDS_BYTES, s, g);
-  } else {
-    using Cfg = GemmCfg<64, 64, 1>;
-    hipLaunchKernelGGL(linear_grouped_kernel<1>, dim3(total), dim3(256), Cfg::LDS_BYTES, s, g);
-  }
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  if (args[0].nsplit == 3)
+    return rmem::launch<GroupedLinear, linear_grouped_kernel<3>, 256>(g, dim3(total), dim3(256),
+                                                                      GemmCfg<64, 64, 3>::LDS_BYTES, s);
+  return rmem::launch<GroupedLinear, linear_grouped_kernel<1>, 256>(g, dim3(total), dim3(256),
+                                                                    GemmCfg<64, 64, 1>::LDS_BYTES, s);
 }
 
 extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {

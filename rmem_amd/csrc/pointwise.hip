@@ -3,6 +3,7 @@
 // RMem attention-mass reduction, fp32 -> planes.  See include/rmem_hip.h.
 #include "../../include/rmem_hip.h"
 #include "rmem_common.h"
+#include "launch.h"
 
 // ------------------------------------------------------------------ LayerNorm -> planes
 // one wave per row, C = 256: 4 consecutive channels per lane (16-byte loads).
@@ -66,10 +67,10 @@ extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, i
 }
 
 // residual reduce (split-K partials, fixed order) + LayerNorm
-__global__ __launch_bounds__(256) void layernorm_red_kernel(float* x, long ldx, const float* parts, int nparts,
-                                                            long part_stride, long ldpart, const float* gamma,
-                                                            const float* beta, int N, float eps, h16_t* oh,
-                                                            h16_t* ol, long ldo, float* of32, long ldof) {
+__device__ __forceinline__ void layernorm_red_body(float* x, long ldx, const float* parts, int nparts,
+                                                   long part_stride, long ldpart, const float* gamma,
+                                                   const float* beta, int N, float eps, h16_t* oh,
+                                                   h16_t* ol, long ldo, float* of32, long ldof) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
@@ -106,6 +107,15 @@ __global__ __launch_bounds__(256) void layernorm_red_kernel(float* x, long ldx, 
   }
 }
 
+struct LnRedArgs {
+  float* x; long ldx; const float* parts; int nparts; long part_stride, ldpart; const float* gamma; const float* beta;
+  int N; float eps; h16_t* oh; h16_t* ol; long ldo; float* of32; long ldof;
+};
+__device__ void layernorm_red_kernel(const LnRedArgs& a, int) {
+  layernorm_red_body(a.x, a.ldx, a.parts, a.nparts, a.part_stride, a.ldpart, a.gamma, a.beta, a.N, a.eps, a.oh, a.ol,
+                     a.ldo, a.of32, a.ldof);
+}
+
 extern "C" int rmem_layernorm_red(float* x, int64_t ldx, const float* parts, int32_t nparts, int64_t part_stride,
                                   int64_t ldpart, const float* gamma, const float* beta, int32_t N, int32_t C,
                                   float eps, rmem_f16* oh, rmem_f16* ol, int64_t ldo, float* of32, int64_t ldof,
@@ -113,11 +123,10 @@ extern "C" int rmem_layernorm_red(float* x, int64_t ldx, const float* parts, int
   if (!x || !gamma || !beta || N <= 0 || C != 256 || (ldx % 4) || (ldo % 4) || (ldof % 4) || nparts < 0 ||
       (nparts > 0 && (!parts || (ldpart % 4) || (part_stride % 4))))
     return RMEM_ERR_INVALID;
-  hipLaunchKernelGGL(layernorm_red_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     (long)ldx, parts, nparts, (long)part_stride, (long)ldpart, gamma, beta, N, eps, oh, ol,
-                     (long)ldo, of32, (long)ldof);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  LnRedArgs a{x, (long)ldx, parts, nparts, (long)part_stride, (long)ldpart, gamma, beta, N, eps, oh, ol, (long)ldo, of32,
+              (long)ldof};
+  return rmem::launch<LnRedArgs, layernorm_red_kernel, 256>(a, dim3((N + 3) / 4), dim3(256), 0,
+                                                             static_cast<hipStream_t>(stream));
 }
 
 // two independent rows-of-256 problems of the same shape in one launch (blockIdx.y selects):
@@ -131,9 +140,15 @@ struct LnRedOne {
   h16_t* ol;
   long ldo;
 };
-__global__ __launch_bounds__(256) void layernorm_red2_kernel(LnRedOne p0, LnRedOne p1, long ldx, int nparts,
-                                                             long part_stride, long ldpart, int N, float eps) {
-  const LnRedOne p = blockIdx.y ? p1 : p0;
+struct LnRed2Args {
+  LnRedOne p[2];
+  long ldx; int nparts; long part_stride, ldpart; int N; float eps;
+};
+__device__ void layernorm_red2_kernel(const LnRed2Args& a, int) {
+  const LnRedOne& p = a.p[blockIdx.y];
+  const long ldx = a.ldx, part_stride = a.part_stride, ldpart = a.ldpart;
+  const int nparts = a.nparts, N = a.N;
+  const float eps = a.eps;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
@@ -176,12 +191,10 @@ extern "C" int rmem_layernorm_red2(float* x0, float* x1, int64_t ldx, const floa
       (ldo0 % 4) || (ldo1 % 4) || nparts < 0 ||
       (nparts > 0 && (!parts0 || !parts1 || (ldpart % 4) || (part_stride % 4))))
     return RMEM_ERR_INVALID;
-  LnRedOne p0{x0, parts0, gamma0, beta0, oh0, ol0, (long)ldo0};
-  LnRedOne p1{x1, parts1, gamma1, beta1, oh1, ol1, (long)ldo1};
-  hipLaunchKernelGGL(layernorm_red2_kernel, dim3((N + 3) / 4, 2), dim3(256), 0, static_cast<hipStream_t>(stream), p0,
-                     p1, (long)ldx, nparts, (long)part_stride, (long)ldpart, N, eps);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  LnRed2Args a{{{x0, parts0, gamma0, beta0, oh0, ol0, (long)ldo0}, {x1, parts1, gamma1, beta1, oh1, ol1, (long)ldo1}},
+               (long)ldx, nparts, (long)part_stride, (long)ldpart, N, eps};
+  return rmem::launch<LnRed2Args, layernorm_red2_kernel, 256>(a, dim3((N + 3) / 4, 2), dim3(256), 0,
+                                                               static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta,
@@ -262,18 +275,17 @@ __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const f
   }
 }
 
+// one map (p[0], nmaps = 1) or two maps of the same geometry (the gated long-term and short-term
+// aggregates of a layer) in one launch: z = map * nz + channel block
+struct DwArgs {
+  DwOne p[2];
+  long ldg; int h, w, C; long ldo; int nz;
+};
 template <int RX>
-__global__ __launch_bounds__(256) void dwconv5x5_split_kernel(const float* g, long ldg, const float* wt, int h,
-                                                              int w, int C, h16_t* oh, h16_t* ol, long ldo) {
-  dwconv5x5_body<RX>(g, ldg, wt, h, w, C, oh, ol, ldo, blockIdx.z);
-}
-
-// two maps of the same geometry (the gated long-term and short-term aggregates of a layer) in one launch
-template <int RX>
-__global__ __launch_bounds__(256) void dwconv5x5_split2_kernel(DwOne p0, DwOne p1, long ldg, int h, int w, int C,
-                                                               long ldo, int nz) {
-  const DwOne p = (int)blockIdx.z < nz ? p0 : p1;
-  dwconv5x5_body<RX>(p.g, ldg, p.wt, h, w, C, p.oh, p.ol, ldo, (int)blockIdx.z < nz ? blockIdx.z : blockIdx.z - nz);
+__device__ void dwconv5x5_split_kernel(const DwArgs& a, int bz) {
+  const int which = bz < a.nz ? 0 : 1;
+  const DwOne& p = a.p[which];
+  dwconv5x5_body<RX>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, which ? bz - a.nz : bz);
 }
 
 extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t ldg, const float* wt0, const float* wt1,
@@ -283,27 +295,29 @@ extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t l
     return RMEM_ERR_INVALID;
   constexpr int RX = 6;
   const int nz = (C + 1023) / 1024;
-  DwOne p0{g0, wt0, oh0, ol0}, p1{g1, wt1, oh1, ol1};
-  hipLaunchKernelGGL(dwconv5x5_split2_kernel<RX>, dim3((w + RX - 1) / RX, h, 2 * nz), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p0, p1, (long)ldg, h, w, C, (long)ldo, nz);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  DwArgs a{{{g0, wt0, oh0, ol0}, {g1, wt1, oh1, ol1}}, (long)ldg, h, w, C, (long)ldo, nz};
+  return rmem::launch<DwArgs, dwconv5x5_split_kernel<RX>, 256>(a, dim3((w + RX - 1) / RX, h, 2 * nz), dim3(256), 0,
+                                                                static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt, int32_t h, int32_t w,
                                     int32_t C, rmem_f16* oh, rmem_f16* ol, int64_t ldo, void* stream) {
   if (!g || !wt || !oh || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
   constexpr int RX = 6;
-  hipLaunchKernelGGL(dwconv5x5_split_kernel<RX>, dim3((w + RX - 1) / RX, h, (C + 1023) / 1024), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), g, (long)ldg, wt, h, w, C, oh, ol, (long)ldo);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  const int nz = (C + 1023) / 1024;
+  DwArgs a{{{g, wt, oh, ol}, {g, wt, oh, ol}}, (long)ldg, h, w, C, (long)ldo, nz};
+  return rmem::launch<DwArgs, dwconv5x5_split_kernel<RX>, 256>(a, dim3((w + RX - 1) / RX, h, nz), dim3(256), 0,
+                                                                static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------ final GroupNorm (2 groups)
 // pass A: per-block (64 tokens) double partial (sum, sumsq) for both groups
-__global__ __launch_bounds__(256) void gn2_stats_kernel(const float* tgt, const float* tgt_id, int N, int C,
-                                                        double* ws) {
+struct Gn2Args {
+  const float* tgt; const float* tgt_id; int N, C; const float* gamma; const float* beta; float eps; double* ws;
+  int nblk; float* out; long ldo;
+};
+__device__ void gn2_stats_kernel(const Gn2Args& a, int) {
+  const float* tgt = a.tgt; const float* tgt_id = a.tgt_id; const int N = a.N, C = a.C; double* ws = a.ws;
   __shared__ double red[2][2][4];
   const int t0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -338,9 +352,10 @@ __global__ __launch_bounds__(256) void gn2_stats_kernel(const float* tgt, const 
   }
 }
 
-__global__ __launch_bounds__(256) void gn2_apply_kernel(const float* tgt, const float* tgt_id, int N, int C,
-                                                        const float* gamma, const float* beta, float eps,
-                                                        const double* ws, int nblk, float* out, long ldo) {
+__device__ void gn2_apply_kernel(const Gn2Args& a, int) {
+  const float* tgt = a.tgt; const float* tgt_id = a.tgt_id; const int N = a.N, C = a.C; const double* ws = a.ws;
+  const float* gamma = a.gamma; const float* beta = a.beta; const float eps = a.eps; const int nblk = a.nblk;
+  float* out = a.out; const long ldo = a.ldo;
   __shared__ float stat[4];  // mean0, rstd0, mean1, rstd1
   const int tid = threadIdx.x;
   if (tid < 2) {
@@ -384,21 +399,25 @@ extern "C" int rmem_groupnorm2(const float* tgt, const float* tgt_id, int32_t N,
   if (!tgt || !tgt_id || !gamma || !beta || !ws || !out || N <= 0 || (C % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
   const int nblk = (N + 63) / 64;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn2_stats_kernel, dim3(nblk), dim3(256), 0, s, tgt, tgt_id, N, C, ws);
-  hipLaunchKernelGGL(gn2_apply_kernel, dim3(nblk), dim3(256), 0, s, tgt, tgt_id, N, C, gamma, beta, eps, ws, nblk,
-                     out, (long)ldo);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  Gn2Args a{tgt, tgt_id, N, C, gamma, beta, eps, ws, nblk, out, (long)ldo};
+  const int rc = rmem::launch<Gn2Args, gn2_stats_kernel, 256>(a, dim3(nblk), dim3(256), 0, s);
+  if (rc != RMEM_OK) return rc;
+  return rmem::launch<Gn2Args, gn2_apply_kernel, 256>(a, dim3(nblk), dim3(256), 0, s);
 }
 
 // ------------------------------------------------------------------ ID assignment
 // block = one output token, thread = one of C = 256 channels; gather-sum over the
 // k x k receptive field of the one-hot(+ignore) label map, then LayerNorm over C.
-__global__ __launch_bounds__(256) void id_assign_kernel(const uint8_t* label, int H, int W, const float* wt,
-                                                        const float* bias, int ncls, int ksize, int stride,
-                                                        int pad, int ew, const float* gamma, const float* beta,
-                                                        float eps, h16_t* oh, h16_t* ol, long ldo, float* of32,
-                                                        long ldof, int ignore_channel) {
+struct IdAssignArgs {
+  const uint8_t* label; int H, W; const float* wt; const float* bias; int ncls, ksize, stride, pad, ew;
+  const float* gamma; const float* beta; float eps; h16_t* oh; h16_t* ol; long ldo; float* of32; long ldof;
+  int ignore_channel;
+};
+__device__ void id_assign_kernel(const IdAssignArgs& a, int) {
+  const uint8_t* label = a.label; const int H = a.H, W = a.W; const float* wt = a.wt; const float* bias = a.bias;
+  const int ncls = a.ncls, ksize = a.ksize, stride = a.stride, pad = a.pad, ew = a.ew;
+  const float* gamma = a.gamma; const float* beta = a.beta; const float eps = a.eps; h16_t* oh = a.oh; h16_t* ol = a.ol;
+  const long ldo = a.ldo; float* of32 = a.of32; const long ldof = a.ldof; const int ignore_channel = a.ignore_channel;
   __shared__ float red[4];
   __shared__ float red2[4];
   __shared__ int cls_s[1024];          // class per tap of the receptive field (-1 = no channel)
@@ -461,16 +480,18 @@ extern "C" int rmem_id_assign(const uint8_t* label, int32_t H, int32_t W, const 
                               void* stream) {
   if (!label || !wt || !bias || C != 256 || eh <= 0 || ew <= 0 || ncls < 2 || ksize <= 0 || ksize > 32)
     return RMEM_ERR_INVALID;
-  hipLaunchKernelGGL(id_assign_kernel, dim3(eh * ew), dim3(256), 0, static_cast<hipStream_t>(stream), label, H, W,
-                     wt, bias, ncls, ksize, stride, pad, ew, gamma, beta, eps, oh, ol, (long)ldo, of32,
-                     (long)ldof, ignore_channel);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  IdAssignArgs a{label, H, W, wt, bias, ncls, ksize, stride, pad, ew, gamma, beta, eps, oh, ol, (long)ldo, of32,
+                 (long)ldof, ignore_channel};
+  return rmem::launch<IdAssignArgs, id_assign_kernel, 256>(a, dim3(eh * ew), dim3(256), 0,
+                                                            static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------ RMem relevance reduce
-__global__ __launch_bounds__(1024) void mass_reduce_kernel(const float* mass, int N, int T, const float* fg,
-                                                           float* out) {
+struct MassReduceArgs {
+  const float* mass; int N, T; const float* fg; float* out;
+};
+__device__ void mass_reduce_kernel(const MassReduceArgs& a, int) {
+  const float* mass = a.mass; const int N = a.N, T = a.T; const float* fg = a.fg; float* out = a.out;
   __shared__ float red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int t = 0; t < T; ++t) {
@@ -492,10 +513,9 @@ __global__ __launch_bounds__(1024) void mass_reduce_kernel(const float* mass, in
 extern "C" int rmem_attn_mass_reduce(const float* mass, int32_t N, int32_t T, const float* fg, float* out,
                                      void* stream) {
   if (!mass || !fg || !out || N <= 0 || T <= 0) return RMEM_ERR_INVALID;
-  hipLaunchKernelGGL(mass_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), mass, N, T, fg,
-                     out);
-  RMEM_CHECK_LAUNCH();
-  return RMEM_OK;
+  MassReduceArgs a{mass, N, T, fg, out};
+  return rmem::launch<MassReduceArgs, mass_reduce_kernel, 1024>(a, dim3(1), dim3(1024), 0,
+                                                                 static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------ fp32 -> planes
@@ -959,4 +979,4 @@ extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 8; }   // 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_abi_version(void) { return 9; }   // 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

@@ -126,7 +126,11 @@ EXPORTS = [
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2",
     "rmem_bias_act_nchw_batched", "rmem_attn_scores2", "rmem_attn_combine2", "rmem_dwconv5x5_split2",
     "rmem_attn_read", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
+    "rmem_rec_end", "rmem_launch_recorded",
 ]
+# exports with a non-int return type
+EXPORTS_OTHER = ["rmem_rec_begin", "rmem_rec_free", "rmem_rec_count", "rmem_rec_size", "rmem_rec_data",
+                 "rmem_rec_signature"]
 
 
 def lib_path() -> str:
@@ -185,6 +189,14 @@ def load():
     lib.rmem_upsample_add_nchw.argtypes = [c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p]
     lib.rmem_upsample_add_nchw_out.argtypes = [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p]
     lib.rmem_label_resize_nearest.argtypes = [c_p, i32, i32, c_p, i32, i32, i32, c_p]
+    lib.rmem_rec_begin.restype, lib.rmem_rec_begin.argtypes = c_p, []
+    lib.rmem_rec_end.argtypes = [c_p]
+    lib.rmem_rec_free.restype, lib.rmem_rec_free.argtypes = None, [c_p]
+    lib.rmem_rec_count.restype, lib.rmem_rec_count.argtypes = i32, [c_p]
+    lib.rmem_rec_size.restype, lib.rmem_rec_size.argtypes = i64, [c_p]
+    lib.rmem_rec_data.restype, lib.rmem_rec_data.argtypes = c_p, [c_p]
+    lib.rmem_rec_signature.restype, lib.rmem_rec_signature.argtypes = C.c_uint64, [c_p]
+    lib.rmem_launch_recorded.argtypes = [c_p, c_p, i64, i32, c_p]
     _LIB = lib
     return lib
 
@@ -276,28 +288,30 @@ def linear_grouped(args):
 
 
 def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool, conv_bias=None) -> torch.Tensor:
-    """GroupNorm(+ReLU) of a batch-1 NCHW fp32 tensor through rmem_groupnorm_nchw; with
-    `conv_bias`, x is the output of a bias-free convolution and the bias is added in the kernel."""
+    """GroupNorm(+ReLU) of an NCHW fp32 tensor through rmem_groupnorm_nchw (one pair of launches per
+    sample: the statistics are per sample anyway); with `conv_bias`, x is the output of a bias-free
+    convolution and the bias is added in the kernel."""
     x = x.contiguous()
     n, c, h, w = x.shape
-    if n != 1 or x.dtype != torch.float32 or ((c // gn.num_groups) * h * w) % 4:
+    if x.dtype != torch.float32 or ((c // gn.num_groups) * h * w) % 4:
         if conv_bias is not None:
             x = x + conv_bias.view(1, -1, 1, 1)
         y = torch.nn.functional.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
         return torch.relu_(y) if relu else y
     # per-call workspace (stream-ordered caching allocator / graph pool): engines running
     # concurrently on different streams must not share it; the stats pass overwrites all of it
-    ws = torch.empty(2 * 32 * gn.num_groups, dtype=torch.float64, device=x.device)
+    ws = torch.empty(n, 2 * 32 * gn.num_groups, dtype=torch.float64, device=x.device)
     y = torch.empty_like(x)
-    if conv_bias is not None:
-        check(load().rmem_groupnorm_nchw_bias(x.data_ptr(), conv_bias.data_ptr(), y.data_ptr(), c, h * w,
-                                              gn.num_groups, gn.weight.data_ptr(), gn.bias.data_ptr(), gn.eps,
-                                              int(relu), ws.data_ptr(), stream_ptr()),
-              "rmem_groupnorm_nchw_bias")
-        return y
-    check(load().rmem_groupnorm_nchw(x.data_ptr(), y.data_ptr(), c, h * w, gn.num_groups, gn.weight.data_ptr(),
-                                     gn.bias.data_ptr(), gn.eps, int(relu), ws.data_ptr(), stream_ptr()),
-          "rmem_groupnorm_nchw")
+    lib, st = load(), stream_ptr()
+    for i in range(n):
+        if conv_bias is not None:
+            check(lib.rmem_groupnorm_nchw_bias(x[i].data_ptr(), conv_bias.data_ptr(), y[i].data_ptr(), c, h * w,
+                                               gn.num_groups, gn.weight.data_ptr(), gn.bias.data_ptr(), gn.eps,
+                                               int(relu), ws[i].data_ptr(), st), "rmem_groupnorm_nchw_bias")
+        else:
+            check(lib.rmem_groupnorm_nchw(x[i].data_ptr(), y[i].data_ptr(), c, h * w, gn.num_groups,
+                                          gn.weight.data_ptr(), gn.bias.data_ptr(), gn.eps, int(relu),
+                                          ws[i].data_ptr(), st), "rmem_groupnorm_nchw")
     return y
 
 
@@ -320,26 +334,27 @@ def bias_act_nchw_(x: torch.Tensor, bias: torch.Tensor, residual=None, relu: boo
 
 
 def upsample_add_nchw_(y: torch.Tensor, bias, x: torch.Tensor, align_corners: bool, inplace: bool = True) -> torch.Tensor:
-    """y = (y + bias[c]) + bilinear(x -> y's size) for contiguous batch-1 NCHW fp32 maps; in place,
-    or into a new tensor (inplace=False: y is left untouched)."""
+    """y = (y + bias[c]) + bilinear(x -> y's size) for contiguous NCHW fp32 maps (one launch per
+    sample); in place, or into a new tensor (inplace=False: y is left untouched)."""
     n, c, H, W = y.shape
-    if n != 1 or x.shape[0] != 1 or x.shape[1] != c or not y.is_contiguous() or y.dtype != torch.float32 \
-            or c * H > 65535:
+    if x.shape[0] != n or x.shape[1] != c or not y.is_contiguous() or y.dtype != torch.float32 or c * H > 65535:
         if bias is not None:
             y = y + bias.view(1, -1, 1, 1)
         if x.shape[-2:] != y.shape[-2:]:
             x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=align_corners)
         return y + x
     x = x.contiguous()
-    if not inplace:
-        out = torch.empty_like(y)
-        check(load().rmem_upsample_add_nchw_out(y.data_ptr(), out.data_ptr(), ptr(bias), x.data_ptr(), c, H, W,
-                                                x.shape[2], x.shape[3], int(bool(align_corners)), stream_ptr()),
-              "rmem_upsample_add_nchw_out")
-        return out
-    check(load().rmem_upsample_add_nchw(y.data_ptr(), ptr(bias), x.data_ptr(), c, H, W, x.shape[2], x.shape[3],
-                                        int(bool(align_corners)), stream_ptr()), "rmem_upsample_add_nchw")
-    return y
+    lib, st = load(), stream_ptr()
+    out = y if inplace else torch.empty_like(y)
+    for i in range(n):
+        if not inplace:
+            check(lib.rmem_upsample_add_nchw_out(y[i].data_ptr(), out[i].data_ptr(), ptr(bias), x[i].data_ptr(), c, H, W,
+                                                 x.shape[2], x.shape[3], int(bool(align_corners)), st),
+                  "rmem_upsample_add_nchw_out")
+        else:
+            check(lib.rmem_upsample_add_nchw(y[i].data_ptr(), ptr(bias), x[i].data_ptr(), c, H, W, x.shape[2],
+                                             x.shape[3], int(bool(align_corners)), st), "rmem_upsample_add_nchw")
+    return out
 
 
 def set_ints(dst: torch.Tensor, values):
@@ -379,3 +394,40 @@ def label_resize_nearest(src: torch.Tensor, size, flip: bool = False, out: torch
     check(load().rmem_label_resize_nearest(src.data_ptr(), src.shape[0], src.shape[1], out.data_ptr(), Hd, Wd,
                                            int(bool(flip)), stream_ptr()), "rmem_label_resize_nearest")
     return out
+
+
+class Recording:
+    """A recorded launch sequence of the memory path (include/rmem_hip.h, "several clips' memory
+    banks in one launch"): `with Recording() as r: <launch code>` launches nothing and leaves the
+    argument blob in r.blob (bytes), the op count in r.count and the geometry hash in r.signature."""
+
+    def __init__(self):
+        self.handle = None
+        self.blob = b""
+        self.count = 0
+        self.signature = 0
+
+    def __enter__(self):
+        self.handle = load().rmem_rec_begin()
+        if not self.handle:
+            raise RmemError("rmem_rec_begin: this thread is already recording")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        lib = load()
+        check(lib.rmem_rec_end(self.handle), "rmem_rec_end")
+        if et is None:
+            n = lib.rmem_rec_size(self.handle)
+            self.blob = C.string_at(lib.rmem_rec_data(self.handle), n) if n > 0 else b""
+            self.count = lib.rmem_rec_count(self.handle)
+            self.signature = lib.rmem_rec_signature(self.handle)
+        return False
+
+    def launch(self, dev_args: torch.Tensor, clip_stride: int, B: int):
+        check(load().rmem_launch_recorded(self.handle, dev_args.data_ptr(), clip_stride, B, stream_ptr()),
+              "rmem_launch_recorded")
+
+    def __del__(self):
+        if self.handle and _LIB is not None:
+            _LIB.rmem_rec_free(self.handle)
+            self.handle = None

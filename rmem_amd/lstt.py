@@ -89,8 +89,14 @@ class DeAOTLSTT:
     E = 512          # expanded width per branch
     WIN = 225
 
-    def __init__(self, model, h: int, w: int, device, nsplit: int = 3):
+    def __init__(self, model, h: int, w: int, device, nsplit: int = 3, clips_per_launch: int = 1,
+                 weights_from: "Optional[DeAOTLSTT]" = None):
+        """clips_per_launch > 1: this LSTT is one of that many clips served by shared launches
+        (rmem_amd.batched): the key splits of the fused reads are sized for the whole launch.
+        weights_from: another LSTT of the same model whose packed weights are shared."""
         hip.load()
+        self.clips_per_launch = max(1, int(clips_per_launch))
+        self._batched = False              # set by rmem_amd.batched: tgt / tgt_id / out are slices of shared buffers
         self.cfg = model.cfg
         self.h, self.w = int(h), int(w)
         self.N = self.h * self.w
@@ -106,7 +112,12 @@ class DeAOTLSTT:
         self._timing = False
         self._events = []
         self.scale = 1.0 / math.sqrt(self.DATT)
-        self._pack_weights(model)
+        if weights_from is not None:
+            for k in ("cur_pe", "mem_pe", "id_ksize", "id_ncls", "id_stride", "id_pad", "id_wt", "id_bias", "id_gamma",
+                      "id_beta", "gn_gamma", "gn_beta", "lw"):
+                setattr(self, k, getattr(weights_from, k))
+        else:
+            self._pack_weights(model)
         self._alloc()
         self.clear_memory()
 
@@ -186,7 +197,14 @@ class DeAOTLSTT:
         # the windowed read of a layer share ONE launch (ks_long + ks_win splits), the self read
         # gets all of them.
         nq = Np // 128
-        total = max(2, min(32, 256 // (2 * nq)))
+        # several clips per launch: the same 256 resident units are shared by all of them (two rounds
+        # of workgroups: longer units amortise the prologue -- Q staging, reference pass -- better)
+        # (measured at 480p K=4, frames/s for long,win,self: 4 clips 3,1,4 479 / 4,2,4 476 / 7,2,6 461;
+        #  8 clips 2,1,2 492 / 3,1,3 489 / 1,1,2 477)
+        if self.clips_per_launch == 1:
+            total = max(2, min(32, 256 // (2 * nq)))
+        else:
+            total = max(3, min(32, 512 // (2 * nq * self.clips_per_launch)))
         tv = (N + 63) // 64
         # measured at 480p K=4 (bench.py frames/s / read2 us isolated, for ks_long, ks_win, ks_self):
         # 7,2,6 385.9 / 242;  6,3,6 397.7 / 197;  5,4,6 388.5 / 207 -- a windowed tile costs more than a
@@ -412,7 +430,9 @@ class DeAOTLSTT:
         # [0:16] bank map, [16] short-term slot of this frame, [17] short-term slot of the NEXT frame
         # (= this frame's slot): read by the next frame's hoisted front part, see _forward_device
         vals = list(bank_map) + [0] * (16 - self._T) + [short, self.cur]
-        hip.set_ints(self.maps, vals)
+        self._map_vals = vals
+        if not self._batched:              # batched: one upload for all clips (rmem_amd.batched)
+            hip.set_ints(self.maps, vals)
 
     def next_free_slot(self) -> int:
         """The slot _prepare() will pick for the next frame if this frame's update does not touch
@@ -455,7 +475,7 @@ class DeAOTLSTT:
         map_bank = self.maps.data_ptr()
         map_short = self.maps.data_ptr() + 16 * 4
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
-        if do_front:
+        if do_front and not self._batched:     # batched: the shared buffer is cleared once for all clips
             self.tgt_id.zero_()
 
         for l in range(self.L):
@@ -580,11 +600,16 @@ class DeAOTLSTT:
     def restrict_long_memories(self, indexes: List[int], fg: torch.Tensor) -> Optional[int]:
         """restrict_long_memories (transformer.py:880-991).  fg: [N] fp32 on device.
         Mutates ``indexes`` like the reference; returns the dropped position or None."""
-        T = self.mass_T
-        hip.check(hip.load().rmem_attn_mass_reduce(self.mass.data_ptr(), self.N, T, fg.data_ptr(),
+        self._mass_reduce_device(fg)
+        w = self.w_out[:self.mass_T].cpu().numpy().astype(np.float32)        # the one D2H per long update
+        return self._restrict_host(indexes, w)
+
+    def _mass_reduce_device(self, fg: torch.Tensor):
+        hip.check(hip.load().rmem_attn_mass_reduce(self.mass.data_ptr(), self.N, self.mass_T, fg.data_ptr(),
                                                    self.w_out.data_ptr(), hip.stream_ptr()),
                   "rmem_attn_mass_reduce")
-        w = self.w_out[:T].cpu().numpy().astype(np.float32)        # the one D2H per long update
+
+    def _restrict_host(self, indexes: List[int], w: np.ndarray) -> Optional[int]:
         w = w / w.sum(dtype=np.float32)
         drop, self.ema, self.visits = rmem_policy_step(w, indexes, self.ema, self.visits,
                                                        self.cfg.FORMER_MEM_LEN)

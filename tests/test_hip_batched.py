@@ -1,0 +1,153 @@
+"""GPU: several clips per launch (rmem_amd.batched).
+
+The reference has nothing to compare with here -- its attention asserts batch 1
+(aot_plus/networks/layers/transformer.py:641,1190) -- so the statement is: B clips served by shared
+launches give, per clip, exactly what B single-clip runs give (bit for bit on the LSTT, whose
+kernels are the same code reading its arguments from device memory; within MIOpen's
+batch-size-dependent rounding on whole frames), and the single-clip path is pinned to the oracle
+and the reference's golden vectors elsewhere (tests/test_hip_engine.py)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(former=1, latter=3):
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    cfg = get_config("r50_deaotl", former, latter)
+    model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(model)
+    return cfg, copy.deepcopy(model).to(DEV)
+
+
+@pytest.mark.parametrize("h,w,B", [(12, 17, 3), (20, 23, 4)])
+def test_batched_lstt_equals_single_clips_bit_for_bit(h, w, B):
+    """Reference frame + 9 frames with long-term updates every second frame (K = 4: evictions from
+    frame 6 on), different token features and label maps per clip.  Every frame: LSTT output, the
+    attention mass, the eviction decision and the bank map of clip i from the shared launches ==
+    those of a single-clip DeAOTLSTT with the same key splits."""
+    from rmem_amd.batched import BatchedLSTT
+    from rmem_amd.lstt import DeAOTLSTT
+    cfg, model = _model()
+    N = h * w
+    H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
+    bat = BatchedLSTT(model, h, w, DEV, B)
+    singles = [DeAOTLSTT(model, h, w, DEV, 3, clips_per_launch=B) for _ in range(B)]
+    assert (bat.clips[0].ks_long, bat.clips[0].ks_win, bat.clips[0].ks_self) == \
+        (singles[0].ks_long, singles[0].ks_win, singles[0].ks_self)
+    rs = np.random.RandomState(1)
+    idx_b = [[0] for _ in range(B)]
+    idx_s = [[0] for _ in range(B)]
+    drops = []
+    for t in range(10):
+        emb = torch.from_numpy(rs.standard_normal((B, N, 256)).astype(np.float32)).to(DEV)
+        lab = torch.from_numpy(rs.randint(0, 4, (B, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
+        lab = F.interpolate(lab, size=(H, W), mode="nearest")[:, 0].to(torch.uint8).to(DEV).contiguous()
+        fg = torch.from_numpy(rs.uniform(0.05, 1.0, (B, N)).astype(np.float32)).to(DEV)
+        if t == 0:
+            bat.assign_identity(lab, ignore=False)
+            out = bat.forward(emb, ref_frame=True)
+            for i, s in enumerate(singles):
+                s.assign_identity(lab[i], ignore=False)
+                so = s.forward(emb[i], ref_frame=True)
+                assert torch.equal(out[i], so), (t, i)
+            continue
+        launches0 = bat.launches
+        out = bat.forward(emb)
+        n_fwd = bat.launches - launches0
+        upd = (t % 2 == 0)
+        bat.assign_identity(lab, ignore=True)
+        bat.update_short_memories(upd)
+        if upd:
+            for i in range(B):
+                idx_b[i].append(t)
+            db = bat.restrict_long_memories(idx_b, fg)
+        for i, s in enumerate(singles):
+            so = s.forward(emb[i])
+            assert torch.equal(out[i], so), (t, i, (out[i] - so).abs().max().item())
+            T = s.mass_T
+            assert torch.equal(bat.clips[i].mass.flatten()[:N * T], s.mass.flatten()[:N * T]), (t, i)
+            s.assign_identity(lab[i], ignore=True)
+            s.update_short_memories(upd)
+            if upd:
+                idx_s[i].append(t)
+                ds = s.restrict_long_memories(idx_s[i], fg[i])
+                assert ds == db[i] and idx_s[i] == idx_b[i], (t, i, ds, db[i])
+                drops.append(ds)
+            assert bat.clips[i].bank == s.bank and bat.clips[i].short == s.short
+            for l in range(s.L):
+                assert torch.equal(bat.clips[i].bankV[l].hi[s.cur], s.bankV[l].hi[s.cur]), (t, i, l)
+                assert torch.equal(bat.clips[i].bankK[l].lo[s.cur], s.bankK[l].lo[s.cur]), (t, i, l)
+    assert any(d is not None for d in drops), "no eviction happened"
+    print(f"B={B} {h}x{w}: {n_fwd} launches per batched forward pass (every one serves {B} clips); drops {drops}")
+
+
+def test_batched_engine_vs_single_engines_small_clips():
+    """BatchedDeAOTEngine (encoder, LSTT, decoder at batch 3) against three single-clip engines on
+    97x129 clips, teacher-forced with the single engines' label maps: eviction sequences equal,
+    label maps equal up to MIOpen's batch-size-dependent rounding (<= 2 pixels of 12.5k)."""
+    from rmem_amd.batched import BatchedDeAOTEngine
+    from rmem_amd.engine import DeAOTEngine
+    from rmem_amd.synth import synth_clip
+    cfg, model = _model()
+    model.optimize_for_inference(True)
+    B, frames, Hh, Ww = 3, 9, 97, 129
+    clips = [synth_clip(200 + i, frames, Hh, Ww, 3) for i in range(B)]
+    objs = [3, 2, 3]
+    labs = []
+    for i in range(B):
+        lab = clips[i][1].clone()
+        lab[lab > objs[i]] = 0
+        labs.append(lab)
+    singles = []
+    for i in range(B):
+        # the per-clip engine itself (the multi-object wrapper would pass obj_nums = [10] whatever the clip holds)
+        e = DeAOTEngine(model, 0, long_term_mem_gap=2)
+        e.eval()
+        e.add_reference_frame(clips[i][0][0].to(DEV), labs[i].to(DEV), obj_nums=[objs[i]], frame_step=0)
+        singles.append(e)
+    bat = BatchedDeAOTEngine(model, B, long_term_mem_gap=2)
+    imgs0 = torch.cat([clips[i][0][0] for i in range(B)]).to(DEV)
+    bat.add_reference_frame(imgs0, torch.cat(labs).to(DEV), obj_nums=objs, frame_step=0)
+    worst = 0
+    for t in range(1, frames):
+        imgs = torch.cat([clips[i][0][t] for i in range(B)]).to(DEV)
+        lg_b = bat.match_propogate_one_frame(imgs, output_size=(Hh, Ww))
+        lab_b = lg_b.argmax(1)
+        fed = []
+        for i, e in enumerate(singles):
+            lg = e.match_propogate_one_frame(clips[i][0][t].to(DEV), output_size=(Hh, Ww))
+            lab = lg.argmax(1)
+            mism = int((lab[0] != lab_b[i]).sum())
+            worst = max(worst, mism)
+            assert mism <= 2, (t, i, mism)
+            assert float((lg[0, :objs[i] + 1] - lg_b[i, :objs[i] + 1]).abs().max()) < 2e-3, (t, i)
+            cur = F.interpolate(lab[None].float(), size=e.input_size_2d, mode="nearest")
+            e.update_short_term_memory(cur)
+            fed.append(cur)
+        bat.update_memory(torch.cat(fed))
+        for i, e in enumerate(singles):
+            assert bat.long_memories_indexes[i] == list(e.long_memories_indexes), (t, i)
+    assert len(bat.long_memories_indexes[0]) == cfg.mem_cap
+    print("batched engine vs single engines: worst label mismatch per frame", worst)
+
+
+def test_batched_rejects_mismatching_launch_sequences():
+    from rmem_amd import hip
+    from rmem_amd.batched import BatchedLSTT
+    cfg, model = _model()
+    bat = BatchedLSTT(model, 12, 17, DEV, 2)
+    emb = torch.zeros(2, 12 * 17, 256, device=DEV)
+    lab = torch.zeros(2, 177, 257, dtype=torch.uint8, device=DEV)
+    bat.assign_identity(lab, ignore=False)
+    bat.forward(emb, ref_frame=True)
+    bat.clips[1].bank = bat.clips[1].bank + [bat.clips[1]._free_slot()]      # clip 1 one slot deeper
+    with pytest.raises(hip.RmemError):
+        bat.forward(emb)

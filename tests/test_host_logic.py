@@ -20,10 +20,41 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "rmem_hip.h")).read()
     declared = set(re.findall(r"\bint\s+(rmem_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
-    for name in declared:
+    every = set(re.findall(r"^[a-z][a-z0-9_ ]*[ *](rmem_[a-z0-9_]+)\s*\(", header, re.M))
+    for name in every:
         assert hasattr(lib, name), f"{name} declared in include/rmem_hip.h but not exported"
     assert declared == set(hip.EXPORTS)
-    assert lib.rmem_abi_version() == 8
+    assert every - declared == set(hip.EXPORTS_OTHER)
+    assert lib.rmem_abi_version() == 9
+
+
+def test_launch_recorder_records_without_a_gpu():
+    """include/rmem_hip.h, "several clips' memory banks in one launch": while a thread records, the
+    memory-path entry points validate and append their argument block instead of launching -- no HIP
+    call is made, so this runs on the CPU.  Two recordings of the same calls with different buffers
+    have the same signature and different blobs."""
+    from rmem_amd import hip
+    hip.load()
+    recs = []
+    for base in (0x10000, 0x90000):
+        with hip.Recording() as r:
+            lib = hip.load()
+            rc = lib.rmem_layernorm_red(base, 256, None, 0, 0, 0, base + 0x1000, base + 0x2000, 100, 256, 1e-5,
+                                        base + 0x3000, base + 0x4000, 256, None, 0, None)
+            assert rc == 0
+            assert lib.rmem_attn_mass_reduce(base, 100, 4, base + 64, base + 128, None) == 0
+            assert lib.rmem_attn_mass_reduce(None, 100, 4, base + 64, base + 128, None) == -1   # still validated
+        recs.append(r)
+    a, b = recs
+    assert a.count == b.count == 2 and len(a.blob) == len(b.blob) > 0
+    assert a.signature == b.signature != 0 and a.blob != b.blob
+    with hip.Recording() as c:
+        assert hip.load().rmem_attn_mass_reduce(0x10000, 100, 4, 0x10040, 0x10080, None) == 0
+    assert c.signature != a.signature
+    with hip.Recording():
+        with pytest.raises(hip.RmemError):
+            with hip.Recording():
+                pass
 
 
 def test_ctypes_struct_sizes_match_header_layout():

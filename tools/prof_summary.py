@@ -26,7 +26,7 @@ def from_trace(path, frames):
     excludes MIOpen find-mode / first-call kernels of the warm-up."""
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("gn2_apply_kernel")]
+    marks = [i for i, r in enumerate(rows) if "gn2_apply_kernel" in r["Kernel_Name"]]
     start = marks[-frames - 1] + 1 if len(marks) > frames else 0
     end = marks[-1] + 1
     agg = {}
