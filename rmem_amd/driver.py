@@ -357,6 +357,72 @@ class ClipDriver:
         return res
 
 
+class BatchedClipDriver:
+    """B equal-length clips of one frame size in lockstep through rmem_amd.batched.BatchedDeAOTEngine:
+    ONE launch per kernel of the memory path for all clips, encoder / decoder at batch B
+    (BASELINE.json configs[3] runs 8 such clips per GPU).  Per clip the protocol is
+    ClipDriver.run_clip's for one augmentation without mid-clip new objects (managers/evaluator.py:
+    344-523): gap rule, reference frame, per frame decoder logits -> label map at the original size
+    -> nearest resize to the network size -> update_memory."""
+
+    def __init__(self, model, B: int, cfg=None, gpu_id: int = 0, no_memory_gap: Optional[bool] = None,
+                 fixed_gap: Optional[int] = None):
+        from .batched import BatchedDeAOTEngine
+        self.cfg = cfg if cfg is not None else model.cfg
+        self.B = int(B)
+        self.engine = BatchedDeAOTEngine(model, self.B, gpu_id=gpu_id,
+                                         long_term_mem_gap=getattr(self.cfg, "TEST_LONG_TERM_MEM_GAP", 9999))
+        self.no_memory_gap = bool(getattr(self.cfg, "NO_MEMORY_GAP", False)) if no_memory_gap is None \
+            else no_memory_gap
+        self.fixed_gap = fixed_gap
+        self.align_corners = bool(self.cfg.MODEL_ALIGN_CORNERS)
+
+    @torch.no_grad()
+    def run_clips(self, clips: Sequence[Sequence[List[Dict]]], num_frames: Optional[int] = None) -> List[ClipResult]:
+        """clips[i][t] = the sample list (one augmentation) of frame t of clip i."""
+        from . import hip
+        B, eng = self.B, self.engine
+        if len(clips) != B:
+            raise ValueError(f"{B} clips per batch")
+        if num_frames is None:
+            num_frames = len(clips[0])
+        if any(len(c) != num_frames for c in clips) or any(len(c[0]) != 1 for c in clips):
+            raise ValueError("batched clips must have the same length and one augmentation")
+        if any(s[0].get("current_label") is not None for c in clips for s in c[1:]):
+            raise NotImplementedError("mid-clip new objects: use ClipDriver")
+        gap = self.fixed_gap if self.fixed_gap is not None else memory_gap(num_frames, self.no_memory_gap)
+        eng.restart_engine()
+        eng.long_term_mem_gap = gap
+        meta = [c[0][0]["meta"] for c in clips]
+        ori_hw = (int(meta[0]["height"]), int(meta[0]["width"]))
+        if any((int(m["height"]), int(m["width"])) != ori_hw for m in meta):
+            raise ValueError("batched clips must share the frame size")
+        stack = lambda t: torch.cat([c[t][0]["current_img"] for c in clips])
+        imgs = stack(0)
+        labs = torch.cat([F.interpolate(c[0][0]["current_label"].float(), size=imgs.shape[2:], mode="nearest")
+                          for c in clips]).int()
+        # the per-clip engine wrapper hands max_obj_num to its engine whatever the clip holds
+        # (engines/aot_engine.py:675-690): same here
+        eng.add_reference_frame(imgs, labs, obj_nums=[eng.AOT.max_obj_num] * B, frame_step=0)
+        lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
+        out = torch.zeros(B, num_frames - 1, ori_hw[0], ori_hw[1], dtype=torch.uint8, device=imgs.device)
+        nxt = stack(1) if num_frames > 1 else None
+        for t in range(1, num_frames):
+            cur, nxt = nxt, (stack(t + 1) if t + 1 < num_frames else None)
+            logit = eng.match_propogate_one_frame(cur, output_size=None, next_imgs=nxt)
+            for i in range(B):
+                lab = hip.labels_from_logits([logit[i:i + 1]], [False], ori_hw, self.align_corners, out=out[i, t - 1])
+                hip.label_resize_nearest(lab, eng.input_size_2d, False, out=lab_in[i])
+            eng.update_memory(lab_in)
+        results = []
+        for i, c in enumerate(clips):
+            r = ClipResult()
+            r.gap, r.masks, r.obj_idx = gap, out[i], meta[i].get("obj_idx")
+            r.names = [str(s[0]["meta"].get("current_name", "")) for s in c[1:]]
+            results.append(r)
+        return results
+
+
 def make_samples(img: torch.Tensor, label: Optional[torch.Tensor], ori_hw, obj_num: int, flip_aug: bool = False,
                  name: str = "", obj_idx=None) -> List[Dict]:
     """Sample list for one frame from a network-sized image [1,3,H,W] (and an original-sized
