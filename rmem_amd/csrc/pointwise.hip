@@ -4,6 +4,7 @@
 #include "../../include/rmem_hip.h"
 #include "rmem_common.h"
 #include "launch.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ LayerNorm -> planes
 // one wave per row, C = 256: 4 consecutive channels per lane (16-byte loads).
@@ -204,55 +205,69 @@ extern "C" int rmem_layernorm_split(const float* x, int64_t ldx, const float* ga
 }
 
 // ------------------------------------------------------------------ depth-wise 5x5 -> planes
-// thread = 4 channels x a run of RX output tokens along x; the 5 x (RX+4) input window is
-// loaded once (sliding-window reuse: 50 loads for 6 outputs instead of 150) and the 25
-// taps of its channels stay in registers.  block = 256 threads = 1024 channels.
+// thread = V channels x a run of RX output tokens along x; the 5 x (RX+4) input window is
+// loaded once (sliding-window reuse: 65 loads for 9 outputs instead of 225) and the 25 taps of its
+// channels stay in registers.  block = 256 threads = 256 V channels.  V = 1 (90-100 registers, 4-5
+// waves per SIMD, every load of a thread in flight at once) beats V = 4 (256 registers, one wave per
+// SIMD, one memory round trip per input row): the kernel is latency-bound, not bandwidth-bound.
 struct DwOne {
   const float* g;
   const float* wt;
   h16_t* oh;
   h16_t* ol;
 };
-template <int RX>
+template <int V> struct DwVec;
+template <> struct DwVec<4> { typedef float4 T; };
+template <> struct DwVec<2> { typedef float2 T; };
+template <> struct DwVec<1> { typedef float T; };
+
+template <int RX, int V>
 __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const float* wt, int h, int w, int C,
                                                h16_t* oh, h16_t* ol, long ldo, int bz) {
+  typedef typename DwVec<V>::T VT;
   const int x0 = blockIdx.x * RX, y = blockIdx.y;
-  const int c = (bz * 256 + threadIdx.x) * 4;
+  const int c = (bz * 256 + threadIdx.x) * V;
   if (c >= C) return;
-  float4 k[25];
+  // every load of the thread is issued before the first use (clamped addresses; out-of-image taps are
+  // zeroed by a select afterwards): ONE memory round trip per thread instead of one per input row
+  float k[25][V];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) k[t] = *reinterpret_cast<const float4*>(wt + (long)t * C + c);
-  float4 acc[RX];
-#pragma unroll
-  for (int o = 0; o < RX; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < 25; ++t) {
+    const VT kv = *reinterpret_cast<const VT*>(wt + (long)t * C + c);
+    __builtin_memcpy(k[t], &kv, sizeof(VT));
+  }
+  float v[5][RX + 4][V];
 #pragma unroll
   for (int iy = 0; iy < 5; ++iy) {
     const int yy = y + iy - 2;
-    const bool vy = yy >= 0 && yy < h;
     const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
-    // all loads of the row first (unconditional, clamped addresses) so they are in flight
-    // together; out-of-image taps are zeroed by a select afterwards.
-    float4 v[RX + 4];
 #pragma unroll
     for (int ix = 0; ix < RX + 4; ++ix) {
       const int xx = x0 + ix - 2;
       const int xc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-      v[ix] = *reinterpret_cast<const float4*>(g + (long)(yc * w + xc) * ldg + c);
+      const VT vv = *reinterpret_cast<const VT*>(g + (long)(yc * w + xc) * ldg + c);
+      __builtin_memcpy(v[iy][ix], &vv, sizeof(VT));
     }
+  }
+  float acc[RX][V];
+#pragma unroll
+  for (int o = 0; o < RX; ++o)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[o][e] = 0.f;
+#pragma unroll
+  for (int iy = 0; iy < 5; ++iy) {
+    const int yy = y + iy - 2;
+    const bool vy = yy >= 0 && yy < h;
 #pragma unroll
     for (int ix = 0; ix < RX + 4; ++ix) {
       const int xx = x0 + ix - 2;
       const bool ok = vy && xx >= 0 && xx < w;
-      const float4 vv = ok ? v[ix] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int o = 0; o < RX; ++o) {
         const int dx = ix - o;  // tap column for output o
         if (dx < 0 || dx > 4) continue;
-        const float4 kk = k[iy * 5 + dx];
-        acc[o].x += vv.x * kk.x;
-        acc[o].y += vv.y * kk.y;
-        acc[o].z += vv.z * kk.z;
-        acc[o].w += vv.w * kk.w;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[o][e] += (ok ? v[iy][ix][e] : 0.f) * k[iy * 5 + dx][e];
       }
     }
   }
@@ -261,17 +276,11 @@ __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const f
     const int x = x0 + o;
     if (x >= w) continue;
     const long p = (long)y * w + x;
-    const float yv[4] = {acc[o].x, acc[o].y, acc[o].z, acc[o].w};
-    h16_t hi[4], lo[4];
+    h16_t hi[V], lo[V];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split_f16(yv[e], hi[e], lo[e]);
-    uint2 vh, vl;
-    vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
-    vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
-    vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
-    vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
-    *reinterpret_cast<uint2*>(oh + p * ldo + c) = vh;
-    if (ol) *reinterpret_cast<uint2*>(ol + p * ldo + c) = vl;
+    for (int e = 0; e < V; ++e) split_f16(acc[o][e], hi[e], lo[e]);
+    __builtin_memcpy(oh + p * ldo + c, hi, sizeof(hi));
+    if (ol) __builtin_memcpy(ol + p * ldo + c, lo, sizeof(lo));
   }
 }
 
@@ -281,11 +290,26 @@ struct DwArgs {
   DwOne p[2];
   long ldg; int h, w, C; long ldo; int nz;
 };
-template <int RX>
+template <int RX, int V>
 __device__ void dwconv5x5_split_kernel(const DwArgs& a, int bz) {
   const int which = bz < a.nz ? 0 : 1;
   const DwOne& p = a.p[which];
-  dwconv5x5_body<RX>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, which ? bz - a.nz : bz);
+  dwconv5x5_body<RX, V>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, which ? bz - a.nz : bz);
+}
+
+// (RX, V) chosen by measurement; RMEM_DW="rx,v" overrides (tuning aid)
+static int launch_dwconv(DwArgs& a, int nmaps, hipStream_t s) {
+  static const char* env = getenv("RMEM_DW");
+  int rx = 9, v = 1;   // 480p one / two maps: 14.7 / 24.7 us with (6, 4), 9.6 / 16.7 with (9, 1); 720p 26.4 / 47.7 -> 18.9 / 30.6
+  if (env) sscanf(env, "%d,%d", &rx, &v);
+  if (a.C % (256 * v)) rx = 6, v = 4;
+  a.nz = (a.C + 256 * v - 1) / (256 * v);
+  const dim3 grid((a.w + rx - 1) / rx, a.h, nmaps * a.nz);
+#define RMEM_DW_CASE(RX_, V_) \
+  if (rx == RX_ && v == V_) return rmem::launch<DwArgs, dwconv5x5_split_kernel<RX_, V_>, 256>(a, grid, dim3(256), 0, s);
+  RMEM_DW_CASE(9, 1) RMEM_DW_CASE(6, 4) RMEM_DW_CASE(6, 1) RMEM_DW_CASE(8, 1) RMEM_DW_CASE(12, 1) RMEM_DW_CASE(6, 2)
+#undef RMEM_DW_CASE
+  return RMEM_ERR_INVALID;
 }
 
 extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t ldg, const float* wt0, const float* wt1,
@@ -293,21 +317,15 @@ extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t l
                                      rmem_f16* ol1, int64_t ldo, void* stream) {
   if (!g0 || !g1 || !wt0 || !wt1 || !oh0 || !oh1 || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4))
     return RMEM_ERR_INVALID;
-  constexpr int RX = 6;
-  const int nz = (C + 1023) / 1024;
-  DwArgs a{{{g0, wt0, oh0, ol0}, {g1, wt1, oh1, ol1}}, (long)ldg, h, w, C, (long)ldo, nz};
-  return rmem::launch<DwArgs, dwconv5x5_split_kernel<RX>, 256>(a, dim3((w + RX - 1) / RX, h, 2 * nz), dim3(256), 0,
-                                                                static_cast<hipStream_t>(stream));
+  DwArgs a{{{g0, wt0, oh0, ol0}, {g1, wt1, oh1, ol1}}, (long)ldg, h, w, C, (long)ldo, 0};
+  return launch_dwconv(a, 2, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt, int32_t h, int32_t w,
                                     int32_t C, rmem_f16* oh, rmem_f16* ol, int64_t ldo, void* stream) {
   if (!g || !wt || !oh || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
-  constexpr int RX = 6;
-  const int nz = (C + 1023) / 1024;
-  DwArgs a{{{g, wt, oh, ol}, {g, wt, oh, ol}}, (long)ldg, h, w, C, (long)ldo, nz};
-  return rmem::launch<DwArgs, dwconv5x5_split_kernel<RX>, 256>(a, dim3((w + RX - 1) / RX, h, nz), dim3(256), 0,
-                                                                static_cast<hipStream_t>(stream));
+  DwArgs a{{{g, wt, oh, ol}, {g, wt, oh, ol}}, (long)ldg, h, w, C, (long)ldo, 0};
+  return launch_dwconv(a, 1, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------ final GroupNorm (2 groups)
