@@ -357,6 +357,13 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
                       "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
                       "parallelism": f"clips sharded {B}-per-GPU x{world}, batched launches, all-gather of masks"}}
     if rank == 0:
+        iso = eng.lstt.time_read_isolated()
+        flops = B * c0.read_flops(len(c0.bank))
+        ach = flops / (iso * 1e-6) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": f"read2_many_kernel (fused long-term T={len(c0.bank)} + windowed memory read of {B} clips in one launch)",
+                           "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                           "traffic": None, "mean_us": iso, "algorithmic_flops_per_launch": flops,
+                           "note": "isolated launches (HIP events, back to back); includes the upload of the clips' argument blocks"}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

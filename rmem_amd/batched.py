@@ -157,6 +157,31 @@ class BatchedLSTT:
             c._finish(ref_frame)
         return self.out
 
+    def time_read_isolated(self, iters: int = 20) -> float:
+        """Mean duration (us) of ONE launch of the fused long-term + windowed read of layer 0 for all
+        clips (read2_many_kernel) on the current bank state, with nothing else on the GPU."""
+        import ctypes as C
+
+        def issue(c):
+            T = len(c.bank)
+            c._layer = 0
+            A = c._read_args(c.ws_main, 0, T, c.bankK[0], c.bankV[0], c.maps.data_ptr(), c.Qpe, c.bias_pe, c.Ucat0,
+                             True, c.ks_long)
+            Bq = c._read_args(c.ws_side, 1, 1, c.bankK[0], c.bankV[0], c.maps.data_ptr() + 64,
+                              hip.Planes(c.bankK[0].hi[c.cur], c.bankK[0].lo[c.cur]), None, c.Ucat0, False, c.ks_win)
+            hip.check(hip.load().rmem_attn_read2(C.byref(A[0]), C.byref(Bq[0]), hip.stream_ptr()), "rmem_attn_read2")
+        keys = [(c.cur, len(c.bank)) for c in self.clips]
+        torch.cuda.synchronize()
+        for _ in range(3):
+            self._run("probe_read2", keys, issue)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            self._run("probe_read2", keys, issue)
+        e1.record()
+        e1.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / iters
+
     def update_short_memories(self, update_long: bool):
         self._run("upd", [(c.cur,) for c in self.clips], lambda c: c._update_device(update_long))
         for c in self.clips:

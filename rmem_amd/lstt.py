@@ -166,6 +166,20 @@ class DeAOTLSTT:
             W.bp_ls = self._f(g("long_term_attn.projection.bias") + g("short_term_attn.projection.bias"))
             W.Wrel = self._pl(g("short_term_attn.relative_emb_k.weight").reshape(self.WIN, self.DATT))
             W.brel = self._f(g("short_term_attn.relative_emb_k.bias"))
+            # The relative-position bias (attention.py:314: a 1x1 conv of the UNSCALED key = Q projection)
+            # and the temporal-PE bias (transformer.py:1140-1172: (Q + cur_pe) . mem_pe[row]) are linear in
+            # the layer input x = norm1(tgt): with the weight products formed once in fp64 they become two
+            # more members of the grouped Q / V / U launch instead of two dependent launches after it.
+            wq64, bq64 = qv_w[:self.DATT].double(), qv_b[:self.DATT].double()
+            wrel64 = g("short_term_attn.relative_emb_k.weight").reshape(self.WIN, self.DATT).double()
+            W.Wrel_x = self._pl((wrel64 @ wq64).float())                                   # [225][256]
+            W.brel_x = self._f((wrel64 @ bq64 + g("short_term_attn.relative_emb_k.bias").double()).float())
+            mem64, cur64 = sd["mem_pos_emb"].double(), sd["cur_pos_emb"][0].double()
+            pe4_w, pe4_b = mem64 @ wq64, mem64 @ (bq64 + cur64)                            # [4][256], [4]
+            W.pe_x = {}                                                                    # T -> (planes [T][256], bias [T])
+            for T in range(1, self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN + 2):
+                r = temporal_pe_rows(T)
+                W.pe_x[T] = (self._pl(pe4_w[r].float()), self._f(pe4_b[r].float()))
             W.Wqk, W.bqk = self._pl(g("self_attn.linear_QK.weight")), self._f(g("self_attn.linear_QK.bias"))
             W.Wv12 = self._pl(torch.cat([g("self_attn.linear_V1.weight"), g("self_attn.linear_V2.weight")], 0))
             W.bv12 = self._f(torch.cat([g("self_attn.linear_V1.bias"), g("self_attn.linear_V2.bias")], 0))
@@ -183,7 +197,6 @@ class DeAOTLSTT:
         self.x_pl = Planes.empty((Np, 256), dev)
         self.z_pl = [Planes.empty((Np, 256), dev) for _ in range(self.L)]
         self.idemb_pl = Planes.empty((Np, 256), dev)
-        self.Qf32 = z(N, 128)
         self.Qpe = Planes.empty((Np, 128), dev)
         self.bankK = [Planes.empty((self.S, Np, 128), dev) for _ in range(self.L)]
         self.bankV = [Planes.empty((self.S, Np // 16, 1024, 16), dev) for _ in range(self.L)]   # blocked-16
@@ -505,10 +518,16 @@ class DeAOTLSTT:
                 self._ln2(W.ln1, self.x_pl, 256, 0, W.lnid1, self.z_pl[l], 256, 0, parts=True)
             else:
                 self._ln(self.tgt, W.ln1, self.x_pl, 256, parts_col=None)
+            pe = W.pe_x[T]
             grp = [
-                hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
-                           d0=self.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128,
+                hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq, pa=curK, ldpa=128,
                            pb=self.Qpe, ldpb=128, addvec=self.cur_pe, nsplit=ns, tile=64, launch=False),
+                # relative-position bias of the windowed read, anti-diagonal layout (rmem_read_args.rcs)
+                hip.linear(self.x_pl, W.Wrel_x, N, self.WIN, 256, ldx=256, ldy=256, bias=W.brel_x,
+                           d0=self.R.data_ptr(), ldd0=self.ldr, d0_cs=self.rcs, nsplit=ns, tile=64, launch=False),
+                # temporal-PE bias of the long-term read: bias_pe[q][t] = (Q[q] + cur_pe) . mem_pe[row(t, T)]
+                hip.linear(self.x_pl, pe[0], N, T, 256, ldx=256, ldy=256, bias=pe[1],
+                           d0=self.bias_pe.data_ptr(), ldd0=T, nsplit=ns, tile=64, launch=False),
                 # V = silu(linear_V(x)) -> columns 0..511 of the current slot's blocked-16 V planes
                 hip.linear(self.x_pl, W.Wv, N, 512, 256, ldx=256, ldy=256, bias=W.bv, act=1,
                            pa=curV, ldpa=1024, pa_blocked=True, nsplit=ns, tile=64, launch=False),
@@ -521,13 +540,6 @@ class DeAOTLSTT:
             hip.linear_grouped(grp)
             if ref_frame:
                 self._idv(l, cur)
-            # relative-position bias of the windowed read (attention.py:314) and temporal-PE bias of
-            # the long-term read (transformer.py:1140-1172)
-            hip.linear(curK, W.Wrel, N, self.WIN, 128, ldx=128, ldy=128, bias=W.brel,
-                       d0=self.R.data_ptr(), ldd0=self.ldr, d0_cs=self.rcs, nsplit=ns)
-            hip.check(lib.rmem_pe_bias(self.Qf32.data_ptr(), 128, self.cur_pe.data_ptr(),
-                                       self.mem_pe.data_ptr(), rows, T, N, 128,
-                                       self.bias_pe.data_ptr(), hip.stream_ptr()), "rmem_pe_bias")
         if not seg_b:
             return
         # -- long-term memory read (transformer.py:1140-1192, attention.py:174-209) and short-term

@@ -64,7 +64,6 @@ def main():
     L.tgt_id.normal_()
     L.maps.copy_(torch.tensor(list(range(16)) + [T - 1] + [0] * 15, dtype=torch.int32))
     L.Ucat.normal_()
-    L.Qf32.normal_()
     q = hip.Planes.from_f32(torch.randn(Np, 128, device=dev))
     L.Qpe.hi.copy_(q.hi); L.Qpe.lo.copy_(q.lo)
     W = L.lw[1]
@@ -98,7 +97,7 @@ def main():
     ns = L.nsplit
     res["ln"] = timeit(lambda: L._ln(L.tgt, W.ln1, L.x_pl, 256), args.iters)
     res["gemm_Q(128x256)"] = timeit(lambda: hip.linear(L.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq,
-                                                       d0=L.Qf32.data_ptr(), ldd0=128, pa=curK, ldpa=128, pb=L.Qpe,
+                                                       pa=curK, ldpa=128, pb=L.Qpe,
                                                        ldpb=128, addvec=L.cur_pe, nsplit=ns), args.iters)
     curV = L.bankV[1][T]
     res["gemm_V(512x256,blocked-16 out)"] = timeit(lambda: hip.linear(
@@ -113,6 +112,29 @@ def main():
     res["gemm_proj_self(512x1024)"] = timeit(lambda: hip.linear(
         L.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, d0=L.tgt.data_ptr(), ldd0=256,
         d1=L.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns), args.iters)
+    for tile, ks in ((64, 4), (128, 4), (128, 8), (64, 8), (128, 2)):
+        parts = torch.zeros(ks, N, 512, device=dev)
+        res[f"proj_ls_splitk(tile{tile},ks{ks})"] = timeit(lambda: hip.linear(
+            L.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=L.Yst, ldx2=1024, kx_split=1024, bias=W.bp_ls,
+            nsplit=ns, tile=tile, ksplits=ks, parts=parts, part_stride=N * 512), args.iters)
+        res[f"proj_self_splitk(tile{tile},ks{ks})"] = timeit(lambda: hip.linear(
+            L.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns, tile=tile, ksplits=ks,
+            parts=parts, part_stride=N * 512), args.iters)
+    Ucat = L.Ucat
+    grp = lambda: hip.linear_grouped([
+        hip.linear(L.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq, pa=curK,
+                   ldpa=128, pb=L.Qpe, ldpb=128, addvec=L.cur_pe, nsplit=ns, tile=64, launch=False),
+        hip.linear(L.x_pl, W.Wrel_x, N, 225, 256, ldx=256, ldy=256, bias=W.brel_x, d0=L.R.data_ptr(), ldd0=L.ldr,
+                   d0_cs=L.rcs, nsplit=ns, tile=64, launch=False),
+        hip.linear(L.x_pl, W.pe_x[T][0], N, T, 256, ldx=256, ldy=256, bias=W.pe_x[T][1], d0=L.bias_pe.data_ptr(),
+                   ldd0=T, nsplit=ns, tile=64, launch=False),
+        hip.linear(L.x_pl, W.Wv, N, 512, 256, ldx=256, ldy=256, bias=W.bv, act=1, pa=curV, ldpa=1024,
+                   pa_blocked=True, nsplit=ns, tile=64, launch=False),
+        hip.linear(L.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1, d0=Ucat.data_ptr(), ldd0=1024,
+                   nsplit=ns, tile=64, launch=False),
+        hip.linear(L.z_pl[1], W.Widu, N, 512, 256, ldx=256, ldy=256, bias=W.bidu, act=1,
+                   d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns, tile=64, launch=False)])
+    res["grouped_Q_R_pe_V_U_IDU"] = timeit(grp, args.iters)
     res["gemm_R(225x128)"] = timeit(lambda: hip.linear(curK, W.Wrel, N, 225, 128, ldx=128, ldy=128, bias=W.brel,
                                                        d0=L.R.data_ptr(), ldd0=L.ldr, d0_cs=L.rcs, nsplit=ns), args.iters)
     lab = torch.randint(0, 11, (481, 849), dtype=torch.uint8, device=dev) if (args.h, args.w) == (31, 54) else \
