@@ -424,70 +424,102 @@ extern "C" int rmem_groupnorm2(const float* tgt, const float* tgt_id, int32_t N,
 }
 
 // ------------------------------------------------------------------ ID assignment
-// block = one output token, thread = one of C = 256 channels; gather-sum over the
-// k x k receptive field of the one-hot(+ignore) label map, then LayerNorm over C.
+// gather-sum over the k x k receptive field of the one-hot(+ignore) label map, then LayerNorm over C.
 struct IdAssignArgs {
   const uint8_t* label; int H, W; const float* wt; const float* bias; int ncls, ksize, stride, pad, ew;
   const float* gamma; const float* beta; float eps; h16_t* oh; h16_t* ol; long ldo; float* of32; long ldof;
   int ignore_channel;
 };
+// block = TOK x-adjacent output tokens (1 by default), thread = one of C = 256 channels.  A token
+// reads 289 weight rows of 1 KB: 484 MB per 480p launch, all L2 hits -- 25.8 us = 18.8 TB/s.  Per
+// token the taps are summed in conv order.
+template <int TOK, int UNR>
 __device__ void id_assign_kernel(const IdAssignArgs& a, int) {
   const uint8_t* label = a.label; const int H = a.H, W = a.W; const float* wt = a.wt; const float* bias = a.bias;
   const int ncls = a.ncls, ksize = a.ksize, stride = a.stride, pad = a.pad, ew = a.ew;
   const float* gamma = a.gamma; const float* beta = a.beta; const float eps = a.eps; h16_t* oh = a.oh; h16_t* ol = a.ol;
   const long ldo = a.ldo; float* of32 = a.of32; const long ldof = a.ldof; const int ignore_channel = a.ignore_channel;
-  __shared__ float red[4];
-  __shared__ float red2[4];
-  __shared__ int cls_s[1024];          // class per tap of the receptive field (-1 = no channel)
-  const int tok = blockIdx.x;
-  const int oy = tok / ew, ox = tok - oy * ew;
+  __shared__ float red[TOK][4];
+  __shared__ float red2[TOK][4];
+  __shared__ int cls_s[TOK][1024];     // weight-row offset per tap of the receptive field (-1 = no channel)
+  const int nbx = (ew + TOK - 1) / TOK;
+  const int oy = blockIdx.x / nbx, ox0 = (blockIdx.x - oy * nbx) * TOK;
   const int c = threadIdx.x;
   const int lane = c & 63, wave = c >> 6;
   const int ntap = ksize * ksize;
-  for (int t = c; t < ntap; t += 256) {
+  const int ntap_pad = (ntap + UNR - 1) / UNR * UNR;       // <= 1024: ksize <= 31 (checked by the launcher)
+  for (int i = c; i < TOK * ntap_pad; i += 256) {
+    const int j = i / ntap_pad, t = i - j * ntap_pad;
+    if (t >= ntap) {
+      cls_s[j][t] = -1;
+      continue;
+    }
     const int dy = t / ksize, dx = t - dy * ksize;
-    const int y = oy * stride - pad + dy, x = ox * stride - pad + dx;
+    const int y = oy * stride - pad + dy, x = (ox0 + j) * stride - pad + dx;
     int cls = -1;
-    if (y >= 0 && y < H && x >= 0 && x < W) {
+    if (ox0 + j < ew && y >= 0 && y < H && x >= 0 && x < W) {
       cls = label[(long)y * W + x];
       if (cls == 255) cls = ignore_channel ? ncls - 1 : -1;   // ignore channel is the last one; reference frames carry none
       else if (cls >= ncls - 1) cls = -1;  // ids above max_obj have no one-hot channel
     }
-    cls_s[t] = cls;
+    cls_s[j][t] = cls >= 0 ? (cls * ntap + t) * 256 : -1;      // element offset of the tap's weight row
   }
   __syncthreads();
-  // taps are summed in conv order; the loads are independent of each other, so the
-  // unrolled loop keeps 8 weight rows in flight.
-  float acc = bias[c];
-#pragma unroll 8
-  for (int t = 0; t < ntap; ++t) {
-    const int cls = cls_s[t];              // LDS broadcast, block-uniform
-    const float wv = cls >= 0 ? wt[((long)cls * ntap + t) * 256 + c] : 0.f;
-    acc += wv;
+  float acc[TOK];
+#pragma unroll
+  for (int j = 0; j < TOK; ++j) acc[j] = bias[c];
+  // UNR taps per step: their row offsets move to SGPRs (block-uniform: the address arithmetic runs
+  // on the scalar unit -- as per-lane 64-bit multiplies it was the bound of this kernel), the UNR loads
+  // are unconditional (row 0 stands in for "no channel", zeroed by a select) and in flight together;
+  // the sums stay in conv order.
+  for (int t0 = 0; t0 < ntap; t0 += UNR) {
+#pragma unroll
+    for (int j = 0; j < TOK; ++j) {
+      int off[UNR];
+      float wv[UNR];
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) off[i] = __builtin_amdgcn_readfirstlane(cls_s[j][t0 + i]);
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) wv[i] = (wt + (off[i] > 0 ? off[i] : 0))[c];
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) acc[j] += off[i] >= 0 ? wv[i] : 0.f;
+    }
   }
-  float yv = acc;
-  if (gamma) {
-    float s = acc;
+#pragma unroll
+  for (int j = 0; j < TOK; ++j) {
+    float s = acc[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / 256.0f);
-    const float d = acc - mean;
-    float ss = d * d;
+    if (lane == 0) red[j][wave] = s;
+  }
+  __syncthreads();
+  float d[TOK];
+#pragma unroll
+  for (int j = 0; j < TOK; ++j) {
+    const float mean = (red[j][0] + red[j][1] + red[j][2] + red[j][3]) * (1.0f / 256.0f);
+    d[j] = acc[j] - mean;
+    float ss = d[j] * d[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if (lane == 0) red2[wave] = ss;
-    __syncthreads();
-    const float var = (red2[0] + red2[1] + red2[2] + red2[3]) * (1.0f / 256.0f);
-    yv = d / sqrtf(var + eps) * gamma[c] + beta[c];
+    if (lane == 0) red2[j][wave] = ss;
   }
-  if (of32) of32[(long)tok * ldof + c] = yv;
-  if (oh) {
-    h16_t hi, lo;
-    split_f16(yv, hi, lo);
-    oh[(long)tok * ldo + c] = hi;
-    if (ol) ol[(long)tok * ldo + c] = lo;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TOK; ++j) {
+    if (ox0 + j >= ew) continue;
+    const long tok = (long)oy * ew + ox0 + j;
+    float yv = acc[j];
+    if (gamma) {
+      const float var = (red2[j][0] + red2[j][1] + red2[j][2] + red2[j][3]) * (1.0f / 256.0f);
+      yv = d[j] / sqrtf(var + eps) * gamma[c] + beta[c];
+    }
+    if (of32) of32[tok * ldof + c] = yv;
+    if (oh) {
+      h16_t hi, lo;
+      split_f16(yv, hi, lo);
+      oh[tok * ldo + c] = hi;
+      if (ol) ol[tok * ldo + c] = lo;
+    }
   }
 }
 
@@ -496,12 +528,20 @@ extern "C" int rmem_id_assign(const uint8_t* label, int32_t H, int32_t W, const 
                               int32_t C, const float* gamma, const float* beta, float eps, rmem_f16* oh,
                               rmem_f16* ol, int64_t ldo, float* of32, int64_t ldof, int32_t ignore_channel,
                               void* stream) {
-  if (!label || !wt || !bias || C != 256 || eh <= 0 || ew <= 0 || ncls < 2 || ksize <= 0 || ksize > 32)
+  if (!label || !wt || !bias || C != 256 || eh <= 0 || ew <= 0 || ncls < 2 || ksize <= 0 || ksize > 31)
     return RMEM_ERR_INVALID;
   IdAssignArgs a{label, H, W, wt, bias, ncls, ksize, stride, pad, ew, gamma, beta, eps, oh, ol, (long)ldo, of32,
                  (long)ldof, ignore_channel};
-  return rmem::launch<IdAssignArgs, id_assign_kernel, 256>(a, dim3(eh * ew), dim3(256), 0,
-                                                            static_cast<hipStream_t>(stream));
+  static const char* env = getenv("RMEM_IDA");       // "tokens per block, unroll" (tuning aid)
+  int tok = 1, unr = 16;   // 480p: 25.8 us (35 us before the offsets moved to SGPRs); 2 tokens per block 30.6
+  if (env) sscanf(env, "%d,%d", &tok, &unr);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define RMEM_IDA_CASE(T_, U_) \
+  if (tok == T_ && unr == U_) \
+    return rmem::launch<IdAssignArgs, id_assign_kernel<T_, U_>, 256>(a, dim3(eh * ((ew + T_ - 1) / T_)), dim3(256), 0, s);
+  RMEM_IDA_CASE(1, 16) RMEM_IDA_CASE(1, 8) RMEM_IDA_CASE(1, 32) RMEM_IDA_CASE(2, 16)
+#undef RMEM_IDA_CASE
+  return RMEM_ERR_INVALID;
 }
 
 // ------------------------------------------------------------------ RMem relevance reduce
