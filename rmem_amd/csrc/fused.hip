@@ -774,11 +774,25 @@ __device__ __forceinline__ void read_combine_body(const rmem_read_combine_args& 
   }
   for (int c = tid * 4; c < a.ncols; c += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < a.ksplits; ++z) {
-      const float w = wz[z];
-      if (w == 0.f) continue;
-      const float4 v = *reinterpret_cast<const float4*>(a.part + ((long)z * a.Npad + q) * a.ncols + c);
-      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    // 4 splits per step: their loads are unconditional and in flight together (an empty split's
+    // partial is never written: its value is dropped by the select, not by a branch around the load)
+    for (int z0 = 0; z0 < a.ksplits; z0 += 4) {
+      float4 v[4];
+      float w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int z = z0 + i < a.ksplits ? z0 + i : a.ksplits - 1;
+        w[i] = z0 + i < a.ksplits ? wz[z] : 0.f;
+        v[i] = *reinterpret_cast<const float4*>(a.part + ((long)z * a.Npad + q) * a.ncols + c);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool on = w[i] != 0.f;
+        acc.x += w[i] * (on ? v[i].x : 0.f);
+        acc.y += w[i] * (on ? v[i].y : 0.f);
+        acc.z += w[i] * (on ? v[i].z : 0.f);
+        acc.w += w[i] * (on ? v[i].w : 0.f);
+      }
     }
     const float4 uu = *reinterpret_cast<const float4*>(a.U + (long)q * a.ldu + c);
     float4 g;
