@@ -154,9 +154,18 @@ __device__ void layernorm_red2_kernel(const LnRed2Args& a, int) {
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
   float4 v = *reinterpret_cast<const float4*>(p.x + (long)row * ldx + lane * 4);
-  for (int z = 0; z < nparts; ++z) {
-    const float4 w = *reinterpret_cast<const float4*>(p.parts + (long)z * part_stride + (long)row * ldpart + lane * 4);
-    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  // split-K partials, summed in order; four loads in flight per step (the tail repeats the last
+  // partial's address and drops the value)
+  for (int z0 = 0; z0 < nparts; z0 += 4) {
+    float4 w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int z = z0 + i < nparts ? z0 + i : nparts - 1;
+      w[i] = *reinterpret_cast<const float4*>(p.parts + (long)z * part_stride + (long)row * ldpart + lane * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (z0 + i < nparts) { v.x += w[i].x; v.y += w[i].y; v.z += w[i].z; v.w += w[i].w; }
   }
   if (nparts > 0) *reinterpret_cast<float4*>(p.x + (long)row * ldx + lane * 4) = v;
   float s = v.x + v.y + v.z + v.w;
