@@ -6,6 +6,18 @@ import sqlite3
 import sys
 
 
+def short_name(n: str) -> str:
+    """rmem::k_one<Args, &body, 256> / rmem::k_many<...> (csrc/launch.h) -> `body [one clip]` /
+    `body [clips batched]`; rocprofv3 reports these template instances mangled."""
+    import re
+    m = re.match(r"_ZN4rmem(5k_one|6k_many)I.*?EXadL_Z\d+([A-Za-z0-9_]+?)(I[A-Za-z0-9_]*?Ev)?RK", n)
+    if m:
+        tp = m.group(3) or ""
+        tp = "<" + ",".join(re.findall(r"Li(\d+)E", tp)) + ">" if tp else ""
+        return f"{m.group(2)}{tp} [{'one clip' if m.group(1) == '5k_one' else 'clips batched'}; rmem::{m.group(1)[1:]}]"
+    return n
+
+
 def from_db(path):
     cur = sqlite3.connect(path).cursor()
     return [(r[0], int(r[1]), float(r[2]), float(r[3]), float(r[4]))
@@ -68,6 +80,7 @@ def main():
     else:
         rows = from_csv(path) if path.endswith(".csv") else from_db(path)
     rows.sort(key=lambda r: -r[2])
+    rows = [(short_name(r[0]),) + tuple(r[1:]) for r in rows]
     tot = sum(r[2] for r in rows)
     ours = ("read2_kernel", "read_kernel", "read_combine", "linear_kernel", "linear_grouped", "pv_kernel", "pv16_kernel", "scores_kernel", "scores2_kernel",
             "combine_kernel", "combine2_kernel", "dwconv5x5",
