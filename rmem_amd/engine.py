@@ -104,6 +104,7 @@ class DeAOTEngine(nn.Module):
         self._enc_done = None
         self._launcher = None
         self._eager_frames = 0
+        self._geoms = []                     # (output size, image shape) with live graphs, least recently used first
         self.prefetch_at = os.environ.get("RMEM_PREFETCH_AT", "lstt")   # decoder | lstt
         if short_term_mem_skip != 1:
             raise NotImplementedError("short_term_mem_skip != 1 (reference evaluator always uses 1)")
@@ -141,6 +142,7 @@ class DeAOTEngine(nn.Module):
         if self.lstt is not None and self._lstt_wv != self.AOT.__dict__.get("_weights_version", 0):
             self.lstt = None                 # weights were (re)loaded: re-pack at the next reference frame
             self._fg, self._ug, self._dg = {}, {}, {}
+            self._geoms = []
         if self.lstt is not None:
             self.lstt.clear_memory()
 
@@ -155,6 +157,7 @@ class DeAOTEngine(nn.Module):
             cls = DeAOTLSTT if self.cfg.MODEL_VOS == "deaot" else AOTLSTT
             self.lstt = cls(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.nsplit)
             self._fg, self._ug, self._dg = {}, {}, {}      # graphs hold pointers into the old LSTT buffers
+            self._geoms = []
             self._drop_pending()
             self._drop_hoist()
             self._eg, self._g_lab, self._feats = {}, {}, {}
@@ -424,6 +427,7 @@ class DeAOTEngine(nn.Module):
             g.replay()
         par = self._par                                   # the copy that holds this frame's features
         key = (l.graph_key(), osz, shape, par, tuple(self.obj_nums))     # obj_nums is baked into the decoder graph
+        self._touch_geometry(osz, shape)
         ent = self._fg.get(key)
         if ent is None:
             # capture every slot variant for this (T, shapes, feature copy) at once: capture
@@ -484,6 +488,30 @@ class DeAOTEngine(nn.Module):
         l._finish(False)
         self.pred_id_logits = ent[1]
         return ent[2]
+
+    def _touch_geometry(self, osz, shape):
+        """Graph caches are bounded per (output size, image shape): a dataset whose clips differ in
+        their original size would otherwise keep every geometry's frame / decoder graphs (and their
+        activation pools) alive.  The least recently used geometry beyond RMEM_GRAPH_GEOMS (default 3)
+        is dropped; its encoder graphs go with the last geometry that uses the image shape."""
+        g = (osz, shape)
+        order = self._geoms
+        if order and order[-1] == g:
+            return
+        if g in order:
+            order.remove(g)
+        order.append(g)
+        limit = max(1, int(os.environ.get("RMEM_GRAPH_GEOMS", "3")))
+        while len(order) > limit:
+            old = order.pop(0)
+            self._drop_hoist()
+            self._drop_pending()
+            torch.cuda.synchronize()
+            self._fg = {k: v for k, v in self._fg.items() if (k[1], k[2]) != old}
+            self._dg = {k: v for k, v in self._dg.items() if (k[0], k[1]) != old}
+            if not any(o[1] == old[1] for o in order):
+                self._eg = {k: v for k, v in self._eg.items() if k[0] != old[1]}
+                self._feats = {k: v for k, v in self._feats.items() if k[0] != old[1]}
 
     def decode_current_logits(self, enc, lstt_out, output_size=None):      # aot_engine.py:438-465
         logits = self.AOT.decode_id_logits(lstt_out, enc)

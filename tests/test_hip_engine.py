@@ -386,3 +386,31 @@ def test_paired_launches_bit_identical():
     for order in ("serial_unpaired",):
         for (o0, m0), (o1, m1) in zip(outs["serial"], outs[order]):
             assert torch.equal(o0, o1) and torch.equal(m0, m1), order
+
+
+def test_graph_caches_are_bounded_per_geometry(monkeypatch):
+    """A caller that keeps changing the output size (a dataset with clips of different original
+    sizes) must not accumulate frame / decoder graphs: at most RMEM_GRAPH_GEOMS geometries stay
+    captured, and a replayed frame after an eviction still equals the eagerly issued one."""
+    from rmem_amd.engine import DeAOTEngine
+    from rmem_amd.synth import synth_clip
+    monkeypatch.setenv("RMEM_GRAPH_GEOMS", "2")
+    cfg, cpu_model, gpu_model, _ = _build(gap=3)
+    gpu_model.optimize_for_inference(True)
+    imgs, lab = synth_clip(7, 12, 97, 129, 3)
+    eng = DeAOTEngine(gpu_model, 0, long_term_mem_gap=3)
+    ref = DeAOTEngine(gpu_model, 0, long_term_mem_gap=3, use_graphs=False)
+    for e in (eng, ref):
+        e.eval()
+        e.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    sizes = [(97, 129), (120, 160), (97, 129), (64, 80), (150, 200), (97, 129), (64, 80), (120, 160), (97, 129), (97, 129), (64, 80)]
+    for t, osz in zip(range(1, 12), sizes):
+        a = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=osz).clone()
+        b = ref.match_propogate_one_frame(imgs[t].to(DEV), output_size=osz)
+        assert a.shape[-2:] == osz
+        assert float((a[:, :4] - b[:, :4]).abs().max()) < 2e-3, (t, osz)
+        cur = F.interpolate(b.argmax(1, keepdim=True).float(), size=eng.input_size_2d, mode="nearest")
+        eng.update_short_term_memory(cur)
+        ref.update_short_term_memory(cur)
+        assert len({(k[1], k[2]) for k in eng._fg}) <= 2 and len({(k[0], k[1]) for k in eng._dg}) <= 2, t
+    assert eng.long_memories_indexes == ref.long_memories_indexes
