@@ -12,6 +12,12 @@ SOURCES = ["linear.hip", "attn.hip", "fused.hip", "mha.hip", "pointwise.hip", "p
 HEADERS = ["rmem_common.h", "gemm_core.h", "attn_common.h", "launch.h", os.path.join("..", "..", "include", "rmem_hip.h")]
 
 
+# mha.hip: VGPR form of every MFMA (no AGPRs: the 32x32 score and output tiles are read and written by
+# the softmax VALU code, so the accumulator form costs a v_accvgpr move per element and s_nops in
+# front of each; 128 registers instead of 128 + 32 also give 4 waves per SIMD instead of 3)
+EXTRA_FLAGS = {"mha.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -27,7 +33,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+               os.path.join(CSRC, src), "-o", obj] + EXTRA_FLAGS.get(src, [])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -31,9 +31,8 @@ constexpr int MHA_KPL = 64 * 64, MHA_VROW = 136, MHA_VPL = 32 * MHA_VROW;
 template <int NS>
 __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   constexpr int NPL = NS == 1 ? 1 : 2;
-  __shared__ __attribute__((aligned(16))) char smem[NPL * (MHA_KPL + MHA_VPL)];
-  char* ks_lds = smem;
-  char* vs_lds = smem + NPL * MHA_KPL;
+  constexpr int STAGE_BYTES = NPL * (MHA_KPL + MHA_VPL);
+  __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, j = lane & 31;
@@ -73,7 +72,9 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
                                                 tok0 + v_ch * 8);
     }
   };
-  auto lstore = [&]() __attribute__((always_inline)) {
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    char* ks_lds = smem + buf * STAGE_BYTES;
+    char* vs_lds = ks_lds + NPL * MHA_KPL;
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
       *reinterpret_cast<u32x4_t*>(ks_lds + p * MHA_KPL + k_dst) = kr[p];
@@ -96,9 +97,12 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
   if (lo < hi_s) gload(lo);
   for (int stage = lo; stage < hi_s; ++stage) {
     __syncthreads();            // every wave is done with the previous stage
-    lstore();
+    lstore(0);
     __syncthreads();
     if (stage + 1 < hi_s) gload(stage + 1);          // in flight while this stage is processed
+    const int buf = 0;
+    const char* ks_lds = smem + buf * STAGE_BYTES;
+    const char* vs_lds = ks_lds + NPL * MHA_KPL;
     const int t = stage / sps;
     if (t != cur_t) {
       if (sml && cur_t >= 0 && hi == 0) {
@@ -143,33 +147,51 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
       // ---- online softmax for this lane's query, in the log2 domain: y = (s + bias) * scale * log2(e),
       // weights 2^(y - m).  The kernel is VALU-bound, so the token mask is applied only on the
       // tile that contains padding and the accumulator rescale only when some maximum moved.
-      float sv[16];
-      float tmax = -3.0e38f;
+      // The kernel is VALU-bound (PMC: the VALU is ~85 % busy, 219 instructions per 32-key tile before
+      // this form), so the common path is kept to the minimum: the row maximum is taken over the raw
+      // scores (scale > 0: max commutes with the affine map), the subtraction of the new maximum
+      // rides in the addend of the scaling fma, and the token mask lives on its own branch (written
+      // as selects it is if-converted into two v_cndmask per element on EVERY tile).
       const bool padded = tok0 + 32 > a.N;      // wave-uniform
+      float tmax = -3.0e38f;
       if (!padded) {
+        float tm = s[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          sv[r] = fmaf(s[r], sl2e, bias_t);
-          tmax = fmaxf(tmax, sv[r]);
-        }
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
+        tmax = fmaf(tm, sl2e, bias_t);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          sv[r] = tok < a.N ? fmaf(s[r], sl2e, bias_t) : -3.0e38f;
-          tmax = fmaxf(tmax, sv[r]);
+          tmax = fmaxf(tmax, tok < a.N ? fmaf(s[r], sl2e, bias_t) : -3.0e38f);
         }
       }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m, tmax);
-      float psum = 0.f;
+      const float cadd = bias_t - m_new;
       float pv[16];
+      f32x2_t ps2 = {0.f, 0.f};
+      if (!padded) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(sv[r] - m_new);
-        if (padded) pv[r] = sv[r] > -2.9e38f ? pv[r] : 0.f;   // (a split may start on an all-padding tile: m is still the sentinel)
-        psum += pv[r];
+        for (int r = 0; r < 16; r += 2) {
+          f32x2_t pp;
+          pp[0] = __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, cadd));
+          pp[1] = __builtin_amdgcn_exp2f(fmaf(s[r + 1], sl2e, cadd));
+          pv[r] = pp[0];
+          pv[r + 1] = pp[1];
+          ps2 += pp;
+        }
+      } else {
+        asm volatile("" ::: "memory");          // keeps this block a branch
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          // (a split may start on an all-padding tile: m_new is still the sentinel there, nothing is valid)
+          pv[r] = tok < a.N ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, cadd)) : 0.f;
+          ps2[r & 1] += pv[r];
+        }
       }
+      float psum = ps2[0] + ps2[1];
       psum += __shfl_xor(psum, 32);
       if (__any(m_new != m)) {
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);

@@ -119,7 +119,8 @@ class AOTLSTT:
         self.sQK = Planes.empty((Np, 512), dev)
         self.sVt = Planes.empty((1, 256, Np), dev)
         # key splits: ~448 blocks (2 per CU x 224) of 4 independent waves each
-        self.ks = max(1, min(8, int(round(1024.0 / ((Np // 128) * self.HEADS)))))   # ~4 waves per SIMD
+        # key splits: ~5 waves per SIMD in flight (3 resident); 480p: 12 (T = 4: 78.8 us at 8, 64.5 at 12, 63.8 at 16)
+        self.ks = max(1, min(16, int(round(1344.0 / ((Np // 128) * self.HEADS)))))
         self.opart = z(self.ks, Np, 256)
         self.ml = z(self.ks, Np, self.HEADS, 2)
         self.slot_ml = z(self.ks, Np, self.HEADS, self.Tmax, 2)

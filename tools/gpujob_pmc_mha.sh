@@ -1,0 +1,18 @@
+mkdir -p gpurun_out; export TMPDIR=/tmp
+rm -rf gpurun_out/pmc_mha*
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_MISC"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_mha_$i -o p -- python tools/kbench_mha.py --splits 12 --only-long > gpurun_out/pmc_mha_$i.log 2>&1
+done
+python - <<'PY'
+import csv, glob, collections, json
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_mha_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "mha_flash" in k:
+            agg[(k[:40], r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in agg.items():
+    print(k, {c: round(sum(v) / len(v) / 1e6, 2) for c, v in cs.items()}, "n", len(next(iter(cs.values()))))
+PY
