@@ -477,32 +477,56 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
       need_break = tmax > m + RD_THR;
     }
     float psum = 0.f;
+    // weights of 4 consecutive keys -> fp16 hi / lo planes of the P image
+    auto emit4 = [&](const f32x2_t (&pp)[2], int sub, int g) __attribute__((always_inline)) {
+      // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
+      const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
+      const f32x2_t r0 = pp[0] - __builtin_convertvector(h0, f32x2_t), r1 = pp[1] - __builtin_convertvector(h1, f32x2_t);
+      const f16x2_t l0 = __builtin_convertvector(r0, f16x2_t), l1 = __builtin_convertvector(r1, f16x2_t);
+      u32x2_t wh, wl;
+      wh[0] = __builtin_bit_cast(uint32_t, h0);
+      wh[1] = __builtin_bit_cast(uint32_t, h1);
+      wl[0] = __builtin_bit_cast(uint32_t, l0);
+      wl[1] = __builtin_bit_cast(uint32_t, l1);
+      // keys sub*32 + 8g + 4hi + 0..3 of row wave*32 + j: chunk sub*4 + g, half hi
+      *reinterpret_cast<u32x2_t*>(smem + apst[sub * 4 + g]) = wh;
+      *reinterpret_cast<u32x2_t*>(smem + apst[sub * 4 + g] + 16384) = wl;
+    };
+    // The masked form (windowed read, tiles with padding keys) lives on its own branch: as a select
+    // under a wave-uniform condition it is if-converted into a compare and two v_cndmask per element
+    // on EVERY tile (96 of the ~400 VALU instructions of this phase, found in the ISA).
+    if (!(MODE == 1 || padded)) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x2_t pp[2];
+        for (int g = 0; g < 4; ++g) {
+          f32x2_t pp[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sv = s[sub][4 * g + e];
-          float p = __builtin_amdgcn_exp2f(sv - m);   // sentinels (-3e38) give exactly 0 unless m is one too
-          if (MODE == 1 || padded) p = sv > -2.9e38f ? p : 0.f;
-          psum += p;
-          pp[e >> 1][e & 1] = p;
+          for (int e = 0; e < 4; ++e) {
+            const float p = __builtin_amdgcn_exp2f(s[sub][4 * g + e] - m);
+            psum += p;
+            pp[e >> 1][e & 1] = p;
+          }
+          emit4(pp, sub, g);
         }
-        // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
-        const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
-        const f32x2_t r0 = pp[0] - __builtin_convertvector(h0, f32x2_t), r1 = pp[1] - __builtin_convertvector(h1, f32x2_t);
-        const f16x2_t l0 = __builtin_convertvector(r0, f16x2_t), l1 = __builtin_convertvector(r1, f16x2_t);
-        u32x2_t wh, wl;
-        wh[0] = __builtin_bit_cast(uint32_t, h0);
-        wh[1] = __builtin_bit_cast(uint32_t, h1);
-        wl[0] = __builtin_bit_cast(uint32_t, l0);
-        wl[1] = __builtin_bit_cast(uint32_t, l1);
-        // keys sub*32 + 8g + 4hi + 0..3 of row wave*32 + j: chunk sub*4 + g, half hi
-        *reinterpret_cast<u32x2_t*>(smem + apst[sub * 4 + g]) = wh;
-        *reinterpret_cast<u32x2_t*>(smem + apst[sub * 4 + g] + 16384) = wl;
-      }
+    } else {
+      asm volatile("" ::: "memory");                  // keeps this block a branch
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x2_t pp[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sv = s[sub][4 * g + e];
+            float p = __builtin_amdgcn_exp2f(sv - m);   // sentinels (-3e38) give exactly 0 unless m is one too
+            p = sv > -2.9e38f ? p : 0.f;
+            psum += p;
+            pp[e >> 1][e & 1] = p;
+          }
+          emit4(pp, sub, g);
+        }
+    }
     psum += __shfl_xor(psum, 32);
     const int any_break = __any(need_break) ? 1 : 0;
     if (lane == 0) flag[wave] = any_break;
