@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void read2_kernel(Read2Args g) {
 // block is read from device memory
 __global__ __launch_bounds__(256, 1) void read_many_kernel(const char* __restrict__ argv, long stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const rmem_read_args a = *reinterpret_cast<const rmem_read_args*>(argv + (long)blockIdx.z * stride);
+  const rmem_read_args a = rmem::uniform_copy(reinterpret_cast<const rmem_read_args*>(argv + (long)blockIdx.z * stride));
   read_body<0>(a, blockIdx.x, smem);
 }
 
@@ -687,8 +687,8 @@ __global__ __launch_bounds__(256, 1) void read2_many_kernel(const char* __restri
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Read2Args& g = *reinterpret_cast<const Read2Args*>(argv + (long)blockIdx.z * stride);
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int which = jj < g.cha ? 0 : 1;
-  const rmem_read_args a = g.p[which];
+  const int which = jj < __builtin_amdgcn_readfirstlane(g.cha) ? 0 : 1;
+  const rmem_read_args a = rmem::uniform_copy(&g.p[which]);
   read_body<0>(a, (which ? jj - g.cha : jj) * 8 + xcd, smem);
 }
 

@@ -56,6 +56,28 @@ inline void rec_push(Recorder* r, ManyFn fn, dim3 grid, dim3 block, unsigned lds
   r->ops.push_back(op);
 }
 
+// Copy of an argument block that lives in device memory at a wave-uniform address, read through the
+// CONSTANT address space: the loads are invariant scalar loads, the fields land in SGPRs (and can be
+// re-loaded where they are used), like kernel arguments.  Read through a generic reference the
+// compiler can prove neither the address uniform nor the memory unclobbered and keeps every field in
+// VGPRs -- the 64x64 GEMM needed 165 registers instead of 65 (2 waves per SIMD instead of 5).  The
+// block must not be written while the launch runs (rmem_launch_recorded's contract).
+template <class T>
+__device__ __forceinline__ T uniform_copy(const T* src) {
+  static_assert(sizeof(T) % 4 == 0, "argument blocks are dword multiples");
+  constexpr int NW = sizeof(T) / 4;
+  typedef const unsigned __attribute__((address_space(4))) * ConstU;
+  const unsigned long u = reinterpret_cast<unsigned long>(src);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  ConstU p = (ConstU)(((unsigned long)hi << 32) | lo);
+  unsigned w[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) w[i] = p[i];
+  T dst;
+  __builtin_memcpy(&dst, w, sizeof(T));
+  return dst;
+}
+
 template <class A, void (*Body)(const A&, int), int LB>
 __global__ __launch_bounds__(LB) void k_one(A a) {
   Body(a, blockIdx.z);
@@ -64,8 +86,13 @@ __global__ __launch_bounds__(LB) void k_one(A a) {
 template <class A, void (*Body)(const A&, int), int LB>
 __global__ __launch_bounds__(LB) void k_many(const char* __restrict__ argv, long stride, int nz) {
   const int clip = blockIdx.z / nz;
-  const A& a = *reinterpret_cast<const A*>(argv + (long)clip * stride);
-  Body(a, blockIdx.z - clip * nz);
+  const A& src = *reinterpret_cast<const A*>(argv + (long)clip * stride);
+  if constexpr (sizeof(A) <= 640) {
+    const A a = uniform_copy(&src);            // fields in SGPRs, like kernel arguments
+    Body(a, blockIdx.z - clip * nz);
+  } else {
+    Body(src, blockIdx.z - clip * nz);         // (large blocks: the body copies what it selects)
+  }
 }
 
 template <class A, void (*Body)(const A&, int), int LB>
@@ -81,10 +108,13 @@ int many_thunk(const RecOp& op, const char* dev_args, long stride, int B, hipStr
   return RMEM_OK;
 }
 
-template <class A, void (*Body)(const A&, int), int LB>
+// BodyMany: the body of the several-clips launch when it differs (argument blocks too large to copy
+// whole: the body then copies what it selects with uniform_copy, which must not be applied to a
+// kernel argument -- taking its address would move it to scratch).
+template <class A, void (*Body)(const A&, int), int LB, void (*BodyMany)(const A&, int) = Body>
 int launch(const A& a, dim3 grid, dim3 block, unsigned lds, hipStream_t s) {
   if (Recorder* r = current_recorder()) {
-    rec_push(r, &many_thunk<A, Body, LB>, grid, block, lds, &a, (unsigned)sizeof(A));
+    rec_push(r, &many_thunk<A, BodyMany, LB>, grid, block, lds, &a, (unsigned)sizeof(A));
     return RMEM_OK;
   }
   // per launch: the attribute belongs to the (device, function) pair; no process-wide "already set" flag

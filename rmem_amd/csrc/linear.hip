@@ -162,12 +162,16 @@ struct GroupedLinear {
   rmem_linear_args p[8];
 };
 
-template <int NS>
-__device__ void linear_grouped_kernel(const GroupedLinear& g, int) {
+template <int NS, bool DEV>
+__device__ void linear_grouped_body(const GroupedLinear& g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.tile_start[i + 1]) ++i;
-  const rmem_linear_args& a = g.p[i];
+  // DEV: the group lives in device memory (several clips per launch, launch.h): the selected problem
+  // is copied through scalar loads so that its fields sit in SGPRs like kernel arguments
+  rmem_linear_args acopy;
+  if constexpr (DEV) acopy = rmem::uniform_copy(&g.p[__builtin_amdgcn_readfirstlane(i)]);
+  const rmem_linear_args& a = DEV ? acopy : g.p[i];
   int local = blockIdx.x - g.tile_start[i];
   const int mt = (a.M + 63) / 64, nt = (a.N + 63) / 64;
   const int bz = local / (mt * nt);
@@ -175,6 +179,10 @@ __device__ void linear_grouped_kernel(const GroupedLinear& g, int) {
   const int ny = local / mt, mx = local - ny * mt;
   linear_body<64, 64, NS>(a, mx, ny, bz, smem);
 }
+template <int NS>
+__device__ void linear_grouped_kernel(const GroupedLinear& g, int) { linear_grouped_body<NS, false>(g); }
+template <int NS>
+__device__ void linear_grouped_many(const GroupedLinear& g, int) { linear_grouped_body<NS, true>(g); }
 
 template <int BM, int BN, int NS>
 static int launch_linear(const rmem_linear_args& a, hipStream_t s) {
@@ -213,10 +221,10 @@ extern "C" int rmem_linear_grouped(const rmem_linear_args* args, int32_t n, void
   g.tile_start[n] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (args[0].nsplit == 3)
-    return rmem::launch<GroupedLinear, linear_grouped_kernel<3>, 256>(g, dim3(total), dim3(256),
-                                                                      GemmCfg<64, 64, 3>::LDS_BYTES, s);
-  return rmem::launch<GroupedLinear, linear_grouped_kernel<1>, 256>(g, dim3(total), dim3(256),
-                                                                    GemmCfg<64, 64, 1>::LDS_BYTES, s);
+    return rmem::launch<GroupedLinear, linear_grouped_kernel<3>, 256, linear_grouped_many<3>>(
+        g, dim3(total), dim3(256), GemmCfg<64, 64, 3>::LDS_BYTES, s);
+  return rmem::launch<GroupedLinear, linear_grouped_kernel<1>, 256, linear_grouped_many<1>>(
+      g, dim3(total), dim3(256), GemmCfg<64, 64, 1>::LDS_BYTES, s);
 }
 
 extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {

@@ -146,7 +146,7 @@ struct LnRed2Args {
   long ldx; int nparts; long part_stride, ldpart; int N; float eps;
 };
 __device__ void layernorm_red2_kernel(const LnRed2Args& a, int) {
-  const LnRedOne& p = a.p[blockIdx.y];
+  const LnRedOne p = blockIdx.y ? a.p[1] : a.p[0];   // (a select, not an index: the block may be a local copy in SGPRs)
   const long ldx = a.ldx, part_stride = a.part_stride, ldpart = a.ldpart;
   const int nparts = a.nparts, N = a.N;
   const float eps = a.eps;
