@@ -414,3 +414,38 @@ def test_graph_caches_are_bounded_per_geometry(monkeypatch):
         ref.update_short_term_memory(cur)
         assert len({(k[1], k[2]) for k in eng._fg}) <= 2 and len({(k[0], k[1]) for k in eng._dg}) <= 2, t
     assert eng.long_memories_indexes == ref.long_memories_indexes
+
+
+def test_closed_loop_vs_oracle_small_clips():
+    """Closed loop (each side is fed its OWN label maps, the way the evaluator runs): HIP engine vs
+    CPU oracle on four 97x129 clips, 10 propagated frames, K = 4, gap 2 (evictions from frame 8).
+    With the synthetic weights a flipped pixel is amplified by the loop (the memory moves ~2500 of
+    the 12.5k pixels per frame, tools/closed_loop_probe.py), so a clip either matches pixel for
+    pixel through the last frame or starts to differ with a near-tie flip of <= 2 pixels; most
+    clips match completely (measured: 3 of 5 seeds over 11 frames, the other two start with 1 px)."""
+    from oracle.engine_ref import OracleDeAOTInferEngine
+    from rmem_amd.synth import synth_clip
+    cfg, cpu_model, gpu_model, eng = _build(gap=2)
+    ora = OracleDeAOTInferEngine(cpu_model, long_term_mem_gap=2)
+    H, W, frames = 97, 129, 11
+    exact = 0
+    for seed in (1, 3, 4, 11):
+        imgs, lab = synth_clip(seed, frames, H, W, 3)
+        outs = []
+        for e, dev in ((ora, "cpu"), (eng, DEV)):
+            e.restart_engine()
+            e.add_reference_frame(imgs[0].to(dev), lab.to(dev), obj_nums=[3], frame_step=0)
+            labs = []
+            for t in range(1, frames):
+                logit = e.match_propogate_one_frame(imgs[t].to(dev), output_size=(H, W))
+                pred = torch.argmax(logit, dim=1, keepdim=True).float()
+                labs.append(pred[0, 0].cpu().numpy().astype(np.uint8))
+                e.update_memory(F.interpolate(pred, size=e.input_size_2d, mode="nearest"))
+            outs.append(labs)
+        mism = [int((a != b).sum()) for a, b in zip(*outs)]
+        print("closed loop seed", seed, "mismatching pixels per frame:", mism)
+        first = next((m for m in mism if m), 0)
+        assert first <= 2, (seed, mism)
+        exact += int(not any(mism))
+        assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.engines[0].long_memories_indexes) or any(mism)
+    assert exact >= 2, exact
