@@ -67,7 +67,7 @@ typedef struct {
   int32_t nbatch;                          /* gridDim.z; strides below in elements    */
   int64_t bsx, bsy, bsd, bsbias, bspa;
   int32_t nsplit;                          /* 1 or 3                                   */
-  int32_t tile;                            /* 0 auto, 64 or 128                        */
+  int32_t tile;                            /* 0 auto, 64 (64x64), 128 (128x128), 192 (64 rows x 128 cols) */
   int32_t ksplits;                         /* >1: split K; raw partial sums (+bias in split 0) go to
                                               parts[split][M][N] instead of the outputs above; the
                                               consumer sums them in split order (rmem_layernorm_red) */

@@ -240,5 +240,6 @@ extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
   }
   if (tile == 128) return a.nsplit == 3 ? launch_linear<128, 128, 3>(a, s) : launch_linear<128, 128, 1>(a, s);
   if (tile == 64) return a.nsplit == 3 ? launch_linear<64, 64, 3>(a, s) : launch_linear<64, 64, 1>(a, s);
+  if (tile == 192) return a.nsplit == 3 ? launch_linear<64, 128, 3>(a, s) : launch_linear<64, 128, 1>(a, s);   // 64 rows x 128 columns
   return RMEM_ERR_INVALID;
 }

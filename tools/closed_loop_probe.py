@@ -30,13 +30,16 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--scales", default="1,0.5,0.25,0.1")
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--hw", default="97,129")
+    ap.add_argument("--gap", type=int, default=2)
+    ap.add_argument("--no-zero-run", action="store_true")
     args = ap.parse_args()
     from oracle.engine_ref import OracleDeAOTInferEngine
     from rmem_amd.config import get_config
     from rmem_amd.engine import build_engine
     from rmem_amd.model import build_vos_model
     from rmem_amd.synth import load_synthetic_weights, synth_clip
-    H, W = 97, 129
+    H, W = (int(x) for x in args.hw.split(","))
     imgs, lab = synth_clip(args.seed, args.frames, H, W, 3)
     for s in [float(x) for x in args.scales.split(",")]:
         cfg = get_config("r50_deaotl", 1, 3)
@@ -46,12 +49,12 @@ def main():
             cpu.patch_wise_id_bank.weight.mul_(s)
             cpu.patch_wise_id_bank.bias.mul_(s)
         gpu = copy.deepcopy(cpu).to("cuda:0")
-        ora = OracleDeAOTInferEngine(cpu, long_term_mem_gap=2)
-        hip_e = build_engine("deaotengine", phase="eval", aot_model=gpu, gpu_id=0, long_term_mem_gap=2)
+        ora = OracleDeAOTInferEngine(cpu, long_term_mem_gap=args.gap)
+        hip_e = build_engine("deaotengine", phase="eval", aot_model=gpu, gpu_id=0, long_term_mem_gap=args.gap)
         hip_e.eval()
         a = run(ora, imgs, lab, "cpu", H, W, args.frames)
         b = run(hip_e, imgs, lab, "cuda:0", H, W, args.frames)
-        z = run(ora, imgs, lab, "cpu", H, W, args.frames, feed_zero=True)
+        z = a if args.no_zero_run else run(ora, imgs, lab, "cpu", H, W, args.frames, feed_zero=True)
         mism = [int((x != y).sum()) for x, y in zip(a, b)]
         moved = [int((x != y).sum()) for x, y in zip(a, z)]
         print(f"id scale {s}: closed-loop HIP vs oracle mismatching px/frame {mism}; memory moves (vs labels never fed) {moved}")
