@@ -272,7 +272,7 @@ def main():
             out["roofline"]["frac_isolated"] = out["roofline"]["algorithmic_flops_per_launch"] / (iso * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
         # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
-        pmc_name = "r02_t_pmc_read.json"
+        pmc_name = "r02_x_pmc_read.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if out["roofline"] and args.config == "480p_k4" and args.model == "r50_deaotl" and os.path.exists(pmc):
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
