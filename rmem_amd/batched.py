@@ -314,6 +314,9 @@ class BatchedDeAOTEngine:
             return self._decode_eager(enc, osz)
         key = (osz, id(enc), tuple(self.obj_nums))
         ent = self._dg.get(key)
+        if ent is None and len(self._dg) >= 8:        # a caller that keeps changing the output size: bounded cache
+            torch.cuda.synchronize()
+            self._dg = {}
         if ent is None:
             self._decode_eager(enc, osz)
             torch.cuda.synchronize()
