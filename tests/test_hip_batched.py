@@ -27,7 +27,7 @@ def _model(former=1, latter=3):
     return cfg, copy.deepcopy(model).to(DEV)
 
 
-@pytest.mark.parametrize("h,w,B", [(12, 17, 3), (20, 23, 4)])
+@pytest.mark.parametrize("h,w,B", [(12, 17, 3), (20, 23, 4), (31, 54, 2)])
 def test_batched_lstt_equals_single_clips_bit_for_bit(h, w, B):
     """Reference frame + 9 frames with long-term updates every second frame (K = 4: evictions from
     frame 6 on), different token features and label maps per clip.  Every frame: LSTT output, the
