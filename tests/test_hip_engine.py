@@ -449,3 +449,37 @@ def test_closed_loop_vs_oracle_small_clips():
         exact += int(not any(mism))
         assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.engines[0].long_memories_indexes) or any(mism)
     assert exact >= 1, exact
+
+
+def test_long_clip_eviction_history_vs_oracle():
+    """60 frames at 97x129, K = 4, gap 2: 26 evictions decided by the EMA + UCB rule
+    (transformer.py:880-991) on attention masses that come from the HIP kernels.  Teacher-forced with
+    the oracle's label maps; every frame: the list of kept frame indexes equals the oracle's, label
+    maps differ by at most 2 of 12.5k pixels."""
+    from oracle.engine_ref import OracleDeAOTInferEngine
+    from rmem_amd.synth import synth_clip
+    cfg, cpu_model, gpu_model, eng = _build(gap=2)
+    ora = OracleDeAOTInferEngine(cpu_model, long_term_mem_gap=2)
+    H, W, frames = 97, 129, 61
+    imgs, lab = synth_clip(23, frames, H, W, 3)
+    ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    worst, evictions, prev = 0, 0, None
+    for t in range(1, frames):
+        lo = ora.match_propogate_one_frame(imgs[t], output_size=(H, W))
+        lh = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(H, W))
+        po = torch.argmax(lo, dim=1, keepdim=True).float()
+        ph = torch.argmax(lh, dim=1, keepdim=True).float().cpu()
+        mism = int((po != ph).sum())
+        worst = max(worst, mism)
+        assert mism <= 2, (t, mism)
+        fed = F.interpolate(po, size=ora.input_size_2d, mode="nearest")
+        ora.update_memory(fed)
+        eng.update_memory(fed.to(DEV))
+        io, ih = list(ora.engines[0].long_memories_indexes), list(eng.aot_engines[0].long_memories_indexes)
+        assert io == ih, (t, io, ih)
+        if prev is not None and len(io) == len(prev) and io != prev:
+            evictions += 1
+        prev = io
+    print("long clip: evictions", evictions, "worst label mismatch", worst, "final indexes", prev)
+    assert evictions >= 20
