@@ -178,3 +178,43 @@ def test_batched_clip_driver_vs_clip_driver():
         assert mism[0] <= 2, mism
     with pytest.raises(ValueError):
         D.BatchedClipDriver(model, 2, cfg).run_clips(clips[:1], num_frames=frames)
+
+
+def test_batched_engine_vs_oracle():
+    """Two clips in lockstep through BatchedDeAOTEngine against one CPU oracle engine per clip,
+    teacher-forced with the oracle's label maps over 20 frames (K = 4, gap 2: 7 evictions per clip):
+    kept-frame indexes equal every frame, label maps within 2 of 12.5k pixels."""
+    from oracle.engine_ref import OracleDeAOTInferEngine
+    from rmem_amd.batched import BatchedDeAOTEngine
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+    cfg = get_config("r50_deaotl", 1, 3)
+    cpu_model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(cpu_model)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    B, frames, Hh, Ww = 2, 21, 97, 129
+    clips = [synth_clip(400 + i, frames, Hh, Ww, 3) for i in range(B)]
+    oras = [OracleDeAOTInferEngine(cpu_model, long_term_mem_gap=2) for _ in range(B)]
+    for i, o in enumerate(oras):
+        o.add_reference_frame(clips[i][0][0], clips[i][1], obj_nums=[3], frame_step=0)
+    bat = BatchedDeAOTEngine(gpu_model, B, long_term_mem_gap=2)
+    bat.add_reference_frame(torch.cat([clips[i][0][0] for i in range(B)]).to(DEV),
+                            torch.cat([clips[i][1] for i in range(B)]).to(DEV), obj_nums=[10] * B, frame_step=0)
+    worst = 0
+    for t in range(1, frames):
+        lg = bat.match_propogate_one_frame(torch.cat([clips[i][0][t] for i in range(B)]).to(DEV), output_size=(Hh, Ww))
+        pb = lg.argmax(1).cpu()
+        fed = []
+        for i, o in enumerate(oras):
+            po = o.match_propogate_one_frame(clips[i][0][t], output_size=(Hh, Ww)).argmax(1, keepdim=True).float()
+            mism = int((po[0, 0] != pb[i]).sum())
+            worst = max(worst, mism)
+            assert mism <= 2, (t, i, mism)
+            cur = F.interpolate(po, size=o.input_size_2d, mode="nearest")
+            o.update_memory(cur)
+            fed.append(cur)
+        bat.update_memory(torch.cat(fed).to(DEV))
+        for i, o in enumerate(oras):
+            assert bat.long_memories_indexes[i] == list(o.engines[0].long_memories_indexes), (t, i)
+    print("batched engine vs oracle: worst label mismatch", worst, "final indexes", bat.long_memories_indexes)
