@@ -344,6 +344,9 @@ class BatchedDeAOTEngine:
         if len(obj_nums) != self.B or imgs.shape[0] != self.B:
             raise ValueError("one image, mask and object count per clip")
         self.obj_nums = [int(n) for n in obj_nums]
+        if any(n > self.AOT.max_obj_num for n in self.obj_nums):
+            raise NotImplementedError(f"more than {self.AOT.max_obj_num} objects per clip: use DeAOTInferEngine (one sub-engine "
+                                      "per 10 objects, engines/aot_engine.py:675-702)")
         if frame_step == -1:
             frame_step = self.frame_step
         self._drop_pending()
