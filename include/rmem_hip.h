@@ -315,7 +315,7 @@ int rmem_groupnorm2(const float *tgt, const float *tgt_id, int32_t N, int32_t C,
 
 /* ID assignment: label map -> one-hot(+ignore) -> Conv2d(k,stride,pad) -> LayerNorm_C
  * (utils/image.py:69-74, engines/aot_engine.py:208-232, models/aot.py:67-74,
- * models/deaot.py:65-69).  wt is [ncls][k][k][C]; gamma NULL skips the LayerNorm (AOT).
+ * models/deaot.py:65-69).  wt is [ncls][k][k][C] (k <= 31, C = 256); gamma NULL skips the LayerNorm (AOT).
  * ignore_channel != 0: label 255 selects the ignore channel ncls-1 (update_short_term_memory,
  * aot_engine.py:330-336, passes the real ignore mask); ignore_channel == 0: label 255 contributes
  * nothing (add_reference_frame, aot_engine.py:304, calls assign_identity without an ignore mask,
