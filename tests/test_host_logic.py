@@ -260,3 +260,26 @@ def test_sharded_clips_hashes_do_not_depend_on_world_size():
             p.join(timeout=600)
             assert p.exitcode == 0
     assert out[1] == out[2] and len(set(out[1])) == 4      # same per clip, and the clips differ
+
+
+def test_batched_clip_driver_validates_its_input_on_the_host():
+    """BatchedClipDriver refuses what it cannot run in lockstep before anything is launched (no GPU
+    needed): wrong clip count, clips of different lengths, flip augmentation, mid-clip labels."""
+    from rmem_amd import driver as D
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    cfg = get_config("r50_deaotl", 1, 3)
+    model = build_vos_model("deaot", cfg).eval()
+    drv = D.BatchedClipDriver(model, 2, cfg)
+    img = torch.zeros(1, 3, 33, 49)
+    lab = torch.zeros(1, 1, 33, 49)
+    clip = lambda n, aug=False, mid=False: [D.make_samples(img, lab if (t == 0 or (mid and t == 2)) else None, (33, 49), 3,
+                                                           flip_aug=aug, name=f"{t:05d}.jpg") for t in range(n)]
+    with pytest.raises(ValueError):
+        drv.run_clips([clip(4)], num_frames=4)
+    with pytest.raises(ValueError):
+        drv.run_clips([clip(4), clip(5)], num_frames=4)
+    with pytest.raises(ValueError):
+        drv.run_clips([clip(4, aug=True), clip(4, aug=True)], num_frames=4)
+    with pytest.raises(NotImplementedError):
+        drv.run_clips([clip(4, mid=True), clip(4)], num_frames=4)
