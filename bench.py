@@ -13,7 +13,12 @@ as rmem_amd.driver does).
 Frames are resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...          # spawns N ranks itself (one per GPU), like the reference's
+                                          # tools/eval.py:137-143 (mp.spawn over --gpu_num)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # same ranks, external launcher
+
+Environment: RMEM_DIST_BACKEND (default "nccl" = RCCL; "gloo" lets N ranks share ONE GPU for a launcher
+smoke test), RMEM_DEVICE_OVERRIDE=<index> (every rank uses that device instead of LOCAL_RANK).
 
 Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the
 dominant kernel (HIP-event timed inside the timed region) and `cpu_baseline` (the
@@ -77,20 +82,69 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this script as N ranks of one node through
+    torch.distributed.run (one process per GPU, LOCAL_RANK -> device), the role mp.spawn(main_worker,
+    nprocs=cfg.TEST_GPU_NUM) plays in the reference (aot_plus/tools/eval.py:137-143).  Rank 0 prints the
+    JSON line; the children's output passes through."""
+    import socket
+    import subprocess
+    if "RMEM_DEVICE_OVERRIDE" not in os.environ and torch.cuda.is_available() and torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible "
+                         "(RMEM_DEVICE_OVERRIDE=0 RMEM_DIST_BACKEND=gloo runs the ranks on one device)")
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def rank_device(local_rank: int) -> int:
+    """Device index of this rank: LOCAL_RANK, or RMEM_DEVICE_OVERRIDE for every rank."""
+    return int(os.environ["RMEM_DEVICE_OVERRIDE"]) if os.environ.get("RMEM_DEVICE_OVERRIDE", "") != "" else local_rank
+
+
+def init_dist(world: int):
+    """None for one rank, else the initialised torch.distributed module (RCCL unless RMEM_DIST_BACKEND says gloo)."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=os.environ.get("RMEM_DIST_BACKEND", "nccl"))
+    return dist
+
+
+def max_over_ranks(dist, elapsed: float, dev):
+    """(max over ranks, list of every rank's value): the job takes as long as its slowest rank."""
+    if dist is None:
+        return elapsed, [elapsed]
+    on = dev if dist.get_backend() != "gloo" else torch.device("cpu")
+    mine = torch.tensor([elapsed], dtype=torch.float64, device=on)
+    every = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=on)
+    dist.all_gather_into_tensor(every, mine)
+    vals = [float(v) for v in every.cpu()]
+    return max(vals), vals
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher around us: become one
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+    if world != max(1, args.gpus) and rank == 0:               # the launcher's world is what runs and what is reported
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus = {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local_rank = rank_device(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = init_dist(world)
 
     from rmem_amd import hip
     from rmem_amd.config import get_config
@@ -217,10 +271,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
 
     fps = world * C * args.steps / elapsed
 
@@ -262,6 +313,13 @@ def main():
                    "parallelism": f"clips sharded {C}-per-GPU x{world}" + (" (one engine + HIP stream per clip)" if C > 1 else "")
                    + ", all-gather of masks"},
     }
+    if dist is not None:
+        import hashlib
+        out["config"]["per_rank_frames_per_sec"] = [C * args.steps / t_ for t_ in per_rank_s]
+        out["config"]["dist_backend"] = dist.get_backend()
+        if rank == 0:      # outside the timed region: what the exchange step delivered, [world*C, steps, H, W] uint8
+            out["config"]["gathered_masks_shape"] = list(gathered.shape)
+            out["config"]["gathered_masks_sha256"] = hashlib.sha256(gathered.cpu().numpy().tobytes()).hexdigest()
     if rank == 0:
         out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)
         if out["roofline"] and hasattr(lstt, "time_read_isolated"):
@@ -332,16 +390,13 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
     host_issue = time.perf_counter() - t0
     if dist is not None:
         from rmem_amd.driver import gather_masks
-        gather_masks(masks, world)
+        gathered = gather_masks(masks, world)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
     fps = world * B * args.steps / elapsed
     c0 = eng.lstt.clips[0]
     out = {"metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref" if args.config == "480p_k4"
@@ -356,6 +411,12 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
                       "key_splits_long_win_self": [c0.ks_long, c0.ks_win, c0.ks_self],
                       "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
                       "parallelism": f"clips sharded {B}-per-GPU x{world}, batched launches, all-gather of masks"}}
+    if dist is not None:
+        import hashlib
+        out["config"]["per_rank_frames_per_sec"] = [B * args.steps / t_ for t_ in per_rank_s]
+        out["config"]["dist_backend"] = dist.get_backend()
+        if rank == 0:
+            out["config"]["gathered_masks_sha256"] = hashlib.sha256(gathered.cpu().numpy().tobytes()).hexdigest()
     if rank == 0:
         iso = eng.lstt.time_read_isolated()
         flops = B * c0.read_flops(len(c0.bank))
@@ -421,10 +482,7 @@ def clips64(args, world, rank, local_rank, dev, dist):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
     total_frames = n_clips * (F_ - 1)               # propagated frames (the reference frame is not a "frame/s" frame in evaluator.py:571-587)
     if rank == 0:
         print(json.dumps({
@@ -436,6 +494,8 @@ def clips64(args, world, rank, local_rank, dev, dist):
                                    f"(clip i -> rank i mod {world}), evaluator gap rule (gap {D.memory_gap(F_)}), reference frame + bank fill timed",
                        "clips": n_clips, "frames_per_clip": F_, "frames_per_sec_per_gpu": total_frames / elapsed / world,
                        "batched": bool(args.batched),
+                       "per_rank_seconds": per_rank_s,
+                       "dist_backend": dist.get_backend() if dist is not None else None,
                        "parallelism": f"clips sharded {args.clips_per_rank}-per-GPU x{world}"
                                       + (" in lockstep (one launch per kernel for all clips of a rank)" if args.batched else "")
                                       + ", one all-gather of uint8 masks "

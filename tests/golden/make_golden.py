@@ -11,6 +11,7 @@ Fixtures are data only (inputs + the reference's outputs):
   idassign_*.npz             one_hot_mask + assign_identity + get_id_emb
   clip_small_*.json/.npz     engine state machine on small clips (indexes, EMA, visits, labels)
   clip_480p.json/.npz        481x849 clip: per-frame label hashes + a few logits (fp16)
+  multiengine_wrapper.*      AOTInferEngine.separate_mask / soft_logit_aggregation (> 10 objects)
 """
 from __future__ import annotations
 
@@ -341,6 +342,46 @@ def gen_tta():
     print("tta clip indexes", indexes[-1], "labels max", int(torch.stack(labels).max()))
 
 
+def gen_multiengine():
+    """the multi-engine wrapper's pure tensor functions, called on the imported reference
+    itself (AOTInferEngine.separate_mask, aot_engine.py:604-618 label branch; soft_logit_aggregation,
+    :650-673) with a dummy `aot_engines` list of length 2 / 3 -- the reference's shared-LSTT crash
+    (see the note in this file) is never reached.  Inputs are seeded here and stored with the outputs."""
+    cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
+    g = torch.Generator().manual_seed(8604)
+    out = {}
+    for n_eng, hw in ((2, (37, 53)), (3, (21, 29))):
+        engine.aot_engines = [object()] * n_eng           # only len() is read by the two functions
+        # label maps with ids 0 .. n_eng*10 (+ beyond the last engine's range) and the ignore id 255
+        ids = torch.randint(0, n_eng * engine.max_aot_obj_num + 3, (1, 1) + hw, generator=g).float()
+        ids[0, 0, :3, :5] = 255.0
+        sep = engine.separate_mask(ids)
+        sep3 = engine.separate_mask(ids[0])               # 3-d mask branch (len(mask.size()) == 3)
+        logits = [torch.randn(1, engine.max_aot_obj_num + 1, *hw, generator=g) * 6.0 for _ in range(n_eng)]
+        logits[0][0, 0, :4] = 40.0                         # saturates the clamp(1e-5, 1 - 1e-5) on both sides
+        logits[1][0, 3, 5:9] = 40.0
+        agg = engine.soft_logit_aggregation(logits)
+        k = f"e{n_eng}"
+        out[k + "_mask"] = ids.numpy()
+        for i, (a, b) in enumerate(zip(sep, sep3)):
+            out[f"{k}_sep{i}"] = a.numpy()
+            out[f"{k}_sep3d{i}"] = b.numpy()
+        for i, lg in enumerate(logits):
+            out[f"{k}_logit{i}"] = lg.numpy()
+        out[k + "_agg"] = agg.numpy()
+    # single-engine fast paths return their input (aot_engine.py:607-608, 651-652)
+    engine.aot_engines = [object()]
+    m1 = torch.randint(0, 11, (1, 1, 9, 11), generator=g).float()
+    l1 = torch.randn(1, 11, 9, 11, generator=g)
+    assert engine.separate_mask(m1)[0] is m1 and engine.soft_logit_aggregation([l1]) is l1
+    engine.aot_engines = []
+    np.savez_compressed(os.path.join(HERE, "multiengine_wrapper.npz"), **out)
+    json.dump({"max_aot_obj_num": int(engine.max_aot_obj_num), "cases": {"e2": [37, 53], "e3": [21, 29]},
+               "single_engine_identity": True, "seed": 8604},
+              open(os.path.join(HERE, "multiengine_wrapper.json"), "w"))
+    print("multi-engine wrapper vectors:", sorted(out)[:6], "...")
+
+
 def main():
     torch.manual_seed(0)
     if "--tta-only" in sys.argv:
@@ -348,6 +389,9 @@ def main():
         return
     if "--ignore-only" in sys.argv:
         gen_ignore_clip()
+        return
+    if "--multiengine-only" in sys.argv:
+        gen_multiengine()
         return
     if "--aot-only" not in sys.argv and "--swin-only" not in sys.argv:
         cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
@@ -364,6 +408,7 @@ def main():
     gen_swin()
     gen_tta()
     gen_ignore_clip()
+    gen_multiengine()
     os.system(f"du -sh {HERE}")
 
 

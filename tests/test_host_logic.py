@@ -283,3 +283,41 @@ def test_batched_clip_driver_validates_its_input_on_the_host():
         drv.run_clips([clip(4, aug=True), clip(4, aug=True)], num_frames=4)
     with pytest.raises(NotImplementedError):
         drv.run_clips([clip(4, mid=True), clip(4)], num_frames=4)
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_multi_engine_wrapper_vs_reference_vectors(which, golden_dir, deaot_model):
+    """SURVEY 8f-4 pinned: separate_mask (label branch, 4-d and 3-d masks) and soft_logit_aggregation of
+    the > 10-object wrapper against the outputs of the reference's OWN functions
+    (engines/aot_engine.py:604-618, 650-673; tests/golden/make_golden.py:gen_multiengine), for 2 and 3
+    sub-engines, ids beyond the last engine's range, the ignore id 255 and logits that hit the
+    clamp(1e-5, 1 - 1e-5).  Checked for the oracle's wrapper and for the product's (host functions)."""
+    import json
+    meta = json.load(open(os.path.join(golden_dir, "multiengine_wrapper.json")))
+    gold = np.load(os.path.join(golden_dir, "multiengine_wrapper.npz"))
+    if which == "oracle":
+        from oracle.engine_ref import OracleDeAOTInferEngine
+        w = OracleDeAOTInferEngine(deaot_model, long_term_mem_gap=5)
+        assert w.max_obj == meta["max_aot_obj_num"]
+        attr = "engines"
+    else:
+        from rmem_amd.engine import DeAOTInferEngine
+        w = DeAOTInferEngine(deaot_model, gpu_id=0, long_term_mem_gap=5, fold_bn=False)
+        assert w.max_aot_obj_num == meta["max_aot_obj_num"]
+        attr = "aot_engines"
+    for case in meta["cases"]:
+        n = int(case[1:])
+        setattr(w, attr, [object()] * n)
+        mask = torch.from_numpy(gold[f"{case}_mask"])
+        for tag, m in (("sep", mask), ("sep3d", mask[0])):
+            got = w.separate_mask(m)
+            assert len(got) == n
+            for i in range(n):
+                assert np.array_equal(got[i].numpy(), gold[f"{case}_{tag}{i}"]), (case, tag, i)
+        agg = w.soft_logit_aggregation([torch.from_numpy(gold[f"{case}_logit{i}"]) for i in range(n)])
+        assert agg.shape[1] == 1 + n * meta["max_aot_obj_num"]
+        assert np.array_equal(agg.numpy(), gold[f"{case}_agg"]), case          # same torch ops, same order: bit-equal
+    setattr(w, attr, [object()])                                              # single-engine fast paths: identity
+    m1, l1 = torch.zeros(1, 1, 4, 4), torch.zeros(1, 11, 4, 4)
+    assert w.separate_mask(m1)[0] is m1 and w.soft_logit_aggregation([l1]) is l1
+    setattr(w, attr, [])
