@@ -88,13 +88,12 @@ int rmem_linear(const rmem_linear_args *a, void *stream);
  * of one LSTT stage share their input and individually cannot fill 256 CUs. */
 int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
 
-/* ------------------------------------------------------------------ attention
- * Memory-read attention of GatedPropagation.forward (layers/attention.py:174-206) in
- * three launches over a materialised split-fp16 probability matrix:
- *   rmem_attn_scores(pass=0)  running row max of S = scale*(Q.K^T + bias)   (plain fp16) 
- *   rmem_attn_scores(pass=1)  P = exp(S - max) -> planes, partial row sums   (nsplit)
- *   rmem_attn_pv              partial O = P . V per key split                 (nsplit)
- *   rmem_attn_combine         G = (sum_splits O) / rowsum * U, per-slot attention mass
+/* ------------------------------------------------------------------ fused memory read
+ * The memory read of GatedPropagation.forward / LocalGatedPropagation.forward (layers/attention.py:
+ * 174-209 and 289-358, call sites layers/transformer.py:1183, 1199, 1227) as ONE flash-style
+ * launch: S = scale*(Q.K^T + bias), softmax, O = P.V per key split; the probability matrix
+ * stays in LDS.  rmem_attn_read_combine merges the splits, normalises, gates with U and emits the
+ * per-slot attention mass (record_attn_weight, transformer.py:1186-1192).
  *
  * mode 0 ("bank", long-term / self): keys are T logical slots of the ring bank,
  *   slot t lives at physical slot slot_map[t]; the temporal positional embedding
@@ -105,66 +104,7 @@ int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
  *   R[q][(ky-qy+7)*15 + (kx-qx+7)] (layers/attention.py:305-346: out-of-image keys are
  *   the -1e8 entries, which softmax turns into exact zeros).
  *
- * Layouts: K planes [slot][Npad][128]; V^T planes [slot][ncols][Npad] (channel-major);
- * Q planes [Npad][128]; P planes blocked [key/32][Npad][32]; Npad = N rounded up to 128.
- */
-typedef struct {
-  int32_t mode;                            /* 0 bank, 1 window                         */
-  int32_t pass;                            /* 0 row max, 1 probabilities               */
-  const rmem_f16 *kh, *kl; int64_t k_slot_stride;   /* K planes base, elements per slot */
-  const int32_t *slot_map;                 /* device [T] logical -> physical slot       */
-  int32_t T, N, Npad;
-  const rmem_f16 *qh, *ql;                /* Q planes [Npad][128]                      */
-  float scale;                             /* 1/sqrt(d_att)                             */
-  const float *bias;                       /* mode 0: [N][T] or NULL                    */
-  const float *R; int32_t ldr; int32_t h, w;  /* mode 1                                 */
-  uint32_t *rowmax;                        /* [Npad] order-encoded running max (memset 0 before pass 0) */
-  rmem_f16 *ph, *pl;                      /* pass 1: P planes; nsplit 3 with pl == NULL: P is ONE fp16 plane in ph */
-  float *lpart; int32_t nparts;            /* pass 1: [Npad][nparts] partial row sums, part = key/64 */
-  int32_t nsplit;                          /* pass 1 precision (pass 0 always runs plain fp16) */
-} rmem_scores_args;
-
-int rmem_attn_scores(const rmem_scores_args *a, void *stream);
-
-/* Two independent reads of one frame in ONE launch (the long-term bank read and the windowed
- * short-term read of a GPM layer, layers/transformer.py:1183 and :1199): same pass and nsplit. */
-int rmem_attn_scores2(const rmem_scores_args *a, const rmem_scores_args *b, void *stream);
-
-typedef struct {
-  int32_t mode;                            /* 0 bank, 1 window (banded k range)         */
-  const rmem_f16 *ph, *pl;                /* P planes blocked [key/32][Npad][32]; nsplit 3 with pl == NULL (mode 0): one fp16 plane, 2 MFMAs per product */
-  const rmem_f16 *vh, *vl; int64_t v_slot_stride;   /* V^T planes [slot][ncols][Npad]  */
-  const int32_t *slot_map; int32_t T, N, Npad;
-  int32_t ncols;                           /* 1024 (V | ID_V)                           */
-  int32_t h, w;                            /* mode 1                                    */
-  float *part;                             /* [ksplits][Npad][ncols] fp32               */
-  int32_t ksplits;
-  int32_t nsplit;
-} rmem_pv_args;
-
-int rmem_attn_pv(const rmem_pv_args *a, void *stream);
-
-typedef struct {
-  int32_t mode; int32_t T, N, Npad, ncols, h, w;
-  const float *part; int32_t ksplits;
-  const float *lpart; int32_t nparts;
-  const float *U; int64_t ldu;             /* gate [N][ncols] (attention.py:206)        */
-  float *G; int64_t ldg;                   /* out: gated aggregate [N][ncols] fp32      */
-  float *mass;                             /* out (may be NULL): [N][T] = record_attn_weight (transformer.py:1186-1192) */
-} rmem_combine_args;
-
-int rmem_attn_combine(const rmem_combine_args *a, void *stream);
-
-/* The combine steps of two reads in one launch (see rmem_attn_scores2). */
-int rmem_attn_combine2(const rmem_combine_args *a, const rmem_combine_args *b, void *stream);
-
-/* ------------------------------------------------------------------ fused memory read
- * The same read (GatedPropagation.forward / LocalGatedPropagation.forward, layers/attention.py:
- * 174-209 and 289-358, call sites layers/transformer.py:1183, 1199, 1227) as ONE flash-style
- * launch: S = scale*(Q.K^T + bias), online softmax, O = P.V per key split, the probability matrix
- * stays in LDS.  rmem_attn_read_combine merges the splits, normalises, gates with U and emits the
- * per-slot attention mass (record_attn_weight, transformer.py:1186-1192).
- * Modes and the K / Q layouts are those of rmem_attn_scores.  V is "blocked-16":
+ * Layouts: K planes [slot][Npad][128]; Q planes [Npad][128]; Npad = N rounded up to 128.  V is "blocked-16":
  * planes [slot][Npad/16][ncols][16] (element (key k, column c) at ((k/16)*ncols + c)*16 + k%16),
  * written by rmem_linear with pa_blocked = 1, so that an MFMA B fragment of 32 columns is one
  * contiguous KiB.  ncols must be a multiple of 512.
@@ -205,11 +145,6 @@ typedef struct {
 int rmem_attn_read_combine(const rmem_read_combine_args *a, void *stream);
 /* two reads of one layer in one launch (long-term bank + windowed short-term) */
 int rmem_attn_read_combine2(const rmem_read_combine_args *a, const rmem_read_combine_args *b, void *stream);
-
-/* bias[q][t] = (Q[q] + cur_pe) . mem_pe[pe_row[t]]   (layers/transformer.py:1140-1172) */
-int rmem_pe_bias(const float *Q, int64_t ldq, const float *cur_pe, const float *mem_pe,
-                 const int32_t *pe_row_host, int32_t T, int32_t N, int32_t d, float *bias,
-                 void *stream);
 
 /* ------------------------------------------------------------------ AOT multi-head attention
  * MultiheadAttention.forward of the AOT block (layers/attention.py:28-81; 8 heads x 32,
@@ -405,7 +340,7 @@ int rmem_label_resize_nearest(const uint8_t *src, int32_t Hs, int32_t Ws, uint8_
  *   h = rmem_rec_begin();  ...any sequence of the calls below...;  rmem_rec_end(h);
  *
  * While a host thread is recording, rmem_linear / rmem_linear_grouped / rmem_layernorm_red[2] /
- * rmem_pe_bias / rmem_attn_read[2] / rmem_attn_read_combine[2] / rmem_dwconv5x5_split[2] /
+ * rmem_attn_read[2] / rmem_attn_read_combine[2] / rmem_dwconv5x5_split[2] /
  * rmem_groupnorm2 / rmem_id_assign / rmem_attn_mass_reduce on that thread validate their arguments
  * as usual but launch nothing: the argument block and launch geometry are appended to the
  * recording (other entry points are not recordable and launch immediately).  Recording the same

@@ -218,6 +218,7 @@ class BatchedDeAOTEngine:
         if fold_bn and next(aot_model.parameters()).is_cuda:
             aot_model.optimize_for_inference(True)
         self.lstt: Optional[BatchedLSTT] = None
+        self._lstt_wv = 0                    # weights version (rmem_amd.checkpoint.load_network) the packed LSTT was built from
         self._eg, self._dg = {}, {}
         self._par = 0                        # encoder feature copy (of two) that holds the current frame
         self._pending = None                 # (images, copy, done event) of the announced next frame
@@ -232,17 +233,32 @@ class BatchedDeAOTEngine:
         self.long_memories_indexes: List[List[int]] = [[] for _ in range(self.B)]
         self.pred_id_logits = None
         self._drop_pending()
+        if self._stale_weights():
+            # load_network() on a model this engine already holds: the packed LSTT / ID-bank planes and the
+            # captured encoder / decoder graphs (which replay the OLD folded tensors) are stale -- drop them,
+            # as DeAOTEngine.restart_engine does; the next reference frame re-packs and re-captures
+            if self._eg or self._dg:
+                torch.cuda.synchronize()
+            self.lstt, self._eg, self._dg = None, {}, {}
         if self.lstt is not None:
             self.lstt.clear_memory()
+
+    def _stale_weights(self) -> bool:
+        return self._lstt_wv != self.AOT.__dict__.get("_weights_version", 0)
 
     def update_size(self, input_size, enc_size):                # aot_engine.py:565-568
         self.input_size_2d = tuple(int(v) for v in input_size)
         self.enc_size_2d = tuple(int(v) for v in enc_size)
         self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
-        if self.lstt is None or (self.lstt.h, self.lstt.w) != self.enc_size_2d:
+        if self.lstt is None or (self.lstt.h, self.lstt.w) != self.enc_size_2d or self._stale_weights():
+            replaced = self.lstt is not None
+            self._lstt_wv = self.AOT.__dict__.get("_weights_version", 0)
             dev = next(self.AOT.parameters()).device
             self.lstt = BatchedLSTT(self.AOT, self.enc_size_2d[0], self.enc_size_2d[1], dev, self.B, self.nsplit)
-            self._eg, self._dg = {}, {}
+            if replaced:       # geometry / weights changed under live graphs (a first LSTT invalidates nothing:
+                self._drop_pending()      # encoder and decoder graphs do not depend on it)
+                torch.cuda.synchronize()
+                self._eg, self._dg = {}, {}
 
     # ------------------------------------------------------------------ encoder / decoder at batch B
     def _encoder_graph(self, imgs: torch.Tensor, par: int):
@@ -350,8 +366,11 @@ class BatchedDeAOTEngine:
         if frame_step == -1:
             frame_step = self.frame_step
         self._drop_pending()
+        if self._stale_weights() and (self._eg or self._dg):    # load_network() since the graphs were captured
+            torch.cuda.synchronize()
+            self._eg, self._dg = {}, {}
         enc = self._encode(imgs)
-        if self.input_size_2d is None:
+        if self.input_size_2d is None or self._stale_weights():
             self.update_size(imgs.shape[2:], enc[-1].shape[2:])
         # no ignore channel on reference frames (aot_engine.py:304 -> :209-213)
         self.lstt.assign_identity(self._labels_u8(masks), ignore=False)

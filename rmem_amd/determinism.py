@@ -1,0 +1,49 @@
+"""Parity mode: the reference's ``--fix_random`` switch (aot_plus/tools/eval.py:21-37) for this build.
+
+The reference fixes its seeds and asks cuDNN for deterministic algorithms
+(``torch.backends.cudnn.deterministic = True``, ``benchmark = False``, ``CUDNN_DETERMINISTIC=1``).  On
+PyTorch-ROCm the same two flags steer MIOpen: ``benchmark = False`` selects convolutions through MIOpen's
+immediate mode (no timing-based search whose winner can differ between processes) and
+``deterministic = True`` excludes solvers marked non-deterministic.  ``fix_random()`` sets them, plus the
+MIOpen find-mode environment (only effective before the first convolution of the process).
+
+Whether two PROCESSES then produce bit-identical encoder features on this ROCm is measured by
+``tools/parity_mode_probe.py`` (result under ``profiles/``); the hot path itself (rmem_amd/csrc) has no
+floating-point atomics and is bit-reproducible with or without this switch.
+
+``RMEM_DETERMINISTIC=1`` in the environment applies it when ``rmem_amd.engine`` builds its first engine.
+"""
+from __future__ import annotations
+
+import os
+import random
+
+_applied = False
+
+
+def fix_random(seed: int = 1) -> None:
+    """Mirror of tools/eval.py:21-37 (same seed offsets), with the MIOpen counterparts of the cuDNN flags."""
+    global _applied
+    import numpy as np
+    import torch
+    os.environ["CUDNN_DETERMINISTIC"] = "1"
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    # MIOpen: "fast" find mode (2) = find-db hit or the immediate-mode fallback, never a timed search
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    os.environ.setdefault("MIOPEN_FIND_ENFORCE", "1")          # NONE: never (re)search / update the find-db
+    random.seed(seed + 1)
+    np.random.seed(seed + 2)
+    torch.manual_seed(seed + 3)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed + 4)
+        torch.cuda.manual_seed_all(seed + 5)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+    _applied = True
+
+
+def maybe_fix_random() -> bool:
+    """Apply fix_random() once if RMEM_DETERMINISTIC=1 (called when an engine is built)."""
+    if not _applied and os.environ.get("RMEM_DETERMINISTIC", "") == "1":
+        fix_random()
+    return _applied

@@ -401,9 +401,22 @@ class BatchedClipDriver:
         imgs = stack(0)
         labs = torch.cat([F.interpolate(c[0][0]["current_label"].float(), size=imgs.shape[2:], mode="nearest")
                           for c in clips]).int()
+        # Object count per clip (meta['obj_num'], else the label map's largest id): a clip with more than
+        # max_obj_num objects needs one sub-engine per 10 ids (engines/aot_engine.py:675-702) -- the batched
+        # engine has none, and rmem_id_assign drops ids above max_obj_num, so such a clip must not run here.
+        maxo = int(eng.AOT.max_obj_num)
+        for i, m in enumerate(meta):
+            n = m.get("obj_num")
+            n = int(n[0] if isinstance(n, (list, tuple)) else n) if n is not None else None
+            if n is None:
+                ids = labs[i][labs[i] != 255]
+                n = int(ids.max().item()) if ids.numel() else 0
+            if n > maxo:
+                raise NotImplementedError(f"clip {i} holds {n} objects (> {maxo}): use ClipDriver (one sub-engine per "
+                                          f"{maxo} objects, engines/aot_engine.py:675-702)")
         # the per-clip engine wrapper hands max_obj_num to its engine whatever the clip holds
         # (engines/aot_engine.py:675-690): same here
-        eng.add_reference_frame(imgs, labs, obj_nums=[eng.AOT.max_obj_num] * B, frame_step=0)
+        eng.add_reference_frame(imgs, labs, obj_nums=[maxo] * B, frame_step=0)
         lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
         out = torch.zeros(B, num_frames - 1, ori_hw[0], ori_hw[1], dtype=torch.uint8, device=imgs.device)
         nxt = stack(1) if num_frames > 1 else None

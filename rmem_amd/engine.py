@@ -598,6 +598,8 @@ class DeAOTInferEngine(nn.Module):
                  max_aot_obj_num=None, nsplit: int = 3, fold_bn: bool = True,
                  use_graphs: Optional[bool] = None):
         super().__init__()
+        from .determinism import maybe_fix_random
+        maybe_fix_random()                     # RMEM_DETERMINISTIC=1: the reference's --fix_random (tools/eval.py:21-37)
         self.use_graphs = use_graphs
         self.cfg = aot_model.cfg
         self.AOT = aot_model
@@ -622,6 +624,12 @@ class DeAOTInferEngine(nn.Module):
         self._pool = self.aot_engines + [e for e in self._pool if e not in self.aot_engines]
         self.aot_engines = []
         self.obj_nums = None
+
+    def _new_engine(self) -> DeAOTEngine:
+        """One sub-engine (<= max_aot_obj_num objects); tests substitute engines that run the encoder and
+        the decoder on the CPU around the HIP LSTT (tests/sandwich.py)."""
+        return DeAOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip, self.nsplit,
+                           self.use_graphs)
 
     def separate_mask(self, mask):                              # aot_engine.py:604-628
         if mask is None:
@@ -660,8 +668,7 @@ class DeAOTInferEngine(nn.Module):
                 eng = self._pool.pop(0)
                 eng.long_term_mem_gap = self.long_term_mem_gap
             else:
-                eng = DeAOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap,
-                                  self.short_term_mem_skip, self.nsplit, self.use_graphs)
+                eng = self._new_engine()
             eng.eval()
             self.aot_engines.append(eng)
         img_embs = self.AOT.encode_image(img) if len(self.aot_engines) > 1 else None    # shared encoder pass

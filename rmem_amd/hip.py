@@ -63,36 +63,6 @@ class ReadCombineArgs(C.Structure):
     ]
 
 
-class ScoresArgs(C.Structure):
-    _fields_ = [
-        ("mode", i32), ("pass_", i32),
-        ("kh", c_p), ("kl", c_p), ("k_slot_stride", i64),
-        ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32),
-        ("qh", c_p), ("ql", c_p), ("scale", f32),
-        ("bias", c_p), ("R", c_p), ("ldr", i32), ("h", i32), ("w", i32),
-        ("rowmax", c_p), ("ph", c_p), ("pl", c_p),
-        ("lpart", c_p), ("nparts", i32), ("nsplit", i32),
-    ]
-
-
-class PVArgs(C.Structure):
-    _fields_ = [
-        ("mode", i32), ("ph", c_p), ("pl", c_p),
-        ("vh", c_p), ("vl", c_p), ("v_slot_stride", i64),
-        ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32),
-        ("ncols", i32), ("h", i32), ("w", i32),
-        ("part", c_p), ("ksplits", i32), ("nsplit", i32),
-    ]
-
-
-class CombineArgs(C.Structure):
-    _fields_ = [
-        ("mode", i32), ("T", i32), ("N", i32), ("Npad", i32), ("ncols", i32), ("h", i32), ("w", i32),
-        ("part", c_p), ("ksplits", i32), ("lpart", c_p), ("nparts", i32),
-        ("U", c_p), ("ldu", i64), ("G", c_p), ("ldg", i64), ("mass", c_p),
-    ]
-
-
 class MHAArgs(C.Structure):
     _fields_ = [
         ("qh", c_p), ("ql", c_p), ("ldq", i64),
@@ -117,14 +87,14 @@ class LabelSrc(C.Structure):
 
 
 EXPORTS = [
-    "rmem_abi_version", "rmem_linear", "rmem_attn_scores", "rmem_attn_pv", "rmem_attn_combine",
-    "rmem_pe_bias", "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
+    "rmem_abi_version", "rmem_linear",
+    "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2",
-    "rmem_bias_act_nchw_batched", "rmem_attn_scores2", "rmem_attn_combine2", "rmem_dwconv5x5_split2",
+    "rmem_bias_act_nchw_batched", "rmem_dwconv5x5_split2",
     "rmem_attn_read", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
     "rmem_rec_end", "rmem_launch_recorded",
 ]
@@ -157,17 +127,11 @@ def load():
     lib.rmem_layernorm_red2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i64, i64, c_p, c_p, c_p, c_p, i32, i32, f32,
                                         c_p, c_p, i64, c_p, c_p, i64, c_p]
     lib.rmem_set_ints.argtypes = [c_p, C.POINTER(i32), i32, c_p]
-    lib.rmem_attn_scores.argtypes = [C.POINTER(ScoresArgs), c_p]
-    lib.rmem_attn_scores2.argtypes = [C.POINTER(ScoresArgs), C.POINTER(ScoresArgs), c_p]
-    lib.rmem_attn_combine2.argtypes = [C.POINTER(CombineArgs), C.POINTER(CombineArgs), c_p]
     lib.rmem_dwconv5x5_split2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p]
-    lib.rmem_attn_pv.argtypes = [C.POINTER(PVArgs), c_p]
     lib.rmem_attn_read.argtypes = [C.POINTER(ReadArgs), c_p]
     lib.rmem_attn_read2.argtypes = [C.POINTER(ReadArgs), C.POINTER(ReadArgs), c_p]
     lib.rmem_attn_read_combine.argtypes = [C.POINTER(ReadCombineArgs), c_p]
     lib.rmem_attn_read_combine2.argtypes = [C.POINTER(ReadCombineArgs), C.POINTER(ReadCombineArgs), c_p]
-    lib.rmem_attn_combine.argtypes = [C.POINTER(CombineArgs), c_p]
-    lib.rmem_pe_bias.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]
     lib.rmem_layernorm_split.argtypes = [c_p, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64, c_p, i64, c_p]
     lib.rmem_dwconv5x5_split.argtypes = [c_p, i64, c_p, i32, i32, i32, c_p, c_p, i64, c_p]
     lib.rmem_groupnorm2.argtypes = [c_p, c_p, i32, i32, c_p, c_p, f32, c_p, c_p, i64, c_p]

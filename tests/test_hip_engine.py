@@ -174,7 +174,7 @@ def test_480p_teacher_forced(nsplit, golden_dir):
     if nsplit == 3:
         # measured 1-7 on every box so far; the encoder's MIOpen convolutions are not bit-reproducible
         # between processes (tools/determinism_probe.py), each flip of a near-tie pixel counts one
-        assert max(mism) <= 8, mism           # measured 0-4 (0-3 with RMEM_P16=0; 2-8 when the planes were bf16)
+        assert max(mism) <= 4, mism           # measured 0-3 per frame of 409,920 on every box (round 2): measured max + 1
     else:
         assert max(mism) <= 600, mism         # plain fp16 (one plane per operand): measured 69-197
     assert max(lerrs.values()) < (2e-2 if nsplit == 3 else 0.2)
@@ -348,7 +348,7 @@ def test_720p_k8_vs_oracle():
     assert len(ora.long_memories_indexes) == 8 and ora.long_memories_indexes[0] == 0      # K = 8 steady state, evictions happened
     assert ora.long_memories_indexes != list(range(8))
     # 1-3 measured (decoder logits within 2e-5); 2-18 when the planes were bf16
-    assert max(mism) <= 12 and max(lerr) < 2e-4, (mism, lerr)
+    assert max(mism) <= 4 and max(lerr) < 2e-4, (mism, lerr)
 
 
 def test_paired_launches_bit_identical():
@@ -416,34 +416,67 @@ def test_graph_caches_are_bounded_per_geometry(monkeypatch):
     assert eng.long_memories_indexes == ref.long_memories_indexes
 
 
+def _closed_loop(e, dev, imgs, lab, H, W):
+    e.restart_engine()
+    e.add_reference_frame(imgs[0].to(dev), lab.to(dev), obj_nums=[3], frame_step=0)
+    labs = []
+    for t in range(1, len(imgs)):
+        logit = e.match_propogate_one_frame(imgs[t].to(dev), output_size=(H, W))
+        pred = torch.argmax(logit, dim=1, keepdim=True).float()
+        labs.append(pred[0, 0].cpu().numpy().astype(np.uint8))
+        e.update_memory(F.interpolate(pred, size=e.input_size_2d, mode="nearest"))
+    return labs
+
+
+CLOSED_LOOP_SEEDS = (1, 3, 4, 11)
+
+
 def test_closed_loop_vs_oracle_small_clips():
-    """Closed loop (each side is fed its OWN label maps, the way the evaluator runs): HIP engine vs
-    CPU oracle on four 97x129 clips, 10 propagated frames, K = 4, gap 2 (evictions from frame 8).
-    With the synthetic weights a flipped pixel is amplified by the loop (the memory moves ~2500 of
-    the 12.5k pixels per frame, tools/closed_loop_probe.py), so a clip either matches pixel for
-    pixel through the last frame or starts to differ with a near-tie flip of <= 2 pixels; most
-    clips match completely (measured: 3 of 5 seeds over 11 frames, the other two start with 1 px)."""
+    """Closed loop (each side is fed its OWN label maps, the way the evaluator runs) where the HIP path
+    owns the arithmetic: CPU encoder -> HIP LSTT / ID assignment / memory update / RMem eviction -> CPU
+    decoder (tests/sandwich.py) against the CPU oracle on four 97x129 clips, 10 propagated frames, K = 4,
+    gap 2 (evictions from frame 8).  Both sides see the same encoder features and run the same decoder,
+    so the only difference is the LSTT's fp32-class rounding (1e-5 on its output): EVERY label map of
+    EVERY clip must equal the oracle's, and so must the kept-frame histories.  (With the synthetic
+    weights the loop amplifies a single flipped pixel to thousands within a few frames, so equality
+    through frame 10 is a statement about all frames.)"""
+    from oracle.engine_ref import OracleDeAOTInferEngine
+    from rmem_amd.synth import synth_clip
+    from sandwich import SandwichInferEngine
+    cfg, cpu_model, gpu_model, _ = _build(gap=2)
+    eng = SandwichInferEngine(cpu_model, DEV, long_term_mem_gap=2, gpu_model=gpu_model)
+    eng.eval()
+    ora = OracleDeAOTInferEngine(cpu_model, long_term_mem_gap=2)
+    H, W, frames = 97, 129, 11
+    report = {}
+    for seed in CLOSED_LOOP_SEEDS:
+        imgs, lab = synth_clip(seed, frames, H, W, 3)
+        a = _closed_loop(ora, "cpu", imgs, lab, H, W)
+        b = _closed_loop(eng, DEV, imgs, lab, H, W)
+        report[seed] = [int((x != y).sum()) for x, y in zip(a, b)]
+        assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.engines[0].long_memories_indexes), seed
+    print("closed loop, CPU encoder/decoder around the HIP memory path: mismatching pixels per frame", report)
+    assert all(not any(m) for m in report.values()), report
+
+
+def test_closed_loop_product_engine_vs_oracle():
+    """The same closed loop on the PRODUCT engine (MIOpen encoder and decoder on the GPU).  MIOpen's
+    convolutions differ from the CPU's by ~1e-5 on the features, which can flip a near-tie pixel that
+    the loop then amplifies: a clip either matches pixel for pixel through the last frame or starts to
+    differ with a flip of <= 2 pixels.  The exact statement for the code this repository owns is
+    test_closed_loop_vs_oracle_small_clips above; this one bounds what MIOpen adds."""
     from oracle.engine_ref import OracleDeAOTInferEngine
     from rmem_amd.synth import synth_clip
     cfg, cpu_model, gpu_model, eng = _build(gap=2)
     ora = OracleDeAOTInferEngine(cpu_model, long_term_mem_gap=2)
     H, W, frames = 97, 129, 11
     exact = 0
-    for seed in (1, 3, 4, 11):
+    for seed in CLOSED_LOOP_SEEDS:
         imgs, lab = synth_clip(seed, frames, H, W, 3)
-        outs = []
-        for e, dev in ((ora, "cpu"), (eng, DEV)):
-            e.restart_engine()
-            e.add_reference_frame(imgs[0].to(dev), lab.to(dev), obj_nums=[3], frame_step=0)
-            labs = []
-            for t in range(1, frames):
-                logit = e.match_propogate_one_frame(imgs[t].to(dev), output_size=(H, W))
-                pred = torch.argmax(logit, dim=1, keepdim=True).float()
-                labs.append(pred[0, 0].cpu().numpy().astype(np.uint8))
-                e.update_memory(F.interpolate(pred, size=e.input_size_2d, mode="nearest"))
-            outs.append(labs)
-        mism = [int((a != b).sum()) for a, b in zip(*outs)]
-        print("closed loop seed", seed, "mismatching pixels per frame:", mism)
+        a = _closed_loop(ora, "cpu", imgs, lab, H, W)
+        b = _closed_loop(eng, DEV, imgs, lab, H, W)
+        mism = [int((x != y).sum()) for x, y in zip(a, b)]
+        print("closed loop (product engine) seed", seed, "mismatching pixels per frame:", mism)
         first = next((m for m in mism if m), 0)
         assert first <= 2, (seed, mism)
         exact += int(not any(mism))

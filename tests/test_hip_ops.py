@@ -102,199 +102,13 @@ def test_linear_swapped_silu_batch_segments(hip):
     assert (pa.float()[:, :ntok].cpu().double() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
 
 
-def _unblock_P(P, T, Npad, N):
-    """blocked [key/32][Npad][32] -> dense [N][T*Npad]."""
-    kb = T * Npad // 32
-    return P[:kb].permute(1, 0, 2).reshape(Npad, T * Npad)[:N]
-
-
-def _run_attention(hip, mode, T, N, Npad, K, V, slot_map, Q, bias, U, h, w, R, nsplit, ksplits=3, p16=False):
-    """K: [S][Npad][128] planes, V: [S][1024][Npad] planes, Q planes [Npad][128].
-    p16: P as ONE fp16 plane (pl = NULL in the scores and P.V arguments; bank reads, nsplit 3)."""
-    lib, st = hip.load(), hip.stream_ptr()
-    rowmax = torch.zeros(Npad, dtype=torch.int32, device=DEV)
-    P = hip.Planes.empty((T * Npad // 32, Npad, 32), DEV)
-    nparts = T * Npad // 64
-    lpart = torch.zeros(Npad, nparts, device=DEV)
-    part = torch.zeros(ksplits, Npad, 1024, device=DEV)
-    G = torch.zeros(N, 1024, device=DEV)
-    mass = torch.zeros(N, T, device=DEV)
-    sm = torch.tensor(slot_map, dtype=torch.int32, device=DEV) if slot_map is not None else None
-    sa = hip.ScoresArgs()
-    sa.mode, sa.kh, sa.kl, sa.k_slot_stride = mode, K.hi.data_ptr(), K.lo.data_ptr(), Npad * 128
-    sa.slot_map, sa.T, sa.N, sa.Npad = (sm.data_ptr() if sm is not None else None), T, N, Npad
-    sa.qh, sa.ql, sa.scale = Q.hi.data_ptr(), Q.lo.data_ptr(), 1.0 / math.sqrt(128)
-    sa.bias = bias.data_ptr() if bias is not None else None
-    if R is not None:
-        sa.R, sa.ldr = R.data_ptr(), R.shape[1]
-    sa.h, sa.w = h, w
-    sa.rowmax, sa.ph, sa.pl = rowmax.data_ptr(), P.hi.data_ptr(), (None if p16 else P.lo.data_ptr())
-    sa.lpart, sa.nparts, sa.nsplit = lpart.data_ptr(), nparts, nsplit
-    sa.pass_ = 0
-    hip.check(lib.rmem_attn_scores(C.byref(sa), st), "scores0")
-    sa.pass_ = 1
-    hip.check(lib.rmem_attn_scores(C.byref(sa), st), "scores1")
-    pa = hip.PVArgs()
-    pa.mode, pa.ph, pa.pl = mode, P.hi.data_ptr(), (None if p16 else P.lo.data_ptr())
-    pa.vh, pa.vl, pa.v_slot_stride = V.hi.data_ptr(), V.lo.data_ptr(), 1024 * Npad
-    pa.slot_map, pa.T, pa.N, pa.Npad, pa.ncols = sa.slot_map, T, N, Npad, 1024
-    pa.h, pa.w, pa.part, pa.ksplits, pa.nsplit = h, w, part.data_ptr(), ksplits, nsplit
-    hip.check(lib.rmem_attn_pv(C.byref(pa), st), "pv")
-    ca = hip.CombineArgs()
-    ca.mode, ca.T, ca.N, ca.Npad, ca.ncols, ca.h, ca.w = mode, T, N, Npad, 1024, h, w
-    ca.part, ca.ksplits, ca.lpart, ca.nparts = part.data_ptr(), ksplits, lpart.data_ptr(), nparts
-    ca.U, ca.ldu, ca.G, ca.ldg, ca.mass = U.data_ptr(), 1024, G.data_ptr(), 1024, mass.data_ptr()
-    hip.check(lib.rmem_attn_combine(C.byref(ca), st), "combine")
-    torch.cuda.synchronize()
-    return G, mass, P, rowmax, lpart
-
-
-@pytest.mark.parametrize("nsplit", [3, 1, 16])
-@pytest.mark.parametrize("T,h,w", [(1, 9, 13), (3, 9, 13), (5, 12, 17), (4, 31, 54)])
-def test_attention_bank(hip, nsplit, T, h, w):
-    """Long-term / self read: softmax(scale*(Q.K^T + bias)) . V * U, attention mass per slot.
-    (4, 31, 54) is the full BASELINE.json configs[1] size: 480p, K=4, N=1674, 6696 keys."""
-    # nsplit 16 = split precision with P as ONE fp16 plane (the shipped plan of the bank reads)
-    p16, nsplit = (nsplit == 16), (3 if nsplit == 16 else nsplit)
-    if nsplit == 1 and h * w > 1000:
-        pytest.skip("full size is checked for the split precisions only")
-    rs = np.random.RandomState(T * 100 + h)
-    N = h * w
-    Npad = (N + 127) // 128 * 128
-    S = T + 2
-    slot_map = list(rs.permutation(S)[:T])
-    Kf = torch.zeros(S, Npad, 128)
-    Vf = torch.zeros(S, 1024, Npad)
-    Kf[:, :N] = _rand(rs, S, N, 128, scale=1.5)
-    Vf[:, :, :N] = _rand(rs, S, 1024, N)
-    Kf[:, N:] = 37.0      # padding rows must be ignored (masked), not merely zero
-    Vf[:, :, N:] = -53.0
-    Qf = torch.zeros(Npad, 128)
-    Qf[:N] = _rand(rs, N, 128, scale=1.5)
-    bias = _rand(rs, N, T, scale=3.0)
-    U = _rand(rs, N, 1024)
-    G, mass, P, rowmax, lpart = _run_attention(
-        hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, Vf), slot_map, _planes(hip, Qf),
-        bias.to(DEV), U.to(DEV), h, w, None, nsplit, p16=p16)
-    # fp64 reference on the logical bank
-    Kl = torch.stack([Kf[s, :N] for s in slot_map]).double()            # [T][N][128]
-    Vl = torch.stack([Vf[s, :, :N].t() for s in slot_map]).double()     # [T][N][1024]
-    S_ = torch.einsum("qc,tkc->qtk", Qf[:N].double(), Kl) + bias.double()[:, :, None]
-    S_ = S_ / math.sqrt(128)
-    A = torch.softmax(S_.reshape(N, T * N), dim=1).reshape(N, T, N)
-    ref = torch.einsum("qtk,tkc->qc", A, Vl) * U.double()
-    tol = (3e-4 if p16 else 5e-5) if nsplit == 3 else 3e-2
-    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    print(f"bank read T={T} {h}x{w} nsplit={nsplit} p16={p16}: G rel err {err:.2e}")
-    assert err < tol, f"G rel err {err}"
-    assert (mass.cpu().double() - A.sum(dim=2)).abs().max().item() < ((3e-4 if p16 else 1e-5) if nsplit == 3 else 2e-2)
-    # probabilities (unnormalised, relative to the running max) are zero on padding keys
-    Pf = P.hi.view(torch.float16).float() if p16 else P.float()
-    Pd = _unblock_P(Pf.cpu(), T, Npad, N).reshape(N, T, Npad)
-    assert torch.all(Pd[:, :, N:] == 0)
-    if nsplit == 3:   # attention logits within 1e-3 (north star): log P - log P_ref is the logit error
-        l = Pd[:, :, :N].double().sum(dim=(1, 2))
-        An = Pd[:, :, :N].double() / l[:, None, None]
-        # P is stored in fp16 (one plane, or hi/lo): weights below 2^-14 of the row maximum are
-        # subnormal (absolute error 3e-8, nothing in the output); the logit is recovered from the others
-        big = Pd[:, :, :N] >= 1e-4
-        logit_err = (torch.log(An[big]) - torch.log(A[big])).abs().max().item()
-        assert logit_err < 1e-3, logit_err
-
-
-@pytest.mark.parametrize("p16", [False, True])
-def test_attention_bank_720p_k8_properties(hip, p16):
-    """BASELINE.json configs[2] size (720p: 46x81 = 3726 tokens, K=8: 29808 keys), where a fp64
-    reference is too slow for a test: size-independent properties of the long-term read, for both
-    P formats (bf16 hi/lo planes; one fp16 plane = the shipped plan of the bank reads).
-    (a) the per-slot attention mass of every query sums to 1; (b) doubling V doubles the output
-    (to 1e-7: fp16 subnormals in the low planes) (split planes, MFMA products and fp32 sums all scale exactly by 2); (c) storing
-    the bank slots in another physical order, with the slot map compensating, changes nothing."""
-    T, h, w = 8, 46, 81
-    rs = np.random.RandomState(7)
-    N = h * w
-    Npad = (N + 127) // 128 * 128
-    S = T + 2
-    Kf = torch.zeros(S, Npad, 128)
-    Vf = torch.zeros(S, 1024, Npad)
-    Kf[:, :N] = _rand(rs, S, N, 128, scale=1.5)
-    Vf[:, :, :N] = _rand(rs, S, 1024, N)
-    Qf = torch.zeros(Npad, 128)
-    Qf[:N] = _rand(rs, N, 128, scale=1.5)
-    bias = _rand(rs, N, T, scale=3.0).to(DEV)
-    U = _rand(rs, N, 1024).to(DEV)
-    Qp = _planes(hip, Qf)
-    map_a = [int(x) for x in rs.permutation(S)[:T]]
-    G, mass, *_ = _run_attention(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, Vf), map_a, Qp, bias, U,
-                                 h, w, None, 3, ksplits=2, p16=p16)
-    assert torch.isfinite(G).all()
-    assert (mass.sum(dim=1) - 1).abs().max().item() < 2e-6                      # (a)
-    G2, *_ = _run_attention(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, 2 * Vf), map_a, Qp, bias, U,
-                            h, w, None, 3, ksplits=2, p16=p16)
-    # (b): low-plane values below 2^-14 are fp16 subnormals (resolution 2^-24), so doubling is exact
-    # up to 1e-7 of the output rather than bit for bit
-    assert (G2 - 2 * G).abs().max().item() <= 2e-7 * (2 * G).abs().max().item()
-    perm = [int(x) for x in rs.permutation(S)]                                  # new physical position of slot s
-    Kp, Vp = torch.zeros_like(Kf), torch.zeros_like(Vf)
-    for s_old, s_new in enumerate(perm):
-        Kp[s_new], Vp[s_new] = Kf[s_old], Vf[s_old]
-    map_b = [perm[s] for s in map_a]
-    G3, mass3, *_ = _run_attention(hip, 0, T, N, Npad, _planes(hip, Kp), _planes(hip, Vp), map_b, Qp, bias, U,
-                                   h, w, None, 3, ksplits=2, p16=p16)
-    assert torch.equal(G3, G) and torch.equal(mass3, mass)                      # (c)
-
-
-@pytest.mark.parametrize("nsplit", [3, 1])
-@pytest.mark.parametrize("h,w", [(9, 13), (20, 23), (31, 54)])
-def test_attention_window(hip, nsplit, h, w):
-    """Short-term 15x15 windowed read against the oracle's LocalGatedPropagation core."""
-    from oracle import lstt_ref as R
-    rs = np.random.RandomState(h * 10 + w)
-    N = h * w
-    Npad = (N + 127) // 128 * 128
-    q, k = _rand(rs, N, 128, scale=1.5), _rand(rs, N, 128, scale=1.5)
-    v, u = _rand(rs, N, 1024), _rand(rs, N, 1024)
-    rel_w, rel_b = _rand(rs, 225, 128, scale=0.15), _rand(rs, 225, scale=0.1)
-    # oracle pieces (no dwconv / projection here)
-    idx, inside = R.local_window_index(h, w)
-    rel = q.double() @ rel_w.double().t() + rel_b.double()
-    kg = k.double()[idx.clamp(min=0)] * inside.unsqueeze(-1)
-    qk = torch.einsum("nc,noc->no", q.double() / math.sqrt(128), kg) + rel
-    qk = qk.masked_fill(~inside, -1e8)
-    attn = torch.softmax(qk, dim=1)
-    vg = v.double()[idx.clamp(min=0)] * inside.unsqueeze(-1)
-    ref = torch.einsum("no,noc->nc", attn, vg) * u.double()
-
-    Kf, Vf, Qf = torch.zeros(2, Npad, 128), torch.zeros(2, 1024, Npad), torch.zeros(Npad, 128)
-    Kf[1, :N], Vf[1, :, :N], Qf[:N] = k, v.t(), q
-    Kf[0] = 99.0
-    Rm = torch.zeros(N, 232)
-    Rm[:, :225] = rel.float()
-    G, mass, P, rowmax, lpart = _run_attention(
-        hip, 1, 1, N, Npad, _planes(hip, Kf), _planes(hip, Vf), [1], _planes(hip, Qf), None,
-        u.to(DEV), h, w, Rm.to(DEV), nsplit, ksplits=2)
-    tol = 5e-5 if nsplit == 3 else 3e-2
-    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
-    assert err < tol, f"G rel err {err}"
-
-
-def test_pe_bias_layernorm_dwconv_groupnorm(hip):
+def test_layernorm_dwconv_groupnorm(hip):
     from oracle import lstt_ref as R
     lib, st = hip.load(), hip.stream_ptr()
     rs = np.random.RandomState(3)
     h, w = 7, 9
     N = h * w
     g_ = lambda t: t.to(DEV).contiguous()      # keep device tensors alive across the launch
-    # pe bias
-    Q, cur, mem = _rand(rs, N, 128), _rand(rs, 128, scale=0.5), _rand(rs, 4, 128, scale=0.5)
-    dQ, dcur, dmem = g_(Q), g_(cur), g_(mem)
-    rows = [0, 1, 2, 3, 3]
-    out = torch.zeros(N, 5, device=DEV)
-    arr = (C.c_int32 * 16)(*(rows + [0] * 11))
-    hip.check(lib.rmem_pe_bias(dQ.data_ptr(), 128, dcur.data_ptr(), dmem.data_ptr(),
-                               arr, 5, N, 128, out.data_ptr(), st), "pe_bias")
-    ref = (Q.double() + cur.double()) @ mem.double()[rows].t()
-    assert (out.cpu().double() - ref).abs().max().item() < 1e-4
     # layernorm -> planes (+ fp32)
     x, g, b = _rand(rs, N, 256, scale=2.0) + 0.5, _rand(rs, 256) * 0.2 + 1, _rand(rs, 256) * 0.1
     dx, dg, db = g_(x), g_(g), g_(b)
@@ -552,6 +366,47 @@ def test_read_bank(hip, ksplits, T, h, w):
     assert torch.isfinite(ml[:, :N]).all()
     live = ml[:, :N, 1] > 0                      # splits without a key tile leave their partial unwritten
     assert torch.isfinite(part[:, :N][live]).all()
+
+
+def test_read_bank_720p_k8_properties(hip):
+    """BASELINE.json configs[2] size (720p: 46x81 = 3726 tokens, K=8: 29808 keys), where a fp64 reference
+    is too slow for a test: size-independent properties of the fused long-term read.
+    (a) the per-slot attention mass of every query sums to 1; (b) doubling V doubles the output (split
+    planes, MFMA products and fp32 sums all scale exactly by 2; low-plane values below 2^-14 are fp16
+    subnormals with resolution 2^-24, hence 2e-7 instead of bit for bit); (c) storing the bank slots in
+    another physical order, with the slot map compensating, changes nothing -- bit for bit; (d) the
+    number of key splits only re-associates fp32 sums: 1e-5 relative."""
+    T, h, w = 8, 46, 81
+    rs = np.random.RandomState(7)
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    S = T + 2
+    Kf = torch.zeros(S, Npad, 128)
+    Vf = torch.zeros(S, 1024, Npad)
+    Kf[:, :N] = _rand(rs, S, N, 128, scale=1.5)
+    Vf[:, :, :N] = _rand(rs, S, 1024, N)
+    Qf = torch.zeros(Npad, 128)
+    Qf[:N] = _rand(rs, N, 128, scale=1.5)
+    bias = _rand(rs, N, T, scale=3.0).to(DEV)
+    U = _rand(rs, N, 1024).to(DEV)
+    Qp = _planes(hip, Qf)
+    map_a = [int(x) for x in rs.permutation(S)[:T]]
+    run = lambda K_, V_, m_, ks: _run_read(hip, 0, T, N, Npad, _planes(hip, K_), _planes(hip, _block16(V_)), m_, Qp,
+                                           bias, U, h, w, None, ks)
+    G, mass, *_ = run(Kf, Vf, map_a, 4)
+    assert torch.isfinite(G).all()
+    assert (mass.sum(dim=1) - 1).abs().max().item() < 2e-6                      # (a)
+    G2, *_ = run(Kf, 2 * Vf, map_a, 4)
+    assert (G2 - 2 * G).abs().max().item() <= 2e-7 * (2 * G).abs().max().item()   # (b)
+    perm = [int(x) for x in rs.permutation(S)]                                  # new physical position of slot s
+    Kp, Vp = torch.zeros_like(Kf), torch.zeros_like(Vf)
+    for s_old, s_new in enumerate(perm):
+        Kp[s_new], Vp[s_new] = Kf[s_old], Vf[s_old]
+    G3, mass3, *_ = run(Kp, Vp, [perm[s] for s in map_a], 4)
+    assert torch.equal(G3, G) and torch.equal(mass3, mass)                      # (c)
+    G4, mass4, *_ = run(Kf, Vf, map_a, 2)
+    assert (G4 - G).abs().max().item() <= 1e-5 * G.abs().max().item()          # (d)
+    assert (mass4 - mass).abs().max().item() < 2e-6
 
 
 def test_read_bank_logits_and_rescale(hip):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/rmem_hip.h but not exported"
     assert declared == set(hip.EXPORTS)
     assert every - declared == set(hip.EXPORTS_OTHER)
-    assert lib.rmem_abi_version() == 9
+    assert lib.rmem_abi_version() == 10
 
 
 def test_launch_recorder_records_without_a_gpu():
@@ -63,8 +63,7 @@ def test_ctypes_struct_sizes_match_header_layout():
     src = r'''
     #include "rmem_hip.h"
     #include <stdio.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_scores_args),
-                       sizeof(rmem_pv_args), sizeof(rmem_combine_args), sizeof(rmem_mha_args),
+    int main(){ printf("%zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_mha_args),
                        sizeof(rmem_mha_combine_args), sizeof(rmem_read_args), sizeof(rmem_read_combine_args)); return 0; }'''
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -72,8 +71,7 @@ def test_ctypes_struct_sizes_match_header_layout():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"),
                                "-o", os.path.join(d, "s")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
-    assert sizes == [ctypes.sizeof(hip.LinearArgs), ctypes.sizeof(hip.ScoresArgs),
-                     ctypes.sizeof(hip.PVArgs), ctypes.sizeof(hip.CombineArgs), ctypes.sizeof(hip.MHAArgs),
+    assert sizes == [ctypes.sizeof(hip.LinearArgs), ctypes.sizeof(hip.MHAArgs),
                      ctypes.sizeof(hip.MHACombineArgs), ctypes.sizeof(hip.ReadArgs), ctypes.sizeof(hip.ReadCombineArgs)]
 
 
@@ -196,14 +194,14 @@ def test_c_abi_rejects_invalid_arguments():
     assert lib.rmem_linear(C.byref(a), None) == -1                      # nsplit must be 1 or 3
     a.nsplit = 3
     assert lib.rmem_linear(C.byref(a), None) == -1                      # nsplit 3 needs lo planes
-    s = hip.ScoresArgs()
-    s.N, s.Npad, s.T = 100, 100, 1
-    assert lib.rmem_attn_scores(C.byref(s), None) == -1                 # Npad not a multiple of 128
-    p = hip.PVArgs()
-    assert lib.rmem_attn_pv(C.byref(p), None) == -1
+    r = hip.ReadArgs()
+    r.N, r.Npad, r.T, r.ksplits, r.ncols = 100, 100, 1, 1, 1024
+    assert lib.rmem_attn_read(C.byref(r), None) == -1                   # Npad not a multiple of 128
+    assert lib.rmem_attn_read2(C.byref(r), C.byref(r), None) == -1
+    rc = hip.ReadCombineArgs()
+    assert lib.rmem_attn_read_combine(C.byref(rc), None) == -1
     m = hip.MHAArgs()
     assert lib.rmem_mha_flash(C.byref(m), None) == -1
-    assert lib.rmem_pe_bias(None, 0, None, None, None, 0, 0, 0, None, None) == -1
     assert lib.rmem_layernorm_split(None, 0, None, None, 0, 256, 1e-5, None, None, 0, None, 0, None) == -1
     assert lib.rmem_id_assign(None, 0, 0, None, None, 12, 17, 16, 8, 1, 1, 256, None, None, 1e-5,
                               None, None, 0, None, 0, 1, None) == -1
@@ -283,6 +281,19 @@ def test_batched_clip_driver_validates_its_input_on_the_host():
         drv.run_clips([clip(4, aug=True), clip(4, aug=True)], num_frames=4)
     with pytest.raises(NotImplementedError):
         drv.run_clips([clip(4, mid=True), clip(4)], num_frames=4)
+    # more objects than one engine holds (meta['obj_num'], or the label map when the meta has none): the
+    # reference spawns a sub-engine per 10 ids (engines/aot_engine.py:675-702); the batched engine has none
+    many = lambda n: [D.make_samples(img, lab if t == 0 else None, (33, 49), 12, name=f"{t:05d}.jpg") for t in range(n)]
+    with pytest.raises(NotImplementedError, match="12 objects"):
+        drv.run_clips([clip(4), many(4)], num_frames=4)
+    lab13 = lab.clone()
+    lab13[0, 0, :4, :4] = 13
+    lab13[0, 0, 5:, 5:] = 255                              # the ignore id is not an object
+    nometa = [D.make_samples(img, lab13 if t == 0 else None, (33, 49), 3, name=f"{t:05d}.jpg") for t in range(4)]
+    for fr in nometa:
+        fr[0]["meta"].pop("obj_num")
+    with pytest.raises(NotImplementedError, match="13 objects"):
+        drv.run_clips([nometa, clip(4)], num_frames=4)
 
 
 @pytest.mark.parametrize("which", ["oracle", "product"])
