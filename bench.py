@@ -330,7 +330,7 @@ def main():
             out["roofline"]["frac_isolated"] = out["roofline"]["algorithmic_flops_per_launch"] / (iso * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
         # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
-        pmc_name = "r02_x_pmc_read.json"
+        pmc_name = "r03_pmc_read.json"
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if out["roofline"] and args.config == "480p_k4" and args.model == "r50_deaotl" and os.path.exists(pmc):
             out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
@@ -421,7 +421,7 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
         iso = eng.lstt.time_read_isolated()
         flops = B * c0.read_flops(len(c0.bank))
         ach = flops / (iso * 1e-6) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": f"read2_many_kernel (fused long-term T={len(c0.bank)} + windowed memory read of {B} clips in one launch)",
+        out["roofline"] = {"bound": "mfma", "kernel": f"read64x2_many_kernel (fused long-term T={len(c0.bank)} + windowed memory read of {B} clips in one launch)",
                            "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                            "traffic": None, "mean_us": iso, "algorithmic_flops_per_launch": flops,
                            "note": "isolated launches (HIP events, back to back); includes the upload of the clips' argument blocks"}

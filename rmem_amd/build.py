@@ -8,14 +8,18 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librmem_hip.so")
-SOURCES = ["linear.hip", "fused.hip", "mha.hip", "pointwise.hip", "postproc.hip", "batch.hip"]
+SOURCES = ["linear.hip", "fused.hip", "read64.hip", "mha.hip", "pointwise.hip", "postproc.hip", "batch.hip"]
 HEADERS = ["rmem_common.h", "gemm_core.h", "attn_common.h", "launch.h", os.path.join("..", "..", "include", "rmem_hip.h")]
 
 
 # mha.hip: VGPR form of every MFMA (no AGPRs: the 32x32 score and output tiles are read and written by
 # the softmax VALU code, so the accumulator form costs a v_accvgpr move per element and s_nops in
 # front of each; 128 registers instead of 128 + 32 also give 4 waves per SIMD instead of 3)
-EXTRA_FLAGS = {"mha.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"mha.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # read64.hip: no SLP vectorisation -- it turns the eight per-lane softmax updates into <8 x float>
+               # operations whose splat operands (the row reference m, eight copies) it then spills; every reload is a
+               # compiler-visible vector-memory access that drains the hand-counted V-fragment ring (s_waitcnt vmcnt(0))
+               "read64.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale() -> bool:

@@ -88,7 +88,10 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
   const bool qvalid = q < a.N;
   const bool writer = cp == 0 && hi == 0;             // statistics are written once per (split, query)
   float* mlp = a.ml + ((long)z * a.Npad + q) * 2;
-  float* lsp = a.lslot ? a.lslot + ((long)z * a.Npad + q) * a.T * 2 : nullptr;
+  // debug aid (read_kernel<1> only): a tracing launch receives 16 shader-clock stamps per block through R (bank
+  // mode, where R is unused) or through lslot (window mode, which never records per-slot sums in the product)
+  const bool tracing = TRACE && ((MODE == 0 && a.R) || (MODE == 1 && a.lslot));
+  float* lsp = (a.lslot && !(TRACE && MODE == 1)) ? a.lslot + ((long)z * a.Npad + q) * a.T * 2 : nullptr;
   if (lo >= hi_t) {                                   // no key tile in this split (narrow band)
     if (writer) {
       mlp[0] = RD_NEG;
@@ -102,8 +105,7 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
       lsp[2 * t + 1] = 0.f;
     }
 
-  // debug aid: in bank mode (R unused) a non-NULL R receives 4 shader-clock stamps per block
-  long long* trace = (TRACE && MODE == 0 && a.R) ? reinterpret_cast<long long*>(const_cast<float*>(a.R)) + (long)blk * 16 : nullptr;
+  long long* trace = tracing ? reinterpret_cast<long long*>(MODE == 0 ? const_cast<float*>(a.R) : a.lslot) + (long)blk * 16 : nullptr;
   long long tph[5] = {0, 0, 0, 0, 0}, tlast = 0;      // TRACE: cycles in score / softmax / barrier A / P.V / barrier B
 #define RD_STAMP(k) do { if (TRACE) { const long long t__ = __builtin_readcyclecounter(); tph[k] += t__ - tlast; tlast = t__; } } while (0)
   if (trace && tid == 0) trace[0] = __builtin_readcyclecounter();
@@ -157,6 +159,7 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
     });
   }
 
+  if (trace && tid == 0) trace[11] = __builtin_readcyclecounter();   // Q tile requested and stored
   // ---- staging helpers
   u32x4_t kr[8];
   auto tile_slot = [&](int i, int& key0) __attribute__((always_inline)) {
@@ -342,6 +345,10 @@ __device__ __forceinline__ void read_body(const rmem_read_args& a, const int blk
     }
     mest = fmaxf(mest, __shfl_xor(mest, 32));
     if (mest > -2.9e38f) m = mest;
+  }
+  if (trace && tid == 0) {
+    trace[9] = __builtin_readcyclecounter();           // end of the reference pass
+    trace[10] = hi_t - lo;                             // key tiles of this unit
   }
   kload(lo);
   kstore();
@@ -719,7 +726,7 @@ static int read_chunk(const rmem_read_args& a) {
   return ((a.Npad / 128) * (a.ncols / 512) * a.ksplits + 7) / 8;
 }
 
-extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* bp, void* stream) {
+extern "C" int rmem_attn_read2_v128(const rmem_read_args* ap, const rmem_read_args* bp, void* stream) {
   if (!ap || !bp || !read_args_ok(*ap) || !read_args_ok(*bp) || ap->mode != 0 || bp->mode != 1) return RMEM_ERR_INVALID;
   const int cha = read_chunk(*ap), chb = read_chunk(*bp);
   // per launch: the attribute belongs to the (device, function) pair; no process-wide "already set" flag
@@ -738,12 +745,12 @@ extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* b
   return RMEM_OK;
 }
 
-extern "C" int rmem_attn_read(const rmem_read_args* ap, void* stream) {
+extern "C" int rmem_attn_read_v128(const rmem_read_args* ap, void* stream) {
   if (!ap || !read_args_ok(*ap)) return RMEM_ERR_INVALID;
   const rmem_read_args& a = *ap;
   const int chunk = read_chunk(a);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int var = (a.mode == 0 && a.R) ? 1 : 0;       // bank mode with R != NULL: the tracing build (debug aid)
+  const int var = ((a.mode == 0 && a.R) || (a.mode == 1 && a.lslot)) ? 1 : 0;   // the tracing build (debug aid, see read_body)
   if (rmem::Recorder* r = rmem::current_recorder()) {
     if (var) return RMEM_ERR_INVALID;
     rmem::rec_push(r, &read_many, dim3(8 * chunk), dim3(256), RD_LDS, &a, (unsigned)sizeof(a));

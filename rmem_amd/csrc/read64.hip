@@ -1,0 +1,794 @@
+// read64.hip -- the memory read of GatedPropagation / LocalGatedPropagation (layers/attention.py:
+// 174-209, 289-358; call sites layers/transformer.py:1183, 1199, 1227) as ONE flash-style launch per
+// read: S = Q.K^T, softmax and O = P.V without ever writing the probability matrix to HBM.
+//
+// Work unit = (64-query tile, ALL 1024 columns of [V | ID_V], key split).  One workgroup = 8 waves,
+// TWO per SIMD with 256 registers each: wave w owns the 64 queries x 128 columns [128 w, 128 w + 128)
+// of O = 2 x 4 MFMA tiles = 128 accumulator registers.  (Round 2's unit was 128 queries x a 512-column
+// half on 4 waves with the whole register file each: Q.K^T was computed once per column half, and
+// with one wave per SIMD the matrix pipe idled through every score / softmax phase -- 24-29 % busy,
+// profiles/r02_x_pmc_read.json.)
+//
+// Per 64-key tile a wave does two things that touch disjoint buffers and can therefore run in either
+// order inside ONE barrier interval:
+//   SCORE(i+1): S^T = K.Q^T for 16 queries x 32 keys (wave w: query group w & 3, key half w >> 2) on
+//       v_mfma_f32_16x16x32_f16, K and Q fragments from LDS; "swapped" (rows = keys) so that a query's
+//       scores live in 4 lanes; weights P = 2^(y - m) against a FIXED per-query reference m go to the
+//       other P image as fp16 hi / lo planes;
+//   PV(i): O += P.V for all 64 queries x this wave's 128 columns on v_mfma_f32_32x32x16_f16: A = P
+//       fragments from LDS (shared by the eight waves), B = V fragments straight from global memory
+//       ("blocked-16" layout: one contiguous KiB per load instruction).
+// Waves 0-3 run SCORE then PV, waves 4-7 PV then SCORE: wave w and wave w + 4 share a SIMD, so each
+// SIMD always has one wave in the matrix-heavy P.V phase while the other does LDS reads, exp2 and
+// conversions.  K tiles arrive by LDS-DMA (global_load_lds_dwordx4, two tiles ahead, XOR swizzle applied
+// to the SOURCE address: no staging registers, no ds_write phase); P and K are double-buffered.
+//
+// The fixed reference m is the row maximum over the unit's keys from a first pass with the hi planes
+// only (8 small MFMAs per wave per tile; error a few hundredths), so the weights stay within a few per
+// cent of 1 at the maximum and the accumulators never need a rescale.  Exactness for ANY input: the
+// main pass flags a score above m + RD_THR (weights would leave fp16); a flagged unit is simply redone
+// with the reference taken from the exact three-product scores (bit-identical to the main pass's, so
+// the weights are <= 1).  Never taken on real data; tests/test_hip_ops.py forces it.
+//
+// Split precision: every product is hi*lo' + lo*hi' + hi*hi' (fp32 accumulate).  Key splits write
+// un-normalised partials + (max, sum) [+ per-slot (sum, max)]; rmem_attn_read_combine merges them.
+#include "../../include/rmem_hip.h"
+#include "gemm_core.h"
+#include "attn_common.h"
+#include "launch.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+#define RMEM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+// LDS map.  Operand images of Q and K have 256-byte rows (128 fp16 of one plane); the 16-byte chunk c of
+// row r sits at position c ^ (r & 15): conflict-free for the 16x16x32 fragment reads (row = lane & 15,
+// chunk = 4 k-step + lane >> 4) and reachable by LDS-DMA, whose destination is lane-linear.  The P image
+// has 128-byte rows (64 keys of one plane) with chunk c at c ^ ((r >> 1) & 7) (gemm_core.h).
+constexpr int R6_Q = 0;                     // [plane][64 queries][256 B]
+constexpr int R6_K = 32768;                 // 2 buffers x [plane][64 keys][256 B]
+constexpr int R6_P = 98304;                 // 2 buffers x [plane][64 queries][128 B]
+constexpr int R6_SL = 131072;               // per-slot sums [16 slots][2 key halves][64 queries] fp32
+constexpr int R6_MX = R6_SL + 8192;         // [2 key halves][64 queries] row maximum (reference pass)
+constexpr int R6_L = R6_MX + 512;           // [2][64] row sums
+constexpr int R6_FL = R6_L + 512;           // [8] overflow flags
+constexpr int R6_LDS = R6_FL + 64;
+constexpr int R6_RING = 6;                  // hi-plane K tiles of the reference pass live in [R6_K, R6_SL): 6 x 16 KB
+constexpr float RD_NEG = -3.0e38f;
+constexpr float RD_THR = 14.0f;             // log2 domain: weights up to 2^14 = 16384 < 65504 (fp16 hi plane)
+
+#define R6_OPAQUE(x) asm volatile("" : "+v"(x))
+
+// VAR (experiments, tracing kernel only): bit 0 = every wave runs SCORE then PV (no alternation between the two
+// waves of a SIMD); bit 1 = s_setprio 1 around the P.V MFMA cluster; bit 2 = NO s_setprio 1 around the rest of the
+// iteration (requests + SCORE); bit 3 = never wait for V fragments (timing only: results are wrong).
+template <int TRACE, int VAR = 0>
+__device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr) {
+  const int MODE = a.mode;                            // wave-uniform: one code path serves both reads
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qg = wave & 3, kh = wave >> 2;            // score role: query group (16 queries), key half (32 keys)
+  const int jq = lane & 15, lb = lane >> 4;           // 16x16 tile: column (query) / row block (4 keys)
+  const int j = lane & 31, hi = lane >> 5;            // 32x32 tile (P.V)
+  const bool group_a = (VAR & 1) ? true : kh == 0;    // waves 0-3: SCORE then PV; waves 4-7: PV then SCORE
+
+  // ---- work unit.  Units are ordered (split, query tile); every XCD (block b runs on XCD b % 8:
+  // observed placement, used for speed only) owns a contiguous chunk, so the units of one XCD share a
+  // key split, i.e. the same K / V bytes in that XCD's L2.
+  const int nq = (a.N + 63) / 64;
+  const int nunits = nq * a.ksplits;
+  const int chunk = (nunits + 7) / 8;
+  const int jj = blk >> 3;
+  const int u = (blk & 7) * chunk + jj;
+  if (jj >= chunk || u >= nunits) return;
+  const int qtile = u % nq;
+  const int z = u / nq;
+
+  const int tv = (a.N + 63) / 64;            // 64-key tiles of a slot that hold valid keys
+  int k_lo, k_hi;
+  if (MODE == 0) {
+    k_lo = 0;
+    k_hi = a.T * tv;
+  } else {                                   // key tiles visible under the 15x15 window to this query tile
+    const int q_lo = qtile * 64;
+    const int q_hi = q_lo + 63 < a.N - 1 ? q_lo + 63 : a.N - 1;
+    int y_lo = q_lo / a.w - 7, y_hi = q_hi / a.w + 7;
+    if (y_lo < 0) y_lo = 0;
+    if (y_hi > a.h - 1) y_hi = a.h - 1;
+    k_lo = (y_lo * a.w) / 64;
+    k_hi = ((y_hi + 1) * a.w + 63) / 64;
+  }
+  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
+  const int lo = k_lo + z * per;
+  const int hi_t = lo + per < k_hi ? lo + per : k_hi;
+  const int n = hi_t - lo;
+
+  const int q = qtile * 64 + qg * 16 + jq;            // this lane's query in the score phase
+  const bool qvalid = q < a.N;
+  if (n <= 0) {                                       // no key tile in this split (narrow band)
+    if (tid < 64) {
+      float* mlp = a.ml + ((long)z * a.Npad + qtile * 64 + tid) * 2;
+      mlp[0] = RD_NEG;
+      mlp[1] = 0.f;
+    }
+    return;
+  }
+  long long* trace = (TRACE && trace_base) ? trace_base + (long)blk * 64 : nullptr;   // debug aid: shader-clock stamps per block
+  float* lslot_out = a.lslot;
+  long long tacc[4] = {0, 0, 0, 0};                     // TRACE: this wave's cycles in SCORE / PV / waiting at barriers
+  if (trace && tid == 0) trace[0] = __builtin_readcyclecounter();
+
+  SlotLut lut;
+  lut.load(a.slot_map, MODE == 0 ? a.T : 1);
+
+  float* sl_sum = reinterpret_cast<float*>(smem + R6_SL);
+  float* mx_ex = reinterpret_cast<float*>(smem + R6_MX);
+  float* l_ex = reinterpret_cast<float*>(smem + R6_L);
+  int* flag = reinterpret_cast<int*>(smem + R6_FL);
+
+  // ---- LDS addresses.  ONE opaque register per family: the swizzles are XORs of disjoint bit fields, so the
+  // address of d-step k4 / k-step ks / key group kt is the base XOR a constant (eight separate registers per
+  // family were the ones the allocator spilled -- reloaded inside the P.V cluster, where every compiler-visible
+  // vector-memory access drains the V ring: s_waitcnt vmcnt(0); measured 6.5 k instead of 4.2 k cycles per tile).
+  int ak0 = R6_K + (kh * 32 + jq) * 256 + ((lb ^ jq) << 4);   // score fragments: K row kh*32 (+ kt*16) + jq, chunk 4 k4 + lb
+  int aq0 = R6_Q + (qg * 16 + jq) * 256 + ((lb ^ jq) << 4);   //                  Q row qg*16 + jq
+  R6_OPAQUE(ak0);
+  R6_OPAQUE(aq0);
+  // (the copy is made opaque AT THE USE: a plain `base ^ constant` is loop-invariant, gets hoisted into the
+  // prologue with its thirty siblings and spilled there)
+  auto here = [&](int b) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(b));
+    return b;
+  };
+  auto ak = [&](int k4) __attribute__((always_inline)) { return here(ak0) ^ (k4 << 6); };
+  auto aq = [&](int k4) __attribute__((always_inline)) { return here(aq0) ^ (k4 << 6); };
+  int apw0;                                           // P stores: row qg*16 + jq, keys kh*32 + kt*16 + lb*4 .. +3
+  {
+    const int row = qg * 16 + jq;
+    const int ch = kh * 4 + (lb >> 1);
+    apw0 = R6_P + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4) + (lb & 1) * 8;
+    R6_OPAQUE(apw0);
+  }
+  auto apw = [&](int kt) __attribute__((always_inline)) { return here(apw0) ^ (kt << 5); };
+  int apr0 = R6_P + j * 128 + ((hi ^ ((j >> 1) & 7)) << 4);   // P fragments: row j (+ 32 qi), chunk 2 ks + hi
+  R6_OPAQUE(apr0);
+  auto apr = [&](int ks) __attribute__((always_inline)) { return here(apr0) ^ (ks << 5); };
+  // LDS-DMA: a wave-instruction moves 1 KiB = 4 rows x 256 B; lane L lands at row L >> 4, position L & 15,
+  // and therefore fetches source chunk (L & 15) ^ (row & 15) of its row.  Pieces wave and wave + 8 of a
+  // [64 rows][256 B] plane tile: rows 4 wave + lb and 32 more (same row & 15).
+  int dma_off0 = (wave * 4 + lb) * 256 + ((jq ^ ((wave * 4 + lb) & 15)) << 4);
+  R6_OPAQUE(dma_off0);
+  // (inline assembly: the builtin form makes the compiler wait for the transfer -- s_waitcnt vmcnt(0) -- before the
+  // next vector-memory instruction; this way the only waits are the explicit ones in front of the barriers.  The
+  // compiler does not count these requests: its own vmcnt waits can only become stricter, never too weak.)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma_plane = [&](const h16_t* plane_rows, int lds_base) __attribute__((always_inline)) {
+    const char* src = reinterpret_cast<const char*>(plane_rows);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + lds_base + (wave + 8 * pc) * 1024);
+      const char* g = src + dma_off0 + pc * 8192;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(g) : "memory");
+    }
+  };
+  // Key tile index -> (logical slot, key offset inside the slot).  One division per pass; the loops then step
+  // (a division per use was ~60 scalar instructions, three times per tile)
+  struct TileIter {
+    int t, kt;
+    __device__ __forceinline__ void init(int i, int tv, int mode) {
+      t = 0;
+      kt = i;
+      if (mode == 0) {
+        t = i / tv;
+        kt = i - t * tv;
+      }
+    }
+    __device__ __forceinline__ void step(int tv, int mode) {
+      ++kt;
+      if (mode == 0 && kt == tv) {
+        kt = 0;
+        ++t;
+      }
+    }
+    __device__ __forceinline__ int key0() const { return kt * 64; }
+  };
+  auto dma_k = [&](const TileIter& ti, int buf, bool both) __attribute__((always_inline)) {
+    const long base = (long)lut(ti.t) * a.k_slot_stride + (long)ti.key0() * 128;
+    dma_plane(a.kh + base, R6_K + buf * 32768);
+    if (both) dma_plane(a.kl + base, R6_K + buf * 32768 + 16384);
+  };
+  auto dma_khi = [&](const TileIter& ti, int ring_slot) __attribute__((always_inline)) {
+    dma_plane(a.kh + (long)lut(ti.t) * a.k_slot_stride + (long)ti.key0() * 128, R6_K + ring_slot * 16384);
+  };
+
+  // ---- Q tile -> LDS (once)
+  dma_plane(a.qh + (long)qtile * 64 * 128, R6_Q);
+  dma_plane(a.ql + (long)qtile * 64 * 128, R6_Q + 16384);
+
+  const float sl2e = a.scale * 1.44269504088896341f;
+  constexpr float LN2 = 0.693147180559945f;
+  int qy = 0, qx = 0;
+  const float inv_w = MODE == 1 ? 1.0f / (float)a.w : 0.f;   // (a.w >= 1 is validated for mode 1)
+  const float* Rq = nullptr;
+  const int rcs = a.rcs > 0 ? a.rcs : 1;
+  if (MODE == 1) {
+    qy = fast_div(qvalid ? q : 0, inv_w);
+    qx = (qvalid ? q : 0) - qy * a.w;
+    Rq = a.R + (long)(qvalid ? q : 0) * a.ldr;
+  }
+  // Windowed read: relative bias (log2 domain) of this lane's 8 keys of the tile at key0, RD_NEG where the key
+  // is outside the 15x15 window / the image.  All gathers are issued unconditionally (index 0 where masked)
+  // and back to back; one division per 4 consecutive keys.
+  auto window_terms = [&](int key0, float (&rb)[8]) __attribute__((always_inline)) {
+    int idx[8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int tok0 = key0 + kh * 32 + kt * 16 + lb * 4;
+      const int ky0 = fast_div(tok0, inv_w);
+      const int kx0 = tok0 - ky0 * a.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int ky = ky0, kx = kx0 + e;
+        if (kx >= a.w) {
+          kx -= a.w;
+          ky += 1;
+        }
+        const int dy = ky - qy, dx = kx - qx;
+        const bool valid = qvalid && tok0 + e < a.N && dy >= -7 && dy <= 7 && dx >= -7 && dx <= 7;
+        idx[kt * 4 + e] = valid ? ((dy + 7) * 15 + dx + 7) * rcs : -1;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rb[r] = Rq[idx[r] < 0 ? 0 : idx[r]];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rb[r] = idx[r] < 0 ? RD_NEG : rb[r] * 1.44269504088896341f;
+  };
+
+  // ---- scores of one tile for this lane: y[kt*4 + r] = log2-domain logit of key kh*32 + kt*16 + lb*4 + r
+  // (RD_NEG where masked).  EXACT: the three-product form; else the hi planes only (reference pass).
+  // kb = byte offset of the tile's K image relative to R6_K.
+  int cur_t = -1;
+  float bias2 = 0.f;
+  auto scores = [&](const TileIter& ti, int kb, auto EX, float (&y)[8]) __attribute__((always_inline)) {
+    constexpr bool EXACT = decltype(EX)::value;
+    const int t = ti.t, key0 = ti.key0();
+    if (MODE == 0 && t != cur_t) {
+      cur_t = t;
+      bias2 = ((a.bias && qvalid) ? a.bias[(long)q * a.T + t] : 0.f) * sl2e;     // (padding queries: no row in bias)
+    }
+    f32x4_t s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[kt][r] = 0.f;
+    // fragments of d-step k4 + 1 are requested before the MFMAs of step k4 (two register sets): read one step at
+    // a time the phase was four LDS round trips long (~3.4 k cycles per tile beside the partner wave's P.V)
+    constexpr int NF = EXACT ? 6 : 3;                 // [0] Q hi, [1] K hi (keys 0-15), [2] K hi (16-31), [3..5] the lo planes
+    frag8_t fa[NF], fb[NF];
+    auto fload = [&](frag8_t (&f)[NF], auto K4) __attribute__((always_inline)) {
+      constexpr int k4 = decltype(K4)::value;
+      f[0] = *reinterpret_cast<const frag8_t*>(smem + aq(k4));
+      f[1] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb);
+      f[2] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + 4096);
+      if constexpr (EXACT) {
+        f[3] = *reinterpret_cast<const frag8_t*>(smem + aq(k4) + 16384);
+        f[4] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + 16384);
+        f[5] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + 4096));
+      }
+    };
+    fload(fa, std::integral_constant<int, 0>{});
+    static_for<4>([&](auto K4) {
+      constexpr int k4 = K4.value;
+      frag8_t (&c)[NF] = (k4 & 1) ? fb : fa;
+      if constexpr (k4 < 3) fload((k4 & 1) ? fa : fb, std::integral_constant<int, (k4 < 3 ? k4 + 1 : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (EXACT) {
+        s[0] = RMEM_MFMA16(c[1], c[3], s[0]);         // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
+        s[1] = RMEM_MFMA16(c[2], c[3], s[1]);
+        s[0] = RMEM_MFMA16(c[4], c[0], s[0]);
+        s[1] = RMEM_MFMA16(c[5], c[0], s[1]);
+      }
+      s[0] = RMEM_MFMA16(c[1], c[0], s[0]);
+      s[1] = RMEM_MFMA16(c[2], c[0], s[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    const bool padded = key0 + 64 > a.N;
+    if (MODE == 0 && !padded) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[kt * 4 + r] = fmaf(s[kt][r], sl2e, bias2);
+    } else if (MODE == 0) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tok = key0 + kh * 32 + kt * 16 + lb * 4 + r;
+          y[kt * 4 + r] = tok < a.N ? fmaf(s[kt][r], sl2e, bias2) : RD_NEG;
+        }
+    } else {
+      float rb[8];
+      window_terms(key0, rb);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float rbv = rb[kt * 4 + r];
+          y[kt * 4 + r] = rbv > -2.9e38f ? fmaf(s[kt][r], sl2e, rbv) : RD_NEG;
+        }
+    }
+    return t;
+  };
+
+  int vcol = (wave * 128 + j) * 16 + hi * 8;           // V fragments: lane = column, 8 consecutive keys (16 B)
+  R6_OPAQUE(vcol);
+
+  float m = RD_NEG;                                   // this query's reference (log2 domain)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // ================= reference pass: m = max over the unit's keys of the (approximate) scores
+    {
+      float mest = RD_NEG;
+      cur_t = -1;
+      // hi planes only: a ring of R6_RING tiles in [R6_K, R6_SL), in PAIRS, one barrier per pair (one barrier per
+      // tile left this pass latency-bound: 2.0-2.5 k cycles per tile for 8 small MFMAs per wave); exact (redo):
+      // both planes, the two K buffers, one tile per barrier
+      const bool exact = attempt > 0;
+      const int G = exact ? 1 : 2;                    // tiles per barrier
+      const int ring_groups = exact ? 2 : R6_RING / 2;
+      const int ring = G * ring_groups;               // tiles resident: 2 (both planes, the K buffers) / R6_RING (hi plane)
+      const int ngroups = (n + G - 1) / G;
+      const int pieces = exact ? 4 : 2;               // DMA instructions per tile per wave
+      TileIter tdma, tcmp;
+      tdma.init(lo, tv, MODE);
+      tcmp = tdma;
+      int issued = 0;                                 // tiles requested so far
+      auto request = [&](int upto) __attribute__((always_inline)) {        // request tiles [issued, upto)
+        for (; issued < upto && issued < n; ++issued) {
+          if (exact) dma_k(tdma, issued & 1, true);
+          else dma_khi(tdma, issued % ring);
+          tdma.step(tv, MODE);
+        }
+      };
+      __syncthreads();                                // (redo: every wave is done with the images of the main pass)
+      request(ring);
+#pragma clang loop unroll(disable)
+      for (int jp = 0; jp < ngroups; ++jp) {
+        // wait for the tiles of group jp: everything requested after them may stay in flight
+        const int done_upto = G * (jp + 1) < n ? G * (jp + 1) : n;
+        const int cnt = (issued - done_upto) * pieces;
+        if (cnt >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (cnt >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (cnt >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (cnt >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // group jp landed for every wave; the slots of group jp - 1 are free
+        if (jp >= 1) request(G * (jp - 1 + ring_groups) + G);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int x = G * jp + e;
+          if (e < G && x < n) {
+            float y[8];
+            if (exact) scores(tcmp, (x & 1) * 32768, std::true_type{}, y);
+            else scores(tcmp, (x % ring) * 16384, std::false_type{}, y);
+            tcmp.step(tv, MODE);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) mest = fmaxf(mest, y[r]);
+          }
+        }
+      }
+      mest = fmaxf(mest, __shfl_xor(mest, 16));
+      mest = fmaxf(mest, __shfl_xor(mest, 32));
+      __syncthreads();                                // all fragment reads of the pass are done: the K / P regions are free
+      if (lb == 0) mx_ex[kh * 64 + qg * 16 + jq] = mest;
+      // per-slot sums and flags start from zero
+      for (int e = tid; e < 2048; e += 512) sl_sum[e] = 0.f;
+      if (tid < 8) flag[tid] = 0;
+      // first K tiles of the main pass
+      TileIter t01;
+      t01.init(lo, tv, MODE);
+      dma_k(t01, 0, true);
+      t01.step(tv, MODE);
+      if (n > 1) dma_k(t01, 1, true);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      m = fmaxf(mx_ex[qg * 16 + jq], mx_ex[64 + qg * 16 + jq]);
+    }
+    if (trace && tid == 0) trace[1] = __builtin_readcyclecounter();
+
+    // ================= main pass
+    f32x16_t o[2][4];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[qi][ci][r] = 0.f;
+    float l = 0.f, lcur = 0.f;
+    int sum_t = -1;                                   // slot lcur belongs to
+    bool over = false;
+    cur_t = -1;
+    u32x4_t vr[4][2];                                 // ring of V fragments: step s = (k-step, ci) lives in vr[s & 3][plane]
+
+    // SCORE(i): weights of tile i -> P image pbuf (K image kbuf)
+    auto score_phase = [&](const TileIter& ti, int kbuf, int pbuf) __attribute__((always_inline)) {
+      float y[8];
+      const int t = scores(ti, kbuf * 32768, std::true_type{}, y);
+      if (t != sum_t) {
+        if (sum_t >= 0) {                             // (wave-uniform) slot finished: park its sum
+          float v = lcur + __shfl_xor(lcur, 16);
+          v += __shfl_xor(v, 32);
+          if (lb == 0) sl_sum[(sum_t * 2 + kh) * 64 + qg * 16 + jq] = v;
+        }
+        lcur = 0.f;
+        sum_t = t;
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x2_t pp[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sv = y[kt * 4 + e];
+          over = over || (sv - m > RD_THR);
+          float p = __builtin_amdgcn_exp2f(sv - m);   // sentinels (-3e38) give exactly 0 unless m is one too
+          p = sv > -2.9e38f ? p : 0.f;
+          psum += p;
+          pp[e >> 1][e & 1] = p;
+        }
+        // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
+        const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
+        const f32x2_t r0 = pp[0] - __builtin_convertvector(h0, f32x2_t), r1 = pp[1] - __builtin_convertvector(h1, f32x2_t);
+        const f16x2_t l0 = __builtin_convertvector(r0, f16x2_t), l1 = __builtin_convertvector(r1, f16x2_t);
+        u32x2_t wh, wl;
+        wh[0] = __builtin_bit_cast(uint32_t, h0);
+        wh[1] = __builtin_bit_cast(uint32_t, h1);
+        wl[0] = __builtin_bit_cast(uint32_t, l0);
+        wl[1] = __builtin_bit_cast(uint32_t, l1);
+        *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384) = wh;
+        *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384 + 8192) = wl;
+      }
+      l += psum;
+      lcur += psum;
+    };
+    // V fragments of step s = 4 ks + ci of the tile whose blocked-16 planes start at vhp / vlp -> ring slot s & 3.
+    // Requested by inline assembly and waited for by vwait() below with COUNTED vmcnt: left to the compiler, the
+    // loads and their use sit in different branches of the loop body, and its wait-count pass then protects the
+    // ring registers with s_waitcnt vmcnt(0) at the top of every iteration -- i.e. it waits for the K transfer
+    // that was just requested (measured: 1.3-4 k cycles per tile).  The compiler sees no vector-memory load in the
+    // loop any more; the "+v" ties keep every use of a ring slot behind its vwait().
+    const h16_t* vhp = a.vh;
+    const h16_t* vlp = a.vl;
+    auto vstep = [&](auto S) __attribute__((always_inline)) {
+      constexpr int sidx = decltype(S)::value;
+      constexpr int ks = sidx >> 2, ci = sidx & 3;
+      const h16_t* ph = vhp + ks * (1024 * 16) + vcol;      // (k-step: 16 keys x 1024 columns)
+      const h16_t* pl = vlp + ks * (1024 * 16) + vcol;
+      u32x4_t& d0 = vr[sidx & 3][0];                        // (asm operands do not capture: name the slots first)
+      u32x4_t& d1 = vr[sidx & 3][1];
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d0) : "v"(ph), "n"(ci * 1024));
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d1) : "v"(pl), "n"(ci * 1024));
+    };
+    // the fragments of step s have landed: every request up to step s + 3 has been issued by now, so at most the
+    // 6 loads of steps s + 1 .. s + 3 may still be in flight (fewer at the end of the tile)
+    auto vwait = [&](auto S) __attribute__((always_inline)) {
+      constexpr int sidx = decltype(S)::value;
+      constexpr int younger = sidx <= 12 ? 6 : 2 * (15 - sidx);
+      u32x4_t& d0 = vr[sidx & 3][0];
+      u32x4_t& d1 = vr[sidx & 3][1];
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(d0), "+v"(d1) : "n"(younger));
+    };
+    // PV(i): O += P(pbuf) . V(tile i).  16 steps (k-step, 32-column tile) of 6 MFMAs; the V fragments of a step
+    // are requested 4 steps ahead (steps 0-3 before this phase), the P fragments of a k-step one k-step ahead.
+    auto pv_phase = [&](int pbuf) __attribute__((always_inline)) {
+      frag8_t pa[4], pb[4];                           // P fragments [qi][plane] of one k-step
+      auto pload = [&](frag8_t (&pf)[4], auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            pf[qi * 2 + p] = *reinterpret_cast<const frag8_t*>(smem + apr(ks) + (pbuf * 16384 + p * 8192 + qi * 4096));
+      };
+      pload(pa, std::integral_constant<int, 0>{});
+      static_for<16>([&](auto S) {
+        constexpr int sidx = S.value;
+        constexpr int ks = sidx >> 2, ci = sidx & 3;
+        frag8_t (&pc)[4] = (ks & 1) ? pb : pa;
+        if constexpr (ci == 0 && ks < 3) pload((ks & 1) ? pa : pb, std::integral_constant<int, (ks < 3 ? ks + 1 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        vwait(S);
+        const frag8_t vh = __builtin_bit_cast(frag8_t, vr[sidx & 3][0]);
+        const frag8_t vl = __builtin_bit_cast(frag8_t, vr[sidx & 3][1]);
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {              // small terms first
+          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vl, o[qi][ci]);
+          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 1], vh, o[qi][ci]);
+          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vh, o[qi][ci]);
+        }
+        if constexpr (sidx + 4 < 16) vstep(std::integral_constant<int, (sidx + 4 < 16 ? sidx + 4 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    // One loop body for both wave groups; group B (waves 4-7) meets the interval's barrier BETWEEN its two
+    // phases and runs the P.V of the tile whose weights were just finished, i.e. it is half an interval behind:
+    //   A:  [SCORE(it+1)  PV(it)]   barrier
+    //   B:   SCORE(it+1)  barrier  [PV(it+1)]
+    // Both pass exactly one barrier per iteration.  K(it + 2) is requested at the top of iteration it -- every
+    // wave is then past barrier it - 1, which ends the readers of K(it) (same buffer) -- and waited for before
+    // the wave's next barrier; being OLDER than the V loads that follow, it never lengthens a wait for those.
+    TileIter t_sc, t_dma, t_v;                        // tiles of the next SCORE (it + 1), K request (it + 2), P.V (px)
+    t_sc.init(lo, tv, MODE);
+    t_dma.init(lo + 2 < hi_t ? lo + 2 : lo, tv, MODE);
+    t_v = t_sc;
+#pragma clang loop unroll(disable)
+    for (int it = -1; it < n; ++it) {
+      const int px = group_a ? it : it + 1;           // tile (relative) whose P.V this wave runs now
+      const bool do_pv = px >= 0 && px < n;
+      const bool do_sc = it + 1 < n;
+      long long tt0 = 0;
+      if (TRACE) tt0 = __builtin_readcyclecounter();
+      // Priority: the wave that is NOT in its P.V cluster goes first.  Both at priority 0, the older wave's MFMAs
+      // sit at the head of the SIMD's vector issue and the younger wave's requests / address arithmetic / exp2
+      // crawl beside them (measured: 4.1 k cycles for this block beside a P.V, 1.1 k otherwise).
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
+      // K(it + 2) into the buffer of K(it): its readers, SCORE(it), are past barrier it - 1 (for both groups)
+      if (it >= 0 && it + 2 < n) {
+        dma_k(t_dma, it & 1, true);
+        t_dma.step(tv, MODE);
+      }
+      if (do_pv) {                                    // V fragments of the first four steps: in flight during SCORE
+        const long vb = (long)lut(t_v.t) * a.v_slot_stride + (long)(t_v.key0() >> 4) * (1024 * 16);
+        t_v.step(tv, MODE);
+        vhp = a.vh + vb;
+        vlp = a.vl + vb;
+        vstep(std::integral_constant<int, 0>{});
+        vstep(std::integral_constant<int, 1>{});
+        vstep(std::integral_constant<int, 2>{});
+        vstep(std::integral_constant<int, 3>{});
+      }
+      long long t0 = 0;
+      if (TRACE) {
+        t0 = __builtin_readcyclecounter();
+        tacc[3] += t0 - tt0;
+      }
+      if (do_sc) {
+        score_phase(t_sc, (it + 1) & 1, (it + 1) & 1);
+        t_sc.step(tv, MODE);
+      }
+      if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
+      if (!group_a) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[2] += t1 - t0; t0 = t1; }
+      }
+      if ((VAR & 2) && do_pv) __builtin_amdgcn_s_setprio(1);
+      if (do_pv) pv_phase(px & 1);
+      if ((VAR & 2) && do_pv) __builtin_amdgcn_s_setprio(0);
+      if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
+      if (group_a) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (TRACE) tacc[2] += __builtin_readcyclecounter() - t0;
+      }
+    }
+    if (trace && tid == 0) trace[2] = __builtin_readcyclecounter();
+
+    // ---- overflow?  (wave-uniform flags; the unit is redone against the exact reference)
+    if (attempt == 0) {
+      const int any_over = __any(over) ? 1 : 0;
+      if (lane == 0) flag[wave] = any_over;
+      __syncthreads();
+      int f = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f |= flag[k];
+      if (__builtin_amdgcn_readfirstlane(f)) continue;
+    }
+
+    // ---- statistics: the last slot's sum, row sums of the two key halves
+    {
+      float v = lcur + __shfl_xor(lcur, 16);
+      v += __shfl_xor(v, 32);
+      float lt = l + __shfl_xor(l, 16);
+      lt += __shfl_xor(lt, 32);
+      if (lb == 0) {
+        if (sum_t >= 0) sl_sum[(sum_t * 2 + kh) * 64 + qg * 16 + jq] = v;
+        l_ex[kh * 64 + qg * 16 + jq] = lt;
+        if (kh == 0) mx_ex[qg * 16 + jq] = m;          // (reference of query qg*16 + jq, for the writers below)
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float* mlp = a.ml + ((long)z * a.Npad + qtile * 64 + tid) * 2;
+      const float mq = mx_ex[tid];
+      mlp[0] = mq > -2.9e38f ? mq * LN2 : RD_NEG;
+      mlp[1] = l_ex[tid] + l_ex[64 + tid];
+    }
+    if (lslot_out)
+      for (int e = tid; e < 64 * a.T; e += 512) {
+        const int qq = e & 63, t = e >> 6;
+        float* lsp = lslot_out + (((long)z * a.Npad + qtile * 64 + qq) * a.T + t) * 2;
+        lsp[0] = sl_sum[(t * 2) * 64 + qq] + sl_sum[(t * 2 + 1) * 64 + qq];
+        lsp[1] = mx_ex[qq] * LN2;
+      }
+    __syncthreads();                                  // the images are dead, the statistics read: LDS is reused below
+
+    // ---- flush O: transposed through LDS (the accumulator layout gives one column per lane, i.e. 4-byte
+    // stores; staged as [32 rows][128 columns] per wave the tile leaves as 16-byte stores of 512-byte rows)
+    {
+      char* stg = smem + wave * 16384;
+      int lrow = hi, lcol = j;                        // opaque: keeps the row pointers out of the prologue
+      R6_OPAQUE(lrow);
+      R6_OPAQUE(lcol);
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci)
+            *reinterpret_cast<float*>(stg + row * 512 + (ci * 32 + lcol) * 4) = o[qi][ci][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS operations complete in order
+        float* orow = a.part + ((long)z * a.Npad + qtile * 64 + qi * 32) * a.ncols + wave * 128;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 2 + lrow;
+          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + lcol * 16);
+          *reinterpret_cast<f32x4_t*>(orow + (long)row * a.ncols + lcol * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
+      }
+    }
+    break;
+  }
+  if (trace && lane == 0) {
+    if (wave == 0) {
+      trace[3] = __builtin_readcyclecounter();
+      trace[28] = n;
+    }
+    trace[4 + wave] = tacc[0];
+    trace[12 + wave] = tacc[1];
+    trace[20 + wave] = tacc[2];
+    trace[40 + wave] = tacc[3];
+    trace[32 + wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave / SIMD / CU this wave ran on
+  }
+}
+
+__global__ __launch_bounds__(512) void read64_kernel(rmem_read_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  read64_body<0>(a, blockIdx.x, smem);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(512) void read64_trace_kernel(rmem_read_args a, long long* trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  read64_body<1, VAR>(a, blockIdx.x, smem, trace);
+}
+
+// The bank read (p[0], mode 0) and the windowed read (p[1], mode 1) of one layer in ONE launch.  Per
+// XCD (block % 8) the first cha blocks serve p[0]'s units, the next chb blocks p[1]'s.
+struct Read2Args {
+  rmem_read_args p[2];
+  int cha, chb;
+};
+
+__global__ __launch_bounds__(512) void read64x2_kernel(Read2Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int which = jj < g.cha ? 0 : 1;
+  read64_body<0>(g.p[which], (which ? jj - g.cha : jj) * 8 + xcd, smem);
+}
+
+// the same two kernels for several clips in one launch (launch.h): block z = clip, whose argument
+// block is read from device memory
+__global__ __launch_bounds__(512) void read64_many_kernel(const char* __restrict__ argv, long stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const rmem_read_args a = rmem::uniform_copy(reinterpret_cast<const rmem_read_args*>(argv + (long)blockIdx.z * stride));
+  read64_body<0>(a, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(512) void read64x2_many_kernel(const char* __restrict__ argv, long stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Read2Args& g = *reinterpret_cast<const Read2Args*>(argv + (long)blockIdx.z * stride);
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int which = jj < __builtin_amdgcn_readfirstlane(g.cha) ? 0 : 1;
+  const rmem_read_args a = rmem::uniform_copy(&g.p[which]);
+  read64_body<0>(a, (which ? jj - g.cha : jj) * 8 + xcd, smem);
+}
+
+template <class K>
+static int read_many_thunk(K kernel, const rmem::RecOp& op, const char* dev_args, long stride, int B, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+  hipLaunchKernelGGL(kernel, dim3(op.grid.x, 1, B), dim3(512), R6_LDS, s, dev_args + op.off, stride);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+static int read_many(const rmem::RecOp& op, const char* d, long st, int B, hipStream_t s) {
+  return read_many_thunk(&read64_many_kernel, op, d, st, B, s);
+}
+static int read2_many(const rmem::RecOp& op, const char* d, long st, int B, hipStream_t s) {
+  return read_many_thunk(&read64x2_many_kernel, op, d, st, B, s);
+}
+
+static int read_args_ok(const rmem_read_args& a) {
+  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.T > 16 || a.ksplits <= 0 || a.ksplits > 32) return 0;
+  if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.part || !a.ml) return 0;
+  if (a.ncols != 1024) return 0;                      // eight waves x 128 columns of [V | ID_V]
+  if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1 || a.w < 1 || a.ldr < 1)) return 0;
+  if (a.mode != 0 && a.mode != 1) return 0;
+  return 1;
+}
+
+static int read_chunk(const rmem_read_args& a) {
+  return (((a.N + 63) / 64) * a.ksplits + 7) / 8;
+}
+
+extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* bp, void* stream) {
+  if (!ap || !bp || !read_args_ok(*ap) || !read_args_ok(*bp) || ap->mode != 0 || bp->mode != 1) return RMEM_ERR_INVALID;
+  const int cha = read_chunk(*ap), chb = read_chunk(*bp);
+  // per launch: the attribute belongs to the (device, function) pair; no process-wide "already set" flag
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+  Read2Args g;
+  g.p[0] = *ap;
+  g.p[1] = *bp;
+  g.cha = cha;
+  g.chb = chb;
+  if (rmem::Recorder* r = rmem::current_recorder()) {
+    rmem::rec_push(r, &read2_many, dim3(8 * (cha + chb)), dim3(512), R6_LDS, &g, (unsigned)sizeof(g));
+    return RMEM_OK;
+  }
+  hipLaunchKernelGGL(read64x2_kernel, dim3(8 * (cha + chb)), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_attn_read(const rmem_read_args* ap, void* stream) {
+  if (!ap || !read_args_ok(*ap)) return RMEM_ERR_INVALID;
+  const rmem_read_args& a = *ap;
+  const int chunk = read_chunk(a);
+  if (rmem::Recorder* r = rmem::current_recorder()) {
+    rmem::rec_push(r, &read_many, dim3(8 * chunk), dim3(512), R6_LDS, &a, (unsigned)sizeof(a));
+    return RMEM_OK;
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+  hipLaunchKernelGGL(read64_kernel, dim3(8 * chunk), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), a);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+// Debug aid (tools/kbench_read.py): the same launch with shader-clock stamps per block written to
+// trace[block][64]: [0] start, [1] reference pass done, [2] tile loop done, [3] end, [4 + w] / [12 + w] / [20 + w] cycles
+// wave w spent in its SCORE / PV phases / waiting at the interval barriers, [28] key tiles of the unit, [32 + w]
+// HW_REG_HW_ID of wave w, [40 + w] cycles at the top of the iterations (K request, first V requests).  trace must
+// hold 8 * ceil(units / 8) * 64 int64.
+extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, void* stream) {
+  if (!ap || !trace || !read_args_ok(*ap) || rmem::current_recorder()) return RMEM_ERR_INVALID;
+  const int chunk = read_chunk(*ap);
+  const char* ev = getenv("RMEM_READ_VAR");           // experiments (see read64_body)
+  const int var = ev ? atoi(ev) & 15 : 0;
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+    hipLaunchKernelGGL(kern, dim3(8 * chunk), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), *ap,
+                       reinterpret_cast<long long*>(trace));
+  };
+  if (var == 0) go(&read64_trace_kernel<0>);
+  else if (var == 1) go(&read64_trace_kernel<1>);
+  else if (var == 2) go(&read64_trace_kernel<2>);
+  else if (var == 3) go(&read64_trace_kernel<3>);
+  else if (var == 4) go(&read64_trace_kernel<4>);
+  else if (var == 5) go(&read64_trace_kernel<5>);
+  else if (var == 6) go(&read64_trace_kernel<6>);
+  else if (var == 7) go(&read64_trace_kernel<7>);
+  else if (var == 8) go(&read64_trace_kernel<8>);
+  else go(&read64_trace_kernel<9>);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}

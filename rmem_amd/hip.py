@@ -95,7 +95,7 @@ EXPORTS = [
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2",
     "rmem_bias_act_nchw_batched", "rmem_dwconv5x5_split2",
-    "rmem_attn_read", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
+    "rmem_attn_read", "rmem_attn_read_trace", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
     "rmem_rec_end", "rmem_launch_recorded",
 ]
 # exports with a non-int return type
@@ -129,6 +129,7 @@ def load():
     lib.rmem_set_ints.argtypes = [c_p, C.POINTER(i32), i32, c_p]
     lib.rmem_dwconv5x5_split2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p]
     lib.rmem_attn_read.argtypes = [C.POINTER(ReadArgs), c_p]
+    lib.rmem_attn_read_trace.argtypes = [C.POINTER(ReadArgs), c_p, c_p]
     lib.rmem_attn_read2.argtypes = [C.POINTER(ReadArgs), C.POINTER(ReadArgs), c_p]
     lib.rmem_attn_read_combine.argtypes = [C.POINTER(ReadCombineArgs), c_p]
     lib.rmem_attn_read_combine2.argtypes = [C.POINTER(ReadCombineArgs), C.POINTER(ReadCombineArgs), c_p]

@@ -189,6 +189,53 @@ class DeAOTLSTT:
                                     self._f(g("self_attn.projection.bias")))
             self.lw.append(W)
 
+    # ------------------------------------------------------------------ key splits
+    @staticmethod
+    def choose_splits(N: int, h: int, w: int, cap: int, clips: int = 1, cus: int = 256):
+        """(ks_long, ks_win) of the paired long-term + windowed read launch: the pair that minimises the
+        launch's makespan on `cus` CUs under a simple cost model measured on MI355X
+        (profiles/r03_*_kbench_read.json, cycles per 64-key tile incl. its share of the reference pass:
+        long-term 11.8 k, windowed 19.8 k -- relative-bias gathers and window arithmetic; ~12 k per unit for
+        the Q staging, statistics and the flush).  Units are dispatched long-term first; with more units
+        than CUs the surplus starts as the first units finish.  Several clips per launch share the CUs."""
+        nq = (N + 63) // 64
+        tv = (N + 63) // 64
+        if clips > 1:
+            # several clips per launch: two rounds of workgroups (longer units amortise the reference pass);
+            # measured at 480p K=4 (frames/s for long,win,self: 4 clips 3,1,4 479 / 4,2,4 476 / 7,2,6 461;
+            # 8 clips 2,1,2 492 / 3,1,3 489 / 1,1,2 477) -- the model below does not cover the clip-major dispatch order
+            total = max(3, min(32, 512 // (nq * clips)))
+            kw = max(1, min(8, int(round(total * 0.33 * min(1.0, 4.0 / max(cap, 1))))))
+            return max(1, total - kw), kw
+        long_tiles = cap * tv
+        band = min(tv, ((min(h, 3 + 14) * w) + 63) // 64 + 1)       # key tiles visible to a 64-query tile (15x15 window)
+        LONG, WIN, FIX = 11.8, 19.8, 12.0
+        best = None
+        for kl in range(1, 33):
+            for kw in range(1, 9):
+                if kl > long_tiles or kw > band:
+                    continue
+                cl = -(-long_tiles // kl) * LONG + FIX
+                cw = -(-band // kw) * WIN + FIX
+                units = [cl] * (nq * kl * clips) + [cw] * (nq * kw * clips)
+                if len(units) <= cus:
+                    span = max(cl, cw)
+                elif len(units) > 4 * cus:
+                    continue
+                else:                                               # greedy list schedule in dispatch order
+                    import heapq
+                    free = [0.0] * cus
+                    heapq.heapify(free)
+                    span = 0.0
+                    for c in units:
+                        t0 = heapq.heappop(free)
+                        heapq.heappush(free, t0 + c)
+                        span = max(span, t0 + c)
+                key = (round(span, 1), kl + kw)
+                if best is None or key < best[0]:
+                    best = (key, kl, kw)
+        return best[1], best[2]
+
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
         N, Np, dev = self.N, self.Npad, self.dev
@@ -205,28 +252,16 @@ class DeAOTLSTT:
         self.Ucat = z(N, 1024)
         self.bias_pe = z(N, self.Tmax)
         self._layer = 0
-        # Key splits of the fused reads.  A unit = (128-query tile, 512-column half, split) fills a
-        # CU's accumulator file, so one resident wave of workgroups = 256 units: the long-term and
-        # the windowed read of a layer share ONE launch (ks_long + ks_win splits), the self read
-        # gets all of them.
-        nq = Np // 128
-        # several clips per launch: the same 256 resident units are shared by all of them (two rounds
-        # of workgroups: longer units amortise the prologue -- Q staging, reference pass -- better)
-        # (measured at 480p K=4, frames/s for long,win,self: 4 clips 3,1,4 479 / 4,2,4 476 / 7,2,6 461;
-        #  8 clips 2,1,2 492 / 3,1,3 489 / 1,1,2 477)
-        if self.clips_per_launch == 1:
-            total = max(2, min(32, 256 // (2 * nq)))
-        else:
-            total = max(3, min(32, 512 // (2 * nq * self.clips_per_launch)))
+        # Key splits of the fused reads (csrc/read64.hip).  A unit = (64-query tile, key split) is one 8-wave
+        # workgroup that owns a CU; the long-term and the windowed read of a layer share ONE launch, the
+        # self read gets a launch of its own.
+        self.ks_long, self.ks_win = self.choose_splits(N, self.h, self.w, self.cap, self.clips_per_launch)
+        nq = (N + 63) // 64
         tv = (N + 63) // 64
-        # measured at 480p K=4 (bench.py frames/s / read2 us isolated, for ks_long, ks_win, ks_self):
-        # 7,2,6 385.9 / 242;  6,3,6 397.7 / 197;  5,4,6 388.5 / 207 -- a windowed tile costs more than a
-        # long-term one (mask arithmetic + relative-bias gather), so it gets a third of the splits at K = 4
-        self.ks_win = max(1, min(8, int(round(total * 0.33 * min(1.0, 4.0 / max(self.cap, 1))))))
-        self.ks_long = max(1, min(total - self.ks_win, 32))
-        # self read (T = 1, 27 tiles at 480p): 9 splits are faster isolated (36.5 + 12.9 us read + combine against
-        # 46.2 + 10.0 with 6) but not in the frame (479.6 vs 481.9 frames/s: more partials beside the encoder stream)
-        self.ks_self = max(1, min(total, tv, 6))
+        budget = 256 if self.clips_per_launch == 1 else max(1, 512 // self.clips_per_launch)
+        # self read (T = 1, 27 tiles at 480p): 9 splits are faster isolated (33.8 + 13.1 us read + combine against
+        # 38.2 + 10.1 with 6) but not in the frame (more partials beside the encoder stream)
+        self.ks_self = max(1, min(budget // nq, tv, 6))
         if os.environ.get("RMEM_KS"):                             # tuning override: "long,win,self"
             self.ks_long, self.ks_win, self.ks_self = (int(x) for x in os.environ["RMEM_KS"].split(","))
         self.ksplits_max = max(self.ks_long, self.ks_win, self.ks_self)
@@ -256,7 +291,7 @@ class DeAOTLSTT:
     # ------------------------------------------------------------------ measurement
     def enable_kernel_timing(self, on: bool):
         """HIP-event pairs around the dominant kernel (the fused long-term + windowed read of a
-        layer, read2_kernel) on the launch stream."""
+        layer, read64x2_kernel) on the launch stream."""
         self._timing = bool(on)
         if on:
             self._events = []
@@ -275,7 +310,7 @@ class DeAOTLSTT:
         flops = self.read_flops(T)
         mean_ms = sum(ms) / len(ms)
         ach = flops / (mean_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": f"read2_kernel (fused long-term T={T} + windowed memory read: Q.K^T, softmax, P.V)",
+        return {"bound": "mfma", "kernel": f"read64x2_kernel (fused long-term T={T} + windowed memory read: Q.K^T, softmax, P.V)",
                 "achieved": ach, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach / mfma_peak_tflops,
                 "traffic": None, "launches": len(ms), "mean_us": 1e3 * mean_ms,
                 "algorithmic_flops_per_launch": flops}

@@ -85,7 +85,7 @@ def main():
             hip.check(lib.rmem_attn_read(C.byref(S[0]), st), "read")
         torch.cuda.synchronize()
         return
-    res["splits_long_win_self"] = float(f"{L.ks_long}.{L.ks_win}{L.ks_self}")
+    res["ks_long"], res["ks_win"], res["ks_self"] = L.ks_long, L.ks_win, L.ks_self
     res["read2_long+window"] = timeit(lambda: hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "r2"), args.iters)
     res["read_combine2"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "c2"), args.iters)
     res["read_long_alone"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "r"), args.iters)
@@ -93,6 +93,9 @@ def main():
     res["read_self"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(S[0]), st), "r"), args.iters)
     res["read_combine_self"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine(C.byref(S[1]), st), "c"), args.iters)
     res["read2_TFLOPs_algorithmic"] = L.read_flops(T) / res["read2_long+window"] / 1e6
+    if args.only == "reads":
+        print(json.dumps({k: round(v, 2) for k, v in res.items()}, indent=1))
+        return
     res["dwconv"] = timeit(lambda: L._dwconv(L.ws_main, W.dw_lt, L.Ylt), args.iters)
     ns = L.nsplit
     res["ln"] = timeit(lambda: L._ln(L.tgt, W.ln1, L.x_pl, 256), args.iters)

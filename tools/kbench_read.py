@@ -1,9 +1,11 @@
 #!/usr/bin/env python
 """Micro-benchmark of the fused memory read (rmem_attn_read + rmem_attn_read_combine) at the
 480p K=4 / 720p K=8 problem sizes, isolated, HIP-event timed: long-term bank read, self read
-(T=1) and windowed short-term read, for a sweep of key splits.
+(T=1) and windowed short-term read, for a sweep of key splits; phase stamps of the kernel
+(rmem_attn_read_trace); a numerical cross-check of every configuration against fp64 is NOT done here
+(tests/test_hip_ops.py), only finiteness.
 
-    python tools/kbench_read.py [--h 31 --w 54 --T 4] [--splits 5,7,9,12]
+    python tools/kbench_read.py [--h 31 --w 54 --T 4] [--splits 4,6,9]
 """
 import argparse
 import ctypes as C
@@ -39,11 +41,18 @@ def main():
     ap.add_argument("--w", type=int, default=54)
     ap.add_argument("--T", type=int, default=4)
     ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--splits", default="4,9")
+    ap.add_argument("--splits", default="6,9")
+    ap.add_argument("--win-splits", default="1,2")
     ap.add_argument("--only", default="")
+    ap.add_argument("--no-trace", action="store_true", help="timing only (for rocprofv3 --pmc runs)")
+    ap.add_argument("--old", action="store_true", help="also time the round-2 kernel if the library still has it (rmem_attn_read_v128)")
     args = ap.parse_args()
     from rmem_amd import hip
     lib = hip.load()
+    old_read = getattr(lib, "rmem_attn_read_v128", None) if args.old else None
+    if old_read is not None:
+        old_read.restype = C.c_int
+        old_read.argtypes = [C.POINTER(hip.ReadArgs), C.c_void_p]
     dev = torch.device("cuda:0")
     h, w, T = args.h, args.w, args.T
     N = h * w
@@ -63,7 +72,9 @@ def main():
     mass = torch.zeros(N, T, device=dev)
     st = hip.stream_ptr()
     res = {"N": N, "T": T}
-    maxs = max(int(x) for x in args.splits.split(","))
+    ls = [int(x) for x in args.splits.split(",")]
+    ws = [int(x) for x in args.win_splits.split(",")]
+    maxs = max(ls + ws)
     part = torch.zeros(maxs, Np, 1024, device=dev)
     ml = torch.zeros(maxs, Np, 2, device=dev)
     lslot = torch.zeros(maxs, Np, T, 2, device=dev)
@@ -87,40 +98,58 @@ def main():
         ca.mass = mass.data_ptr() if want_mass else None
         return ra, ca
 
-    for name, mode, Tn, wm in (("long", 0, T, True), ("self", 0, 1, False), ("window", 1, 1, False)):
+    for name, mode, Tn, wm, sweep in (("long", 0, T, True, ls), ("self", 0, 1, False, ls), ("window", 1, 1, False, ws)):
         if args.only and name not in args.only:
             continue
-        for ks in [int(x) for x in args.splits.split(",")]:
+        for ks in sweep:
             ra, ca = mk(mode, Tn, ks, wm)
-            t_read = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(ra), st), "read"), args.iters)
-            t_comb = timeit(lambda: hip.check(lib.rmem_attn_read_combine(C.byref(ca), st), "comb"), args.iters)
-
-            def both():
-                hip.check(lib.rmem_attn_read(C.byref(ra), st), "read")
-                hip.check(lib.rmem_attn_read_combine(C.byref(ca), st), "comb")
-            t_both = timeit(both, args.iters)
-            res[f"{name}_ks{ks}"] = {"read_us": round(t_read, 2), "combine_us": round(t_comb, 2), "both_us": round(t_both, 2)}
+            ent = {}
+            ent["read_us"] = round(timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(ra), st), "read"), args.iters), 2)
+            ent["combine_us"] = round(timeit(lambda: hip.check(lib.rmem_attn_read_combine(C.byref(ca), st), "comb"), args.iters), 2)
+            torch.cuda.synchronize()
+            ent["finite"] = bool(torch.isfinite(G).all())
+            if old_read is not None:
+                ent["old_read_us"] = round(timeit(lambda: hip.check(old_read(C.byref(ra), st), "old"), args.iters), 2)
+            if args.no_trace:
+                res[f"{name}_ks{ks}"] = ent
+                continue
+            # phase stamps
+            nblk = 8 * (((N + 63) // 64 * ks + 7) // 8)
+            tr = torch.zeros(nblk, 64, dtype=torch.int64, device=dev)
+            for var in ("1", "4", "8", "9", "0"):              # experiments of the tracing kernel (RMEM_READ_VAR); 0 = product, last
+                os.environ["RMEM_READ_VAR"] = var
+                tr.zero_()
+                for _ in range(2):
+                    hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace")
+                torch.cuda.synchronize()
+                tt = tr.cpu().double()
+                tt = tt[tt[:, 3] > 0]
+                ent[f"var{var}_unit_cycles_mean"] = round(float((tt[:, 3] - tt[:, 0]).mean()))
+                ent[f"var{var}_loop_per_tile"] = round(float(((tt[:, 2] - tt[:, 1]) / tt[:, 28].clamp(min=1)).mean()))
+                if var in ("8", "9"):
+                    ntv = tt[:, 28:29].clamp(min=1)
+                    ent[f"var{var}_top_score_pv_barrier_w0_w4"] = [[round(float((tt[:, o + w] / ntv[:, 0]).mean())) for o in (40, 4, 12, 20)] for w in (0, 4)]
+            t = tr.cpu().double()
+            t = t[t[:, 3] > 0]
+            if t.shape[0]:
+                nt = t[:, 28:29].clamp(min=1)
+                per = lambda a, b: [round(float(x)) for x in (t[:, a:b] / nt).mean(dim=0)]
+                hw = tr.cpu()[tr.cpu()[:, 3] > 0][0, 32:40]
+                ent["trace_cycles"] = {
+                    "units": int(t.shape[0]), "tiles_per_unit": [float(nt.min()), float(nt.mean()), float(nt.max())],
+                    "unit_total_mean_max": [float((t[:, 3] - t[:, 0]).mean()), float((t[:, 3] - t[:, 0]).max())],
+                    "reference_pass": float((t[:, 1] - t[:, 0]).mean()),
+                    "reference_pass_per_tile": float(((t[:, 1] - t[:, 0]) / nt[:, 0]).mean()),
+                    "loop": float((t[:, 2] - t[:, 1]).mean()), "loop_per_tile": float(((t[:, 2] - t[:, 1]) / nt[:, 0]).mean()),
+                    "stats_and_flush": float((t[:, 3] - t[:, 2]).mean()),
+                    "score_per_tile_by_wave": per(4, 12), "pv_per_tile_by_wave": per(12, 20), "barrier_per_tile_by_wave": per(20, 28), "top_per_tile_by_wave": per(40, 48),
+                    "simd_of_wave_block0": [int((int(x) >> 4) & 3) for x in hw], "cu_of_wave_block0": [int((int(x) >> 8) & 15) for x in hw]}
+            res[f"{name}_ks{ks}"] = ent
         if name == "long":
             flops = 2.0 * N * (T * N) * (1024 + 128)
             best = min(v["read_us"] for k, v in res.items() if k.startswith("long_ks"))
             res["long_best_read_us"] = best
             res["long_algorithmic_TFLOPs"] = round(flops / (best * 1e-6) / 1e12, 1)
-    # phase stamps of the long read (debug aid of the kernel: bank mode with R != NULL)
-    ks = 9
-    ra, ca = mk(0, T, ks, True)
-    nblk = 8 * ((((Np // 128) * 2 * ks) + 7) // 8)
-    tr = torch.zeros(nblk, 16, dtype=torch.int64, device=dev)
-    ra.R = tr.data_ptr()
-    for _ in range(3):
-        hip.check(lib.rmem_attn_read(C.byref(ra), st), "read")
-    torch.cuda.synchronize()
-    t = tr.cpu().double()
-    live = t[:, 3] > 0
-    t = t[live]
-    res["trace_ks9_cycles"] = {"blocks": int(live.sum()), "prologue": float((t[:, 1] - t[:, 0]).mean()),
-                               "loop": float((t[:, 2] - t[:, 1]).mean()), "flush": float((t[:, 3] - t[:, 2]).mean()),
-                               "per_tile": {n: float(t[:, 4 + k].mean()) / 12 for k, n in
-                                            enumerate(["score", "softmax", "barrierA", "pv", "barrierB"])}}
     print(json.dumps(res, indent=1))
 
 
