@@ -1,23 +1,6 @@
-// attn_common.h -- helpers shared by the memory-read kernels (attn.hip, fused.hip).
+// attn_common.h -- helpers of the memory-read kernel (read64.hip).
 #pragma once
 #include "rmem_common.h"
-
-// Key-tile band [t_lo, t_hi) (units of 128 keys) visible under the 15x15 window to query tile
-// `qtile` (128 queries): image rows y(q_lo)-7 .. y(q_hi)+7.  Scores, P.V and combine all use this
-// function with the same 128-query tile, so what one writes (zeros where masked) is what the
-// others read.  At 31x54 tokens a band is 7-8 key tiles (the earlier 256-query granularity, kept
-// from a removed 256-row P.V kernel, made it 9-10).
-__host__ __device__ inline void band_tiles(int qtile, int N, int h, int w, int& t_lo, int& t_hi) {
-  const int q_lo = qtile * 128;
-  int q_hi = q_lo + 127;
-  if (q_hi > N - 1) q_hi = N - 1;
-  int y_lo = q_lo / w - 7;
-  if (y_lo < 0) y_lo = 0;
-  int y_hi = q_hi / w + 7;
-  if (y_hi > h - 1) y_hi = h - 1;
-  t_lo = (y_lo * w) / 128;
-  t_hi = ((y_hi + 1) * w + 127) / 128;
-}
 
 // Logical -> physical slot map held in two 64-bit scalars (8 bits per slot, T <= 16).  A
 // per-k-tile `slot_map[t]` read is a dependent global load followed by s_waitcnt vmcnt(0): it

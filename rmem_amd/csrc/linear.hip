@@ -80,7 +80,7 @@ __device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, i
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm) {
       if (a.pa_blocked) {
-        // plane output in the "blocked-16" layout of the fused memory read (fused.hip): element
+        // plane output in the "blocked-16" layout of the fused memory read (read64.hip): element
         // (row, col) at ((row / 16) * ldpa + col) * 16 + row % 16.  Accumulator registers 4g..4g+3
         // are 4 consecutive rows of one 16-row block: one 8-byte store per plane.
 #pragma unroll

@@ -23,12 +23,12 @@
 // conversions.  K tiles arrive by LDS-DMA (global_load_lds_dwordx4, two tiles ahead, XOR swizzle applied
 // to the SOURCE address: no staging registers, no ds_write phase); P and K are double-buffered.
 //
-// The fixed reference m is the row maximum over the unit's keys from a first pass with the hi planes
-// only (8 small MFMAs per wave per tile; error a few hundredths), so the weights stay within a few per
-// cent of 1 at the maximum and the accumulators never need a rescale.  Exactness for ANY input: the
-// main pass flags a score above m + RD_THR (weights would leave fp16); a flagged unit is simply redone
-// with the reference taken from the exact three-product scores (bit-identical to the main pass's, so
-// the weights are <= 1).  Never taken on real data; tests/test_hip_ops.py forces it.
+// The fixed reference m comes from a first pass over every fourth key with the hi planes only (one small
+// MFMA tile per wave per two key tiles): m <= the row maximum, and within a few units of it, so the weights
+// are O(1) at the maximum and the accumulators never need a rescale.  Exactness for ANY input: the main
+// pass flags a score above m + RD_THR (weights would leave fp16); a flagged unit is simply redone with the
+// reference taken from the exact three-product scores of every key (bit-identical to the main pass's, so
+// the weights are <= 1).  Not taken on real data; tests/test_hip_ops.py forces it.
 //
 // Split precision: every product is hi*lo' + lo*hi' + hi*hi' (fp32 accumulate).  Key splits write
 // un-normalised partials + (max, sum) [+ per-slot (sum, max)]; rmem_attn_read_combine merges them.
@@ -58,7 +58,6 @@ constexpr int R6_MX = R6_SL + 8192;         // [2 key halves][64 queries] row ma
 constexpr int R6_L = R6_MX + 512;           // [2][64] row sums
 constexpr int R6_FL = R6_L + 512;           // [8] overflow flags
 constexpr int R6_LDS = R6_FL + 64;
-constexpr int R6_RING = 6;                  // hi-plane K tiles of the reference pass live in [R6_K, R6_SL): 6 x 16 KB
 constexpr float RD_NEG = -3.0e38f;
 constexpr float RD_THR = 14.0f;             // log2 domain: weights up to 2^14 = 16384 < 65504 (fp16 hi plane)
 
@@ -181,30 +180,34 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   // (a division per use was ~60 scalar instructions, three times per tile)
   struct TileIter {
     int t, kt;
-    __device__ __forceinline__ void init(int i, int tv, int mode) {
-      t = 0;
-      kt = i;
-      if (mode == 0) {
-        t = i / tv;
-        kt = i - t * tv;
-      }
-    }
-    __device__ __forceinline__ void step(int tv, int mode) {
-      ++kt;
-      if (mode == 0 && kt == tv) {
-        kt = 0;
-        ++t;
-      }
-    }
+    long kslot, vslot;                                // element offsets of the slot's K / V planes
     __device__ __forceinline__ int key0() const { return kt * 64; }
   };
+  auto tinit = [&](TileIter& ti, int i) __attribute__((always_inline)) {
+    ti.t = 0;
+    ti.kt = i;
+    if (MODE == 0) {
+      ti.t = i / tv;
+      ti.kt = i - ti.t * tv;
+    }
+    const long sl = lut(ti.t);
+    ti.kslot = sl * a.k_slot_stride;
+    ti.vslot = sl * a.v_slot_stride;
+  };
+  auto tstep = [&](TileIter& ti) __attribute__((always_inline)) {
+    ++ti.kt;
+    if (MODE == 0 && ti.kt == tv) {                   // next slot (once per 27 tiles at 480p): the only place a slot is looked up
+      ti.kt = 0;
+      ++ti.t;
+      const long sl = lut(ti.t);
+      ti.kslot = sl * a.k_slot_stride;
+      ti.vslot = sl * a.v_slot_stride;
+    }
+  };
   auto dma_k = [&](const TileIter& ti, int buf, bool both) __attribute__((always_inline)) {
-    const long base = (long)lut(ti.t) * a.k_slot_stride + (long)ti.key0() * 128;
+    const long base = ti.kslot + (long)ti.key0() * 128;
     dma_plane(a.kh + base, R6_K + buf * 32768);
     if (both) dma_plane(a.kl + base, R6_K + buf * 32768 + 16384);
-  };
-  auto dma_khi = [&](const TileIter& ti, int ring_slot) __attribute__((always_inline)) {
-    dma_plane(a.kh + (long)lut(ti.t) * a.k_slot_stride + (long)ti.key0() * 128, R6_K + ring_slot * 16384);
   };
 
   // ---- Q tile -> LDS (once)
@@ -251,7 +254,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   };
 
   // ---- scores of one tile for this lane: y[kt*4 + r] = log2-domain logit of key kh*32 + kt*16 + lb*4 + r
-  // (RD_NEG where masked).  EXACT: the three-product form; else the hi planes only (reference pass).
+  // (RD_NEG where masked).  EXACT: the three-product form (main pass, redo reference pass); else the hi planes only.
   // kb = byte offset of the tile's K image relative to R6_K.
   int cur_t = -1;
   float bias2 = 0.f;
@@ -331,55 +334,125 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
 
   float m = RD_NEG;                                   // this query's reference (log2 domain)
   for (int attempt = 0; attempt < 2; ++attempt) {
-    // ================= reference pass: m = max over the unit's keys of the (approximate) scores
+    // ================= reference pass: m <= (and close to) the maximum of this query's scores over the unit's keys
     {
       float mest = RD_NEG;
       cur_t = -1;
-      // hi planes only: a ring of R6_RING tiles in [R6_K, R6_SL), in PAIRS, one barrier per pair (one barrier per
-      // tile left this pass latency-bound: 2.0-2.5 k cycles per tile for 8 small MFMAs per wave); exact (redo):
-      // both planes, the two K buffers, one tile per barrier
-      const bool exact = attempt > 0;
-      const int G = exact ? 1 : 2;                    // tiles per barrier
-      const int ring_groups = exact ? 2 : R6_RING / 2;
-      const int ring = G * ring_groups;               // tiles resident: 2 (both planes, the K buffers) / R6_RING (hi plane)
-      const int ngroups = (n + G - 1) / G;
-      const int pieces = exact ? 4 : 2;               // DMA instructions per tile per wave
-      TileIter tdma, tcmp;
-      tdma.init(lo, tv, MODE);
-      tcmp = tdma;
-      int issued = 0;                                 // tiles requested so far
-      auto request = [&](int upto) __attribute__((always_inline)) {        // request tiles [issued, upto)
-        for (; issued < upto && issued < n; ++issued) {
-          if (exact) dma_k(tdma, issued & 1, true);
-          else dma_khi(tdma, issued % ring);
-          tdma.step(tv, MODE);
-        }
-      };
       __syncthreads();                                // (redo: every wave is done with the images of the main pass)
-      request(ring);
-#pragma clang loop unroll(disable)
-      for (int jp = 0; jp < ngroups; ++jp) {
-        // wait for the tiles of group jp: everything requested after them may stay in flight
-        const int done_upto = G * (jp + 1) < n ? G * (jp + 1) : n;
-        const int cnt = (issued - done_upto) * pieces;
-        if (cnt >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (cnt >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (cnt >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (cnt >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                              // group jp landed for every wave; the slots of group jp - 1 are free
-        if (jp >= 1) request(G * (jp - 1 + ring_groups) + G);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int x = G * jp + e;
-          if (e < G && x < n) {
-            float y[8];
-            if (exact) scores(tcmp, (x & 1) * 32768, std::true_type{}, y);
-            else scores(tcmp, (x % ring) * 16384, std::false_type{}, y);
-            tcmp.step(tv, MODE);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) mest = fmaxf(mest, y[r]);
+      if (attempt == 0) {
+        // First attempt: hi planes only and every FOURTH key (rows 0, 4, .. of each tile).  Any m <= max works as long
+        // as max - m <= RD_THR: weights up to 2^14 keep their full hi / lo precision and small weights only move
+        // AWAY from the fp16 underflow; the maximum over a quarter of the keys of every tile is within a few units of
+        // the true one for any realistic score distribution, and where it is not the main pass flags it and the unit
+        // is redone exactly.  (The full hi-plane pass was bound by the LDS-DMA rate: 16 KB per tile, ~1.9 k cycles per
+        // tile for 8 small MFMAs per wave.)  Tiles go in PAIRS: waves 0-3 (kh = 0) take the even tile, waves 4-7 the
+        // odd one; a wave requests ONE 1 KiB piece per pair (4 sampled rows of its tile) and runs one 16 x 16 MFMA
+        // tile (16 sampled keys x 16 queries) per pair.  Ring of 4 pairs at [R6_K, R6_K + 32 KB).
+        constexpr int RP = 4;
+        const int npairs = (n + 1) / 2;
+        const int my_np = (n - kh + 1) / 2;           // pairs in which this wave has a tile
+        const int srow = 4 * qg + lb;                 // sampled row this lane requests (piece qg of the tile)
+        int roff = srow * 1024 + ((jq ^ srow) << 4);  // source: key row 4 srow, chunk jq ^ srow
+        R6_OPAQUE(roff);
+        TileIter tdma, tcmp;
+        tinit(tdma, lo + kh);
+        tcmp = tdma;
+        int requested = 0;                            // pairs requested so far
+        auto request = [&](int upto) __attribute__((always_inline)) {
+          for (; requested < upto && requested < npairs; ++requested) {
+            if (requested < my_np) {
+              const char* g = reinterpret_cast<const char*>(a.kh + tdma.kslot + (long)tdma.key0() * 128) + roff;
+              const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + R6_K + (requested & (RP - 1)) * 8192 + kh * 4096 + qg * 1024);
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(g) : "memory");
+              tstep(tdma);
+              tstep(tdma);
+            }
           }
+        };
+        request(RP);
+#pragma clang loop unroll(disable)
+        for (int p = 0; p < npairs; ++p) {
+          const int mine = requested < my_np ? requested : my_np;      // my pieces requested so far
+          const int done = p + 1 < my_np ? p + 1 : my_np;
+          const int younger = mine - done;
+          if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();                            // pair p landed for every wave; the slot of pair p - 1 is free
+          if (p >= 1) request(p + RP);
+          if (p < my_np) {
+            const int t = tcmp.t, key0 = tcmp.key0();
+            if (MODE == 0 && t != cur_t) {
+              cur_t = t;
+              bias2 = ((a.bias && qvalid) ? a.bias[(long)q * a.T + t] : 0.f) * sl2e;
+            }
+            const int kb = (p & (RP - 1)) * 8192 - kh * 4096;         // the sampled tile's image relative to this wave's K rows
+            frag8_t fq[4], fk[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+              fq[k4] = *reinterpret_cast<const frag8_t*>(smem + aq(k4));
+              fk[k4] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb);
+            }
+            f32x4_t sc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) sc = RMEM_MFMA16(fk[k4], fq[k4], sc);
+            // lane: query jq, sampled rows 4 lb + r, i.e. keys key0 + 16 lb + 4 r
+            if (MODE == 0) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float yv = fmaf(sc[r], sl2e, bias2);
+                mest = fmaxf(mest, key0 + 16 * lb + 4 * r < a.N ? yv : RD_NEG);
+              }
+            } else {
+              int idx[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int tok = key0 + 16 * lb + 4 * r;
+                const int ky = fast_div(tok, inv_w);
+                const int kx = tok - ky * a.w;
+                const int dy = ky - qy, dx = kx - qx;
+                const bool valid = qvalid && tok < a.N && dy >= -7 && dy <= 7 && dx >= -7 && dx <= 7;
+                idx[r] = valid ? ((dy + 7) * 15 + dx + 7) * rcs : -1;
+              }
+              float rb[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) rb[r] = Rq[idx[r] < 0 ? 0 : idx[r]];
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                mest = fmaxf(mest, idx[r] < 0 ? RD_NEG : fmaf(sc[r], sl2e, rb[r] * 1.44269504088896341f));
+            }
+            tstep(tcmp);
+            tstep(tcmp);
+          }
+        }
+      } else {
+        // Redo: the exact three-product scores of EVERY key (bit-identical to the main pass's), both planes through
+        // the two K buffers, one tile per barrier.
+        TileIter tdma, tcmp;
+        tinit(tdma, lo);
+        tcmp = tdma;
+        int issued = 0;                               // tiles requested so far
+        auto request = [&](int upto) __attribute__((always_inline)) {
+          for (; issued < upto && issued < n; ++issued) {
+            dma_k(tdma, issued & 1, true);
+            tstep(tdma);
+          }
+        };
+        request(2);
+#pragma clang loop unroll(disable)
+        for (int x = 0; x < n; ++x) {
+          if (issued - (x + 1) >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 4 pieces per tile per wave
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();                            // tile x landed for every wave; the buffer of tile x - 1 is free
+          if (x >= 1) request(x + 2);
+          float y[8];
+          scores(tcmp, (x & 1) * 32768, std::true_type{}, y);
+          tstep(tcmp);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) mest = fmaxf(mest, y[r]);
         }
       }
       mest = fmaxf(mest, __shfl_xor(mest, 16));
@@ -391,9 +464,9 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       if (tid < 8) flag[tid] = 0;
       // first K tiles of the main pass
       TileIter t01;
-      t01.init(lo, tv, MODE);
+      tinit(t01, lo);
       dma_k(t01, 0, true);
-      t01.step(tv, MODE);
+      tstep(t01);
       if (n > 1) dma_k(t01, 1, true);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -428,18 +501,31 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
         lcur = 0.f;
         sum_t = t;
       }
+      // one overflow test per tile: the largest score against the reference (sentinels are far below)
+      const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+      over = over || (ymax - m > RD_THR);
+      const bool masked = MODE == 1 || ti.key0() + 64 > a.N;      // (wave-uniform) the tile may hold RD_NEG sentinels
       float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         f32x2_t pp[2];
+        if (!masked) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sv = y[kt * 4 + e];
-          over = over || (sv - m > RD_THR);
-          float p = __builtin_amdgcn_exp2f(sv - m);   // sentinels (-3e38) give exactly 0 unless m is one too
-          p = sv > -2.9e38f ? p : 0.f;
-          psum += p;
-          pp[e >> 1][e & 1] = p;
+          for (int e = 0; e < 4; ++e) {
+            const float p = __builtin_amdgcn_exp2f(y[kt * 4 + e] - m);
+            psum += p;
+            pp[e >> 1][e & 1] = p;
+          }
+        } else {
+          asm volatile("" ::: "memory");              // keeps this form a branch (as a select it costs every tile two more VALU per key)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sv = y[kt * 4 + e];
+            float p = __builtin_amdgcn_exp2f(sv - m); // sentinels (-3e38) give exactly 0 unless m is one too
+            p = sv > -2.9e38f ? p : 0.f;
+            psum += p;
+            pp[e >> 1][e & 1] = p;
+          }
         }
         // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
         const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
@@ -524,8 +610,8 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     // wave is then past barrier it - 1, which ends the readers of K(it) (same buffer) -- and waited for before
     // the wave's next barrier; being OLDER than the V loads that follow, it never lengthens a wait for those.
     TileIter t_sc, t_dma, t_v;                        // tiles of the next SCORE (it + 1), K request (it + 2), P.V (px)
-    t_sc.init(lo, tv, MODE);
-    t_dma.init(lo + 2 < hi_t ? lo + 2 : lo, tv, MODE);
+    tinit(t_sc, lo);
+    tinit(t_dma, lo + 2 < hi_t ? lo + 2 : lo);
     t_v = t_sc;
 #pragma clang loop unroll(disable)
     for (int it = -1; it < n; ++it) {
@@ -541,11 +627,11 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       // K(it + 2) into the buffer of K(it): its readers, SCORE(it), are past barrier it - 1 (for both groups)
       if (it >= 0 && it + 2 < n) {
         dma_k(t_dma, it & 1, true);
-        t_dma.step(tv, MODE);
+        tstep(t_dma);
       }
       if (do_pv) {                                    // V fragments of the first four steps: in flight during SCORE
-        const long vb = (long)lut(t_v.t) * a.v_slot_stride + (long)(t_v.key0() >> 4) * (1024 * 16);
-        t_v.step(tv, MODE);
+        const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
+        tstep(t_v);
         vhp = a.vh + vb;
         vlp = a.vl + vb;
         vstep(std::integral_constant<int, 0>{});
@@ -560,7 +646,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       }
       if (do_sc) {
         score_phase(t_sc, (it + 1) & 1, (it + 1) & 1);
-        t_sc.step(tv, MODE);
+        tstep(t_sc);
       }
       if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
       if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
@@ -791,4 +877,109 @@ extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, vo
   else go(&read64_trace_kernel<9>);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
+}
+
+// ------------------------------------------------------------------ merge key splits + gate (+ mass)
+// G[q][c] = U[q][c] * (sum_z w_z part[z][q][c]) / (sum_z w_z l_z),  w_z = exp(m_z - max_z m_z);
+// mass[q][t] = (sum_z lslot[z][q][t].sum * exp(lslot[z][q][t].max - m)) / L   (record_attn_weight,
+// layers/transformer.py:1186-1192).  Splits are visited in order: no floating-point atomics.
+__device__ __forceinline__ void read_combine_body(const rmem_read_combine_args& a, int q, float* sh) {
+  const int tid = threadIdx.x;
+  float* wz = sh;             // [ksplits <= 32]
+  float* stat = sh + 32;      // [0] = max, [1] = 1 / L
+  if (tid < 64) {
+    float mz = RD_NEG, lz = 0.f;
+    if (tid < a.ksplits) {
+      mz = a.ml[((long)tid * a.Npad + q) * 2];
+      lz = a.ml[((long)tid * a.Npad + q) * 2 + 1];
+      if (!(lz > 0.f)) mz = RD_NEG;
+    }
+    float mm = mz;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+    const float w = lz > 0.f ? expf(mz - mm) : 0.f;
+    float L = w * lz;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o);
+    if (tid < a.ksplits) wz[tid] = w;
+    if (tid == 0) {
+      stat[0] = mm;
+      stat[1] = 1.0f / L;
+    }
+  }
+  __syncthreads();
+  const float inv_l = stat[1];
+  if (a.mass && tid < a.T) {
+    float sl = 0.f;
+    for (int z = 0; z < a.ksplits; ++z) {
+      if (wz[z] == 0.f) continue;
+      const float* e = a.lslot + (((long)z * a.Npad + q) * a.T + tid) * 2;
+      if (e[0] != 0.f) sl += e[0] * expf(e[1] - stat[0]);
+    }
+    a.mass[(long)q * a.T + tid] = sl * inv_l;
+  }
+  for (int c = tid * 4; c < a.ncols; c += 1024) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // 4 splits per step: their loads are unconditional and in flight together (an empty split's
+    // partial is never written: its value is dropped by the select, not by a branch around the load)
+    for (int z0 = 0; z0 < a.ksplits; z0 += 4) {
+      float4 v[4];
+      float w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int z = z0 + i < a.ksplits ? z0 + i : a.ksplits - 1;
+        w[i] = z0 + i < a.ksplits ? wz[z] : 0.f;
+        v[i] = *reinterpret_cast<const float4*>(a.part + ((long)z * a.Npad + q) * a.ncols + c);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool on = w[i] != 0.f;
+        acc.x += w[i] * (on ? v[i].x : 0.f);
+        acc.y += w[i] * (on ? v[i].y : 0.f);
+        acc.z += w[i] * (on ? v[i].z : 0.f);
+        acc.w += w[i] * (on ? v[i].w : 0.f);
+      }
+    }
+    const float4 uu = *reinterpret_cast<const float4*>(a.U + (long)q * a.ldu + c);
+    float4 g;
+    g.x = acc.x * inv_l * uu.x;
+    g.y = acc.y * inv_l * uu.y;
+    g.z = acc.z * inv_l * uu.z;
+    g.w = acc.w * inv_l * uu.w;
+    *reinterpret_cast<float4*>(a.G + (long)q * a.ldg + c) = g;
+  }
+}
+
+__device__ void read_combine_kernel(const rmem_read_combine_args& a, int) {
+  __shared__ float sh[40];
+  read_combine_body(a, blockIdx.x, sh);
+}
+
+struct Combine2Args {
+  rmem_read_combine_args a, b;
+};
+__device__ void read_combine2_kernel(const Combine2Args& g, int) {
+  __shared__ float sh[40];
+  if ((int)blockIdx.x < g.a.N) read_combine_body(g.a, blockIdx.x, sh);
+  else read_combine_body(g.b, blockIdx.x - g.a.N, sh);
+}
+
+static int read_combine_ok(const rmem_read_combine_args& a) {
+  if (a.N <= 0 || a.Npad < a.N || a.T <= 0 || a.T > 64 || a.ksplits <= 0 || a.ksplits > 32) return 0;
+  if ((a.ncols % 4) != 0 || !a.part || !a.ml || !a.U || !a.G || (a.ldu % 4) || (a.ldg % 4)) return 0;
+  if (a.mass && !a.lslot) return 0;
+  return 1;
+}
+
+extern "C" int rmem_attn_read_combine(const rmem_read_combine_args* ap, void* stream) {
+  if (!ap || !read_combine_ok(*ap)) return RMEM_ERR_INVALID;
+  return rmem::launch<rmem_read_combine_args, read_combine_kernel, 256>(*ap, dim3(ap->N), dim3(256), 0,
+                                                                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rmem_attn_read_combine2(const rmem_read_combine_args* ap, const rmem_read_combine_args* bp, void* stream) {
+  if (!ap || !bp || !read_combine_ok(*ap) || !read_combine_ok(*bp)) return RMEM_ERR_INVALID;
+  Combine2Args g{*ap, *bp};
+  return rmem::launch<Combine2Args, read_combine2_kernel, 256>(g, dim3(ap->N + bp->N), dim3(256), 0,
+                                                               static_cast<hipStream_t>(stream));
 }

@@ -6,7 +6,7 @@ same state (long-term bank, short-term frame, EMA / visit dictionaries), but
 
   * the memory bank is a pre-allocated ring of ``cap + 2`` physical slots per layer
     (K planes [slot][Npad][128], V planes "blocked-16" [slot][Npad/16][1024][16], the
-    operand layout of the fused read, csrc/fused.hip); append / evict only edit a
+    operand layout of the fused read, csrc/read64.hip); append / evict only edit a
     logical->physical map, no ``torch.cat`` re-allocation (transformer.py:859-878, :967-989);
   * every memory read (long-term bank, windowed short-term, self) is ONE flash-style launch
     (rmem_attn_read / rmem_attn_read2) + one combine: no probability matrix in HBM;

@@ -278,7 +278,7 @@ def test_bias_act_nchw(geom):
             assert torch.equal(got, want), (geom, res is not None, relu)
 
 
-# ------------------------------------------------------------------ fused memory read (fused.hip)
+# ------------------------------------------------------------------ fused memory read (read64.hip)
 def _block16(Vf):
     """channel-major V^T [S][C][Npad] -> blocked-16 [S][Npad/16][C][16] (the layout rmem_attn_read reads)."""
     S, Cn, Np = Vf.shape
