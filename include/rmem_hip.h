@@ -270,6 +270,33 @@ int rmem_id_assign(const uint8_t *label, int32_t H, int32_t W, const float *wt, 
 int rmem_attn_mass_reduce(const float *mass, int32_t N, int32_t T, const float *fg, float *out,
                           void *stream);
 
+/* ---- RMem eviction on the device (restrict_long_memories, layers/transformer.py:880-991; trigger
+ * engines/aot_engine.py:350-369) -- no device-to-host copy on the path.
+ * rmem_fg_weights: fg[q] = 1 - softmax_c(bilinear, align_corners, of logits [C][Hl][Wl] at the h x w token grid)[0].
+ * rmem_bank_state (device memory, one per clip): the per-slot dictionaries of the rule, aligned with the bank
+ * positions of the logical->physical map `maps` (the int32 array rmem_read_args.slot_map points to).
+ * rmem_bank_reset: the bank becomes the one slot `slot` (a reference frame); rmem_bank_append: the frame in `slot`
+ * joins the bank; rmem_bank_policy_step: given w[t] = rmem_attn_mass_reduce(...) over the n_att attended slots,
+ * EMA(0.8) + visit counts + UCB bonus + argmin, and -- when the bank holds more than cap slots -- the dropped
+ * position is deleted from `maps` and the state.  result (may be NULL; pinned host or device memory) receives
+ * {sequence number, dropped position or -1, slots left}, sequence number written last. */
+typedef struct {
+  int32_t T;                               /* slots in the bank                                   */
+  int32_t index[16];                       /* frame index of bank position p (long_memories_indexes) */
+  int32_t visits[16];                      /* stored_frame_times of position p (0 = not stored)   */
+  int32_t has_ema[16];                     /* position p is in stored_attn_weight_dict            */
+  float ema[16];
+  int32_t last_drop;                       /* position dropped by the last step, -1 = none        */
+  int32_t steps;                           /* policy steps taken so far                           */
+} rmem_bank_state;
+
+int rmem_fg_weights(const float *logits, int32_t C, int32_t Hl, int32_t Wl, int32_t h, int32_t w, float *fg,
+                    void *stream);
+int rmem_bank_reset(int32_t *maps, rmem_bank_state *st, int32_t slot, int32_t frame_index, void *stream);
+int rmem_bank_append(int32_t *maps, rmem_bank_state *st, int32_t slot, int32_t frame_index, void *stream);
+int rmem_bank_policy_step(int32_t *maps, rmem_bank_state *st, const float *w, int32_t n_att, int32_t cap,
+                          int32_t former, int32_t *result, void *stream);
+
 /* Support op outside the LSTT: GroupNorm(groups) (+ optional ReLU) on a contiguous NCHW
  * tensor of batch 1, as used by the FPN head's ConvGN blocks (decoders/fpn.py:43-62,
  * layers/basic.py:60-70).  Requires (C/groups)*HW % 4 == 0.  ws: >= 2*32*groups doubles. */

@@ -585,6 +585,164 @@ extern "C" int rmem_attn_mass_reduce(const float* mass, int32_t N, int32_t T, co
                                                                  static_cast<hipStream_t>(stream));
 }
 
+// ------------------------------------------------------------------ RMem eviction on the device
+// restrict_long_memories (layers/transformer.py:880-991) without a host round trip: foreground weights,
+// EMA(0.8) of the normalised attention mass, visit counts, UCB bonus 1.5*sqrt(log(sum c)/(c+8)), argmin, and
+// the deletion of the dropped slot from the logical->physical map -- all in device memory (one thread: the bank
+// holds <= 16 slots).  The arithmetic is the reference's, operation by operation, in fp32 with every product and
+// sum rounded on its own (no fma contraction); the sum that normalises the mass is numpy's pairwise order for
+// < 16 values (what the host rule rmem_amd.lstt.rmem_policy_step uses); log of the (integer) visit total is
+// taken in double and rounded once.
+
+// fg[q] = 1 - softmax_c(bilinear_align_corners(logits -> h x w))[0]   (engines/aot_engine.py:350-356); the
+// interpolation arithmetic of torch's upsample_bilinear2d kernel (fp32 source index = scale * dst)
+__global__ __launch_bounds__(256) void fg_weights_kernel(const float* __restrict__ lg, int C, int Hl, int Wl, int h, int w,
+                                                        float rh, float rw, float* __restrict__ fg) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= h * w) return;
+  const int Y = q / w, X = q - Y * w;
+  const float fy = rh * (float)Y, fx = rw * (float)X;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int yp = (y0 < Hl - 1) ? 1 : 0, xp = (x0 < Wl - 1) ? 1 : 0;
+  const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+  float v[16];
+  float mx = -3.0e38f;
+  for (int c = 0; c < C; ++c) {
+    const float* p = lg + ((long)c * Hl + y0) * Wl + x0;
+    v[c] = ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[(long)yp * Wl] + lx1 * p[(long)yp * Wl + xp]);
+    mx = fmaxf(mx, v[c]);
+  }
+  float sum = 0.f, e0 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float e = expf(v[c] - mx);
+    if (c == 0) e0 = e;
+    sum += e;
+  }
+  fg[q] = 1.f - e0 / sum;
+}
+
+extern "C" int rmem_fg_weights(const float* logits, int32_t C, int32_t Hl, int32_t Wl, int32_t h, int32_t w, float* fg,
+                               void* stream) {
+  if (!logits || !fg || C <= 0 || C > 16 || Hl <= 0 || Wl <= 0 || h <= 0 || w <= 0) return RMEM_ERR_INVALID;
+  const float rh = h > 1 ? (float)(Hl - 1) / (float)(h - 1) : 0.f, rw = w > 1 ? (float)(Wl - 1) / (float)(w - 1) : 0.f;
+  hipLaunchKernelGGL(fg_weights_kernel, dim3((h * w + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), logits, C,
+                     Hl, Wl, h, w, rh, rw, fg);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+__global__ void bank_edit_kernel(int32_t* maps, rmem_bank_state* st, int slot, int frame_index, int reset) {
+  if (threadIdx.x != 0) return;
+  if (reset) {                                       // init_memory (transformer.py:993-998): the bank is this one frame
+    st->T = 0;
+    st->last_drop = -1;
+  }
+  const int T = st->T;
+  if (T >= 16) return;
+  maps[T] = slot;
+  st->index[T] = frame_index;
+  st->visits[T] = 0;                                 // "not in stored_frame_times"
+  st->has_ema[T] = 0;                                // "not in stored_attn_weight_dict"
+  st->ema[T] = 0.f;
+  st->T = T + 1;
+}
+
+extern "C" int rmem_bank_reset(int32_t* maps, rmem_bank_state* st, int32_t slot, int32_t frame_index, void* stream) {
+  if (!maps || !st || slot < 0) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(bank_edit_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), maps, st, slot, frame_index, 1);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_bank_append(int32_t* maps, rmem_bank_state* st, int32_t slot, int32_t frame_index, void* stream) {
+  if (!maps || !st || slot < 0) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(bank_edit_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), maps, st, slot, frame_index, 0);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+__device__ __forceinline__ float sum_np_order(const float* a, int n) {      // numpy's float32 add.reduce for n < 128
+  if (n < 8) {
+    float r = 0.f;
+    for (int i = 0; i < n; ++i) r = __fadd_rn(r, a[i]);
+    return r;
+  }
+  float r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i + 8 <= n; i += 8)
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+  float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                        __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+  for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+  return res;
+}
+
+__global__ void bank_policy_kernel(int32_t* maps, rmem_bank_state* st, const float* __restrict__ w_raw, int n_att, int cap,
+                                   int former, int32_t* result) {
+  if (threadIdx.x != 0) return;
+  const int T = st->T;                               // includes the slot appended by this update (not attended)
+  if (n_att > T) n_att = T;
+  float w[16], c[16];
+  for (int i = 0; i < n_att; ++i) w[i] = w_raw[i];
+  const float wsum = sum_np_order(w, n_att);
+  for (int i = 0; i < n_att; ++i) {                  // normalise, moving mean over the slots seen before (:905-928)
+    float x = __fdiv_rn(w[i], wsum);
+    if (st->has_ema[i]) x = __fadd_rn(__fmul_rn(0.2f, st->ema[i]), __fmul_rn(0.8f, x));
+    w[i] = x;
+    st->ema[i] = x;
+    st->has_ema[i] = 1;
+  }
+  for (int i = n_att; i < T; ++i) st->has_ema[i] = 0;     // the dictionary is rebuilt from the attended slots only
+  for (int i = 0; i < T; ++i) st->visits[i] += 1;         // (:930-941; 0 = "not stored" -> 1)
+  int drop = former;
+  const int nc = T - 1;                              // counts over indexes[:-1]
+  if (nc > 0) {
+    for (int i = 0; i < nc; ++i) c[i] = (float)st->visits[i];
+    c[0] = (float)nc;
+    const float lg = (float)log((double)sum_np_order(c, nc));
+    if (n_att > 1) {
+      float best = 0.f;
+      for (int i = 1; i < n_att; ++i) {
+        const float score = __fadd_rn(w[i], __fmul_rn(1.5f, __fsqrt_rn(__fdiv_rn(lg, __fadd_rn(c[i], 8.0f)))));
+        if (i == 1 || score < best) {
+          best = score;
+          drop = i;
+        }
+      }
+    }
+  }
+  int dropped = -1;
+  if (T > cap && drop < T) {                         // (:967-991) delete the slot in every layer = delete its map entry
+    dropped = drop;
+    for (int i = drop; i + 1 < T; ++i) {
+      maps[i] = maps[i + 1];
+      st->index[i] = st->index[i + 1];
+      st->visits[i] = st->visits[i + 1];
+      st->has_ema[i] = st->has_ema[i + 1];
+      st->ema[i] = st->ema[i + 1];
+    }
+    st->T = T - 1;
+  }
+  st->last_drop = dropped;
+  st->steps += 1;
+  if (result) {
+    result[1] = dropped;
+    result[2] = st->T;
+    __threadfence_system();
+    result[0] = st->steps;                           // sequence number last: a host that sees it sees the rest
+  }
+}
+
+extern "C" int rmem_bank_policy_step(int32_t* maps, rmem_bank_state* st, const float* w, int32_t n_att, int32_t cap,
+                                     int32_t former, int32_t* result, void* stream) {
+  if (!maps || !st || !w || n_att < 0 || n_att > 16 || cap <= 0) return RMEM_ERR_INVALID;
+  hipLaunchKernelGGL(bank_policy_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), maps, st, w, n_att, cap,
+                     former, result);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 // ------------------------------------------------------------------ fp32 -> planes
 __global__ void split_planes_kernel(const float* x, long n, h16_t* hi, h16_t* lo) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -1046,4 +1204,4 @@ extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 10; }   // 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_abi_version(void) { return 11; }   // 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

@@ -119,6 +119,19 @@ class DeAOTEngine(nn.Module):
         self._lstt_wv = 0
         self.restart_engine()
 
+    @property
+    def long_memories_indexes(self) -> List[int]:
+        """Frame indexes of the bank slots (aot_engine.py:322, 346).  With the eviction rule on the device the
+        host's copy may lag by one decision; reading it waits for that decision."""
+        l = self.__dict__.get("_modules", {}).get("lstt") or self.__dict__.get("lstt")
+        if l is not None and hasattr(l, "resolve_policy"):
+            l.resolve_policy(block=True)
+        return self._lmi
+
+    @long_memories_indexes.setter
+    def long_memories_indexes(self, v):
+        self._lmi = v
+
     def restart_engine(self):                                   # aot_engine.py:533-563
         self.frame_step = 0
         self.last_mem_step = -1
@@ -193,6 +206,7 @@ class DeAOTEngine(nn.Module):
         # no ignore channel on reference frames: the reference calls assign_identity without an
         # ignore mask here (aot_engine.py:304 -> :209-213), so a 255 pixel contributes nothing
         self.lstt.assign_identity(self._label_u8(mask), ignore=False)
+        self.lstt.ref_frame_index = self.frame_step
         out = self.lstt.forward(self._tokens(enc[-1]), ref_frame=True)
         self.last_mem_step = frame_step
         # A reference frame re-initialises the bank to one slot.  The reference keeps the old
@@ -572,16 +586,23 @@ class DeAOTEngine(nn.Module):
                     setattr(l, k, v)
                 g = self._ug[key]
             g.replay()
-            l._update_host(update_long)
+            l._update_host(update_long, self.frame_step)
         else:
             l.assign_identity(lab)
-            l.update_short_memories(update_long)
+            l._update_device(update_long)
+            l._update_host(update_long, self.frame_step)
         if update_long:
-            self.long_memories_indexes.append(self.frame_step)
-            lg = F.interpolate(self.pred_id_logits, size=self.enc_size_2d, mode="bilinear",
-                               align_corners=True)
-            fg = (1 - torch.softmax(lg, dim=1)[:, 0]).reshape(-1).contiguous()
-            self.lstt.restrict_long_memories(self.long_memories_indexes, fg)
+            idx = self.long_memories_indexes            # (brings the host's view up to date first)
+            idx.append(self.frame_step)
+            if getattr(self.lstt, "device_policy", False):
+                # foreground weights, attention-mass reduction, EMA / UCB rule and the deletion of the dropped slot
+                # all on the device (rmem_fg_weights, rmem_attn_mass_reduce, rmem_bank_policy_step): no D2H here
+                self.lstt.restrict_long_memories(idx, logits=self.pred_id_logits)
+            else:
+                lg = F.interpolate(self.pred_id_logits, size=self.enc_size_2d, mode="bilinear",
+                                   align_corners=True)
+                fg = (1 - torch.softmax(lg, dim=1)[:, 0]).reshape(-1).contiguous()
+                self.lstt.restrict_long_memories(idx, fg)
 
 
 class DeAOTInferEngine(nn.Module):

@@ -82,6 +82,11 @@ class MHACombineArgs(C.Structure):
     ]
 
 
+class BankState(C.Structure):
+    _fields_ = [("T", i32), ("index", i32 * 16), ("visits", i32 * 16), ("has_ema", i32 * 16), ("ema", f32 * 16),
+                ("last_drop", i32), ("steps", i32)]
+
+
 class LabelSrc(C.Structure):
     _fields_ = [("logits", c_p), ("h", i32), ("w", i32), ("flip", i32)]
 
@@ -89,7 +94,8 @@ class LabelSrc(C.Structure):
 EXPORTS = [
     "rmem_abi_version", "rmem_linear",
     "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
-    "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_split_planes", "rmem_groupnorm_nchw",
+    "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_fg_weights", "rmem_bank_reset", "rmem_bank_append",
+    "rmem_bank_policy_step", "rmem_split_planes", "rmem_groupnorm_nchw",
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
@@ -139,6 +145,10 @@ def load():
     lib.rmem_id_assign.argtypes = [c_p, i32, i32, c_p, c_p, i32, i32, i32, i32, i32, i32, i32,
                                    c_p, c_p, f32, c_p, c_p, i64, c_p, i64, i32, c_p]
     lib.rmem_attn_mass_reduce.argtypes = [c_p, i32, i32, c_p, c_p, c_p]
+    lib.rmem_fg_weights.argtypes = [c_p, i32, i32, i32, i32, i32, c_p, c_p]
+    lib.rmem_bank_reset.argtypes = [c_p, c_p, i32, i32, c_p]
+    lib.rmem_bank_append.argtypes = [c_p, c_p, i32, i32, c_p]
+    lib.rmem_bank_policy_step.argtypes = [c_p, c_p, c_p, i32, i32, i32, c_p, c_p]
     lib.rmem_split_planes.argtypes = [c_p, i64, c_p, c_p, c_p]
     lib.rmem_groupnorm_nchw.argtypes = [c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]
     lib.rmem_groupnorm_nchw_bias.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]
@@ -322,10 +332,12 @@ def upsample_add_nchw_(y: torch.Tensor, bias, x: torch.Tensor, align_corners: bo
     return out
 
 
-def set_ints(dst: torch.Tensor, values):
-    """dst[:len(values)] = values (int32 device tensor), stream-ordered, no host-blocking copy."""
+def set_ints(dst: torch.Tensor, values, offset: int = 0, count: int = None):
+    """dst[offset : offset + count] = values (int32 device tensor; count defaults to all 32 - offset entries,
+    zero-filled past the values), stream-ordered, no host-blocking copy."""
+    n = (32 - offset) if count is None else int(count)
     arr = (i32 * 32)(*(list(values) + [0] * (32 - len(values))))
-    check(load().rmem_set_ints(dst.data_ptr(), arr, 32, stream_ptr()), "rmem_set_ints")
+    check(load().rmem_set_ints(dst.data_ptr() + 4 * offset, arr, n, stream_ptr()), "rmem_set_ints")
 
 
 def labels_from_logits(logits_list, flips, out_hw, align_corners: bool, out: torch.Tensor = None) -> torch.Tensor:

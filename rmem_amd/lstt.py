@@ -107,7 +107,13 @@ class DeAOTLSTT:
         self.Tmax = self.cap + 1          # bank momentarily holds cap+1 before eviction
         if self.Tmax > 16:
             raise hip.RmemError("bank of more than 15 slots is not supported (temporal-PE rows array)")
-        self.S = self.cap + 2             # physical slots
+        # RMem eviction on the device (csrc/pointwise.hip: rmem_fg_weights / rmem_bank_*): the host learns which slot
+        # was dropped from a pinned result word when it next looks (normally one frame later, without waiting), so a
+        # frame may start while the bank momentarily counts cap + 1 candidates: one more physical slot than the
+        # cap + 2 the host-side rule needs.  RMEM_HOST_POLICY=1 (and the several-clips-per-launch path, the AOT
+        # block) keep the rule on the host: one blocking D2H of <= 16 floats per long-memory update.
+        self.device_policy = self.clips_per_launch == 1 and os.environ.get("RMEM_HOST_POLICY") != "1"
+        self.S = self.cap + 3             # physical slots
         self.nsplit = int(nsplit)
         self._timing = False
         self._events = []
@@ -285,6 +291,10 @@ class DeAOTLSTT:
         self.mass = z(N, self.Tmax)
         self.w_out = z(self.Tmax)
         self.maps = z(32, dt=torch.int32)                         # [0:16] bank map, [16] short slot
+        self.bank_state = z(C.sizeof(hip.BankState) // 4, dt=torch.int32)       # rmem_bank_state (device-side eviction)
+        self.policy_result = torch.zeros(4, dtype=torch.int32).pin_memory() if self.dev.type == "cuda" else \
+            torch.zeros(4, dtype=torch.int32)
+        self.fg = z(N)
         self.k_slot_stride = Np * 128
         self.v_slot_stride = 1024 * Np
 
@@ -344,6 +354,34 @@ class DeAOTLSTT:
         self.mass_T = 0
         self.ema: Dict[int, float] = {}
         self.visits: Dict[int, int] = {}
+        self._pending = None               # device-side eviction whose result the host has not read yet
+        self._policy_seq = getattr(self, "_policy_seq", 0)
+
+    @property
+    def _dev_policy(self) -> bool:
+        return self.device_policy and not self._batched
+
+    def resolve_policy(self, block: bool = True) -> bool:
+        """Bring the host's view of the bank (self.bank, the engine's long_memories_indexes) up to date with the
+        last device-side eviction.  block=False: only if its result has already arrived."""
+        p = self._pending
+        if p is None:
+            return True
+        if not block and not p["event"].query():
+            return False
+        p["event"].synchronize()
+        res = self.policy_result
+        if int(res[0]) != p["seq"]:
+            raise hip.RmemError(f"eviction result out of sequence ({int(res[0])} != {p['seq']})")
+        drop = int(res[1])
+        self._pending = None
+        self.last_policy = dict(drop=drop)
+        if p["expect_drop"]:
+            if drop < 0 or int(res[2]) != len(self.bank) - 1:
+                raise hip.RmemError("device-side eviction disagrees with the host's bank length")
+            del self.bank[drop]
+            p["indexes"].remove(p["indexes"][drop])
+        return True
 
     # ------------------------------------------------------------------ helpers
     def _sync_maps(self):
@@ -471,17 +509,25 @@ class DeAOTLSTT:
     def _prepare(self, ref_frame: bool):
         """Host part of a forward pass: pick the slot the frame is written to and publish the
         logical->physical slot map (one small H2D copy).  Nothing here is baked into a graph."""
+        self.resolve_policy(block=False)
         self.cur = self._free_slot()
         if ref_frame:
             bank_map, short = [self.cur], self.cur
         else:
             bank_map, short = self.bank, self.short
-        self._T = len(bank_map)
+        # (a device-side eviction the host has not read yet: the bank already holds one slot less)
+        self._T = len(bank_map) - (1 if (not ref_frame and self._pending is not None and self._pending["expect_drop"]) else 0)
         # [0:16] bank map, [16] short-term slot of this frame, [17] short-term slot of the NEXT frame
         # (= this frame's slot): read by the next frame's hoisted front part, see _forward_device
-        vals = list(bank_map) + [0] * (16 - self._T) + [short, self.cur]
+        vals = list(bank_map)[:16] + [0] * (16 - len(bank_map)) + [short, self.cur]
         self._map_vals = vals
-        if not self._batched:              # batched: one upload for all clips (rmem_amd.batched)
+        if self._dev_policy:               # the bank map lives on the device: only the short-term slots are published
+            hip.set_ints(self.maps, [short, self.cur], offset=16, count=2)
+            if ref_frame:
+                self._pending = None
+                hip.check(hip.load().rmem_bank_reset(self.maps.data_ptr(), self.bank_state.data_ptr(), self.cur,
+                                                     int(getattr(self, "ref_frame_index", 0)), hip.stream_ptr()), "rmem_bank_reset")
+        elif not self._batched:            # batched: one upload for all clips (rmem_amd.batched)
             hip.set_ints(self.maps, vals)
 
     def next_free_slot(self) -> int:
@@ -641,17 +687,39 @@ class DeAOTLSTT:
         """Capturable device part: the three ID_V GEMMs into the current slot (one launch)."""
         hip.linear_grouped([self._idv(l, self.cur, launch=False) for l in range(self.L)])
 
-    def _update_host(self, update_long: bool):
+    def _update_host(self, update_long: bool, frame_index: int = 0):
         self.short = self.cur
         if update_long:
+            self.resolve_policy(block=True)            # (an eviction from `gap` frames ago: long since there)
             self.bank = self.bank + [self.cur]
+            if self._dev_policy:
+                hip.check(hip.load().rmem_bank_append(self.maps.data_ptr(), self.bank_state.data_ptr(), self.cur,
+                                                      int(frame_index), hip.stream_ptr()), "rmem_bank_append")
 
-    def restrict_long_memories(self, indexes: List[int], fg: torch.Tensor) -> Optional[int]:
-        """restrict_long_memories (transformer.py:880-991).  fg: [N] fp32 on device.
-        Mutates ``indexes`` like the reference; returns the dropped position or None."""
+    def restrict_long_memories(self, indexes: List[int], fg: Optional[torch.Tensor] = None,
+                               logits: Optional[torch.Tensor] = None) -> Optional[int]:
+        """restrict_long_memories (transformer.py:880-991).  Give either fg ([N] fp32 on device) or the decoder
+        logits [1,C,Hl,Wl] the foreground weights are taken from (aot_engine.py:350-356).  Mutates ``indexes``
+        like the reference.  Host rule: returns the dropped position or None.  Device rule (the default for one
+        clip per launch): everything is queued on the stream, nothing is read back here -- returns None, and
+        ``indexes`` / self.bank catch up in resolve_policy()."""
+        if logits is not None:
+            lg = logits[0].contiguous()
+            hip.check(hip.load().rmem_fg_weights(lg.data_ptr(), lg.shape[0], lg.shape[1], lg.shape[2], self.h, self.w,
+                                                 self.fg.data_ptr(), hip.stream_ptr()), "rmem_fg_weights")
+            fg = self.fg
         self._mass_reduce_device(fg)
-        w = self.w_out[:self.mass_T].cpu().numpy().astype(np.float32)        # the one D2H per long update
-        return self._restrict_host(indexes, w)
+        if not self._dev_policy:
+            w = self.w_out[:self.mass_T].cpu().numpy().astype(np.float32)        # the one D2H per long update
+            return self._restrict_host(indexes, w)
+        self._policy_seq += 1
+        hip.check(hip.load().rmem_bank_policy_step(
+            self.maps.data_ptr(), self.bank_state.data_ptr(), self.w_out.data_ptr(), self.mass_T, self.cap,
+            self.cfg.FORMER_MEM_LEN, self.policy_result.data_ptr(), hip.stream_ptr()), "rmem_bank_policy_step")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._pending = dict(event=ev, seq=self._policy_seq, indexes=indexes, expect_drop=len(self.bank) > self.cap)
+        return None
 
     def _mass_reduce_device(self, fg: torch.Tensor):
         hip.check(hip.load().rmem_attn_mass_reduce(self.mass.data_ptr(), self.N, self.mass_T, fg.data_ptr(),

@@ -370,7 +370,7 @@ class AOTLSTT:
             hip.linear(self.t3id_pl, W.Wvm, N, 256, 256, ldx=256, ldy=256, bias=W.bvm, d0=nV[l].data_ptr(),
                        ldd0=256, nsplit=ns)
 
-    def _update_host(self, update_long: bool):
+    def _update_host(self, update_long: bool, frame_index: int = 0):
         self._swap_short()
         if update_long:
             self.bank = self.bank + [self.cur]

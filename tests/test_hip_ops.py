@@ -495,3 +495,67 @@ def test_linear_blocked_output(hip):
                      _silu(S[:, 256:].double() @ W2[512:].double().t() + b2[512:].double())], 1)
     got = dst.float().cpu().permute(0, 2, 1).reshape(Np, 1024)
     assert (got[:ntok].double() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
+
+
+def test_fg_weights_vs_torch(hip):
+    """rmem_fg_weights = 1 - softmax(bilinear align_corners resize of the decoder logits to the token grid)[0]
+    (engines/aot_engine.py:350-356) against the torch ops of the reference, on the CPU and on the GPU."""
+    import torch.nn.functional as F
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(5)
+    for (Hl, Wl, h, w) in ((121, 213, 31, 54), (181, 321, 46, 81), (25, 33, 7, 9), (5, 9, 5, 9)):
+        lg = _rand(rs, 1, 11, Hl, Wl, scale=4.0)
+        lg[:, 4:] = -1e10                                   # unused ids are masked like this (aot_engine.py:451-453)
+        d = lg.to(DEV)
+        fg = torch.zeros(h * w, device=DEV)
+        hip.check(lib.rmem_fg_weights(d.data_ptr(), 11, Hl, Wl, h, w, fg.data_ptr(), st), "fg")
+        ref = (1 - torch.softmax(F.interpolate(lg, size=(h, w), mode="bilinear", align_corners=True), dim=1)[:, 0]).reshape(-1)
+        refg = (1 - torch.softmax(F.interpolate(d, size=(h, w), mode="bilinear", align_corners=True), dim=1)[:, 0]).reshape(-1)
+        torch.cuda.synchronize()
+        assert (fg.cpu() - ref).abs().max().item() < 2e-6, (Hl, Wl)
+        assert (fg - refg).abs().max().item() < 2e-6, (Hl, Wl)
+
+
+@pytest.mark.parametrize("cap,former", [(4, 1), (8, 1), (2, 1)])
+def test_bank_policy_on_device_vs_host_rule(hip, cap, former):
+    """rmem_bank_reset / rmem_bank_append / rmem_bank_policy_step against the host rule
+    rmem_amd.lstt.rmem_policy_step (itself pinned to the reference's EMA / visit dictionaries by the golden
+    clips): 60 long-memory updates with random attention masses -- every dropped position, the slot map, the
+    frame indexes and the stored EMA / visit values must be IDENTICAL (same fp32 operations in the same order)."""
+    import ctypes as C
+    from rmem_amd.lstt import rmem_policy_step
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(cap)
+    maps = torch.zeros(32, dtype=torch.int32, device=DEV)
+    state = torch.zeros(C.sizeof(hip.BankState) // 4, dtype=torch.int32, device=DEV)
+    res = torch.zeros(4, dtype=torch.int32, device=DEV)
+    S = cap + 3
+    bank, idx, ema, visits = [0], [0], {}, {}
+    hip.check(lib.rmem_bank_reset(maps.data_ptr(), state.data_ptr(), 0, 0, st), "reset")
+    for step in range(1, 61):
+        slot = next(s for s in range(S) if s not in bank)
+        hip.check(lib.rmem_bank_append(maps.data_ptr(), state.data_ptr(), slot, 5 * step, st), "append")
+        bank.append(slot)
+        idx.append(5 * step)
+        w = (rs.rand(len(bank) - 1).astype(np.float32) ** 3) * 1674.0 + 1e-3
+        if step % 7 == 0:
+            w[1:] = w[1]                                     # ties: the first minimum wins
+        wd = torch.from_numpy(w).to(DEV)
+        hip.check(lib.rmem_bank_policy_step(maps.data_ptr(), state.data_ptr(), wd.data_ptr(), len(w), cap, former,
+                                            res.data_ptr(), st), "policy")
+        wn = w / w.sum(dtype=np.float32)
+        drop, ema, visits = rmem_policy_step(wn, idx, ema, visits, former)
+        dropped = -1
+        if len(bank) > cap:
+            dropped = drop
+            del bank[drop]
+            idx.remove(idx[drop])
+        torch.cuda.synchronize()
+        r = res.cpu().tolist()
+        stc = hip.BankState.from_buffer_copy(state.cpu().numpy().tobytes())
+        assert r[0] == step and r[1] == dropped and r[2] == len(bank) == stc.T, (step, r, dropped, bank)
+        assert maps.cpu().tolist()[:len(bank)] == bank and list(stc.index)[:len(bank)] == idx, step
+        for p, fi in enumerate(idx):                         # dictionaries are keyed by frame index on the host
+            assert (fi in ema) == bool(stc.has_ema[p]) and stc.visits[p] == visits.get(fi, 0), (step, p)
+            if fi in ema:
+                assert np.float32(stc.ema[p]) == np.float32(ema[fi]), (step, p, stc.ema[p], ema[fi])
