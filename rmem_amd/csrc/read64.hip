@@ -23,9 +23,9 @@
 // conversions.  K tiles arrive by LDS-DMA (global_load_lds_dwordx4, two tiles ahead, XOR swizzle applied
 // to the SOURCE address: no staging registers, no ds_write phase); P and K are double-buffered.
 //
-// The fixed reference m comes from a first pass over every fourth key with the hi planes only (one small
-// MFMA tile per wave per two key tiles): m <= the row maximum, and within a few units of it, so the weights
-// are O(1) at the maximum and the accumulators never need a rescale.  Exactness for ANY input: the main
+// The fixed reference m is the row maximum over the unit's keys from a first pass with the hi planes only
+// (8 small MFMAs per wave per tile; error a few hundredths), so the weights stay within a few per cent of 1
+// at the maximum and the accumulators never need a rescale.  Exactness for ANY input: the main
 // pass flags a score above m + RD_THR (weights would leave fp16); a flagged unit is simply redone with the
 // reference taken from the exact three-product scores of every key (bit-identical to the main pass's, so
 // the weights are <= 1).  Not taken on real data; tests/test_hip_ops.py forces it.
@@ -340,93 +340,60 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       cur_t = -1;
       __syncthreads();                                // (redo: every wave is done with the images of the main pass)
       if (attempt == 0) {
-        // First attempt: hi planes only and every FOURTH key (rows 0, 4, .. of each tile).  Any m <= max works as long
-        // as max - m <= RD_THR: weights up to 2^14 keep their full hi / lo precision and small weights only move
-        // AWAY from the fp16 underflow; the maximum over a quarter of the keys of every tile is within a few units of
-        // the true one for any realistic score distribution, and where it is not the main pass flags it and the unit
-        // is redone exactly.  (The full hi-plane pass was bound by the LDS-DMA rate: 16 KB per tile, ~1.9 k cycles per
-        // tile for 8 small MFMAs per wave.)  Tiles go in PAIRS: waves 0-3 (kh = 0) take the even tile, waves 4-7 the
-        // odd one; a wave requests ONE 1 KiB piece per pair (4 sampled rows of its tile) and runs one 16 x 16 MFMA
-        // tile (16 sampled keys x 16 queries) per pair.  Ring of 4 pairs at [R6_K, R6_K + 32 KB).
-        constexpr int RP = 4;
+        // First attempt: the hi planes only (8 small MFMAs per wave per tile; the maximum is off by a few hundredths).
+        // Tiles go in PAIRS, one barrier per pair.  The K tiles of this pass are staged through REGISTERS (4 loads +
+        // 4 ds_write_b128 per wave per pair, swizzle on the source address, the same image the LDS-DMA builds): the
+        // DMA path moves ~12 B / clk / CU, and at 16 KB per tile that alone was 1.3-1.9 k cycles per tile of a pass
+        // whose arithmetic is nothing.  (Every key is looked at: a sub-sampled maximum misses the one dominant key
+        // of peaked attention -- the diagonal of the self read, the same position of the previous frame -- and every
+        // such unit then pays the exact redo: measured, LSTT forward 0.94 -> 1.07 ms.)
+        constexpr int RP = 3;                          // ring of 3 pairs = 6 hi-plane tiles in [R6_K, R6_K + 96 KB)
         const int npairs = (n + 1) / 2;
-        const int my_np = (n - kh + 1) / 2;           // pairs in which this wave has a tile
-        const int srow = 4 * qg + lb;                 // sampled row this lane requests (piece qg of the tile)
-        int roff = srow * 1024 + ((jq ^ srow) << 4);  // source: key row 4 srow, chunk jq ^ srow
-        R6_OPAQUE(roff);
-        TileIter tdma, tcmp;
-        tinit(tdma, lo + kh);
-        tcmp = tdma;
-        int requested = 0;                            // pairs requested so far
-        auto request = [&](int upto) __attribute__((always_inline)) {
-          for (; requested < upto && requested < npairs; ++requested) {
-            if (requested < my_np) {
-              const char* g = reinterpret_cast<const char*>(a.kh + tdma.kslot + (long)tdma.key0() * 128) + roff;
-              const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + R6_K + (requested & (RP - 1)) * 8192 + kh * 4096 + qg * 1024);
-              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(g) : "memory");
-              tstep(tdma);
-              tstep(tdma);
-            }
+        TileIter tld, tcmp;
+        tinit(tld, lo);
+        tcmp = tld;
+        u32x4_t rk[4];                                 // [tile of the pair][piece wave / wave + 8]
+        auto kload = [&]() __attribute__((always_inline)) {             // request the pair at tld (clamped to valid tiles)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const char* src = reinterpret_cast<const char*>(a.kh + tld.kslot + (long)tld.key0() * 128) + dma_off0;
+            rk[e * 2 + 0] = *reinterpret_cast<const u32x4_t*>(src);
+            rk[e * 2 + 1] = *reinterpret_cast<const u32x4_t*>(src + 8192);
+            if (tld.t * tv + tld.kt + 1 < k_hi) tstep(tld);             // (never steps past the last tile of the read:
+                                                                        //  a clamped request repeats a tile nobody uses)
           }
         };
-        request(RP);
+        auto kstore = [&](int pair) __attribute__((always_inline)) {
+          const int base = R6_K + (pair % RP) * 32768 + wave * 1024 + lane * 16;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            *reinterpret_cast<u32x4_t*>(smem + base + e * 16384) = rk[e * 2 + 0];
+            *reinterpret_cast<u32x4_t*>(smem + base + e * 16384 + 8192) = rk[e * 2 + 1];
+          }
+        };
+        kload();
+        kstore(0);
+        if (npairs > 1) kload();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the Q tile's DMA)
+        __syncthreads();
 #pragma clang loop unroll(disable)
         for (int p = 0; p < npairs; ++p) {
-          const int mine = requested < my_np ? requested : my_np;      // my pieces requested so far
-          const int done = p + 1 < my_np ? p + 1 : my_np;
-          const int younger = mine - done;
-          if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-          else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-          else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();                            // pair p landed for every wave; the slot of pair p - 1 is free
-          if (p >= 1) request(p + RP);
-          if (p < my_np) {
-            const int t = tcmp.t, key0 = tcmp.key0();
-            if (MODE == 0 && t != cur_t) {
-              cur_t = t;
-              bias2 = ((a.bias && qvalid) ? a.bias[(long)q * a.T + t] : 0.f) * sl2e;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int x = 2 * p + e;
+            if (x < n) {
+              float y[8];
+              scores(tcmp, (p % RP) * 32768 + e * 16384, std::false_type{}, y);
+              tstep(tcmp);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) mest = fmaxf(mest, y[r]);
             }
-            const int kb = (p & (RP - 1)) * 8192 - kh * 4096;         // the sampled tile's image relative to this wave's K rows
-            frag8_t fq[4], fk[4];
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-              fq[k4] = *reinterpret_cast<const frag8_t*>(smem + aq(k4));
-              fk[k4] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb);
-            }
-            f32x4_t sc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[r] = 0.f;
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) sc = RMEM_MFMA16(fk[k4], fq[k4], sc);
-            // lane: query jq, sampled rows 4 lb + r, i.e. keys key0 + 16 lb + 4 r
-            if (MODE == 0) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float yv = fmaf(sc[r], sl2e, bias2);
-                mest = fmaxf(mest, key0 + 16 * lb + 4 * r < a.N ? yv : RD_NEG);
-              }
-            } else {
-              int idx[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int tok = key0 + 16 * lb + 4 * r;
-                const int ky = fast_div(tok, inv_w);
-                const int kx = tok - ky * a.w;
-                const int dy = ky - qy, dx = kx - qx;
-                const bool valid = qvalid && tok < a.N && dy >= -7 && dy <= 7 && dx >= -7 && dx <= 7;
-                idx[r] = valid ? ((dy + 7) * 15 + dx + 7) * rcs : -1;
-              }
-              float rb[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) rb[r] = Rq[idx[r] < 0 ? 0 : idx[r]];
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                mest = fmaxf(mest, idx[r] < 0 ? RD_NEG : fmaf(sc[r], sl2e, rb[r] * 1.44269504088896341f));
-            }
-            tstep(tcmp);
-            tstep(tcmp);
           }
+          if (p + 1 < npairs) {
+            kstore(p + 1);                             // requested one iteration ago; its slot was last read in iteration p - 2
+            if (p + 2 < npairs) kload();
+          }
+          __syncthreads();
         }
       } else {
         // Redo: the exact three-product scores of EVERY key (bit-identical to the main pass's), both planes through

@@ -63,7 +63,7 @@ def from_trace(path, frames):
     # the dominant kernel of bench.py's roofline entry: the long-term P.V launches are the first
     # pv_kernel launch of every layer on the long chain = the longest third of the pv_kernel dispatches
     pv = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[start:end]
-                if r["Kernel_Name"].startswith("read2_kernel"))
+                if r["Kernel_Name"].startswith(("read64x2_kernel", "read2_kernel")))
     if pv:
         PV_LONG = (len(pv), sum(pv) / len(pv), min(pv), max(pv))
     return [(k, v[0], v[1], v[1] / v[0], 100 * v[1] / tot) for k, v in agg.items()]
@@ -82,7 +82,7 @@ def main():
     rows.sort(key=lambda r: -r[2])
     rows = [(short_name(r[0]),) + tuple(r[1:]) for r in rows]
     tot = sum(r[2] for r in rows)
-    ours = ("read2_kernel", "read_kernel", "read_combine", "linear_kernel", "linear_grouped", "pv_kernel", "pv16_kernel", "scores_kernel", "scores2_kernel",
+    ours = ("read64", "fg_weights", "bank_policy", "bank_edit", "read2_kernel", "read_kernel", "read_combine", "linear_kernel", "linear_grouped", "pv_kernel", "pv16_kernel", "scores_kernel", "scores2_kernel",
             "combine_kernel", "combine2_kernel", "dwconv5x5",
             "layernorm_", "gn2_", "gn_nchw", "gn_tok", "id_assign", "pe_bias", "mass_reduce", "split_planes",
             "bias_act_nchw", "upsample_add", "labels_kernel", "label_resize", "set_ints", "mha_", "transpose_planes",
@@ -96,7 +96,7 @@ def main():
         print(f"wall-clock span {SPAN[0]:.1f} us/frame, GPU busy (union over streams) {SPAN[1]:.1f} us/frame: "
               f"{tot/frames - SPAN[1]:.1f} us/frame of kernel time runs concurrently with other kernels\n")
     if PV_LONG:
-        print(f"`read2_kernel` launches (bench.py roofline kernel: fused long-term + windowed memory read of a layer): "
+        print(f"`read64x2_kernel` launches (bench.py roofline kernel: fused long-term + windowed memory read of a layer): "
               f"{PV_LONG[0]} launches, mean {PV_LONG[1]:.1f} us (min {PV_LONG[2]:.1f}, max {PV_LONG[3]:.1f}) "
               f"-- inside a frame, beside the encoder stream\n")
     print("| kernel | calls | calls/frame | total us | avg us | % |")
