@@ -132,6 +132,9 @@ def max_over_ranks(dist, elapsed: float, dev):
 
 def main():
     args = parse()
+    if not args.batched:       # reproducible convolutions (rmem_amd/determinism.py): free for one clip per engine, so the
+        from rmem_amd.determinism import reproducible_convolutions      # clip hashes of --config clips64 repeat run to run;
+        reproducible_convolutions()                                     # MIOpen at batch B needs the solvers this disables
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher around us: become one
         raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))

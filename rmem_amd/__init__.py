@@ -1,18 +1,4 @@
 """rmem_amd -- MI355X-native RMem (restricted-memory AOT/DeAOT) inference hot path."""
-import os as _os
-
-# MIOpen's implicit-GEMM convolution solvers are switched off for this process (set before the first
-# convolution; an explicit setting in the environment wins).  Measured on MI355X / ROCm 7.2
-# (tools/encoder_race_probe.py, profiles/r03_i_encoder_race_probe_97x129.json): at small frame sizes
-# (97x129) MIOpen picks an implicit-GEMM solver for the encoder's stride-2 1x1 downsample convolutions
-# whose output differs from call to call (~1e-5, kernel launches serialised or not), which is what made
-# every closed-loop comparison of the product engines "almost always" equal instead of equal; with the
-# family disabled the encoder and the decoder are bit-reproducible call to call and process to process
-# at both 97x129 and 481x849 (profiles/r03_parity_mode_probe.json), and the headline bench does not move
-# (466.7 vs 463.8 frames/s on one box, profiles/r03_j_bench_ab_*.json).  The hot path itself (csrc/) has
-# no floating-point atomics and never depended on this.
-_os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM", "0")
-
-from .config import get_config, ModelConfig  # noqa: E402,F401
+from .config import get_config, ModelConfig  # noqa: F401
 
 __version__ = "0.1.0"

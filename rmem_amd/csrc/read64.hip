@@ -46,13 +46,10 @@ typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
 #define RMEM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
-// LDS map.  Operand images of Q and K have 256-byte rows (128 fp16 of one plane); the 16-byte chunk c of
-// row r sits at position c ^ (r & 15): conflict-free for the 16x16x32 fragment reads (row = lane & 15,
-// chunk = 4 k-step + lane >> 4) and reachable by LDS-DMA, whose destination is lane-linear.  The P image
-// has 128-byte rows (64 keys of one plane) with chunk c at c ^ ((r >> 1) & 7) (gemm_core.h).
-constexpr int R6_Q = 0;                     // [plane][64 queries][256 B]
-constexpr int R6_K = 32768;                 // 2 buffers x [plane][64 keys][256 B]
-constexpr int R6_P = 98304;                 // 2 buffers x [plane][64 queries][128 B]
+// LDS map (the images' internal layouts are described where their addresses are formed, read64_body).
+constexpr int R6_Q = 0;                     // [plane][d-step][64 queries][64 B]
+constexpr int R6_K = 32768;                 // 2 buffers x [plane][d-step][64 keys][64 B]
+constexpr int R6_P = 98304;                 // 2 buffers x [plane][k-step][64 queries][32 B]
 constexpr int R6_SL = 131072;               // per-slot sums [16 slots][2 key halves][64 queries] fp32
 constexpr int R6_MX = R6_SL + 8192;         // [2 key halves][64 queries] row maximum (reference pass)
 constexpr int R6_L = R6_MX + 512;           // [2][64] row sums
@@ -131,38 +128,48 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   float* l_ex = reinterpret_cast<float*>(smem + R6_L);
   int* flag = reinterpret_cast<int*>(smem + R6_FL);
 
-  // ---- LDS addresses.  ONE opaque register per family: the swizzles are XORs of disjoint bit fields, so the
-  // address of d-step k4 / k-step ks / key group kt is the base XOR a constant (eight separate registers per
-  // family were the ones the allocator spilled -- reloaded inside the P.V cluster, where every compiler-visible
-  // vector-memory access drains the V ring: s_waitcnt vmcnt(0); measured 6.5 k instead of 4.2 k cycles per tile).
-  int ak0 = R6_K + (kh * 32 + jq) * 256 + ((lb ^ jq) << 4);   // score fragments: K row kh*32 (+ kt*16) + jq, chunk 4 k4 + lb
-  int aq0 = R6_Q + (qg * 16 + jq) * 256 + ((lb ^ jq) << 4);   //                  Q row qg*16 + jq
+  // ---- LDS addresses: ONE opaque register per image; everything that varies inside the loops (d-step, k-step,
+  // key group, plane, buffer) is an ADDITIVE constant that folds into the 16-bit offset field of the DS
+  // instruction.  (Round-3 history: with the XOR swizzle spanning the d-step bits, each d-step needed its own
+  // address -- eight registers per family, hoisted out of the loop, spilled and reloaded inside the P.V cluster,
+  // where every compiler-visible vector-memory access drains the V ring, s_waitcnt vmcnt(0): 6.5 k instead of 4.2 k
+  // cycles per tile; re-deriving them at the use cost ~80 VALU instructions per tile on an issue-bound loop.)
+  //
+  // Q / K images: [d-step k4 (4)][row (64)][64 B]; the 16-byte chunk lb of a (k4, row) segment sits at slot
+  // lb ^ f(row >> 2), f = (0, 3, 2, 1).  A 16x16x32 fragment read (row = lane & 15, chunk = lane >> 4) is served in
+  // groups of 16 lanes {0-3,12-15,20-27}, {4-11,16-19,28-31}, ..: within a group the (row & 3, slot) pairs are all
+  // different, i.e. 16 distinct 16-byte slots of the 256-byte bank row: conflict-free.
+  // P image: [k-step ks (4)][row (64)][32 B]; chunk hi of a (ks, row) segment at slot hi ^ ((row >> 3) & 1):
+  // conflict-free for the 32x32x16 A-fragment reads (row = lane & 31, chunk = lane >> 5).
+  const int fsw = (4 - ((jq >> 2) & 3)) & 3;                          // f of this lane's score rows (rows = .. + jq)
+  int ak0 = R6_K + (kh * 32 + jq) * 64 + ((lb ^ fsw) << 4);           // K row kh*32 (+ kt*16) + jq; + k4*4096 + kt*1024
+  int aq0 = R6_Q + (qg * 16 + jq) * 64 + ((lb ^ fsw) << 4);           // Q row qg*16 + jq;           + k4*4096
   R6_OPAQUE(ak0);
   R6_OPAQUE(aq0);
-  // (the copy is made opaque AT THE USE: a plain `base ^ constant` is loop-invariant, gets hoisted into the
-  // prologue with its thirty siblings and spilled there)
-  auto here = [&](int b) __attribute__((always_inline)) {
-    asm volatile("" : "+v"(b));
-    return b;
-  };
-  auto ak = [&](int k4) __attribute__((always_inline)) { return here(ak0) ^ (k4 << 6); };
-  auto aq = [&](int k4) __attribute__((always_inline)) { return here(aq0) ^ (k4 << 6); };
-  int apw0;                                           // P stores: row qg*16 + jq, keys kh*32 + kt*16 + lb*4 .. +3
+  auto ak = [&](int k4) __attribute__((always_inline)) { return ak0 + k4 * 4096; };
+  auto aq = [&](int k4) __attribute__((always_inline)) { return aq0 + k4 * 4096; };
+  int apw0;                                           // P stores: row qg*16 + jq, keys kh*32 + kt*16 + lb*4 .. +3 = k-step 2 kh + kt
   {
     const int row = qg * 16 + jq;
-    const int ch = kh * 4 + (lb >> 1);
-    apw0 = R6_P + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4) + (lb & 1) * 8;
+    apw0 = R6_P + kh * 4096 + row * 32 + (((lb >> 1) ^ ((row >> 3) & 1)) << 4) + (lb & 1) * 8;
     R6_OPAQUE(apw0);
   }
-  auto apw = [&](int kt) __attribute__((always_inline)) { return here(apw0) ^ (kt << 5); };
-  int apr0 = R6_P + j * 128 + ((hi ^ ((j >> 1) & 7)) << 4);   // P fragments: row j (+ 32 qi), chunk 2 ks + hi
+  auto apw = [&](int kt) __attribute__((always_inline)) { return apw0 + kt * 2048; };
+  int apr0 = R6_P + j * 32 + ((hi ^ ((j >> 3) & 1)) << 4);            // P fragments: row j (+ 32 qi), chunk hi; + ks*2048 + qi*1024
   R6_OPAQUE(apr0);
-  auto apr = [&](int ks) __attribute__((always_inline)) { return here(apr0) ^ (ks << 5); };
-  // LDS-DMA: a wave-instruction moves 1 KiB = 4 rows x 256 B; lane L lands at row L >> 4, position L & 15,
-  // and therefore fetches source chunk (L & 15) ^ (row & 15) of its row.  Pieces wave and wave + 8 of a
-  // [64 rows][256 B] plane tile: rows 4 wave + lb and 32 more (same row & 15).
-  int dma_off0 = (wave * 4 + lb) * 256 + ((jq ^ ((wave * 4 + lb) & 15)) << 4);
-  R6_OPAQUE(dma_off0);
+  auto apr = [&](int ks) __attribute__((always_inline)) { return apr0 + ks * 2048; };
+  // Staging (LDS-DMA and the register-staged reference pass): a wave-instruction moves 1 KiB = 16 rows x 64 B of
+  // one d-step block; lane L lands at row L >> 2, slot L & 3 of the piece and therefore fetches source chunk
+  // (L & 3) ^ f(L >> 4) of its row.  A [64 rows][256 B] plane tile is 16 pieces (d-step k4 = P >> 2, row group P & 3);
+  // wave w moves pieces w and w + 8: the same rows, d-steps w >> 2 and (w >> 2) + 2 (source + 128 B, image + 8 KB).
+  int dma_off0;
+  {
+    const int rowp = lane >> 2, sl = lane & 3;
+    const int g = wave & 3, k4 = wave >> 2;
+    dma_off0 = (16 * g + rowp) * 256 + k4 * 64 + ((sl ^ ((4 - ((rowp >> 2) & 3)) & 3)) << 4);
+    R6_OPAQUE(dma_off0);
+  }
+  const int dma_dst0 = (wave >> 2) * 4096 + (wave & 3) * 1024;        // image offset of piece `wave`
   // (inline assembly: the builtin form makes the compiler wait for the transfer -- s_waitcnt vmcnt(0) -- before the
   // next vector-memory instruction; this way the only waits are the explicit ones in front of the barriers.  The
   // compiler does not count these requests: its own vmcnt waits can only become stricter, never too weak.)
@@ -171,8 +178,8 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     const char* src = reinterpret_cast<const char*>(plane_rows);
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc) {
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + lds_base + (wave + 8 * pc) * 1024);
-      const char* g = src + dma_off0 + pc * 8192;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + lds_base + dma_dst0 + pc * 8192);
+      const char* g = src + dma_off0 + pc * 128;
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(g) : "memory");
     }
   };
@@ -278,11 +285,11 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       constexpr int k4 = decltype(K4)::value;
       f[0] = *reinterpret_cast<const frag8_t*>(smem + aq(k4));
       f[1] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb);
-      f[2] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + 4096);
+      f[2] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + 1024);
       if constexpr (EXACT) {
         f[3] = *reinterpret_cast<const frag8_t*>(smem + aq(k4) + 16384);
         f[4] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + 16384);
-        f[5] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + 4096));
+        f[5] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + 1024));
       }
     };
     fload(fa, std::integral_constant<int, 0>{});
@@ -358,13 +365,13 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
           for (int e = 0; e < 2; ++e) {
             const char* src = reinterpret_cast<const char*>(a.kh + tld.kslot + (long)tld.key0() * 128) + dma_off0;
             rk[e * 2 + 0] = *reinterpret_cast<const u32x4_t*>(src);
-            rk[e * 2 + 1] = *reinterpret_cast<const u32x4_t*>(src + 8192);
+            rk[e * 2 + 1] = *reinterpret_cast<const u32x4_t*>(src + 128);
             if (tld.t * tv + tld.kt + 1 < k_hi) tstep(tld);             // (never steps past the last tile of the read:
                                                                         //  a clamped request repeats a tile nobody uses)
           }
         };
         auto kstore = [&](int pair) __attribute__((always_inline)) {
-          const int base = R6_K + (pair % RP) * 32768 + wave * 1024 + lane * 16;
+          const int base = R6_K + (pair % RP) * 32768 + dma_dst0 + lane * 16;
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             *reinterpret_cast<u32x4_t*>(smem + base + e * 16384) = rk[e * 2 + 0];
@@ -546,7 +553,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
         for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
           for (int p = 0; p < 2; ++p)
-            pf[qi * 2 + p] = *reinterpret_cast<const frag8_t*>(smem + apr(ks) + (pbuf * 16384 + p * 8192 + qi * 4096));
+            pf[qi * 2 + p] = *reinterpret_cast<const frag8_t*>(smem + apr(ks) + (pbuf * 16384 + p * 8192 + qi * 1024));
       };
       pload(pa, std::integral_constant<int, 0>{});
       static_for<16>([&](auto S) {

@@ -12,6 +12,17 @@ Whether two PROCESSES then produce bit-identical encoder features on this ROCm i
 floating-point atomics and is bit-reproducible with or without this switch.
 
 ``RMEM_DETERMINISTIC=1`` in the environment applies it when ``rmem_amd.engine`` builds its first engine.
+
+``reproducible_convolutions()`` is the part that matters on this ROCm (measured, tools/encoder_race_probe.py,
+profiles/r03_i_encoder_race_probe_97x129.json): MIOpen's implicit-GEMM solver family is switched off for the
+process (MIOPEN_DEBUG_CONV_IMPLICIT_GEMM=0, only effective before the first convolution).  At small frame
+sizes (97x129) MIOpen picks an implicit-GEMM solver for the encoder's stride-2 1x1 downsample convolutions
+whose output differs from call to call (~1e-5, kernel launches serialised or not); with the family disabled
+encoder and decoder are bit-reproducible call to call and process to process at 97x129 and at 481x849
+(profiles/r03_parity_mode_probe.json).  One clip per GPU does not slow down (466.7 vs 463.8 frames/s,
+profiles/r03_j_bench_ab_*.json); several clips per launch DO (MIOpen at batch 8: 14.6 -> 21.9 ms per
+step, profiles/r03m_bench_batched8.json vs r03n), so the switch is applied by fix_random(), by the test
+suite (tests/conftest.py) and by bench.py's one-clip-per-engine modes -- not by the library on import.
 """
 from __future__ import annotations
 
@@ -21,6 +32,11 @@ import random
 _applied = False
 
 
+def reproducible_convolutions() -> None:
+    """MIOPEN_DEBUG_CONV_IMPLICIT_GEMM=0 unless the environment already says otherwise (see the module text)."""
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM", "0")
+
+
 def fix_random(seed: int = 1) -> None:
     """Mirror of tools/eval.py:21-37 (same seed offsets), with the MIOpen counterparts of the cuDNN flags."""
     global _applied
@@ -28,6 +44,7 @@ def fix_random(seed: int = 1) -> None:
     import torch
     os.environ["CUDNN_DETERMINISTIC"] = "1"
     os.environ["PYTHONHASHSEED"] = str(seed)
+    reproducible_convolutions()
     # MIOpen: "fast" find mode (2) = find-db hit or the immediate-mode fallback, never a timed search
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     os.environ.setdefault("MIOPEN_FIND_ENFORCE", "1")          # NONE: never (re)search / update the find-db

@@ -244,7 +244,7 @@ def test_sharded_clips_world_invariance_product_engines():
     """The same statement for the PRODUCT engines (MIOpen encoder / decoder on the GPU, hipGraph replay, encoder
     prefetch, hoisted front parts): identical sha256 per clip as one process and as two processes sharing
     cuda:0.  Exact since round 3: the one MIOpen solver family whose output varied from call to call is
-    disabled (rmem_amd/__init__.py, profiles/r03_i_encoder_race_probe_97x129.json) and every clip follows the
+    disabled (rmem_amd/determinism.py via tests/conftest.py, profiles/r03_i_encoder_race_probe_97x129.json) and every clip follows the
     same launch schedule from its first frame (rmem_amd/engine.py:restart_engine)."""
     h1, h2 = _world_1_vs_2(True)
     print("product engines, per-clip sha256, world=1:", [h[:12] for h in h1], "world=2:", [h[:12] for h in h2])
