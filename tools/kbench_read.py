@@ -129,9 +129,18 @@ def main():
                 if var in ("8", "9"):
                     ntv = tt[:, 28:29].clamp(min=1)
                     ent[f"var{var}_top_score_pv_barrier_w0_w4"] = [[round(float((tt[:, o + w] / ntv[:, 0]).mean())) for o in (40, 4, 12, 20)] for w in (0, 4)]
+            ent["trace_kernel_us"] = round(timeit(lambda: hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace"), args.iters), 2)
             t = tr.cpu().double()
             t = t[t[:, 3] > 0]
             if t.shape[0]:
+                # launch shape from the device-wide 100 MHz counter: when units start and end relative to the first start
+                st0 = t[:, 48].min()
+                rel = lambda col: (t[:, col] - st0) / 100.0       # us
+                ent["launch_shape_us"] = {
+                    "last_start": round(float(rel(48).max()), 2), "median_start": round(float(rel(48).median()), 2),
+                    "first_end": round(float(rel(49).min()), 2), "median_end": round(float(rel(49).median()), 2), "last_end": round(float(rel(49).max()), 2),
+                    "unit_us_mean_max": [round(float(((t[:, 49] - t[:, 48]) / 100.0).mean()), 2), round(float(((t[:, 49] - t[:, 48]) / 100.0).max()), 2)],
+                    "shader_cycles_per_us": round(float(((t[:, 3] - t[:, 0]) / ((t[:, 49] - t[:, 48]) / 100.0)).mean()), 1)}
                 nt = t[:, 28:29].clamp(min=1)
                 per = lambda a, b: [round(float(x)) for x in (t[:, a:b] / nt).mean(dim=0)]
                 hw = tr.cpu()[tr.cpu()[:, 3] > 0][0, 32:40]

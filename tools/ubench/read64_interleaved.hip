@@ -1,3 +1,14 @@
+// NOT BUILT, NOT SHIPPED -- round-3 experiment kept for the record ("interleaved slices").
+//
+// Variant of csrc/read64.hip whose main pass folds the scores / weights of tile i + 1, cut into 16 slices, between the
+// MFMAs of the 16 P.V steps of tile i (all 8 waves identical, one barrier per tile, V ring running through the tile
+// boundaries).  Measured on MI355X (gpurun_out r03o / r03p, 480p K=4): loop per tile 8.9 k cycles against 9.75-10.25 k
+// of the alternating-groups kernel that ships, but the exposed first-tile scores, nine scratch reloads in the window
+// instantiation (14 k per tile) and the same launch tail left the whole reads no faster (bank ks=9 100.8 us vs 90-99,
+// self 40.7 vs 35.5-38, window ks=2 82.9 vs 56-70), and one window geometry still aborted.  Lesson worth keeping: a
+// counted wait tied to ring registers ("+v") must be ONE statement -- in two branches the tied input is copied before
+// the wait in one of them, i.e. a register whose load has not landed is copied.
+//
 // read64.hip -- the memory read of GatedPropagation / LocalGatedPropagation (layers/attention.py:
 // 174-209, 289-358; call sites layers/transformer.py:1183, 1199, 1227) as ONE flash-style launch per
 // read: S = Q.K^T, softmax and O = P.V without ever writing the probability matrix to HBM.
@@ -54,25 +65,22 @@ constexpr int R6_SL = 131072;               // per-slot sums [16 slots][2 key ha
 constexpr int R6_MX = R6_SL + 8192;         // [2 key halves][64 queries] row maximum (reference pass)
 constexpr int R6_L = R6_MX + 512;           // [2][64] row sums
 constexpr int R6_FL = R6_L + 512;           // [8] overflow flags
-constexpr int R6_LDS = R6_FL + 64;
+constexpr int R6_DUMMY = R6_FL + 64;        // 1 KiB nobody reads: target of the K requests that fetch no tile
+constexpr int R6_LDS = R6_DUMMY + 1024;
 constexpr float RD_NEG = -3.0e38f;
 constexpr float RD_THR = 14.0f;             // log2 domain: weights up to 2^14 = 16384 < 65504 (fp16 hi plane)
 
 #define R6_OPAQUE(x) asm volatile("" : "+v"(x))
 
-// VAR (experiments, tracing kernel only): bit 0 = every wave runs SCORE then PV (no alternation between the two
-// waves of a SIMD); bit 1 = s_setprio 1 around the P.V MFMA cluster; bit 2 = NO s_setprio 1 around the rest of the
-// iteration (requests + SCORE); bit 3 = never wait for V fragments (timing only: results are wrong).
-template <int TRACE, int VAR = 0>
-__device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr) {
-  const int MODE = a.mode;                            // wave-uniform: one code path serves both reads
+// VAR (experiments, tracing kernel only): 8 = never wait for V fragments (timing only: results are wrong).
+template <int TRACE, int VAR, int MODE>
+__device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int blk, char* smem, long long* trace_base) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qg = wave & 3, kh = wave >> 2;            // score role: query group (16 queries), key half (32 keys)
   const int jq = lane & 15, lb = lane >> 4;           // 16x16 tile: column (query) / row block (4 keys)
   const int j = lane & 31, hi = lane >> 5;            // 32x32 tile (P.V)
-  const bool group_a = (VAR & 1) ? true : kh == 0;    // waves 0-3: SCORE then PV; waves 4-7: PV then SCORE
 
   // ---- work unit.  Units are ordered (split, query tile); every XCD (block b runs on XCD b % 8:
   // observed placement, used for speed only) owns a contiguous chunk, so the units of one XCD share a
@@ -118,10 +126,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   long long* trace = (TRACE && trace_base) ? trace_base + (long)blk * 64 : nullptr;   // debug aid: shader-clock stamps per block
   float* lslot_out = a.lslot;
   long long tacc[4] = {0, 0, 0, 0};                     // TRACE: this wave's cycles in SCORE / PV / waiting at barriers
-  if (trace && tid == 0) {
-    trace[0] = __builtin_readcyclecounter();
-    trace[48] = __builtin_amdgcn_s_memrealtime();     // 100 MHz, one counter for the whole device: launch shape across blocks
-  }
+  if (trace && tid == 0) trace[0] = __builtin_readcyclecounter();
 
   SlotLut lut;
   lut.load(a.slot_map, MODE == 0 ? a.T : 1);
@@ -459,54 +464,126 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[qi][ci][r] = 0.f;
-    float l = 0.f, lcur = 0.f;
+    float l = 0.f, lcur = 0.f;                        // row sum of the finished slots / of the current slot
     int sum_t = -1;                                   // slot lcur belongs to
-    bool over = false;
+    float ytop = RD_NEG;                              // largest logit seen (overflow test at the end of the pass)
     cur_t = -1;
-    u32x4_t vr[4][2];                                 // ring of V fragments: step s = (k-step, ci) lives in vr[s & 3][plane]
 
-    // SCORE(i): weights of tile i -> P image pbuf (K image kbuf)
-    auto score_phase = [&](const TileIter& ti, int kbuf, int pbuf) __attribute__((always_inline)) {
-      float y[8];
-      const int t = scores(ti, kbuf * 32768, std::true_type{}, y);
-      if (t != sum_t) {
-        if (sum_t >= 0) {                             // (wave-uniform) slot finished: park its sum
-          float v = lcur + __shfl_xor(lcur, 16);
-          v += __shfl_xor(v, 32);
-          if (lb == 0) sl_sum[(sum_t * 2 + kh) * 64 + qg * 16 + jq] = v;
+    // ---- SCORE(i) in 16 slices.  Every wave runs the P.V of tile i and, BETWEEN its MFMAs, the scores / weights of
+    // tile i + 1 (other K and P buffers): one slice after the 6 MFMAs of each of the 16 P.V steps, a handful of
+    // instructions per MFMA gap.  (The first form of this kernel alternated whole phases between the two waves of a
+    // SIMD -- one in P.V while the other scored.  Measured per tile: P.V 5.3 k cycles beside a scoring partner against
+    // 3.1 k of MFMA time, 10 k per tile; two waves that both feed the matrix pipe keep it 90 % busy, so the small work
+    // is folded into the stream that feeds it.)  Slices 0-8: fragments and MFMAs of the 4 d-steps x 2 key groups (16
+    // registers of fragments live); 9: logits, masks, overflow test; 10-13: weights; 14-15: fp16 hi / lo planes -> P.
+    f32x4_t sc[2];
+    frag8_t fq[2], fk[2];                             // Q hi / lo of a d-step; K hi / lo of a (d-step, key group)
+    float y[8];                                       // logits, overwritten by the weights
+    auto score_slice = [&](auto S, const TileIter& ti, int kb, int pbuf) __attribute__((always_inline)) {
+      constexpr int sl = decltype(S)::value;
+      auto qload = [&](auto K4) __attribute__((always_inline)) {
+        constexpr int k4 = decltype(K4)::value;
+        fq[0] = *reinterpret_cast<const frag8_t*>(smem + aq(k4));
+        fq[1] = *reinterpret_cast<const frag8_t*>(smem + aq(k4) + 16384);
+      };
+      auto kload = [&](auto K4, auto KT) __attribute__((always_inline)) {
+        constexpr int k4 = decltype(K4)::value, kt = decltype(KT)::value;
+        fk[0] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + kt * 1024);
+        fk[1] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + kt * 1024));
+      };
+      auto fmul = [&](auto KT) __attribute__((always_inline)) {       // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
+        constexpr int kt = decltype(KT)::value;
+        sc[kt] = RMEM_MFMA16(fk[0], fq[1], sc[kt]);
+        sc[kt] = RMEM_MFMA16(fk[1], fq[0], sc[kt]);
+        sc[kt] = RMEM_MFMA16(fk[0], fq[0], sc[kt]);
+      };
+      if constexpr (sl == 0) {
+        const int t = ti.t;
+        if (MODE == 0 && t != cur_t) {
+          cur_t = t;
+          bias2 = ((a.bias && qvalid) ? a.bias[(long)q * a.T + t] : 0.f) * sl2e;     // (padding queries: no row in bias)
         }
-        lcur = 0.f;
-        sum_t = t;
-      }
-      // one overflow test per tile: the largest score against the reference (sentinels are far below)
-      const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
-      over = over || (ymax - m > RD_THR);
-      const bool masked = MODE == 1 || ti.key0() + 64 > a.N;      // (wave-uniform) the tile may hold RD_NEG sentinels
-      float psum = 0.f;
+        if (t != sum_t) {
+          if (sum_t >= 0) {                           // (wave-uniform) slot finished: park its sum
+            float v = lcur + __shfl_xor(lcur, 16);
+            v += __shfl_xor(v, 32);
+            if (lb == 0) sl_sum[(sum_t * 2 + kh) * 64 + qg * 16 + jq] = v;
+          }
+          l += lcur;
+          lcur = 0.f;
+          sum_t = t;
+        }
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x2_t pp[2];
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[kt][r] = 0.f;
+        qload(std::integral_constant<int, 0>{});
+        kload(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      } else if constexpr (sl >= 1 && sl <= 8) {      // multiply pair (sl - 1), fetch pair sl
+        constexpr int done = sl - 1, next = sl;
+        fmul(std::integral_constant<int, (done & 1)>{});
+        if constexpr (next < 8) {
+          if constexpr ((next & 1) == 0) qload(std::integral_constant<int, (next < 8 ? next >> 1 : 0)>{});
+          kload(std::integral_constant<int, (next < 8 ? next >> 1 : 0)>{}, std::integral_constant<int, (next & 1)>{});
+        }
+      } else if constexpr (sl == 9) {
+        const int key0 = ti.key0();
+        const bool masked = MODE == 1 || key0 + 64 > a.N;     // (wave-uniform) the tile may hold RD_NEG sentinels
+        if (MODE == 0 && !masked) {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[kt * 4 + r] = fmaf(sc[kt][r], sl2e, bias2);
+        } else if (MODE == 0) {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int tok = key0 + kh * 32 + kt * 16 + lb * 4 + r;
+              y[kt * 4 + r] = tok < a.N ? fmaf(sc[kt][r], sl2e, bias2) : RD_NEG;
+            }
+        } else {
+          float rb[8];
+          window_terms(key0, rb);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float rbv = rb[kt * 4 + r];
+              y[kt * 4 + r] = rbv > -2.9e38f ? fmaf(sc[kt][r], sl2e, rbv) : RD_NEG;
+            }
+        }
+        // the largest score so far (sentinels are far below): tested against the reference once, after the pass
+        ytop = fmaxf(ytop, fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7]))));
+      } else if constexpr (sl >= 10 && sl <= 13) {
+        constexpr int e0 = 2 * (sl - 10);
+        const bool masked = MODE == 1 || ti.key0() + 64 > a.N;
         if (!masked) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float p = __builtin_amdgcn_exp2f(y[kt * 4 + e] - m);
-            psum += p;
-            pp[e >> 1][e & 1] = p;
+          for (int e = e0; e < e0 + 2; ++e) {
+            y[e] = __builtin_amdgcn_exp2f(y[e] - m);
+            lcur += y[e];
           }
         } else {
           asm volatile("" ::: "memory");              // keeps this form a branch (as a select it costs every tile two more VALU per key)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float sv = y[kt * 4 + e];
-            float p = __builtin_amdgcn_exp2f(sv - m); // sentinels (-3e38) give exactly 0 unless m is one too
-            p = sv > -2.9e38f ? p : 0.f;
-            psum += p;
-            pp[e >> 1][e & 1] = p;
+          for (int e = e0; e < e0 + 2; ++e) {
+            float p = __builtin_amdgcn_exp2f(y[e] - m);       // sentinels (-3e38) give exactly 0 unless m is one too
+            p = y[e] > -2.9e38f ? p : 0.f;
+            y[e] = p;
+            lcur += p;
           }
         }
+      } else if constexpr (sl == 14 || sl == 15) {
+        constexpr int kt = sl - 14;
         // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
-        const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
-        const f32x2_t r0 = pp[0] - __builtin_convertvector(h0, f32x2_t), r1 = pp[1] - __builtin_convertvector(h1, f32x2_t);
+        f32x2_t p0, p1;
+        p0[0] = y[kt * 4 + 0];
+        p0[1] = y[kt * 4 + 1];
+        p1[0] = y[kt * 4 + 2];
+        p1[1] = y[kt * 4 + 3];
+        const f16x2_t h0 = __builtin_convertvector(p0, f16x2_t), h1 = __builtin_convertvector(p1, f16x2_t);
+        const f32x2_t r0 = p0 - __builtin_convertvector(h0, f32x2_t), r1 = p1 - __builtin_convertvector(h1, f32x2_t);
         const f16x2_t l0 = __builtin_convertvector(r0, f16x2_t), l1 = __builtin_convertvector(r1, f16x2_t);
         u32x2_t wh, wl;
         wh[0] = __builtin_bit_cast(uint32_t, h0);
@@ -516,41 +593,99 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
         *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384) = wh;
         *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384 + 8192) = wl;
       }
-      l += psum;
-      lcur += psum;
     };
-    // V fragments of step s = 4 ks + ci of the tile whose blocked-16 planes start at vhp / vlp -> ring slot s & 3.
-    // Requested by inline assembly and waited for by vwait() below with COUNTED vmcnt: left to the compiler, the
-    // loads and their use sit in different branches of the loop body, and its wait-count pass then protects the
-    // ring registers with s_waitcnt vmcnt(0) at the top of every iteration -- i.e. it waits for the K transfer
-    // that was just requested (measured: 1.3-4 k cycles per tile).  The compiler sees no vector-memory load in the
-    // loop any more; the "+v" ties keep every use of a ring slot behind its vwait().
-    const h16_t* vhp = a.vh;
+
+    // ---- V fragments: a ring of 4 steps (step = k-step x 32-column tile, 8 registers) that runs THROUGH the tile
+    // boundaries.  Requested by inline assembly four steps ahead and awaited with COUNTED vmcnt tied to the ring
+    // registers ("+v"): left to the compiler, its wait-count pass protects the ring with s_waitcnt vmcnt(0), i.e.
+    // waits for the K transfer that was just requested.  The compiler sees no vector-memory load in the loop.
+    u32x4_t vr[4][2];
+    const h16_t* vhp = a.vh;                          // blocked-16 planes of the tile whose P.V runs / of the next tile
     const h16_t* vlp = a.vl;
-    auto vstep = [&](auto S) __attribute__((always_inline)) {
+    const h16_t* vhn = a.vh;
+    const h16_t* vln = a.vl;
+    auto vreq = [&](auto S) __attribute__((always_inline)) {     // step S of this tile (S < 16) or S - 16 of the next
       constexpr int sidx = decltype(S)::value;
-      constexpr int ks = sidx >> 2, ci = sidx & 3;
-      const h16_t* ph = vhp + ks * (1024 * 16) + vcol;      // (k-step: 16 keys x 1024 columns)
-      const h16_t* pl = vlp + ks * (1024 * 16) + vcol;
-      u32x4_t& d0 = vr[sidx & 3][0];                        // (asm operands do not capture: name the slots first)
+      constexpr int ks = (sidx & 15) >> 2, ci = sidx & 3;
+      // scalar base + 32-bit lane offset (k-step: 16 keys x 1024 columns = 32 KB) + immediate (32-column tile: 1 KB)
+      const h16_t* bh = sidx < 16 ? vhp : vhn;
+      const h16_t* bl = sidx < 16 ? vlp : vln;
+      const int off = vcol * 2 + ks * 32768;
+      u32x4_t& d0 = vr[sidx & 3][0];                  // (asm operands do not capture: name the slots first)
       u32x4_t& d1 = vr[sidx & 3][1];
-      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d0) : "v"(ph), "n"(ci * 1024));
-      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d1) : "v"(pl), "n"(ci * 1024));
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d0) : "v"(off), "s"(bh), "n"(ci * 1024));
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d1) : "v"(off), "s"(bl), "n"(ci * 1024));
     };
-    // the fragments of step s have landed: every request up to step s + 3 has been issued by now, so at most the
-    // 6 loads of steps s + 1 .. s + 3 may still be in flight (fewer at the end of the tile)
+    // Vector-memory requests in flight, oldest first, when step s waits for its fragments: V(s) .. V(s+3) of the ring
+    // and, for s < 4, the 4 K-transfer pieces issued at the top of the iteration.  Both are ALWAYS issued -- a 1 KiB
+    // dummy target for the K pieces when there is no tile to fetch, a re-read of the current planes for the V steps
+    // past the last tile -- so that each wait is ONE statement with a constant count: vmcnt(10) for s < 4, vmcnt(6)
+    // after.  (A wait that sits in two branches -- "if (more) vmcnt(6) else vmcnt(2)" -- makes the ring registers a
+    // phi; the compiler then copies the tied operand BEFORE the wait in one of the branches, i.e. copies a register
+    // whose load has not landed: wrong, run-to-run varying results on the last tile of a unit.)
     auto vwait = [&](auto S) __attribute__((always_inline)) {
       constexpr int sidx = decltype(S)::value;
-      constexpr int younger = sidx <= 12 ? 6 : 2 * (15 - sidx);
       u32x4_t& d0 = vr[sidx & 3][0];
       u32x4_t& d1 = vr[sidx & 3][1];
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(d0), "+v"(d1) : "n"(younger));
+      if constexpr (VAR & 8) {                        // (timing experiment of the tracing kernel: never wait; wrong results)
+        asm volatile("" : "+v"(d0), "+v"(d1));
+      } else if constexpr (sidx < 4) {
+        asm volatile("s_waitcnt vmcnt(10)" : "+v"(d0), "+v"(d1));
+      } else {
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(d0), "+v"(d1));
+      }
     };
-    // PV(i): O += P(pbuf) . V(tile i).  16 steps (k-step, 32-column tile) of 6 MFMAs; the V fragments of a step
-    // are requested 4 steps ahead (steps 0-3 before this phase), the P fragments of a k-step one k-step ahead.
-    auto pv_phase = [&](int pbuf) __attribute__((always_inline)) {
-      frag8_t pa[4], pb[4];                           // P fragments [qi][plane] of one k-step
-      auto pload = [&](frag8_t (&pf)[4], auto KS) __attribute__((always_inline)) {
+
+    TileIter t_sc, t_dma, t_v;                        // tiles of the next SCORE, K request, V base
+    tinit(t_sc, lo);
+    tinit(t_dma, lo + 2 < hi_t ? lo + 2 : lo);
+    tinit(t_v, lo);
+    // weights of the first tile; V fragments of its first four steps
+    static_for<16>([&](auto S) { score_slice(S, t_sc, 0, 0); });
+    tstep(t_sc);
+    {
+      const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
+      vhp = a.vh + vb;
+      vlp = a.vl + vb;
+      if (n > 1) tstep(t_v);
+    }
+    vreq(std::integral_constant<int, 0>{});
+    vreq(std::integral_constant<int, 1>{});
+    vreq(std::integral_constant<int, 2>{});
+    vreq(std::integral_constant<int, 3>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < n; ++it) {
+      const bool more = it + 1 < n;
+      long long t0 = 0;
+      if (TRACE) t0 = __builtin_readcyclecounter();
+      // K(it + 2) into the buffer of K(it), whose readers (SCORE(it), previous iteration) are past the barrier; when
+      // there is no such tile the 4 pieces go to a 1 KiB dummy target (keeps the request count of vwait() constant)
+      {
+        const bool real = it + 2 < n;
+        const long base = t_dma.kslot + (long)t_dma.key0() * 128;
+        const int dst = real ? R6_K + (it & 1) * 32768 + dma_dst0 : R6_DUMMY;
+        const int dstep = real ? 8192 : 0;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) {
+            const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + dst + pl * (real ? 16384 : 0) + pc * dstep);
+            const char* g = reinterpret_cast<const char*>((pl ? a.kl : a.kh) + base) + dma_off0 + pc * 128;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(g) : "memory");
+          }
+        if (real) tstep(t_dma);
+      }
+      if (more) {                                     // V planes of the next tile (its first steps are requested below)
+        const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
+        vhn = a.vh + vb;
+        vln = a.vl + vb;
+        if (it + 2 < n) tstep(t_v);
+      }
+      const int pbuf = it & 1, kb = ((it + 1) & 1) * 32768, pnext = (it + 1) & 1;
+      frag8_t pf[4];                                  // P fragments [qi][plane] of one k-step (fetched right after the
+      auto pload = [&](auto KS) __attribute__((always_inline)) {      //  last MFMA of the previous k-step issues)
         constexpr int ks = decltype(KS)::value;
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
@@ -558,95 +693,42 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
           for (int p = 0; p < 2; ++p)
             pf[qi * 2 + p] = *reinterpret_cast<const frag8_t*>(smem + apr(ks) + (pbuf * 16384 + p * 8192 + qi * 1024));
       };
-      pload(pa, std::integral_constant<int, 0>{});
+      pload(std::integral_constant<int, 0>{});
       static_for<16>([&](auto S) {
         constexpr int sidx = S.value;
         constexpr int ks = sidx >> 2, ci = sidx & 3;
-        frag8_t (&pc)[4] = (ks & 1) ? pb : pa;
-        if constexpr (ci == 0 && ks < 3) pload((ks & 1) ? pa : pb, std::integral_constant<int, (ks < 3 ? ks + 1 : 0)>{});
         __builtin_amdgcn_sched_barrier(0);
         vwait(S);
         const frag8_t vh = __builtin_bit_cast(frag8_t, vr[sidx & 3][0]);
         const frag8_t vl = __builtin_bit_cast(frag8_t, vr[sidx & 3][1]);
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {              // small terms first
-          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vl, o[qi][ci]);
-          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 1], vh, o[qi][ci]);
-          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vh, o[qi][ci]);
+          o[qi][ci] = RMEM_MFMA(pf[qi * 2 + 0], vl, o[qi][ci]);
+          o[qi][ci] = RMEM_MFMA(pf[qi * 2 + 1], vh, o[qi][ci]);
+          o[qi][ci] = RMEM_MFMA(pf[qi * 2 + 0], vh, o[qi][ci]);
         }
-        if constexpr (sidx + 4 < 16) vstep(std::integral_constant<int, (sidx + 4 < 16 ? sidx + 4 : 0)>{});
+        if constexpr (ci == 3 && ks < 3) pload(std::integral_constant<int, (ks < 3 ? ks + 1 : 0)>{});
+        vreq(std::integral_constant<int, sidx + 4>{});       // (steps 16-19: the next tile's first four, see vwait)
+        if (more) score_slice(S, t_sc, kb, pnext);
         __builtin_amdgcn_sched_barrier(0);
       });
-    };
-
-    // One loop body for both wave groups; group B (waves 4-7) meets the interval's barrier BETWEEN its two
-    // phases and runs the P.V of the tile whose weights were just finished, i.e. it is half an interval behind:
-    //   A:  [SCORE(it+1)  PV(it)]   barrier
-    //   B:   SCORE(it+1)  barrier  [PV(it+1)]
-    // Both pass exactly one barrier per iteration.  K(it + 2) is requested at the top of iteration it -- every
-    // wave is then past barrier it - 1, which ends the readers of K(it) (same buffer) -- and waited for before
-    // the wave's next barrier; being OLDER than the V loads that follow, it never lengthens a wait for those.
-    TileIter t_sc, t_dma, t_v;                        // tiles of the next SCORE (it + 1), K request (it + 2), P.V (px)
-    tinit(t_sc, lo);
-    tinit(t_dma, lo + 2 < hi_t ? lo + 2 : lo);
-    t_v = t_sc;
-#pragma clang loop unroll(disable)
-    for (int it = -1; it < n; ++it) {
-      const int px = group_a ? it : it + 1;           // tile (relative) whose P.V this wave runs now
-      const bool do_pv = px >= 0 && px < n;
-      const bool do_sc = it + 1 < n;
-      long long tt0 = 0;
-      if (TRACE) tt0 = __builtin_readcyclecounter();
-      // Priority: the wave that is NOT in its P.V cluster goes first.  Both at priority 0, the older wave's MFMAs
-      // sit at the head of the SIMD's vector issue and the younger wave's requests / address arithmetic / exp2
-      // crawl beside them (measured: 4.1 k cycles for this block beside a P.V, 1.1 k otherwise).
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
-      // K(it + 2) into the buffer of K(it): its readers, SCORE(it), are past barrier it - 1 (for both groups)
-      if (it >= 0 && it + 2 < n) {
-        dma_k(t_dma, it & 1, true);
-        tstep(t_dma);
-      }
-      if (do_pv) {                                    // V fragments of the first four steps: in flight during SCORE
-        const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
-        tstep(t_v);
-        vhp = a.vh + vb;
-        vlp = a.vl + vb;
-        vstep(std::integral_constant<int, 0>{});
-        vstep(std::integral_constant<int, 1>{});
-        vstep(std::integral_constant<int, 2>{});
-        vstep(std::integral_constant<int, 3>{});
-      }
-      long long t0 = 0;
-      if (TRACE) {
-        t0 = __builtin_readcyclecounter();
-        tacc[3] += t0 - tt0;
-      }
-      if (do_sc) {
-        score_phase(t_sc, (it + 1) & 1, (it + 1) & 1);
+      if (more) {
         tstep(t_sc);
-      }
-      if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
-      if (!group_a) {
+        vhp = vhn;
+        vlp = vln;
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // all but the next tile's first four V steps: the K transfer is in
+      } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[2] += t1 - t0; t0 = t1; }
       }
-      if ((VAR & 2) && do_pv) __builtin_amdgcn_s_setprio(1);
-      if (do_pv) pv_phase(px & 1);
-      if ((VAR & 2) && do_pv) __builtin_amdgcn_s_setprio(0);
       if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
-      if (group_a) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (TRACE) tacc[2] += __builtin_readcyclecounter() - t0;
-      }
+      __syncthreads();                                // P(it + 1), K(it + 2) visible; P(it), K(it + 1) may be overwritten
+      if (TRACE) tacc[2] += __builtin_readcyclecounter() - t0;
     }
     if (trace && tid == 0) trace[2] = __builtin_readcyclecounter();
 
     // ---- overflow?  (wave-uniform flags; the unit is redone against the exact reference)
     if (attempt == 0) {
-      const int any_over = __any(over) ? 1 : 0;
+      const int any_over = __any(ytop - m > RD_THR) ? 1 : 0;
       if (lane == 0) flag[wave] = any_over;
       __syncthreads();
       int f = 0;
@@ -659,7 +741,8 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     {
       float v = lcur + __shfl_xor(lcur, 16);
       v += __shfl_xor(v, 32);
-      float lt = l + __shfl_xor(l, 16);
+      const float lall = l + lcur;
+      float lt = lall + __shfl_xor(lall, 16);
       lt += __shfl_xor(lt, 32);
       if (lb == 0) {
         if (sum_t >= 0) sl_sum[(sum_t * 2 + kh) * 64 + qg * 16 + jq] = v;
@@ -715,7 +798,6 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   if (trace && lane == 0) {
     if (wave == 0) {
       trace[3] = __builtin_readcyclecounter();
-      trace[49] = __builtin_amdgcn_s_memrealtime();
       trace[28] = n;
     }
     trace[4 + wave] = tacc[0];
@@ -724,6 +806,14 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     trace[40 + wave] = tacc[3];
     trace[32 + wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave / SIMD / CU this wave ran on
   }
+}
+
+// mode 0 (bank: long-term / self) and mode 1 (window) are separate instantiations: the window arithmetic's state
+// (query coordinates, bias row pointer) would otherwise sit in registers of the bank read, which has none to spare
+template <int TRACE, int VAR = 0>
+__device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr) {
+  if (a.mode == 0) read64_mode<TRACE, VAR, 0>(a, blk, smem, trace_base);
+  else read64_mode<TRACE, VAR, 1>(a, blk, smem, trace_base);
 }
 
 __global__ __launch_bounds__(512) void read64_kernel(rmem_read_args a) {
@@ -837,22 +927,14 @@ extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, vo
   if (!ap || !trace || !read_args_ok(*ap) || rmem::current_recorder()) return RMEM_ERR_INVALID;
   const int chunk = read_chunk(*ap);
   const char* ev = getenv("RMEM_READ_VAR");           // experiments (see read64_body)
-  const int var = ev ? atoi(ev) & 15 : 0;
+  const int var = ev ? atoi(ev) & 8 : 0;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
     hipLaunchKernelGGL(kern, dim3(8 * chunk), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), *ap,
                        reinterpret_cast<long long*>(trace));
   };
   if (var == 0) go(&read64_trace_kernel<0>);
-  else if (var == 1) go(&read64_trace_kernel<1>);
-  else if (var == 2) go(&read64_trace_kernel<2>);
-  else if (var == 3) go(&read64_trace_kernel<3>);
-  else if (var == 4) go(&read64_trace_kernel<4>);
-  else if (var == 5) go(&read64_trace_kernel<5>);
-  else if (var == 6) go(&read64_trace_kernel<6>);
-  else if (var == 7) go(&read64_trace_kernel<7>);
-  else if (var == 8) go(&read64_trace_kernel<8>);
-  else go(&read64_trace_kernel<9>);
+  else go(&read64_trace_kernel<8>);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }
