@@ -82,6 +82,27 @@ def parse():
     return ap.parse_args()
 
 
+# HBM traffic of the dominant kernel: from separate rocprofv3 --pmc passes of the same bench command
+# (tools/gpujob_profile_r03.sh: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, mean per
+# launch), committed under profiles/.  (model, config, clips) -> (file, kernel-name prefix in that file)
+PMC_FILES = {("r50_deaotl", "480p_k4", "one"): ("r03t_pmc_x3.json", "read64x2_kernel"),
+             ("r50_deaotl", "720p_k8", "one"): ("r03t_pmc_720p_k8.json", "read64x2_kernel"),
+             ("r50_deaotl", "480p_k4", "batched8"): ("r03t_pmc_batched8.json", "read64x2_many_kernel"),
+             ("r50_aotl", "480p_k4", "one"): ("r03t_pmc_aot.json", "mha_flash_kernel")}
+
+
+def pmc_traffic(roofline: dict, key) -> None:
+    name, kernel = PMC_FILES.get(key, (None, None))
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
+        return
+    for k, v in json.load(open(path)).items():
+        if k.startswith(kernel) and isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+            roofline["traffic"] = v["hbm_bytes_per_launch"]
+            roofline["traffic_unit"] = f"bytes/launch (rocprofv3 PMC, profiles/{name})"
+            return
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec this script as N ranks of one node through
     torch.distributed.run (one process per GPU, LOCAL_RANK -> device), the role mp.spawn(main_worker,
@@ -331,13 +352,8 @@ def main():
             iso = lstt.time_read_isolated()
             out["roofline"]["isolated_mean_us"] = iso
             out["roofline"]["frac_isolated"] = out["roofline"]["algorithmic_flops_per_launch"] / (iso * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
-        # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); see profiles/*pmc*.json
-        pmc_name = "r03_pmc_read.json"
-        pmc = os.path.join(ROOT, "profiles", pmc_name)
-        if out["roofline"] and args.config == "480p_k4" and args.model == "r50_deaotl" and os.path.exists(pmc):
-            out["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_unit"] = f"bytes/launch (rocprofv3 PMC, profiles/{pmc_name})"
+        if out["roofline"] and C == 1:
+            pmc_traffic(out["roofline"], (args.model, args.config, "one"))
         if dropin is not None:
             out["dropin"] = dropin
         if world == 1 and not args.no_cpu_baseline and args.model == "r50_deaotl":
@@ -428,6 +444,7 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
                            "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                            "traffic": None, "mean_us": iso, "algorithmic_flops_per_launch": flops,
                            "note": "isolated launches (HIP events, back to back); includes the upload of the clips' argument blocks"}
+        pmc_traffic(out["roofline"], ("r50_deaotl", "480p_k4", f"batched{B}"))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -28,8 +28,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 //                                of a half-wave (row = lane) then cover all 64 banks exactly once
 constexpr int MHA_KPL = 64 * 64, MHA_VROW = 136, MHA_VPL = 32 * MHA_VROW;
 
+// __launch_bounds__(256, 2): two blocks per CU = two waves per SIMD = a budget of 256 registers per lane, which is
+// what makes the compiler keep the MFMA accumulators in VGPRs.  With the default (one wave per SIMD, 512 registers)
+// it parks S^T and O^T in AGPRs and every 32-key tile pays 32 v_accvgpr_read (16 for the scores, 16 for an O^T that
+// is only touched when a maximum moves) on a VALU-bound loop: 180 registers and ~145 VALU per tile against 146
+// registers (3 waves per SIMD) and ~95.
 template <int NS>
-__global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
+__global__ __launch_bounds__(256, 2) void mha_flash_kernel(rmem_mha_args a) {
   constexpr int NPL = NS == 1 ? 1 : 2;
   constexpr int STAGE_BYTES = NPL * (MHA_KPL + MHA_VPL);
   __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES];
@@ -160,14 +165,17 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
         for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
         tmax = fmaf(tm, sl2e, bias_t);
       } else {
-#pragma unroll
+        int tb = tok0 + 4 * hi;
+        asm volatile("" : "+v"(tb));            // the 16 token indexes belong to this branch: without the pin they are
+#pragma unroll                                  // hoisted in front of it and computed on every tile
         for (int r = 0; r < 16; ++r) {
-          const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int tok = tb + (r & 3) + 8 * (r >> 2);
           tmax = fmaxf(tmax, tok < a.N ? fmaf(s[r], sl2e, bias_t) : -3.0e38f);
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m, tmax);
+      float tm_lo, tm_hi;
+      xor32_pair(tmax, tm_lo, tm_hi);                  // the query's other 16 keys sit in lane ^ 32
+      const float m_new = fmaxf(m, fmaxf(tm_lo, tm_hi));
       const float cadd = bias_t - m_new;
       float pv[16];
       f32x2_t ps2 = {0.f, 0.f};
@@ -182,17 +190,19 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
           ps2 += pp;
         }
       } else {
-        asm volatile("" ::: "memory");          // keeps this block a branch
+        int tb = tok0 + 4 * hi;
+        asm volatile("" : "+v"(tb)::"memory");  // keeps this block a branch, and its token indexes inside it
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int tok = tok0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int tok = tb + (r & 3) + 8 * (r >> 2);
           // (a split may start on an all-padding tile: m_new is still the sentinel there, nothing is valid)
           pv[r] = tok < a.N ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, cadd)) : 0.f;
           ps2[r & 1] += pv[r];
         }
       }
-      float psum = ps2[0] + ps2[1];
-      psum += __shfl_xor(psum, 32);
+      float ps_lo, ps_hi;
+      xor32_pair(ps2[0] + ps2[1], ps_lo, ps_hi);
+      const float psum = ps_lo + ps_hi;
       if (__any(m_new != m)) {
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         l *= alpha;
@@ -210,15 +220,17 @@ __global__ __launch_bounds__(256) void mha_flash_kernel(rmem_mha_args a) {
         u32x4_t wh, wl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          // packed conversions (v_cvt_pk_f16_f32, round to nearest even): softmax weights <= 1, no saturation needed
-          f32x2_t pp;
-          pp[0] = pv[8 * ks + 2 * e];
-          pp[1] = pv[8 * ks + 2 * e + 1];
-          const f16x2_t hh = __builtin_convertvector(pp, f16x2_t);
-          wh[e] = __builtin_bit_cast(uint32_t, hh);
+          // softmax weights <= 1: no saturation needed
           if constexpr (NPL == 2) {
-            const f32x2_t rr = pp - __builtin_convertvector(hh, f32x2_t);
-            wl[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rr, f16x2_t));
+            uint32_t h2, l2;
+            split_pair_f16(pv[8 * ks + 2 * e], pv[8 * ks + 2 * e + 1], h2, l2);
+            wh[e] = h2;
+            wl[e] = l2;
+          } else {
+            f32x2_t pp;
+            pp[0] = pv[8 * ks + 2 * e];
+            pp[1] = pv[8 * ks + 2 * e + 1];
+            wh[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pp, f16x2_t));
           }
         }
         pf[0][ks] = __builtin_bit_cast(frag8_t, wh);

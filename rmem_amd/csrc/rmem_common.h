@@ -45,6 +45,33 @@ __device__ __forceinline__ void split_f16(float x, h16_t& hi, h16_t& lo) {   // 
   hi = f2h_bits(xc);
   lo = f2h_bits(__builtin_amdgcn_fmed3f(xc - h_bits2f(hi), -65504.f, 65504.f));
 }
+// Two fp32 values -> their packed fp16 hi / lo planes (hi = fp16(x), lo = fp16(x - hi), round to nearest even) in three
+// instructions: one v_cvt_pk_f16_f32 and two mixed-precision fmas that take hi straight from its fp16 half and write
+// the rounded remainder into the low / high half of `lo` (x - float(hi) is exact in fp32, so the bits are those of the
+// convert / subtract / convert form the compiler emits -- which is five instructions per pair; it does not form
+// v_fma_mix itself).
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t_;
+  f32x2_t_ pp;
+  pp[0] = x0;
+  pp[1] = x1;
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(pp, f16x2_t));
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(x0), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(hi));
+}
+
+// x of lane L and of lane L ^ 32 in ONE instruction (v_permlane32_swap; __shfl_xor(x, 32) is an LDS round trip plus the
+// index arithmetic): lo = x of the lane's copy in lanes 0-31, hi = x of its copy in lanes 32-63, the same pair in both
+// lanes -- so max(lo, hi) / lo + hi are the xor-32 reductions, identical in the two lanes.  (The elements of the
+// builtin's result are copied to scalars before the bit cast: a bit cast applied to `r[1]` directly reads element 0.)
+__device__ __forceinline__ void xor32_pair(float x, float& lo, float& hi) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const uint32_t r0 = r[0], r1 = r[1];
+  lo = __builtin_bit_cast(float, r0);
+  hi = __builtin_bit_cast(float, r1);
+}
+
 #define RMEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 // Monotone float <-> uint encoding so that atomicMax on the uint orders like the

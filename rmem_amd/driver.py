@@ -181,6 +181,7 @@ class ClipResult:
         self.names: List[str] = []
         self.obj_idx = None
         self.gap = None
+        self.batched: Optional[bool] = None            # BatchedClipDriver.run_dataset: shared a lockstep batch / ran alone
 
     @property
     def fps(self) -> float:
@@ -357,18 +358,65 @@ class ClipDriver:
         return res
 
 
+def plan_ragged_batches(clips_info: Sequence[Dict], B: int, no_memory_gap: bool = False,
+                        max_obj_num: int = 10, gap_of: Optional[Callable[[int], int]] = None) -> Dict[str, list]:
+    """Which clips of a dataset can share a lockstep batch (host logic only, no tensors).
+
+    clips_info[i]: {"num_frames", "size" (network H, W), "ori_size" (H0, W0), "n_aug", "mid_labels" (bool),
+    "obj_num"}.  The reference hands clips of any length to its worker processes one at a time
+    (managers/evaluator.py:276-295) and picks the memory gap per clip from its length (:327-331); a
+    lockstep batch needs one gap schedule, one geometry and one augmentation, so clips are grouped by
+    (gap, size, ori_size), longest first inside a group (a shorter clip idles -- its last frame is
+    repeated and the output dropped -- until the longest of its batch ends), B per batch.  A group's
+    remainder of >= 2 clips runs as a batch padded with repeats of its first clip (-1 marks a padding
+    slot); a single left-over clip, and every clip with test-time augmentation, mid-clip labels or more
+    than max_obj_num objects, goes to the one-clip driver.  `gap_of` (optional) replaces the gap rule (a
+    driver with a fixed gap).  Returns {"batches": [[clip ids (or -1)] * B], "singles": [clip ids]}; every
+    clip id appears exactly once."""
+    B = int(B)
+    if B < 1:
+        raise ValueError("B must be >= 1")
+    groups: Dict[tuple, List[int]] = {}
+    singles: List[int] = []
+    for i, c in enumerate(clips_info):
+        n = int(c["num_frames"])
+        if n < 1:
+            raise ValueError(f"clip {i} is empty")
+        if int(c.get("n_aug", 1)) != 1 or bool(c.get("mid_labels", False)) or int(c.get("obj_num", 1)) > max_obj_num:
+            singles.append(i)
+            continue
+        gap = gap_of(n) if gap_of is not None else memory_gap(n, no_memory_gap)
+        key = (gap, tuple(c["size"]), tuple(c["ori_size"]))
+        groups.setdefault(key, []).append(i)
+    batches: List[List[int]] = []
+    for key in sorted(groups):
+        ids = sorted(groups[key], key=lambda i: (-int(clips_info[i]["num_frames"]), i))
+        for k in range(0, len(ids), B):
+            chunk = ids[k:k + B]
+            if len(chunk) == B:
+                batches.append(chunk)
+            elif len(chunk) >= 2:
+                batches.append(chunk + [-1] * (B - len(chunk)))
+            else:
+                singles.extend(chunk)
+    return {"batches": batches, "singles": sorted(singles)}
+
+
 class BatchedClipDriver:
-    """B equal-length clips of one frame size in lockstep through rmem_amd.batched.BatchedDeAOTEngine:
-    ONE launch per kernel of the memory path for all clips, encoder / decoder at batch B
-    (BASELINE.json configs[3] runs 8 such clips per GPU).  Per clip the protocol is
-    ClipDriver.run_clip's for one augmentation without mid-clip new objects (managers/evaluator.py:
-    344-523): gap rule, reference frame, per frame decoder logits -> label map at the original size
-    -> nearest resize to the network size -> update_memory."""
+    """B clips of one frame size and one memory-gap schedule in lockstep through
+    rmem_amd.batched.BatchedDeAOTEngine: ONE launch per kernel of the memory path for all clips,
+    encoder / decoder at batch B (BASELINE.json configs[3] runs 8 such clips per GPU).
+    Per clip the protocol is ClipDriver.run_clip's for one augmentation without mid-clip new objects
+    (managers/evaluator.py:344-523): gap rule, reference frame, per frame decoder logits -> label map at
+    the original size -> nearest resize to the network size -> update_memory.  Clips may differ in
+    length as long as the gap rule gives them the same gap (run_clips); run_dataset() takes any list of
+    clips and sends what cannot share a batch through the one-clip driver."""
 
     def __init__(self, model, B: int, cfg=None, gpu_id: int = 0, no_memory_gap: Optional[bool] = None,
                  fixed_gap: Optional[int] = None):
         from .batched import BatchedDeAOTEngine
         self.cfg = cfg if cfg is not None else model.cfg
+        self.model, self.gpu_id = model, gpu_id
         self.B = int(B)
         self.engine = BatchedDeAOTEngine(model, self.B, gpu_id=gpu_id,
                                          long_term_mem_gap=getattr(self.cfg, "TEST_LONG_TERM_MEM_GAP", 9999))
@@ -376,28 +424,41 @@ class BatchedClipDriver:
             else no_memory_gap
         self.fixed_gap = fixed_gap
         self.align_corners = bool(self.cfg.MODEL_ALIGN_CORNERS)
+        self._single: Optional[ClipDriver] = None
+
+    def _gap_of(self, n: int) -> int:
+        return self.fixed_gap if self.fixed_gap is not None else memory_gap(n, self.no_memory_gap)
 
     @torch.no_grad()
     def run_clips(self, clips: Sequence[Sequence[List[Dict]]], num_frames: Optional[int] = None) -> List[ClipResult]:
-        """clips[i][t] = the sample list (one augmentation) of frame t of clip i."""
+        """clips[i][t] = the sample list (one augmentation) of frame t of clip i.  Lengths may differ when
+        the gap rule gives every clip the same gap: the batch runs for the longest clip, a finished clip
+        is fed its last frame again and those outputs are dropped (clips are independent: what the other
+        slots compute changes nothing a clip computes).  `num_frames` (optional) cuts every clip to that
+        many frames."""
         from . import hip
         B, eng = self.B, self.engine
         if len(clips) != B:
             raise ValueError(f"{B} clips per batch")
-        if num_frames is None:
-            num_frames = len(clips[0])
-        if any(len(c) != num_frames for c in clips) or any(len(c[0]) != 1 for c in clips):
-            raise ValueError("batched clips must have the same length and one augmentation")
-        if any(s[0].get("current_label") is not None for c in clips for s in c[1:]):
+        lens = [len(c) if num_frames is None else min(len(c), int(num_frames)) for c in clips]
+        if min(lens) < 1:
+            raise ValueError("empty clip")
+        if any(len(c[0]) != 1 for c in clips):
+            raise ValueError("batched clips take one augmentation: use ClipDriver for test-time augmentation")
+        if any(s[0].get("current_label") is not None for c, n in zip(clips, lens) for s in c[1:n]):
             raise NotImplementedError("mid-clip new objects: use ClipDriver")
-        gap = self.fixed_gap if self.fixed_gap is not None else memory_gap(num_frames, self.no_memory_gap)
+        gaps = [self._gap_of(n) for n in lens]
+        if any(g != gaps[0] for g in gaps):
+            raise ValueError(f"batched clips must share the memory gap (lengths {lens} give gaps {gaps}): group them with "
+                             "plan_ragged_batches / run_dataset")
+        gap, nmax = gaps[0], max(lens)
         eng.restart_engine()
         eng.long_term_mem_gap = gap
         meta = [c[0][0]["meta"] for c in clips]
         ori_hw = (int(meta[0]["height"]), int(meta[0]["width"]))
         if any((int(m["height"]), int(m["width"])) != ori_hw for m in meta):
             raise ValueError("batched clips must share the frame size")
-        stack = lambda t: torch.cat([c[t][0]["current_img"] for c in clips])
+        stack = lambda t: torch.cat([c[min(t, n - 1)][0]["current_img"] for c, n in zip(clips, lens)])
         imgs = stack(0)
         labs = torch.cat([F.interpolate(c[0][0]["current_label"].float(), size=imgs.shape[2:], mode="nearest")
                           for c in clips]).int()
@@ -418,21 +479,59 @@ class BatchedClipDriver:
         # (engines/aot_engine.py:675-690): same here
         eng.add_reference_frame(imgs, labs, obj_nums=[maxo] * B, frame_step=0)
         lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
-        out = torch.zeros(B, num_frames - 1, ori_hw[0], ori_hw[1], dtype=torch.uint8, device=imgs.device)
-        nxt = stack(1) if num_frames > 1 else None
-        for t in range(1, num_frames):
-            cur, nxt = nxt, (stack(t + 1) if t + 1 < num_frames else None)
+        out = torch.zeros(B, max(nmax - 1, 1), ori_hw[0], ori_hw[1], dtype=torch.uint8, device=imgs.device)
+        nxt = stack(1) if nmax > 1 else None
+        for t in range(1, nmax):
+            cur, nxt = nxt, (stack(t + 1) if t + 1 < nmax else None)
             logit = eng.match_propogate_one_frame(cur, output_size=None, next_imgs=nxt)
             for i in range(B):
+                # (a finished clip's slot keeps running on its last frame; its rows of `out` past the clip's end are cut below)
                 lab = hip.labels_from_logits([logit[i:i + 1]], [False], ori_hw, self.align_corners, out=out[i, t - 1])
                 hip.label_resize_nearest(lab, eng.input_size_2d, False, out=lab_in[i])
             eng.update_memory(lab_in)
         results = []
         for i, c in enumerate(clips):
             r = ClipResult()
-            r.gap, r.masks, r.obj_idx = gap, out[i], meta[i].get("obj_idx")
-            r.names = [str(s[0]["meta"].get("current_name", "")) for s in c[1:]]
+            r.gap, r.masks, r.obj_idx = gap, out[i, :lens[i] - 1], meta[i].get("obj_idx")
+            r.names = [str(s[0]["meta"].get("current_name", "")) for s in c[1:lens[i]]]
             results.append(r)
+        return results
+
+    @staticmethod
+    def clip_info(clip: Sequence[List[Dict]]) -> Dict:
+        """The facts plan_ragged_batches() needs about one clip (see there)."""
+        s0 = clip[0][0]
+        m = s0["meta"]
+        n = m.get("obj_num")
+        n = int(n[0] if isinstance(n, (list, tuple)) else n) if n is not None else 1
+        return {"num_frames": len(clip), "size": tuple(int(x) for x in s0["current_img"].shape[2:]),
+                "ori_size": (int(m["height"]), int(m["width"])), "n_aug": len(clip[0]),
+                "mid_labels": any(s[0].get("current_label") is not None for s in clip[1:]), "obj_num": n}
+
+    @torch.no_grad()
+    def run_dataset(self, clips: Sequence[Sequence[List[Dict]]]) -> List[ClipResult]:
+        """Any list of clips -> one ClipResult per clip, in order.  plan_ragged_batches() decides which
+        clips share a lockstep batch; the rest (test-time augmentation, mid-clip labels, > 10 objects, a
+        lone clip of its (gap, size) group) run through ClipDriver.run_clip -- the reference's one-clip
+        loop.  ClipResult.batched tells which way a clip went."""
+        info = [self.clip_info(c) for c in clips]
+        plan = plan_ragged_batches(info, self.B, max_obj_num=int(self.engine.AOT.max_obj_num), gap_of=self._gap_of)
+        results: List[Optional[ClipResult]] = [None] * len(clips)
+        for batch in plan["batches"]:
+            real = [i for i in batch if i >= 0]
+            res = self.run_clips([clips[i if i >= 0 else real[0]] for i in batch])
+            for slot, i in enumerate(batch):
+                if i >= 0:
+                    res[slot].batched = True
+                    results[i] = res[slot]
+        if plan["singles"]:
+            if self._single is None:
+                self._single = ClipDriver(self.model, self.cfg, gpu_id=self.gpu_id, no_memory_gap=self.no_memory_gap,
+                                          fixed_gap=self.fixed_gap)
+            for i in plan["singles"]:
+                r = self._single.run_clip(clips[i], num_frames=len(clips[i]))
+                r.batched = False
+                results[i] = r
         return results
 
 

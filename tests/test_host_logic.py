@@ -264,7 +264,8 @@ def test_sharded_clips_hashes_do_not_depend_on_world_size():
 
 def test_batched_clip_driver_validates_its_input_on_the_host():
     """BatchedClipDriver refuses what it cannot run in lockstep before anything is launched (no GPU
-    needed): wrong clip count, clips of different lengths, flip augmentation, mid-clip labels."""
+    needed): wrong clip count, clips whose lengths give different memory gaps, flip augmentation, mid-clip
+    labels."""
     from rmem_amd import driver as D
     from rmem_amd.config import get_config
     from rmem_amd.model import build_vos_model
@@ -277,8 +278,8 @@ def test_batched_clip_driver_validates_its_input_on_the_host():
                                                            flip_aug=aug, name=f"{t:05d}.jpg") for t in range(n)]
     with pytest.raises(ValueError):
         drv.run_clips([clip(4)], num_frames=4)
-    with pytest.raises(ValueError):
-        drv.run_clips([clip(4), clip(5)], num_frames=4)
+    with pytest.raises(ValueError, match="share the memory gap"):      # evaluator.py:327-331: 4 frames -> gap 5, 200 -> 7
+        drv.run_clips([clip(4), clip(200)])
     with pytest.raises(ValueError):
         drv.run_clips([clip(4, aug=True), clip(4, aug=True)], num_frames=4)
     with pytest.raises(NotImplementedError):
@@ -296,6 +297,39 @@ def test_batched_clip_driver_validates_its_input_on_the_host():
         fr[0]["meta"].pop("obj_num")
     with pytest.raises(NotImplementedError, match="13 objects"):
         drv.run_clips([nometa, clip(4)], num_frames=4)
+
+
+def test_plan_ragged_batches():
+    """Which clips of a mixed dataset share a lockstep batch (driver.plan_ragged_batches): groups by (gap from the
+    clip's own length -- managers/evaluator.py:327-331 --, network size, original size), longest first, B per batch,
+    a remainder of >= 2 padded with -1 slots, everything else (TTA, mid-clip labels, > 10 objects, a lone clip) to the
+    one-clip driver; every clip exactly once."""
+    from rmem_amd import driver as D
+    mk = lambda n, size=(465, 465), ori=(480, 480), **kw: dict(num_frames=n, size=size, ori_size=ori, **kw)
+    info = [mk(40), mk(100), mk(165), mk(166),               # gaps 5, 5, 6 (round(5.5) = 6: Python rounds half to even, as the reference does), 6
+            mk(60, n_aug=2), mk(70, mid_labels=True), mk(80, obj_num=12),
+            mk(90, size=(481, 849), ori=(480, 848)), mk(30), mk(20), mk(50, size=(481, 849), ori=(480, 848)),
+            mk(400), mk(10)]
+    gaps = [D.memory_gap(c["num_frames"]) for c in info]
+    assert gaps[:4] == [5, 5, 6, 6] and gaps[11] == 13
+    plan = D.plan_ragged_batches(info, 4)
+    seen = sorted([i for b in plan["batches"] for i in b if i >= 0] + plan["singles"])
+    assert seen == list(range(len(info)))                     # every clip exactly once
+    for b in plan["batches"]:
+        real = [i for i in b if i >= 0]
+        assert len(b) == 4 and len(real) >= 2 and b[:len(real)] == real       # padding slots last
+        assert len({(gaps[i], info[i]["size"], info[i]["ori_size"]) for i in real}) == 1
+        lens = [info[i]["num_frames"] for i in real]
+        assert lens == sorted(lens, reverse=True)             # longest first: the batch runs for b[0]'s length
+    # gap 5 at 465x465: clips 1, 0, 8, 9 fill a batch, clip 12 is left alone; gap 6: clips 3, 2 padded; the two
+    # 481x849 clips (gap 5 both) padded; TTA / mid-clip labels / 12 objects / the lone gap-13 clip run alone
+    assert sorted(plan["batches"]) == sorted([[1, 0, 8, 9], [3, 2, -1, -1], [7, 10, -1, -1]])
+    assert plan["singles"] == [4, 5, 6, 11, 12]
+    # a fixed gap removes the length from the key
+    plan2 = D.plan_ragged_batches(info, 4, gap_of=lambda n: 3)
+    assert any(11 in b for b in plan2["batches"])
+    with pytest.raises(ValueError):
+        D.plan_ragged_batches([mk(0)], 4)
 
 
 @pytest.mark.parametrize("which", ["oracle", "product"])

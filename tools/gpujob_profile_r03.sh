@@ -22,8 +22,10 @@ dur = collections.defaultdict(list)
 for f in glob.glob(f"{O}/pmc_{name}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if k.startswith("read64") or "read_combine" in k or k.startswith("mha_"):
+        if k.startswith("read64") or "read_combine" in k or "mha_" in k:
             kk = k.split("(")[0][:48]
+            if kk.startswith("void "):
+                kk = kk[5:]
             agg[kk][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {"note": "rocprofv3 --kernel-trace --pmc <set> in separate passes (4 passes: two SQ sets, FETCH_SIZE, WRITE_SIZE) of the command below; "
                "mean per dispatch over every dispatch of the kernel in the run (pre-roll included); FETCH_SIZE / WRITE_SIZE in KB as reported; "
