@@ -9,26 +9,25 @@
 // with one wave per SIMD the matrix pipe idled through every score / softmax phase -- 24-29 % busy,
 // profiles/r02_x_pmc_read.json.)
 //
-// Per 64-key tile a wave does two things that touch disjoint buffers and can therefore run in either
-// order inside ONE barrier interval:
-//   SCORE(i+1): S^T = K.Q^T for 16 queries x 32 keys (wave w: query group w & 3, key half w >> 2) on
-//       v_mfma_f32_16x16x32_f16, K and Q fragments from LDS; "swapped" (rows = keys) so that a query's
-//       scores live in 4 lanes; weights P = 2^(y - m) against a FIXED per-query reference m go to the
-//       other P image as fp16 hi / lo planes;
-//   PV(i): O += P.V for all 64 queries x this wave's 128 columns on v_mfma_f32_32x32x16_f16: A = P
-//       fragments from LDS (shared by the eight waves), B = V fragments straight from global memory
-//       ("blocked-16" layout: one contiguous KiB per load instruction).
-// Waves 0-3 run SCORE then PV, waves 4-7 PV then SCORE: wave w and wave w + 4 share a SIMD, so each
-// SIMD always has one wave in the matrix-heavy P.V phase while the other does LDS reads, exp2 and
-// conversions.  K tiles arrive by LDS-DMA (global_load_lds_dwordx4, two tiles ahead, XOR swizzle applied
-// to the SOURCE address: no staging registers, no ds_write phase); P and K are double-buffered.
+// Per 64-key tile there are two kinds of work that touch disjoint buffers:
+//   SCORE(i+1): S^T = K.Q^T for 16 queries x ALL 64 keys on v_mfma_f32_16x16x32_f16, K and Q fragments from LDS;
+//       "swapped" (rows = keys) so that a query's scores live in 4 lanes; weights P = 2^(y - m) go to the other P
+//       image as fp16 hi / lo planes.  Wave w scores query group w & 3 on the tiles whose parity is w >> 2: a
+//       query's whole row of a tile is in ONE wave, so the running reference m of the row is a wave-local decision;
+//   PV(i): O += P.V for all 64 queries x this wave's 128 columns on v_mfma_f32_32x32x16_f16: A = P fragments from
+//       LDS (shared by the eight waves), B = V fragments straight from global memory ("blocked-16" layout: one
+//       contiguous KiB per load instruction).
+// One barrier per tile.  In interval i the four waves that own tile i + 1 run SCORE(i+1) then PV(i), the other four
+// PV(i) at once: wave w and wave w + 4 share a SIMD, so the owner's LDS reads, exp2 and conversions run beside its
+// partner's MFMAs, and its own P.V then has the matrix pipe to itself.  K tiles arrive by LDS-DMA
+// (global_load_lds_dwordx4, two tiles ahead, chunk swizzle applied to the SOURCE address: no staging registers, no
+// ds_write phase); P and K are double-buffered.
 //
-// The fixed reference m is the row maximum over the unit's keys from a first pass with the hi planes only
-// (8 small MFMAs per wave per tile; error a few hundredths), so the weights stay within a few per cent of 1
-// at the maximum and the accumulators never need a rescale.  Exactness for ANY input: the main
-// pass flags a score above m + RD_THR (weights would leave fp16); a flagged unit is simply redone with the
-// reference taken from the exact three-product scores of every key (bit-identical to the main pass's, so
-// the weights are <= 1).  Not taken on real data; tests/test_hip_ops.py forces it.
+// Online reference, lazily raised.  m of a row starts at the maximum of its first tile and is raised to a tile's
+// maximum only when that exceeds m by more than RD_BUMP = 12 (log2 domain): weights stay <= 2^12 (fp16 hi plane),
+// and the accumulators are rescaled only on those tiles -- the owner publishes the factor 2^(m_old - m_new) per row and
+// a flag in LDS, and every wave multiplies its O rows at the start of that tile's P.V (a wave-uniform branch that real
+// data takes on the first tiles of a unit and when a dominant key arrives).  No reference pass, no second attempt.
 //
 // Split precision: every product is hi*lo' + lo*hi' + hi*hi' (fp32 accumulate).  Key splits write
 // un-normalised partials + (max, sum) [+ per-slot (sum, max)]; rmem_attn_read_combine merges them.
@@ -50,29 +49,30 @@ typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 constexpr int R6_Q = 0;                     // [plane][d-step][64 queries][64 B]
 constexpr int R6_K = 32768;                 // 2 buffers x [plane][d-step][64 keys][64 B]
 constexpr int R6_P = 98304;                 // 2 buffers x [plane][k-step][64 queries][32 B]
-constexpr int R6_SL = 131072;               // per-slot sums [16 slots][2 key halves][64 queries] fp32
-constexpr int R6_MX = R6_SL + 8192;         // [2 key halves][64 queries] row maximum (reference pass)
-constexpr int R6_L = R6_MX + 512;           // [2][64] row sums
-constexpr int R6_FL = R6_L + 512;           // [8] overflow flags
-constexpr int R6_LDS = R6_FL + 64;
+constexpr int R6_SL = 131072;               // per-slot sums [16 slots][2 tile parities][64 queries] fp32 ...
+constexpr int R6_SM = R6_SL + 8192;         // ... and the reference each was taken against
+constexpr int R6_MX = R6_SM + 8192;         // [64 queries] current reference m of the row (log2 domain)
+constexpr int R6_RS = R6_MX + 512;          // [2 tile parities][64] factor 2^(m_old - m_new) of a tile that raised m
+constexpr int R6_L = R6_RS + 512;           // [2][64] row sums
+constexpr int R6_FL = R6_L + 512;           // [2 tile parities][4 query groups] "this tile raised m"
+constexpr int R6_DUMMY = R6_FL + 64;        // 1 KiB nobody reads: target of the K requests that fetch no tile
+constexpr int R6_LDS = R6_DUMMY + 1024;
 constexpr float RD_NEG = -3.0e38f;
-constexpr float RD_THR = 14.0f;             // log2 domain: weights up to 2^14 = 16384 < 65504 (fp16 hi plane)
+constexpr float RD_BUMP = 12.0f;            // log2 domain: weights up to 2^12 = 4096 << 65504 (fp16 hi plane)
 
 #define R6_OPAQUE(x) asm volatile("" : "+v"(x))
 
-// VAR (experiments, tracing kernel only): bit 0 = every wave runs SCORE then PV (no alternation between the two
-// waves of a SIMD); bit 1 = s_setprio 1 around the P.V MFMA cluster; bit 2 = NO s_setprio 1 around the rest of the
-// iteration (requests + SCORE); bit 3 = never wait for V fragments (timing only: results are wrong).
+// VAR (experiments, tracing kernel only): 4 = NO s_setprio 1 around SCORE; 8 = never wait for V fragments (timing only:
+// results are wrong).
 template <int TRACE, int VAR = 0>
 __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr) {
   const int MODE = a.mode;                            // wave-uniform: one code path serves both reads
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qg = wave & 3, kh = wave >> 2;            // score role: query group (16 queries), key half (32 keys)
+  const int qg = wave & 3, grp = wave >> 2;           // score role: query group (16 queries), parity of the tiles it scores
   const int jq = lane & 15, lb = lane >> 4;           // 16x16 tile: column (query) / row block (4 keys)
   const int j = lane & 31, hi = lane >> 5;            // 32x32 tile (P.V)
-  const bool group_a = (VAR & 1) ? true : kh == 0;    // waves 0-3: SCORE then PV; waves 4-7: PV then SCORE
 
   // ---- work unit.  Units are ordered (split, query tile); every XCD (block b runs on XCD b % 8:
   // observed placement, used for speed only) owns a contiguous chunk, so the units of one XCD share a
@@ -127,9 +127,11 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   lut.load(a.slot_map, MODE == 0 ? a.T : 1);
 
   float* sl_sum = reinterpret_cast<float*>(smem + R6_SL);
-  float* mx_ex = reinterpret_cast<float*>(smem + R6_MX);
+  float* sl_m = reinterpret_cast<float*>(smem + R6_SM);
+  float* mrow = reinterpret_cast<float*>(smem + R6_MX);
+  float* resc = reinterpret_cast<float*>(smem + R6_RS);
   float* l_ex = reinterpret_cast<float*>(smem + R6_L);
-  int* flag = reinterpret_cast<int*>(smem + R6_FL);
+  int* bflag = reinterpret_cast<int*>(smem + R6_FL);
 
   // ---- LDS addresses: ONE opaque register per image; everything that varies inside the loops (d-step, k-step,
   // key group, plane, buffer) is an ADDITIVE constant that folds into the 16-bit offset field of the DS
@@ -145,23 +147,23 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   // P image: [k-step ks (4)][row (64)][32 B]; chunk hi of a (ks, row) segment at slot hi ^ ((row >> 3) & 1):
   // conflict-free for the 32x32x16 A-fragment reads (row = lane & 31, chunk = lane >> 5).
   const int fsw = (4 - ((jq >> 2) & 3)) & 3;                          // f of this lane's score rows (rows = .. + jq)
-  int ak0 = R6_K + (kh * 32 + jq) * 64 + ((lb ^ fsw) << 4);           // K row kh*32 (+ kt*16) + jq; + k4*4096 + kt*1024
+  int ak0 = R6_K + jq * 64 + ((lb ^ fsw) << 4);                       // K row kt*16 + jq;           + k4*4096 + kt*1024
   int aq0 = R6_Q + (qg * 16 + jq) * 64 + ((lb ^ fsw) << 4);           // Q row qg*16 + jq;           + k4*4096
   R6_OPAQUE(ak0);
   R6_OPAQUE(aq0);
   auto ak = [&](int k4) __attribute__((always_inline)) { return ak0 + k4 * 4096; };
   auto aq = [&](int k4) __attribute__((always_inline)) { return aq0 + k4 * 4096; };
-  int apw0;                                           // P stores: row qg*16 + jq, keys kh*32 + kt*16 + lb*4 .. +3 = k-step 2 kh + kt
+  int apw0;                                           // P stores: row qg*16 + jq, keys kt*16 + lb*4 .. +3 = k-step kt
   {
     const int row = qg * 16 + jq;
-    apw0 = R6_P + kh * 4096 + row * 32 + (((lb >> 1) ^ ((row >> 3) & 1)) << 4) + (lb & 1) * 8;
+    apw0 = R6_P + row * 32 + (((lb >> 1) ^ ((row >> 3) & 1)) << 4) + (lb & 1) * 8;
     R6_OPAQUE(apw0);
   }
   auto apw = [&](int kt) __attribute__((always_inline)) { return apw0 + kt * 2048; };
   int apr0 = R6_P + j * 32 + ((hi ^ ((j >> 3) & 1)) << 4);            // P fragments: row j (+ 32 qi), chunk hi; + ks*2048 + qi*1024
   R6_OPAQUE(apr0);
   auto apr = [&](int ks) __attribute__((always_inline)) { return apr0 + ks * 2048; };
-  // Staging (LDS-DMA and the register-staged reference pass): a wave-instruction moves 1 KiB = 16 rows x 64 B of
+  // Staging (LDS-DMA): a wave-instruction moves 1 KiB = 16 rows x 64 B of
   // one d-step block; lane L lands at row L >> 2, slot L & 3 of the piece and therefore fetches source chunk
   // (L & 3) ^ f(L >> 4) of its row.  A [64 rows][256 B] plane tile is 16 pieces (d-step k4 = P >> 2, row group P & 3);
   // wave w moves pieces w and w + 8: the same rows, d-steps w >> 2 and (w >> 2) + 2 (source + 128 B, image + 8 KB).
@@ -235,14 +237,14 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     qx = (qvalid ? q : 0) - qy * a.w;
     Rq = a.R + (long)(qvalid ? q : 0) * a.ldr;
   }
-  // Windowed read: relative bias (log2 domain) of this lane's 8 keys of the tile at key0, RD_NEG where the key
-  // is outside the 15x15 window / the image.  All gathers are issued unconditionally (index 0 where masked)
-  // and back to back; one division per 4 consecutive keys.
-  auto window_terms = [&](int key0, float (&rb)[8]) __attribute__((always_inline)) {
+  // Windowed read: relative bias (log2 domain) of this lane's 8 keys key0 + half*32 + kt*16 + lb*4 + e (kt = 0, 1) of
+  // the tile at key0, RD_NEG where the key is outside the 15x15 window / the image.  All gathers are issued
+  // unconditionally (index 0 where masked) and back to back; one division per 4 consecutive keys.
+  auto window_terms = [&](int key0, int half, float (&rb)[8]) __attribute__((always_inline)) {
     int idx[8];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      const int tok0 = key0 + kh * 32 + kt * 16 + lb * 4;
+      const int tok0 = key0 + half * 32 + kt * 16 + lb * 4;
       const int ky0 = fast_div(tok0, inv_w);
       const int kx0 = tok0 - ky0 * a.w;
 #pragma unroll
@@ -263,78 +265,82 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     for (int r = 0; r < 8; ++r) rb[r] = idx[r] < 0 ? RD_NEG : rb[r] * 1.44269504088896341f;
   };
 
-  // ---- scores of one tile for this lane: y[kt*4 + r] = log2-domain logit of key kh*32 + kt*16 + lb*4 + r
-  // (RD_NEG where masked).  EXACT: the three-product form (main pass, redo reference pass); else the hi planes only.
-  // kb = byte offset of the tile's K image relative to R6_K.
+  // ---- scores of one tile for this lane: y[kt*4 + r] = log2-domain logit of key kt*16 + lb*4 + r, kt = 0..3 (RD_NEG
+  // where masked), the three-product form.  kb = byte offset of the tile's K image relative to R6_K.
   int cur_t = -1;
   float bias2 = 0.f;
-  auto scores = [&](const TileIter& ti, int kb, auto EX, float (&y)[8]) __attribute__((always_inline)) {
-    constexpr bool EXACT = decltype(EX)::value;
+  auto scores64 = [&](const TileIter& ti, int kb, float (&y)[16]) __attribute__((always_inline)) {
     const int t = ti.t, key0 = ti.key0();
     if (MODE == 0 && t != cur_t) {
       cur_t = t;
       bias2 = ((a.bias && qvalid) ? a.bias[(long)q * a.T + t] : 0.f) * sl2e;     // (padding queries: no row in bias)
     }
-    f32x4_t s[2];
+    f32x4_t s[4];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[kt][r] = 0.f;
-    // fragments of d-step k4 + 1 are requested before the MFMAs of step k4 (two register sets): read one step at
-    // a time the phase was four LDS round trips long (~3.4 k cycles per tile beside the partner wave's P.V)
-    constexpr int NF = EXACT ? 6 : 3;                 // [0] Q hi, [1] K hi (keys 0-15), [2] K hi (16-31), [3..5] the lo planes
-    frag8_t fa[NF], fb[NF];
-    auto fload = [&](frag8_t (&f)[NF], auto K4) __attribute__((always_inline)) {
+    // 8 items = (d-step k4, pair of key groups); the fragments of item i + 1 are requested before the MFMAs of item i
+    // (two register sets): read one item at a time the phase is eight LDS round trips long
+    frag8_t fq[2][2], fk[2][4];                       // Q [set][hi, lo] of a d-step; K [set][key group of the pair][hi, lo]
+    auto qload = [&](frag8_t (&f)[2], auto K4) __attribute__((always_inline)) {
       constexpr int k4 = decltype(K4)::value;
       f[0] = *reinterpret_cast<const frag8_t*>(smem + aq(k4));
-      f[1] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb);
-      f[2] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + 1024);
-      if constexpr (EXACT) {
-        f[3] = *reinterpret_cast<const frag8_t*>(smem + aq(k4) + 16384);
-        f[4] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + 16384);
-        f[5] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + 1024));
+      f[1] = *reinterpret_cast<const frag8_t*>(smem + aq(k4) + 16384);
+    };
+    auto kload = [&](frag8_t (&f)[4], auto K4, auto PR) __attribute__((always_inline)) {
+      constexpr int k4 = decltype(K4)::value, pr = decltype(PR)::value;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f[e * 2 + 0] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (2 * pr + e) * 1024);
+        f[e * 2 + 1] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + (2 * pr + e) * 1024));
       }
     };
-    fload(fa, std::integral_constant<int, 0>{});
-    static_for<4>([&](auto K4) {
-      constexpr int k4 = K4.value;
-      frag8_t (&c)[NF] = (k4 & 1) ? fb : fa;
-      if constexpr (k4 < 3) fload((k4 & 1) ? fa : fb, std::integral_constant<int, (k4 < 3 ? k4 + 1 : 0)>{});
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (EXACT) {
-        s[0] = RMEM_MFMA16(c[1], c[3], s[0]);         // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
-        s[1] = RMEM_MFMA16(c[2], c[3], s[1]);
-        s[0] = RMEM_MFMA16(c[4], c[0], s[0]);
-        s[1] = RMEM_MFMA16(c[5], c[0], s[1]);
+    qload(fq[0], std::integral_constant<int, 0>{});
+    kload(fk[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    static_for<8>([&](auto I) {
+      constexpr int i = I.value, k4 = i >> 1, pr = i & 1;
+      if constexpr (i + 1 < 8) {
+        constexpr int n4 = (i + 1 < 8 ? (i + 1) >> 1 : 0), npr = (i + 1) & 1;
+        if constexpr (npr == 0) qload(fq[n4 & 1], std::integral_constant<int, n4>{});
+        kload(fk[(i + 1) & 1], std::integral_constant<int, n4>{}, std::integral_constant<int, npr>{});
       }
-      s[0] = RMEM_MFMA16(c[1], c[0], s[0]);
-      s[1] = RMEM_MFMA16(c[2], c[0], s[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      frag8_t (&fqc)[2] = fq[k4 & 1];
+      frag8_t (&fkc)[4] = fk[i & 1];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {                   // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
+        s[2 * pr + e] = RMEM_MFMA16(fkc[e * 2 + 0], fqc[1], s[2 * pr + e]);
+        s[2 * pr + e] = RMEM_MFMA16(fkc[e * 2 + 1], fqc[0], s[2 * pr + e]);
+        s[2 * pr + e] = RMEM_MFMA16(fkc[e * 2 + 0], fqc[0], s[2 * pr + e]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     const bool padded = key0 + 64 > a.N;
     if (MODE == 0 && !padded) {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[kt * 4 + r] = fmaf(s[kt][r], sl2e, bias2);
     } else if (MODE == 0) {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int tok = key0 + kh * 32 + kt * 16 + lb * 4 + r;
+          const int tok = key0 + kt * 16 + lb * 4 + r;
           y[kt * 4 + r] = tok < a.N ? fmaf(s[kt][r], sl2e, bias2) : RD_NEG;
         }
     } else {
-      float rb[8];
-      window_terms(key0, rb);
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int half = 0; half < 2; ++half) {
+        float rb[8];
+        window_terms(key0, half, rb);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float rbv = rb[kt * 4 + r];
-          y[kt * 4 + r] = rbv > -2.9e38f ? fmaf(s[kt][r], sl2e, rbv) : RD_NEG;
+        for (int e = 0; e < 8; ++e) {
+          const float rbv = rb[e];
+          y[half * 8 + e] = rbv > -2.9e38f ? fmaf(s[half * 2 + (e >> 2)][e & 3], sl2e, rbv) : RD_NEG;
         }
+      }
     }
     return t;
   };
@@ -342,375 +348,362 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   int vcol = (wave * 128 + j) * 16 + hi * 8;           // V fragments: lane = column, 8 consecutive keys (16 B)
   R6_OPAQUE(vcol);
 
-  float m = RD_NEG;                                   // this query's reference (log2 domain)
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    // ================= reference pass: m <= (and close to) the maximum of this query's scores over the unit's keys
-    {
-      float mest = RD_NEG;
-      cur_t = -1;
-      __syncthreads();                                // (redo: every wave is done with the images of the main pass)
-      if (attempt == 0) {
-        // First attempt: the hi planes only (8 small MFMAs per wave per tile; the maximum is off by a few hundredths).
-        // Tiles go in PAIRS, one barrier per pair.  The K tiles of this pass are staged through REGISTERS (4 loads +
-        // 4 ds_write_b128 per wave per pair, swizzle on the source address, the same image the LDS-DMA builds): the
-        // DMA path moves ~12 B / clk / CU, and at 16 KB per tile that alone was 1.3-1.9 k cycles per tile of a pass
-        // whose arithmetic is nothing.  (Every key is looked at: a sub-sampled maximum misses the one dominant key
-        // of peaked attention -- the diagonal of the self read, the same position of the previous frame -- and every
-        // such unit then pays the exact redo: measured, LSTT forward 0.94 -> 1.07 ms.)
-        constexpr int RP = 3;                          // ring of 3 pairs = 6 hi-plane tiles in [R6_K, R6_K + 96 KB)
-        const int npairs = (n + 1) / 2;
-        TileIter tld, tcmp;
-        tinit(tld, lo);
-        tcmp = tld;
-        u32x4_t rk[4];                                 // [tile of the pair][piece wave / wave + 8]
-        auto kload = [&]() __attribute__((always_inline)) {             // request the pair at tld (clamped to valid tiles)
+  // ---- statistics start empty; first K tiles
+  for (int e = tid; e < 2048; e += 512) {
+    sl_sum[e] = 0.f;
+    sl_m[e] = RD_NEG;
+  }
+  if (tid < 64) mrow[tid] = RD_NEG;
+  if (tid < 8) bflag[tid] = 0;
+  {
+    TileIter t01;
+    tinit(t01, lo);
+    dma_k(t01, 0, true);
+    tstep(t01);
+    if (n > 1) dma_k(t01, 1, true);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // Q and the first K tiles are in
+  __syncthreads();
+  if (trace && tid == 0) trace[1] = __builtin_readcyclecounter();
+
+  // ================= the pass
+  f32x16_t o[2][4];
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const char* src = reinterpret_cast<const char*>(a.kh + tld.kslot + (long)tld.key0() * 128) + dma_off0;
-            rk[e * 2 + 0] = *reinterpret_cast<const u32x4_t*>(src);
-            rk[e * 2 + 1] = *reinterpret_cast<const u32x4_t*>(src + 128);
-            if (tld.t * tv + tld.kt + 1 < k_hi) tstep(tld);             // (never steps past the last tile of the read:
-                                                                        //  a clamped request repeats a tile nobody uses)
-          }
-        };
-        auto kstore = [&](int pair) __attribute__((always_inline)) {
-          const int base = R6_K + (pair % RP) * 32768 + dma_dst0 + lane * 16;
+  for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            *reinterpret_cast<u32x4_t*>(smem + base + e * 16384) = rk[e * 2 + 0];
-            *reinterpret_cast<u32x4_t*>(smem + base + e * 16384 + 8192) = rk[e * 2 + 1];
-          }
-        };
-        kload();
-        kstore(0);
-        if (npairs > 1) kload();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the Q tile's DMA)
-        __syncthreads();
-#pragma clang loop unroll(disable)
-        for (int p = 0; p < npairs; ++p) {
+    for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int x = 2 * p + e;
-            if (x < n) {
-              float y[8];
-              scores(tcmp, (p % RP) * 32768 + e * 16384, std::false_type{}, y);
-              tstep(tcmp);
+      for (int r = 0; r < 16; ++r) o[qi][ci][r] = 0.f;
+  float l = 0.f, lcur = 0.f;                          // this lane's part of the row sum (all slots / the current slot) ...
+  float m_known = RD_NEG;                             // ... taken against this reference
+  int sum_t = -1;                                     // slot lcur belongs to
+  bool raised = false;                                // this wave's flag slot is set
+  const int row_s = qg * 16 + jq;                     // this lane's query in the score role
+  u32x4_t vr[4][2];                                   // ring of V fragments: step s = (k-step, ci) lives in vr[s & 3][plane]
+
+  // re-express the sums against the row's reference `mc` (a wave-uniform branch; taken when the other parity's owner, or
+  // this wave, raised m)
+  auto follow = [&](float mc) __attribute__((always_inline)) {
+    if (__any(mc != m_known)) {
+      const float f = __builtin_amdgcn_exp2f(m_known - mc);       // (first reference: 2^(-3e38 - mc) = 0, the sums are 0 too)
+      l *= f;
+      lcur *= f;
+      m_known = mc;
+    }
+  };
+
+  // SCORE(i) by its owner: weights of tile i -> P image pbuf (K image kbuf); par = parity of i = this wave's group
+  auto score_phase = [&](const TileIter& ti, int kbuf, int pbuf) __attribute__((always_inline)) {
+    if (raised) {                                     // (wave-uniform) the P.V of the tile that raised m is two barriers back
+      if (lane == 0) bflag[grp * 4 + qg] = 0;
+      raised = false;
+    }
+    float mc = mrow[row_s];
+    float y[16];
+    const int t = scores64(ti, kbuf * 32768, y);
+    follow(mc);
+    if (t != sum_t) {
+      if (sum_t >= 0) {                               // (wave-uniform) slot finished: park its sum and what it refers to
+        float v = lcur + __shfl_xor(lcur, 16);
+        v += __shfl_xor(v, 32);
+        if (lb == 0) {
+          sl_sum[(sum_t * 2 + grp) * 64 + row_s] = v;
+          sl_m[(sum_t * 2 + grp) * 64 + row_s] = m_known;
+        }
+      }
+      lcur = 0.f;
+      sum_t = t;
+    }
+    // the row's largest score of this tile (sentinels are far below): 4 lanes hold a query
+    float rm = fmaxf(fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7]))),
+                     fmaxf(fmaxf(fmaxf(y[8], y[9]), fmaxf(y[10], y[11])), fmaxf(fmaxf(y[12], y[13]), fmaxf(y[14], y[15]))));
+    rm = fmaxf(rm, __shfl_xor(rm, 16));
+    rm = fmaxf(rm, __shfl_xor(rm, 32));
+    const bool bump = rm > mc + RD_BUMP;              // (mc = -3e38 before the first valid key: any valid score raises it)
+    if (__any(bump)) {                                // (wave-uniform, rare) raise m of those rows to this tile's maximum
+      const float mn = bump ? rm : mc;
+      if (lb == 0) {
+        resc[grp * 64 + row_s] = __builtin_amdgcn_exp2f(mc - mn);   // 1 for the rows that stay
+        mrow[row_s] = mn;
+      }
+      if (lane == 0) bflag[grp * 4 + qg] = 1;
+      raised = true;
+      mc = mn;
+      follow(mc);
+    }
+    const bool masked = MODE == 1 || ti.key0() + 64 > a.N;      // (wave-uniform) the tile may hold RD_NEG sentinels
+    float psum = 0.f;
 #pragma unroll
-              for (int r = 0; r < 8; ++r) mest = fmaxf(mest, y[r]);
-            }
-          }
-          if (p + 1 < npairs) {
-            kstore(p + 1);                             // requested one iteration ago; its slot was last read in iteration p - 2
-            if (p + 2 < npairs) kload();
-          }
-          __syncthreads();
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x2_t pp[2];
+      if (!masked) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __builtin_amdgcn_exp2f(y[kt * 4 + e] - mc);
+          psum += p;
+          pp[e >> 1][e & 1] = p;
         }
       } else {
-        // Redo: the exact three-product scores of EVERY key (bit-identical to the main pass's), both planes through
-        // the two K buffers, one tile per barrier.
-        TileIter tdma, tcmp;
-        tinit(tdma, lo);
-        tcmp = tdma;
-        int issued = 0;                               // tiles requested so far
-        auto request = [&](int upto) __attribute__((always_inline)) {
-          for (; issued < upto && issued < n; ++issued) {
-            dma_k(tdma, issued & 1, true);
-            tstep(tdma);
-          }
-        };
-        request(2);
-#pragma clang loop unroll(disable)
-        for (int x = 0; x < n; ++x) {
-          if (issued - (x + 1) >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 4 pieces per tile per wave
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();                            // tile x landed for every wave; the buffer of tile x - 1 is free
-          if (x >= 1) request(x + 2);
-          float y[8];
-          scores(tcmp, (x & 1) * 32768, std::true_type{}, y);
-          tstep(tcmp);
+        asm volatile("" ::: "memory");                // keeps this form a branch (as a select it costs every tile two more VALU per key)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) mest = fmaxf(mest, y[r]);
+        for (int e = 0; e < 4; ++e) {
+          const float sv = y[kt * 4 + e];
+          float p = __builtin_amdgcn_exp2f(sv - mc);  // sentinels (-3e38) give exactly 0 unless m is one too
+          p = sv > -2.9e38f ? p : 0.f;
+          psum += p;
+          pp[e >> 1][e & 1] = p;
         }
       }
-      mest = fmaxf(mest, __shfl_xor(mest, 16));
-      mest = fmaxf(mest, __shfl_xor(mest, 32));
-      __syncthreads();                                // all fragment reads of the pass are done: the K / P regions are free
-      if (lb == 0) mx_ex[kh * 64 + qg * 16 + jq] = mest;
-      // per-slot sums and flags start from zero
-      for (int e = tid; e < 2048; e += 512) sl_sum[e] = 0.f;
-      if (tid < 8) flag[tid] = 0;
-      // first K tiles of the main pass
-      TileIter t01;
-      tinit(t01, lo);
-      dma_k(t01, 0, true);
-      tstep(t01);
-      if (n > 1) dma_k(t01, 1, true);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      m = fmaxf(mx_ex[qg * 16 + jq], mx_ex[64 + qg * 16 + jq]);
+      // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
+      const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
+      const f32x2_t r0 = pp[0] - __builtin_convertvector(h0, f32x2_t), r1 = pp[1] - __builtin_convertvector(h1, f32x2_t);
+      const f16x2_t l0 = __builtin_convertvector(r0, f16x2_t), l1 = __builtin_convertvector(r1, f16x2_t);
+      u32x2_t wh, wl;
+      wh[0] = __builtin_bit_cast(uint32_t, h0);
+      wh[1] = __builtin_bit_cast(uint32_t, h1);
+      wl[0] = __builtin_bit_cast(uint32_t, l0);
+      wl[1] = __builtin_bit_cast(uint32_t, l1);
+      *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384) = wh;
+      *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384 + 8192) = wl;
     }
-    if (trace && tid == 0) trace[1] = __builtin_readcyclecounter();
+    l += psum;
+    lcur += psum;
+  };
 
-    // ================= main pass
-    f32x16_t o[2][4];
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[qi][ci][r] = 0.f;
-    float l = 0.f, lcur = 0.f;
-    int sum_t = -1;                                   // slot lcur belongs to
-    bool over = false;
-    cur_t = -1;
-    u32x4_t vr[4][2];                                 // ring of V fragments: step s = (k-step, ci) lives in vr[s & 3][plane]
-
-    // SCORE(i): weights of tile i -> P image pbuf (K image kbuf)
-    auto score_phase = [&](const TileIter& ti, int kbuf, int pbuf) __attribute__((always_inline)) {
-      float y[8];
-      const int t = scores(ti, kbuf * 32768, std::true_type{}, y);
-      if (t != sum_t) {
-        if (sum_t >= 0) {                             // (wave-uniform) slot finished: park its sum
-          float v = lcur + __shfl_xor(lcur, 16);
-          v += __shfl_xor(v, 32);
-          if (lb == 0) sl_sum[(sum_t * 2 + kh) * 64 + qg * 16 + jq] = v;
-        }
-        lcur = 0.f;
-        sum_t = t;
-      }
-      // one overflow test per tile: the largest score against the reference (sentinels are far below)
-      const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
-      over = over || (ymax - m > RD_THR);
-      const bool masked = MODE == 1 || ti.key0() + 64 > a.N;      // (wave-uniform) the tile may hold RD_NEG sentinels
-      float psum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x2_t pp[2];
-        if (!masked) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float p = __builtin_amdgcn_exp2f(y[kt * 4 + e] - m);
-            psum += p;
-            pp[e >> 1][e & 1] = p;
-          }
-        } else {
-          asm volatile("" ::: "memory");              // keeps this form a branch (as a select it costs every tile two more VALU per key)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float sv = y[kt * 4 + e];
-            float p = __builtin_amdgcn_exp2f(sv - m); // sentinels (-3e38) give exactly 0 unless m is one too
-            p = sv > -2.9e38f ? p : 0.f;
-            psum += p;
-            pp[e >> 1][e & 1] = p;
-          }
-        }
-        // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
-        const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
-        const f32x2_t r0 = pp[0] - __builtin_convertvector(h0, f32x2_t), r1 = pp[1] - __builtin_convertvector(h1, f32x2_t);
-        const f16x2_t l0 = __builtin_convertvector(r0, f16x2_t), l1 = __builtin_convertvector(r1, f16x2_t);
-        u32x2_t wh, wl;
-        wh[0] = __builtin_bit_cast(uint32_t, h0);
-        wh[1] = __builtin_bit_cast(uint32_t, h1);
-        wl[0] = __builtin_bit_cast(uint32_t, l0);
-        wl[1] = __builtin_bit_cast(uint32_t, l1);
-        *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384) = wh;
-        *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384 + 8192) = wl;
-      }
-      l += psum;
-      lcur += psum;
-    };
-    // V fragments of step s = 4 ks + ci of the tile whose blocked-16 planes start at vhp / vlp -> ring slot s & 3.
-    // Requested by inline assembly and waited for by vwait() below with COUNTED vmcnt: left to the compiler, the
-    // loads and their use sit in different branches of the loop body, and its wait-count pass then protects the
-    // ring registers with s_waitcnt vmcnt(0) at the top of every iteration -- i.e. it waits for the K transfer
-    // that was just requested (measured: 1.3-4 k cycles per tile).  The compiler sees no vector-memory load in the
-    // loop any more; the "+v" ties keep every use of a ring slot behind its vwait().
-    const h16_t* vhp = a.vh;
-    const h16_t* vlp = a.vl;
-    auto vstep = [&](auto S) __attribute__((always_inline)) {
-      constexpr int sidx = decltype(S)::value;
-      constexpr int ks = sidx >> 2, ci = sidx & 3;
-      const h16_t* ph = vhp + ks * (1024 * 16) + vcol;      // (k-step: 16 keys x 1024 columns)
-      const h16_t* pl = vlp + ks * (1024 * 16) + vcol;
-      u32x4_t& d0 = vr[sidx & 3][0];                        // (asm operands do not capture: name the slots first)
-      u32x4_t& d1 = vr[sidx & 3][1];
-      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d0) : "v"(ph), "n"(ci * 1024));
-      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d1) : "v"(pl), "n"(ci * 1024));
-    };
-    // the fragments of step s have landed: every request up to step s + 3 has been issued by now, so at most the
-    // 6 loads of steps s + 1 .. s + 3 may still be in flight (fewer at the end of the tile)
-    auto vwait = [&](auto S) __attribute__((always_inline)) {
-      constexpr int sidx = decltype(S)::value;
-      constexpr int younger = sidx <= 12 ? 6 : 2 * (15 - sidx);
-      u32x4_t& d0 = vr[sidx & 3][0];
-      u32x4_t& d1 = vr[sidx & 3][1];
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(d0), "+v"(d1) : "n"(younger));
-    };
-    // PV(i): O += P(pbuf) . V(tile i).  16 steps (k-step, 32-column tile) of 6 MFMAs; the V fragments of a step
-    // are requested 4 steps ahead (steps 0-3 before this phase), the P fragments of a k-step one k-step ahead.
-    auto pv_phase = [&](int pbuf) __attribute__((always_inline)) {
-      frag8_t pa[4], pb[4];                           // P fragments [qi][plane] of one k-step
-      auto pload = [&](frag8_t (&pf)[4], auto KS) __attribute__((always_inline)) {
-        constexpr int ks = decltype(KS)::value;
+  // ---- V fragments: a ring of 4 steps (step = k-step x 32-column tile, 8 registers) that runs THROUGH the tile
+  // boundaries.  Requested by inline assembly four steps ahead and awaited with COUNTED vmcnt tied to the ring
+  // registers ("+v"): left to the compiler, its wait-count pass protects the ring with s_waitcnt vmcnt(0), i.e. waits
+  // for the K transfer that was just requested.  The compiler sees no vector-memory load in the P.V cluster.
+  const h16_t* vhp = a.vh;                            // blocked-16 planes of the tile whose P.V runs / of the next tile
+  const h16_t* vlp = a.vl;
+  const h16_t* vhn = a.vh;
+  const h16_t* vln = a.vl;
+  auto vreq = [&](auto S) __attribute__((always_inline)) {     // step S of this tile (S < 16) or S - 16 of the next
+    constexpr int sidx = decltype(S)::value;
+    constexpr int ks = (sidx & 15) >> 2, ci = sidx & 3;
+    // scalar base + 32-bit lane offset (k-step: 16 keys x 1024 columns = 32 KB) + immediate (32-column tile: 1 KB)
+    const h16_t* bh = sidx < 16 ? vhp : vhn;
+    const h16_t* bl = sidx < 16 ? vlp : vln;
+    const int off = vcol * 2 + ks * 32768;
+    u32x4_t& d0 = vr[sidx & 3][0];                    // (asm operands do not capture: name the slots first)
+    u32x4_t& d1 = vr[sidx & 3][1];
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d0) : "v"(off), "s"(bh), "n"(ci * 1024));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d1) : "v"(off), "s"(bl), "n"(ci * 1024));
+  };
+  // Vector-memory requests in flight, oldest first, when step s waits for its fragments: V(s) .. V(s+3) of the ring
+  // and, for s < 4, the 4 K-transfer pieces issued at the top of the iteration.  Both are ALWAYS issued -- a 1 KiB
+  // dummy target for the K pieces when there is no tile to fetch, a re-read of the current planes for the V steps
+  // past the last tile -- so that each wait is ONE statement with a constant count: vmcnt(10) for s < 4, vmcnt(6)
+  // after.  (A wait that sits in two branches -- "if (more) vmcnt(6) else vmcnt(2)" -- makes the ring registers a
+  // phi; the compiler then copies the tied operand BEFORE the wait in one of the branches, i.e. copies a register
+  // whose load has not landed.)  Loads the compiler issues itself in SCORE (a bias on a slot change, the window
+  // gathers) are younger than all of these and waited for before SCORE ends: by then nothing is in flight.
+  auto vwait = [&](auto S) __attribute__((always_inline)) {
+    constexpr int sidx = decltype(S)::value;
+    u32x4_t& d0 = vr[sidx & 3][0];
+    u32x4_t& d1 = vr[sidx & 3][1];
+    if constexpr (VAR & 8) {                          // (timing experiment of the tracing kernel: never wait; wrong results)
+      asm volatile("" : "+v"(d0), "+v"(d1));
+    } else if constexpr (sidx < 4) {
+      asm volatile("s_waitcnt vmcnt(10)" : "+v"(d0), "+v"(d1));
+    } else {
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(d0), "+v"(d1));
+    }
+  };
+  // PV(i): O += P(pbuf) . V(tile i).  16 steps (k-step, 32-column tile) of 6 MFMAs; the V fragments of a step are
+  // requested 4 steps ahead (the last four steps request the first four of the next tile), the P fragments of a
+  // k-step one k-step ahead.  A tile that raised m: the rows' factors first.
+  auto pv_phase = [&](int pbuf) __attribute__((always_inline)) {
+    {
+      const int* fp = bflag + pbuf * 4;
+      const int f0 = __builtin_amdgcn_readfirstlane(fp[0]), f1 = __builtin_amdgcn_readfirstlane(fp[1]);
+      const int f2 = __builtin_amdgcn_readfirstlane(fp[2]), f3 = __builtin_amdgcn_readfirstlane(fp[3]);
+      if (f0 | f1 | f2 | f3) {                        // (wave-uniform, rare)
+        // accumulator register r of tile qi is row qi*32 + (r & 3) + 8 (r >> 2) + 4 hi: registers 0-7 belong to query
+        // group 2 qi, 8-15 to 2 qi + 1
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-          for (int p = 0; p < 2; ++p)
-            pf[qi * 2 + p] = *reinterpret_cast<const frag8_t*>(smem + apr(ks) + (pbuf * 16384 + p * 8192 + qi * 1024));
-      };
-      pload(pa, std::integral_constant<int, 0>{});
-      static_for<16>([&](auto S) {
-        constexpr int sidx = S.value;
-        constexpr int ks = sidx >> 2, ci = sidx & 3;
-        frag8_t (&pc)[4] = (ks & 1) ? pb : pa;
-        if constexpr (ci == 0 && ks < 3) pload((ks & 1) ? pa : pb, std::integral_constant<int, (ks < 3 ? ks + 1 : 0)>{});
-        __builtin_amdgcn_sched_barrier(0);
-        vwait(S);
-        const frag8_t vh = __builtin_bit_cast(frag8_t, vr[sidx & 3][0]);
-        const frag8_t vl = __builtin_bit_cast(frag8_t, vr[sidx & 3][1]);
+          for (int hf = 0; hf < 2; ++hf) {
+            const int fl = qi == 0 ? (hf == 0 ? f0 : f1) : (hf == 0 ? f2 : f3);
+            if (fl) {
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {              // small terms first
-          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vl, o[qi][ci]);
-          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 1], vh, o[qi][ci]);
-          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vh, o[qi][ci]);
-        }
-        if constexpr (sidx + 4 < 16) vstep(std::integral_constant<int, (sidx + 4 < 16 ? sidx + 4 : 0)>{});
-        __builtin_amdgcn_sched_barrier(0);
-      });
+              for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = hf * 8 + r8;
+                const float f = resc[pbuf * 64 + qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) o[qi][ci][r] *= f;
+              }
+            }
+          }
+      }
+    }
+    frag8_t pa[4], pb[4];                             // P fragments [qi][plane] of one k-step
+    auto pload = [&](frag8_t (&pf)[4], auto KS) __attribute__((always_inline)) {
+      constexpr int ks = decltype(KS)::value;
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          pf[qi * 2 + p] = *reinterpret_cast<const frag8_t*>(smem + apr(ks) + (pbuf * 16384 + p * 8192 + qi * 1024));
     };
+    pload(pa, std::integral_constant<int, 0>{});
+    static_for<16>([&](auto S) {
+      constexpr int sidx = S.value;
+      constexpr int ks = sidx >> 2, ci = sidx & 3;
+      frag8_t (&pc)[4] = (ks & 1) ? pb : pa;
+      if constexpr (ci == 0 && ks < 3) pload((ks & 1) ? pa : pb, std::integral_constant<int, (ks < 3 ? ks + 1 : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      vwait(S);
+      const frag8_t vh = __builtin_bit_cast(frag8_t, vr[sidx & 3][0]);
+      const frag8_t vl = __builtin_bit_cast(frag8_t, vr[sidx & 3][1]);
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) {                // small terms first
+        o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vl, o[qi][ci]);
+        o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 1], vh, o[qi][ci]);
+        o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vh, o[qi][ci]);
+      }
+      vreq(std::integral_constant<int, sidx + 4>{});  // (steps 16-19: the next tile's first four, see vwait)
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
 
-    // One loop body for both wave groups; group B (waves 4-7) meets the interval's barrier BETWEEN its two
-    // phases and runs the P.V of the tile whose weights were just finished, i.e. it is half an interval behind:
-    //   A:  [SCORE(it+1)  PV(it)]   barrier
-    //   B:   SCORE(it+1)  barrier  [PV(it+1)]
-    // Both pass exactly one barrier per iteration.  K(it + 2) is requested at the top of iteration it -- every
-    // wave is then past barrier it - 1, which ends the readers of K(it) (same buffer) -- and waited for before
-    // the wave's next barrier; being OLDER than the V loads that follow, it never lengthens a wait for those.
-    TileIter t_sc, t_dma, t_v;                        // tiles of the next SCORE (it + 1), K request (it + 2), P.V (px)
-    tinit(t_sc, lo);
-    tinit(t_dma, lo + 2 < hi_t ? lo + 2 : lo);
-    t_v = t_sc;
+  // In interval `it` the owners of tile it + 1 run SCORE(it + 1) then PV(it), the other four waves PV(it) at once; ONE
+  // barrier ends the interval.  K(it + 2) is requested at the top of iteration it -- every wave is then past barrier
+  // it - 1, which ends the readers of K(it) (same buffer) -- and awaited before the barrier.
+  TileIter t_sc, t_dma, t_v;                          // tiles of the next SCORE (it + 1), K request (it + 2), V base (it + 1)
+  tinit(t_sc, lo);
+  tinit(t_dma, lo + 2 < hi_t ? lo + 2 : lo);
+  tinit(t_v, lo);
+  if (grp == 0) score_phase(t_sc, 0, 0);              // tile 0
+  tstep(t_sc);
+  {
+    const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
+    vhp = a.vh + vb;
+    vlp = a.vl + vb;
+    if (n > 1) tstep(t_v);
+  }
+  vreq(std::integral_constant<int, 0>{});
+  vreq(std::integral_constant<int, 1>{});
+  vreq(std::integral_constant<int, 2>{});
+  vreq(std::integral_constant<int, 3>{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
 #pragma clang loop unroll(disable)
-    for (int it = -1; it < n; ++it) {
-      const int px = group_a ? it : it + 1;           // tile (relative) whose P.V this wave runs now
-      const bool do_pv = px >= 0 && px < n;
-      const bool do_sc = it + 1 < n;
-      long long tt0 = 0;
-      if (TRACE) tt0 = __builtin_readcyclecounter();
-      // Priority: the wave that is NOT in its P.V cluster goes first.  Both at priority 0, the older wave's MFMAs
-      // sit at the head of the SIMD's vector issue and the younger wave's requests / address arithmetic / exp2
-      // crawl beside them (measured: 4.1 k cycles for this block beside a P.V, 1.1 k otherwise).
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
-      // K(it + 2) into the buffer of K(it): its readers, SCORE(it), are past barrier it - 1 (for both groups)
-      if (it >= 0 && it + 2 < n) {
-        dma_k(t_dma, it & 1, true);
-        tstep(t_dma);
-      }
-      if (do_pv) {                                    // V fragments of the first four steps: in flight during SCORE
-        const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
-        tstep(t_v);
-        vhp = a.vh + vb;
-        vlp = a.vl + vb;
-        vstep(std::integral_constant<int, 0>{});
-        vstep(std::integral_constant<int, 1>{});
-        vstep(std::integral_constant<int, 2>{});
-        vstep(std::integral_constant<int, 3>{});
-      }
-      long long t0 = 0;
-      if (TRACE) {
-        t0 = __builtin_readcyclecounter();
-        tacc[3] += t0 - tt0;
-      }
-      if (do_sc) {
+  for (int it = 0; it < n; ++it) {
+    const bool more = it + 1 < n;
+    long long t0 = 0;
+    if (TRACE) t0 = __builtin_readcyclecounter();
+    // K(it + 2) into the buffer of K(it); when there is no such tile the 4 pieces go to a 1 KiB dummy target (keeps
+    // the request count of vwait() constant)
+    {
+      const bool real = it + 2 < n;
+      const long base = t_dma.kslot + (long)t_dma.key0() * 128;
+      const int dst = real ? R6_K + (it & 1) * 32768 + dma_dst0 : R6_DUMMY;
+      const int dstep = real ? 8192 : 0;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + dst + pl * (real ? 16384 : 0) + pc * dstep);
+          const char* g = reinterpret_cast<const char*>((pl ? a.kl : a.kh) + base) + dma_off0 + pc * 128;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(g) : "memory");
+        }
+      if (it + 3 < n) tstep(t_dma);                    // (never past the unit's last tile: the dummy requests re-read that one)
+    }
+    if (more) {                                       // V planes of the next tile (its first steps are requested in PV)
+      const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
+      vhn = a.vh + vb;
+      vln = a.vl + vb;
+      if (it + 2 < n) tstep(t_v);
+    }
+    if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[3] += t1 - t0; t0 = t1; }
+    if (more) {
+      if (((it + 1) & 1) == grp) {
+        // Priority: the scoring wave goes first.  Both at priority 0, the partner's queued MFMAs sit at the head of
+        // the SIMD's vector issue and this wave's LDS reads / exp2 / conversions crawl beside them.
+        if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
         score_phase(t_sc, (it + 1) & 1, (it + 1) & 1);
-        tstep(t_sc);
+        if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
       }
-      if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
-      if (!group_a) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[2] += t1 - t0; t0 = t1; }
-      }
-      if ((VAR & 2) && do_pv) __builtin_amdgcn_s_setprio(1);
-      if (do_pv) pv_phase(px & 1);
-      if ((VAR & 2) && do_pv) __builtin_amdgcn_s_setprio(0);
-      if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
-      if (group_a) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (TRACE) tacc[2] += __builtin_readcyclecounter() - t0;
-      }
+      tstep(t_sc);
     }
-    if (trace && tid == 0) trace[2] = __builtin_readcyclecounter();
+    if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
+    pv_phase(it & 1);
+    if (more) {
+      vhp = vhn;
+      vlp = vln;
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // all but the next tile's first four V steps: the K transfer is in
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
+    __syncthreads();                                  // P(it + 1), K(it + 2), m visible; P(it), K(it + 1) may be overwritten
+    if (TRACE) tacc[2] += __builtin_readcyclecounter() - t0;
+  }
+  if (trace && tid == 0) trace[2] = __builtin_readcyclecounter();
 
-    // ---- overflow?  (wave-uniform flags; the unit is redone against the exact reference)
-    if (attempt == 0) {
-      const int any_over = __any(over) ? 1 : 0;
-      if (lane == 0) flag[wave] = any_over;
-      __syncthreads();
-      int f = 0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) f |= flag[k];
-      if (__builtin_amdgcn_readfirstlane(f)) continue;
+  // ---- statistics against the final reference of the row: the last slot's sum, row sums of the two parities
+  {
+    const float mfin = mrow[row_s];
+    follow(mfin);
+    float v = lcur + __shfl_xor(lcur, 16);
+    v += __shfl_xor(v, 32);
+    float lt = l + __shfl_xor(l, 16);
+    lt += __shfl_xor(lt, 32);
+    if (lb == 0) {
+      if (sum_t >= 0) {
+        sl_sum[(sum_t * 2 + grp) * 64 + row_s] = v;
+        sl_m[(sum_t * 2 + grp) * 64 + row_s] = mfin;
+      }
+      l_ex[grp * 64 + row_s] = lt;
     }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float* mlp = a.ml + ((long)z * a.Npad + qtile * 64 + tid) * 2;
+    const float mq = mrow[tid];
+    mlp[0] = mq > -2.9e38f ? mq * LN2 : RD_NEG;
+    mlp[1] = l_ex[tid] + l_ex[64 + tid];
+  }
+  if (lslot_out)
+    for (int e = tid; e < 64 * a.T; e += 512) {
+      const int qq = e & 63, t = e >> 6;
+      float* lsp = lslot_out + (((long)z * a.Npad + qtile * 64 + qq) * a.T + t) * 2;
+      const float mq = mrow[qq];
+      const int i0 = (t * 2) * 64 + qq, i1 = (t * 2 + 1) * 64 + qq;
+      // (a parity that saw no tile of the slot holds sum 0 against -3e38: 0 * 2^0 or 0 * 0)
+      lsp[0] = sl_sum[i0] * __builtin_amdgcn_exp2f(sl_m[i0] - mq) + sl_sum[i1] * __builtin_amdgcn_exp2f(sl_m[i1] - mq);
+      lsp[1] = mq * LN2;
+    }
+  __syncthreads();                                    // the images are dead, the statistics read: LDS is reused below
 
-    // ---- statistics: the last slot's sum, row sums of the two key halves
-    {
-      float v = lcur + __shfl_xor(lcur, 16);
-      v += __shfl_xor(v, 32);
-      float lt = l + __shfl_xor(l, 16);
-      lt += __shfl_xor(lt, 32);
-      if (lb == 0) {
-        if (sum_t >= 0) sl_sum[(sum_t * 2 + kh) * 64 + qg * 16 + jq] = v;
-        l_ex[kh * 64 + qg * 16 + jq] = lt;
-        if (kh == 0) mx_ex[qg * 16 + jq] = m;          // (reference of query qg*16 + jq, for the writers below)
+  // ---- flush O: transposed through LDS (the accumulator layout gives one column per lane, i.e. 4-byte
+  // stores; staged as [32 rows][128 columns] per wave the tile leaves as 16-byte stores of 512-byte rows)
+  {
+    char* stg = smem + wave * 16384;
+    int lrow = hi, lcol = j;                        // opaque: keeps the row pointers out of the prologue
+    R6_OPAQUE(lrow);
+    R6_OPAQUE(lcol);
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+          *reinterpret_cast<float*>(stg + row * 512 + (ci * 32 + lcol) * 4) = o[qi][ci][r];
       }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      float* mlp = a.ml + ((long)z * a.Npad + qtile * 64 + tid) * 2;
-      const float mq = mx_ex[tid];
-      mlp[0] = mq > -2.9e38f ? mq * LN2 : RD_NEG;
-      mlp[1] = l_ex[tid] + l_ex[64 + tid];
-    }
-    if (lslot_out)
-      for (int e = tid; e < 64 * a.T; e += 512) {
-        const int qq = e & 63, t = e >> 6;
-        float* lsp = lslot_out + (((long)z * a.Npad + qtile * 64 + qq) * a.T + t) * 2;
-        lsp[0] = sl_sum[(t * 2) * 64 + qq] + sl_sum[(t * 2 + 1) * 64 + qq];
-        lsp[1] = mx_ex[qq] * LN2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS operations complete in order
+      float* orow = a.part + ((long)z * a.Npad + qtile * 64 + qi * 32) * a.ncols + wave * 128;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 2 + lrow;
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + lcol * 16);
+        *reinterpret_cast<f32x4_t*>(orow + (long)row * a.ncols + lcol * 4) = v;
       }
-    __syncthreads();                                  // the images are dead, the statistics read: LDS is reused below
-
-    // ---- flush O: transposed through LDS (the accumulator layout gives one column per lane, i.e. 4-byte
-    // stores; staged as [32 rows][128 columns] per wave the tile leaves as 16-byte stores of 512-byte rows)
-    {
-      char* stg = smem + wave * 16384;
-      int lrow = hi, lcol = j;                        // opaque: keeps the row pointers out of the prologue
-      R6_OPAQUE(lrow);
-      R6_OPAQUE(lcol);
-#pragma unroll
-      for (int qi = 0; qi < 2; ++qi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
-#pragma unroll
-          for (int ci = 0; ci < 4; ++ci)
-            *reinterpret_cast<float*>(stg + row * 512 + (ci * 32 + lcol) * 4) = o[qi][ci][r];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS operations complete in order
-        float* orow = a.part + ((long)z * a.Npad + qtile * 64 + qi * 32) * a.ncols + wave * 128;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int row = it * 2 + lrow;
-          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + lcol * 16);
-          *reinterpret_cast<f32x4_t*>(orow + (long)row * a.ncols + lcol * 4) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
-      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
     }
-    break;
   }
   if (trace && lane == 0) {
     if (wave == 0) {
@@ -829,7 +822,7 @@ extern "C" int rmem_attn_read(const rmem_read_args* ap, void* stream) {
 }
 
 // Debug aid (tools/kbench_read.py): the same launch with shader-clock stamps per block written to
-// trace[block][64]: [0] start, [1] reference pass done, [2] tile loop done, [3] end, [4 + w] / [12 + w] / [20 + w] cycles
+// trace[block][64]: [0] start, [1] Q / first K tiles in, [2] tile loop done, [3] end, [4 + w] / [12 + w] / [20 + w] cycles
 // wave w spent in its SCORE / PV phases / waiting at the interval barriers, [28] key tiles of the unit, [32 + w]
 // HW_REG_HW_ID of wave w, [40 + w] cycles at the top of the iterations (K request, first V requests).  trace must
 // hold 8 * ceil(units / 8) * 64 int64.
@@ -843,16 +836,9 @@ extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, vo
     hipLaunchKernelGGL(kern, dim3(8 * chunk), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), *ap,
                        reinterpret_cast<long long*>(trace));
   };
-  if (var == 0) go(&read64_trace_kernel<0>);
-  else if (var == 1) go(&read64_trace_kernel<1>);
-  else if (var == 2) go(&read64_trace_kernel<2>);
-  else if (var == 3) go(&read64_trace_kernel<3>);
-  else if (var == 4) go(&read64_trace_kernel<4>);
-  else if (var == 5) go(&read64_trace_kernel<5>);
-  else if (var == 6) go(&read64_trace_kernel<6>);
-  else if (var == 7) go(&read64_trace_kernel<7>);
+  if (var == 4) go(&read64_trace_kernel<4>);
   else if (var == 8) go(&read64_trace_kernel<8>);
-  else go(&read64_trace_kernel<9>);
+  else go(&read64_trace_kernel<0>);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }

@@ -116,7 +116,7 @@ def main():
             # phase stamps
             nblk = 8 * (((N + 63) // 64 * ks + 7) // 8)
             tr = torch.zeros(nblk, 64, dtype=torch.int64, device=dev)
-            for var in ("1", "4", "8", "9", "0"):              # experiments of the tracing kernel (RMEM_READ_VAR); 0 = product, last
+            for var in ("4", "8", "0"):              # experiments of the tracing kernel (RMEM_READ_VAR); 0 = product, last
                 os.environ["RMEM_READ_VAR"] = var
                 tr.zero_()
                 for _ in range(2):
@@ -126,7 +126,7 @@ def main():
                 tt = tt[tt[:, 3] > 0]
                 ent[f"var{var}_unit_cycles_mean"] = round(float((tt[:, 3] - tt[:, 0]).mean()))
                 ent[f"var{var}_loop_per_tile"] = round(float(((tt[:, 2] - tt[:, 1]) / tt[:, 28].clamp(min=1)).mean()))
-                if var in ("8", "9"):
+                if var in ():
                     ntv = tt[:, 28:29].clamp(min=1)
                     ent[f"var{var}_top_score_pv_barrier_w0_w4"] = [[round(float((tt[:, o + w] / ntv[:, 0]).mean())) for o in (40, 4, 12, 20)] for w in (0, 4)]
             ent["trace_kernel_us"] = round(timeit(lambda: hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace"), args.iters), 2)
@@ -147,8 +147,7 @@ def main():
                 ent["trace_cycles"] = {
                     "units": int(t.shape[0]), "tiles_per_unit": [float(nt.min()), float(nt.mean()), float(nt.max())],
                     "unit_total_mean_max": [float((t[:, 3] - t[:, 0]).mean()), float((t[:, 3] - t[:, 0]).max())],
-                    "reference_pass": float((t[:, 1] - t[:, 0]).mean()),
-                    "reference_pass_per_tile": float(((t[:, 1] - t[:, 0]) / nt[:, 0]).mean()),
+                    "prologue": float((t[:, 1] - t[:, 0]).mean()),
                     "loop": float((t[:, 2] - t[:, 1]).mean()), "loop_per_tile": float(((t[:, 2] - t[:, 1]) / nt[:, 0]).mean()),
                     "stats_and_flush": float((t[:, 3] - t[:, 2]).mean()),
                     "score_per_tile_by_wave": per(4, 12), "pv_per_tile_by_wave": per(12, 20), "barrier_per_tile_by_wave": per(20, 28), "top_per_tile_by_wave": per(40, 48),
