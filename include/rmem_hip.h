@@ -132,7 +132,7 @@ typedef struct {
 
 int rmem_attn_read(const rmem_read_args *a, void *stream);
 /* Debug aid (tools/kbench_read.py): the same launch with shader-clock stamps per workgroup in trace[block][64]
- * ([0] start, [1] reference pass done, [2] tile loop done, [3] end, [4+w] / [12+w] / [20+w] cycles of wave w in its
+ * ([0] start, [1] Q and the first K tiles staged, [2] tile loop done, [3] end, [4+w] / [12+w] / [20+w] cycles of wave w in its
  * score / P.V phases / at the interval barriers, [28] key tiles of the unit, [32+w] HW_REG_HW_ID of wave w,
  * [40+w] cycles at the top of the iterations); trace holds 8 * ceil(units / 8) * 64 int64. */
 int rmem_attn_read_trace(const rmem_read_args *a, int64_t *trace, void *stream);

@@ -17,11 +17,13 @@
 //   PV(i): O += P.V for all 64 queries x this wave's 128 columns on v_mfma_f32_32x32x16_f16: A = P fragments from
 //       LDS (shared by the eight waves), B = V fragments straight from global memory ("blocked-16" layout: one
 //       contiguous KiB per load instruction).
-// One barrier per tile.  In interval i the four waves that own tile i + 1 run SCORE(i+1) then PV(i), the other four
-// PV(i) at once: wave w and wave w + 4 share a SIMD, so the owner's LDS reads, exp2 and conversions run beside its
-// partner's MFMAs, and its own P.V then has the matrix pipe to itself.  K tiles arrive by LDS-DMA
-// (global_load_lds_dwordx4, two tiles ahead, chunk swizzle applied to the SOURCE address: no staging registers, no
-// ds_write phase); P and K are double-buffered.
+// One barrier per tile, and SCORE in two parts so that every wave has a P.V and half a SCORE per interval: in interval
+// i the four waves that own tile i + 1 finish SCORE(i+1) (part 2: exp2, fp16 planes -> P) and then run PV(i); the other
+// four run PV(i) and then start SCORE(i+2) (part 1: the 48 small MFMAs, logits, row maxima; the logits wait in
+// registers across the barrier).  Wave w and wave w + 4 share a SIMD, so on each SIMD one wave feeds the matrix pipe
+// while the other reads LDS, takes exp2 and converts.  K tiles arrive by LDS-DMA (global_load_lds_dwordx4, three
+// tiles ahead, chunk swizzle applied to the SOURCE address: no staging registers, no ds_write phase); P and K are
+// double-buffered.
 //
 // Online reference, lazily raised.  m of a row starts at the maximum of its first tile and is raised to a tile's
 // maximum only when that exceeds m by more than RD_BUMP = 12 (log2 domain): weights stay <= 2^12 (fp16 hi plane),
@@ -52,9 +54,9 @@ constexpr int R6_P = 98304;                 // 2 buffers x [plane][k-step][64 qu
 constexpr int R6_SL = 131072;               // per-slot sums [16 slots][2 tile parities][64 queries] fp32 ...
 constexpr int R6_SM = R6_SL + 8192;         // ... and the reference each was taken against
 constexpr int R6_MX = R6_SM + 8192;         // [64 queries] current reference m of the row (log2 domain)
-constexpr int R6_RS = R6_MX + 512;          // [2 tile parities][64] factor 2^(m_old - m_new) of a tile that raised m
-constexpr int R6_L = R6_RS + 512;           // [2][64] row sums
-constexpr int R6_FL = R6_L + 512;           // [2 tile parities][4 query groups] "this tile raised m"
+constexpr int R6_RS = R6_MX + 512;          // [4 tiles in flight][64] factor 2^(m_old - m_new) of a tile that raised m
+constexpr int R6_L = R6_RS + 1024;           // [2][64] row sums
+constexpr int R6_FL = R6_L + 512;           // [4 tiles in flight][4 query groups] "this tile raised m"
 constexpr int R6_DUMMY = R6_FL + 64;        // 1 KiB nobody reads: target of the K requests that fetch no tile
 constexpr int R6_LDS = R6_DUMMY + 1024;
 constexpr float RD_NEG = -3.0e38f;
@@ -280,40 +282,34 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[kt][r] = 0.f;
-    // 8 items = (d-step k4, pair of key groups); the fragments of item i + 1 are requested before the MFMAs of item i
-    // (two register sets): read one item at a time the phase is eight LDS round trips long
-    frag8_t fq[2][2], fk[2][4];                       // Q [set][hi, lo] of a d-step; K [set][key group of the pair][hi, lo]
+    // 16 items = (d-step k4, key group kt); the fragments of item i + 1 are requested before the MFMAs of item i (two
+    // register sets of 2 fragments, + two of Q): read one item at a time the phase is sixteen LDS round trips long
+    frag8_t fq[2][2], fk[2][2];                       // [set][hi, lo]: Q of a d-step; K of a (d-step, key group)
     auto qload = [&](frag8_t (&f)[2], auto K4) __attribute__((always_inline)) {
       constexpr int k4 = decltype(K4)::value;
       f[0] = *reinterpret_cast<const frag8_t*>(smem + aq(k4));
       f[1] = *reinterpret_cast<const frag8_t*>(smem + aq(k4) + 16384);
     };
-    auto kload = [&](frag8_t (&f)[4], auto K4, auto PR) __attribute__((always_inline)) {
-      constexpr int k4 = decltype(K4)::value, pr = decltype(PR)::value;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        f[e * 2 + 0] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (2 * pr + e) * 1024);
-        f[e * 2 + 1] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + (2 * pr + e) * 1024));
-      }
+    auto kload = [&](frag8_t (&f)[2], auto K4, auto KT) __attribute__((always_inline)) {
+      constexpr int k4 = decltype(K4)::value, kt = decltype(KT)::value;
+      f[0] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + kt * 1024);
+      f[1] = *reinterpret_cast<const frag8_t*>(smem + ak(k4) + kb + (16384 + kt * 1024));
     };
     qload(fq[0], std::integral_constant<int, 0>{});
     kload(fk[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    static_for<8>([&](auto I) {
-      constexpr int i = I.value, k4 = i >> 1, pr = i & 1;
-      if constexpr (i + 1 < 8) {
-        constexpr int n4 = (i + 1 < 8 ? (i + 1) >> 1 : 0), npr = (i + 1) & 1;
-        if constexpr (npr == 0) qload(fq[n4 & 1], std::integral_constant<int, n4>{});
-        kload(fk[(i + 1) & 1], std::integral_constant<int, n4>{}, std::integral_constant<int, npr>{});
+    static_for<16>([&](auto I) {
+      constexpr int i = I.value, k4 = i >> 2, kt = i & 3;
+      if constexpr (i + 1 < 16) {
+        constexpr int n4 = (i + 1 < 16 ? (i + 1) >> 2 : 0), nkt = (i + 1) & 3;
+        if constexpr (nkt == 0) qload(fq[n4 & 1], std::integral_constant<int, n4>{});
+        kload(fk[(i + 1) & 1], std::integral_constant<int, n4>{}, std::integral_constant<int, nkt>{});
       }
       __builtin_amdgcn_sched_barrier(0);
       frag8_t (&fqc)[2] = fq[k4 & 1];
-      frag8_t (&fkc)[4] = fk[i & 1];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {                   // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
-        s[2 * pr + e] = RMEM_MFMA16(fkc[e * 2 + 0], fqc[1], s[2 * pr + e]);
-        s[2 * pr + e] = RMEM_MFMA16(fkc[e * 2 + 1], fqc[0], s[2 * pr + e]);
-        s[2 * pr + e] = RMEM_MFMA16(fkc[e * 2 + 0], fqc[0], s[2 * pr + e]);
-      }
+      frag8_t (&fkc)[2] = fk[i & 1];
+      s[kt] = RMEM_MFMA16(fkc[0], fqc[1], s[kt]);     // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
+      s[kt] = RMEM_MFMA16(fkc[1], fqc[0], s[kt]);
+      s[kt] = RMEM_MFMA16(fkc[0], fqc[0], s[kt]);
       __builtin_amdgcn_sched_barrier(0);
     });
     const bool padded = key0 + 64 > a.N;
@@ -354,7 +350,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     sl_m[e] = RD_NEG;
   }
   if (tid < 64) mrow[tid] = RD_NEG;
-  if (tid < 8) bflag[tid] = 0;
+  if (tid < 16) bflag[tid] = 0;
   {
     TileIter t01;
     tinit(t01, lo);
@@ -377,7 +373,6 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   float l = 0.f, lcur = 0.f;                          // this lane's part of the row sum (all slots / the current slot) ...
   float m_known = RD_NEG;                             // ... taken against this reference
   int sum_t = -1;                                     // slot lcur belongs to
-  bool raised = false;                                // this wave's flag slot is set
   const int row_s = qg * 16 + jq;                     // this lane's query in the score role
   u32x4_t vr[4][2];                                   // ring of V fragments: step s = (k-step, ci) lives in vr[s & 3][plane]
 
@@ -392,16 +387,44 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     }
   };
 
-  // SCORE(i) by its owner: weights of tile i -> P image pbuf (K image kbuf); par = parity of i = this wave's group
-  auto score_phase = [&](const TileIter& ti, int kbuf, int pbuf) __attribute__((always_inline)) {
-    if (raised) {                                     // (wave-uniform) the P.V of the tile that raised m is two barriers back
-      if (lane == 0) bflag[grp * 4 + qg] = 0;
-      raised = false;
+  // SCORE(i) by its owner, in two parts that run in consecutive intervals (see the loop):
+  //   part 1 -- scores of tile i (K image kbuf), the row maxima, the decision to raise m (slot i & 3 of the flags /
+  //             factors: the P.V of tile i reads it two intervals later);
+  //   part 2 -- weights against the reference part 1 left, fp16 hi / lo planes -> P image pbuf, row sums.
+  // Between the two the logits and the reference stay in registers (across ONE barrier, no P.V in between).
+  float yc[16];
+  float mcc = RD_NEG;
+  int raised = 0;                                     // bit s: this wave set flag slot s (s = tile & 3, two of them are its own)
+  auto score_p1 = [&](const TileIter& ti, int x, int kbuf) __attribute__((always_inline)) {
+    const int fs = x & 3;
+    if (raised & (1 << fs)) {                         // (wave-uniform) the P.V that read this slot is four barriers back
+      if (lane == 0) bflag[fs * 4 + qg] = 0;
+      raised &= ~(1 << fs);
     }
     float mc = mrow[row_s];
-    float y[16];
-    const int t = scores64(ti, kbuf * 32768, y);
+    scores64(ti, kbuf * 32768, yc);
     follow(mc);
+    // the row's largest score of this tile (sentinels are far below): 4 lanes hold a query
+    float rm = fmaxf(fmaxf(fmaxf(fmaxf(yc[0], yc[1]), fmaxf(yc[2], yc[3])), fmaxf(fmaxf(yc[4], yc[5]), fmaxf(yc[6], yc[7]))),
+                     fmaxf(fmaxf(fmaxf(yc[8], yc[9]), fmaxf(yc[10], yc[11])), fmaxf(fmaxf(yc[12], yc[13]), fmaxf(yc[14], yc[15]))));
+    rm = fmaxf(rm, __shfl_xor(rm, 16));
+    rm = fmaxf(rm, __shfl_xor(rm, 32));
+    const bool bump = rm > mc + RD_BUMP;              // (mc = -3e38 before the first valid key: any valid score raises it)
+    if (__any(bump)) {                                // (wave-uniform, rare) raise m of those rows to this tile's maximum
+      const float mn = bump ? rm : mc;
+      if (lb == 0) {
+        resc[fs * 64 + row_s] = __builtin_amdgcn_exp2f(mc - mn);    // 1 for the rows that stay
+        mrow[row_s] = mn;
+      }
+      if (lane == 0) bflag[fs * 4 + qg] = 1;
+      raised |= 1 << fs;
+      mc = mn;
+      follow(mc);
+    }
+    mcc = mc;
+  };
+  auto score_p2 = [&](const TileIter& ti, int pbuf) __attribute__((always_inline)) {
+    const int t = ti.t;
     if (t != sum_t) {
       if (sum_t >= 0) {                               // (wave-uniform) slot finished: park its sum and what it refers to
         float v = lcur + __shfl_xor(lcur, 16);
@@ -414,23 +437,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       lcur = 0.f;
       sum_t = t;
     }
-    // the row's largest score of this tile (sentinels are far below): 4 lanes hold a query
-    float rm = fmaxf(fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7]))),
-                     fmaxf(fmaxf(fmaxf(y[8], y[9]), fmaxf(y[10], y[11])), fmaxf(fmaxf(y[12], y[13]), fmaxf(y[14], y[15]))));
-    rm = fmaxf(rm, __shfl_xor(rm, 16));
-    rm = fmaxf(rm, __shfl_xor(rm, 32));
-    const bool bump = rm > mc + RD_BUMP;              // (mc = -3e38 before the first valid key: any valid score raises it)
-    if (__any(bump)) {                                // (wave-uniform, rare) raise m of those rows to this tile's maximum
-      const float mn = bump ? rm : mc;
-      if (lb == 0) {
-        resc[grp * 64 + row_s] = __builtin_amdgcn_exp2f(mc - mn);   // 1 for the rows that stay
-        mrow[row_s] = mn;
-      }
-      if (lane == 0) bflag[grp * 4 + qg] = 1;
-      raised = true;
-      mc = mn;
-      follow(mc);
-    }
+    const float mc = mcc;
     const bool masked = MODE == 1 || ti.key0() + 64 > a.N;      // (wave-uniform) the tile may hold RD_NEG sentinels
     float psum = 0.f;
 #pragma unroll
@@ -439,7 +446,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       if (!masked) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(y[kt * 4 + e] - mc);
+          const float p = __builtin_amdgcn_exp2f(yc[kt * 4 + e] - mc);
           psum += p;
           pp[e >> 1][e & 1] = p;
         }
@@ -447,7 +454,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
         asm volatile("" ::: "memory");                // keeps this form a branch (as a select it costs every tile two more VALU per key)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float sv = y[kt * 4 + e];
+          const float sv = yc[kt * 4 + e];
           float p = __builtin_amdgcn_exp2f(sv - mc);  // sentinels (-3e38) give exactly 0 unless m is one too
           p = sv > -2.9e38f ? p : 0.f;
           psum += p;
@@ -513,9 +520,9 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
   // PV(i): O += P(pbuf) . V(tile i).  16 steps (k-step, 32-column tile) of 6 MFMAs; the V fragments of a step are
   // requested 4 steps ahead (the last four steps request the first four of the next tile), the P fragments of a
   // k-step one k-step ahead.  A tile that raised m: the rows' factors first.
-  auto pv_phase = [&](int pbuf) __attribute__((always_inline)) {
+  auto pv_phase = [&](int pbuf, int fs) __attribute__((always_inline)) {
     {
-      const int* fp = bflag + pbuf * 4;
+      const int* fp = bflag + fs * 4;
       const int f0 = __builtin_amdgcn_readfirstlane(fp[0]), f1 = __builtin_amdgcn_readfirstlane(fp[1]);
       const int f2 = __builtin_amdgcn_readfirstlane(fp[2]), f3 = __builtin_amdgcn_readfirstlane(fp[3]);
       if (f0 | f1 | f2 | f3) {                        // (wave-uniform, rare)
@@ -530,7 +537,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
 #pragma unroll
               for (int r8 = 0; r8 < 8; ++r8) {
                 const int r = hf * 8 + r8;
-                const float f = resc[pbuf * 64 + qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+                const float f = resc[fs * 64 + qi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) o[qi][ci][r] *= f;
               }
@@ -568,38 +575,56 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     });
   };
 
-  // In interval `it` the owners of tile it + 1 run SCORE(it + 1) then PV(it), the other four waves PV(it) at once; ONE
-  // barrier ends the interval.  K(it + 2) is requested at the top of iteration it -- every wave is then past barrier
-  // it - 1, which ends the readers of K(it) (same buffer) -- and awaited before the barrier.
-  TileIter t_sc, t_dma, t_v;                          // tiles of the next SCORE (it + 1), K request (it + 2), V base (it + 1)
-  tinit(t_sc, lo);
+  // Interval `it` (ONE barrier ends it): the waves whose parity is that of it + 1 finish SCORE(it + 1) (part 2) and then
+  // run PV(it); the others run PV(it) and then start SCORE(it + 2) (part 1).  Every wave has a P.V and half a SCORE per
+  // interval, and on each SIMD one wave is in its matrix-heavy phase while the other reads LDS, takes exp2, converts.
+  //   K(x) sits in buffer x & 1: read by part 1 of SCORE(x) in interval x - 2, requested at the top of interval x - 3
+  //        (its buffer's previous tile was read in interval x - 4), awaited before barrier x - 3;
+  //   P(x) in buffer x & 1: written in interval x - 1, read by PV(x); PV(x - 2), the previous reader, ended at barrier x - 2;
+  //   flag / factor slot x & 3: written in interval x - 2, read by PV(x).
+  TileIter t_p1, t_p2, t_dma, t_v;                    // tiles of part 1 (it + 2), part 2 (it + 1), K request (it + 3), V base (it + 1)
+  tinit(t_p1, lo);
+  tinit(t_p2, lo);
   tinit(t_dma, lo + 2 < hi_t ? lo + 2 : lo);
   tinit(t_v, lo);
-  if (grp == 0) score_phase(t_sc, 0, 0);              // tile 0
-  tstep(t_sc);
+  // prologue: SCORE(0) by parity 0; then K(2) requested, and part 1 of SCORE(1) by parity 1 beside part 2 of SCORE(0)
+  if (grp == 0) score_p1(t_p1, 0, 0);
+  tstep(t_p1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                    // m after tile 0 visible; K(0) read
+  if (n > 2) {
+    dma_k(t_dma, 0, true);
+    if (lo + 3 < hi_t) tstep(t_dma);
+  }
+  if (grp == 0) score_p2(t_p2, 0);
+  tstep(t_p2);
+  if (n > 1) {
+    if (grp == 1) score_p1(t_p1, 1, 1);
+    tstep(t_p1);
+  }
   {
     const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
     vhp = a.vh + vb;
     vlp = a.vl + vb;
     if (n > 1) tstep(t_v);
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // K(2)
   vreq(std::integral_constant<int, 0>{});
   vreq(std::integral_constant<int, 1>{});
   vreq(std::integral_constant<int, 2>{});
   vreq(std::integral_constant<int, 3>{});
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma clang loop unroll(disable)
   for (int it = 0; it < n; ++it) {
     const bool more = it + 1 < n;
     long long t0 = 0;
     if (TRACE) t0 = __builtin_readcyclecounter();
-    // K(it + 2) into the buffer of K(it); when there is no such tile the 4 pieces go to a 1 KiB dummy target (keeps
+    // K(it + 3) into the buffer of K(it + 1); when there is no such tile the 4 pieces go to a 1 KiB dummy target (keeps
     // the request count of vwait() constant)
     {
-      const bool real = it + 2 < n;
+      const bool real = it + 3 < n;
       const long base = t_dma.kslot + (long)t_dma.key0() * 128;
-      const int dst = real ? R6_K + (it & 1) * 32768 + dma_dst0 : R6_DUMMY;
+      const int dst = real ? R6_K + ((it + 1) & 1) * 32768 + dma_dst0 : R6_DUMMY;
       const int dstep = real ? 8192 : 0;
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
@@ -609,7 +634,7 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
           const char* g = reinterpret_cast<const char*>((pl ? a.kl : a.kh) + base) + dma_off0 + pc * 128;
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(g) : "memory");
         }
-      if (it + 3 < n) tstep(t_dma);                    // (never past the unit's last tile: the dummy requests re-read that one)
+      if (it + 4 < n) tstep(t_dma);                    // (never past the unit's last tile: the dummy requests re-read that one)
     }
     if (more) {                                       // V planes of the next tile (its first steps are requested in PV)
       const long vb = t_v.vslot + (long)(t_v.key0() >> 4) * (1024 * 16);
@@ -618,18 +643,29 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       if (it + 2 < n) tstep(t_v);
     }
     if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[3] += t1 - t0; t0 = t1; }
-    if (more) {
-      if (((it + 1) & 1) == grp) {
-        // Priority: the scoring wave goes first.  Both at priority 0, the partner's queued MFMAs sit at the head of
-        // the SIMD's vector issue and this wave's LDS reads / exp2 / conversions crawl beside them.
-        if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
-        score_phase(t_sc, (it + 1) & 1, (it + 1) & 1);
-        if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
-      }
-      tstep(t_sc);
+    // Priority: the wave that is NOT in its P.V cluster goes first.  Both at priority 0, the partner's queued MFMAs sit
+    // at the head of the SIMD's vector issue and this wave's LDS reads / exp2 / conversions crawl beside them.
+    const bool second = ((it + 1) & 1) == grp;        // this wave owns tile it + 1: part 2 now, P.V after
+    if (second && more) {
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
+      score_p2(t_p2, (it + 1) & 1);
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
     }
+    // (the logits are dead from here to part 1: said explicitly, or they keep 17 registers through the P.V cluster --
+    // the compiler cannot see that a wave alternates between the two kinds of interval)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) asm volatile("" : "=v"(yc[e]));
+    asm volatile("" : "=v"(mcc));
     if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
-    pv_phase(it & 1);
+    pv_phase(it & 1, it & 3);
+    if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
+    if (!second && it + 2 < n) {
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
+      score_p1(t_p1, it + 2, it & 1);
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
+    }
+    if (more) tstep(t_p2);
+    if (it + 2 < n) tstep(t_p1);
     if (more) {
       vhp = vhn;
       vlp = vln;
@@ -637,8 +673,8 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
-    __syncthreads();                                  // P(it + 1), K(it + 2), m visible; P(it), K(it + 1) may be overwritten
+    if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[0] += t1 - t0; t0 = t1; }
+    __syncthreads();                                  // P(it + 1), K(it + 3), m visible; P(it), K(it + 2) may be overwritten
     if (TRACE) tacc[2] += __builtin_readcyclecounter() - t0;
   }
   if (trace && tid == 0) trace[2] = __builtin_readcyclecounter();

@@ -200,14 +200,14 @@ class DeAOTLSTT:
     def choose_splits(N: int, h: int, w: int, cap: int, clips: int = 1, cus: int = 256):
         """(ks_long, ks_win) of the paired long-term + windowed read launch: the pair that minimises the
         launch's makespan on `cus` CUs under a simple cost model measured on MI355X
-        (profiles/r03_*_kbench_read.json, cycles per 64-key tile incl. its share of the reference pass:
-        long-term 11.8 k, windowed 19.8 k -- relative-bias gathers and window arithmetic; ~12 k per unit for
-        the Q staging, statistics and the flush).  Units are dispatched long-term first; with more units
+        (profiles/r03x_kbench_read.json, k cycles per 64-key tile: long-term 9.5, windowed 14.6 -- relative-bias
+        gathers and window arithmetic; ~14 per unit for the Q staging, the first tiles' scores, statistics and
+        the flush; the measured sweep around the choice is profiles/r03y_split_sweep.txt).  Units are dispatched long-term first; with more units
         than CUs the surplus starts as the first units finish.  Several clips per launch share the CUs."""
         nq = (N + 63) // 64
         tv = (N + 63) // 64
         if clips > 1:
-            # several clips per launch: two rounds of workgroups (longer units amortise the reference pass);
+            # several clips per launch: two rounds of workgroups (longer units amortise the per-unit staging and flush);
             # measured at 480p K=4 (frames/s for long,win,self: 4 clips 3,1,4 479 / 4,2,4 476 / 7,2,6 461;
             # 8 clips 2,1,2 492 / 3,1,3 489 / 1,1,2 477) -- the model below does not cover the clip-major dispatch order
             total = max(3, min(32, 512 // (nq * clips)))
@@ -215,7 +215,7 @@ class DeAOTLSTT:
             return max(1, total - kw), kw
         long_tiles = cap * tv
         band = min(tv, ((min(h, 3 + 14) * w) + 63) // 64 + 1)       # key tiles visible to a 64-query tile (15x15 window)
-        LONG, WIN, FIX = 11.8, 19.8, 12.0
+        LONG, WIN, FIX = 9.5, 14.6, 14.0
         best = None
         for kl in range(1, 33):
             for kw in range(1, 9):

@@ -317,7 +317,7 @@ def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, kspli
     return G, mass, part, ml
 
 
-def _bank_case(rs, T, h, w, spike=False):
+def _bank_case(rs, T, h, w, spike=False, rising=False):
     N = h * w
     Npad = (N + 127) // 128 * 128
     S = T + 2
@@ -330,9 +330,15 @@ def _bank_case(rs, T, h, w, spike=False):
     Vf[:, :, N:] = -53.0
     Qf = torch.zeros(Npad, 128)
     Qf[:N] = _rand(rs, N, 128, scale=1.5)
+    if rising:
+        # every 64-key tile scores ~14 bits above the one before: the row reference is raised and the accumulators are
+        # rescaled on EVERY tile (RD_BUMP = 12), through all four flag / factor slots, across slot boundaries
+        Qf[:N] += 1.0
+        for ti, s_ in enumerate(slot_map):
+            Kf[s_, :N] += 0.0134 * (ti * N + torch.arange(N, dtype=torch.float32))[:, None]
     if spike:
-        # force the deferred-rescale path: a few keys late in the bank score far above everything
-        # a query has seen before (row maximum jumps by much more than RD_THR = 10 mid-split)
+        # force the rescale path: a few keys late in the bank score far above everything a query has seen before
+        # (the row maximum jumps by much more than RD_BUMP = 12 mid-split)
         for qq in (0, 5, N // 2, N - 1):
             for (tt, kk) in ((T - 1, N - 3), (T // 2, N // 2 + 1)):
                 Kf[slot_map[tt], kk] = Qf[qq] * (1.0 + 0.5 * (tt + 1))
@@ -366,6 +372,21 @@ def test_read_bank(hip, ksplits, T, h, w):
     assert torch.isfinite(ml[:, :N]).all()
     live = ml[:, :N, 1] > 0                      # splits without a key tile leave their partial unwritten
     assert torch.isfinite(part[:, :N][live]).all()
+
+
+@pytest.mark.parametrize("ksplits", [1, 3])
+def test_read_bank_rising_logits(hip, ksplits):
+    """The online reference of the fused read under its worst case: logits that rise by ~14 bits per 64-key tile, so every
+    tile raises m and rescales O, the row sums and the parked per-slot sums (read64.hip: score_p1 / pv_phase / follow)."""
+    T, h, w = 4, 12, 17
+    rs = np.random.RandomState(11)
+    N, Npad, slot_map, Kf, Vf, Qf, bias, U, A, ref, _ = _bank_case(rs, T, h, w, rising=True)
+    G, mass, part, ml = _run_read(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, _block16(Vf)), slot_map,
+                                  _planes(hip, Qf), bias.to(DEV), U.to(DEV), h, w, None, ksplits)
+    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    merr = (mass.cpu().double() - A.sum(dim=2)).abs().max().item()
+    print(f"rising logits ksplits={ksplits}: G rel err {err:.2e}, mass err {merr:.2e}")
+    assert torch.isfinite(G).all() and err < 5e-5 and merr < 1e-5, (err, merr)
 
 
 def test_read_bank_720p_k8_properties(hip):
