@@ -461,15 +461,15 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
           pp[e >> 1][e & 1] = p;
         }
       }
-      // hi = fp16(p), lo = fp16(p - hi): packed conversions (v_cvt_pk_f16_f32, round to nearest even)
-      const f16x2_t h0 = __builtin_convertvector(pp[0], f16x2_t), h1 = __builtin_convertvector(pp[1], f16x2_t);
-      const f32x2_t r0 = pp[0] - __builtin_convertvector(h0, f32x2_t), r1 = pp[1] - __builtin_convertvector(h1, f32x2_t);
-      const f16x2_t l0 = __builtin_convertvector(r0, f16x2_t), l1 = __builtin_convertvector(r1, f16x2_t);
+      // hi = fp16(p), lo = fp16(p - hi), round to nearest even: one packed conversion and two mixed-precision fmas per pair
+      uint32_t h0, l0, h1, l1;
+      split_pair_f16(pp[0][0], pp[0][1], h0, l0);
+      split_pair_f16(pp[1][0], pp[1][1], h1, l1);
       u32x2_t wh, wl;
-      wh[0] = __builtin_bit_cast(uint32_t, h0);
-      wh[1] = __builtin_bit_cast(uint32_t, h1);
-      wl[0] = __builtin_bit_cast(uint32_t, l0);
-      wl[1] = __builtin_bit_cast(uint32_t, l1);
+      wh[0] = h0;
+      wh[1] = h1;
+      wl[0] = l0;
+      wl[1] = l1;
       *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384) = wh;
       *reinterpret_cast<u32x2_t*>(smem + apw(kt) + pbuf * 16384 + 8192) = wl;
     }
