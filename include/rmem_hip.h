@@ -107,7 +107,7 @@ int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
  * Layouts: K planes [slot][Npad][128]; Q planes [Npad][128]; Npad = N rounded up to 128.  V is "blocked-16":
  * planes [slot][Npad/16][ncols][16] (element (key k, column c) at ((k/16)*ncols + c)*16 + k%16),
  * written by rmem_linear with pa_blocked = 1, so that an MFMA B fragment of 32 columns is one
- * contiguous KiB.  ncols must be a multiple of 512.
+ * contiguous KiB.  ncols must be 1024 (the eight waves of a unit own 128 columns of [V | ID_V] each).
  * Split precision (hi/lo planes, 3 products) only.
 
  */
@@ -134,7 +134,7 @@ int rmem_attn_read(const rmem_read_args *a, void *stream);
 /* Debug aid (tools/kbench_read.py): the same launch with shader-clock stamps per workgroup in trace[block][64]
  * ([0] start, [1] Q and the first K tiles staged, [2] tile loop done, [3] end, [4+w] / [12+w] / [20+w] cycles of wave w in its
  * score / P.V phases / at the interval barriers, [28] key tiles of the unit, [32+w] HW_REG_HW_ID of wave w,
- * [40+w] cycles at the top of the iterations); trace holds 8 * ceil(units / 8) * 64 int64. */
+ * [40+w] cycles at the top of the iterations, [48] / [49] start / end on the device-wide 100 MHz counter); trace holds 8 * ceil(units / 8) * 64 int64. */
 int rmem_attn_read_trace(const rmem_read_args *a, int64_t *trace, void *stream);
 /* the bank read (a: mode 0) and the windowed read (b: mode 1) of one GPM layer in one launch */
 int rmem_attn_read2(const rmem_read_args *a, const rmem_read_args *b, void *stream);
