@@ -64,11 +64,10 @@ constexpr float RD_BUMP = 12.0f;            // log2 domain: weights up to 2^12 =
 
 #define R6_OPAQUE(x) asm volatile("" : "+v"(x))
 
-// VAR (experiments, tracing kernel only): 4 = NO s_setprio 1 around SCORE; 8 = never wait for V fragments (timing only:
+// VAR (experiments, tracing kernel only): 4 = no s_setprio at all; 8 = never wait for V fragments (timing only:
 // results are wrong).
-template <int TRACE, int VAR = 0>
-__device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr) {
-  const int MODE = a.mode;                            // wave-uniform: one code path serves both reads
+template <int TRACE, int VAR, int MODE>
+__device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int blk, char* smem, long long* trace_base) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -239,10 +238,10 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     qx = (qvalid ? q : 0) - qy * a.w;
     Rq = a.R + (long)(qvalid ? q : 0) * a.ldr;
   }
-  // Windowed read: relative bias (log2 domain) of this lane's 8 keys key0 + half*32 + kt*16 + lb*4 + e (kt = 0, 1) of
-  // the tile at key0, RD_NEG where the key is outside the 15x15 window / the image.  All gathers are issued
+  // Windowed read: relative bias of this lane's 8 keys key0 + half*32 + kt*16 + lb*4 + e (kt = 0, 1) of the tile at
+  // key0 -> rb[half*8 ..], and a bit in vm for each key inside the 15x15 window and the image.  All gathers are issued
   // unconditionally (index 0 where masked) and back to back; one division per 4 consecutive keys.
-  auto window_terms = [&](int key0, int half, float (&rb)[8]) __attribute__((always_inline)) {
+  auto window_terms = [&](int key0, int half, float* rb, unsigned& vm) __attribute__((always_inline)) {
     int idx[8];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -258,13 +257,12 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
         }
         const int dy = ky - qy, dx = kx - qx;
         const bool valid = qvalid && tok0 + e < a.N && dy >= -7 && dy <= 7 && dx >= -7 && dx <= 7;
-        idx[kt * 4 + e] = valid ? ((dy + 7) * 15 + dx + 7) * rcs : -1;
+        idx[kt * 4 + e] = valid ? ((dy + 7) * 15 + dx + 7) * rcs : 0;
+        vm |= valid ? 1u << (half * 8 + kt * 4 + e) : 0u;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) rb[r] = Rq[idx[r] < 0 ? 0 : idx[r]];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) rb[r] = idx[r] < 0 ? RD_NEG : rb[r] * 1.44269504088896341f;
+    for (int r = 0; r < 8; ++r) rb[half * 8 + r] = Rq[idx[r]];
   };
 
   // ---- scores of one tile for this lane: y[kt*4 + r] = log2-domain logit of key kt*16 + lb*4 + r, kt = 0..3 (RD_NEG
@@ -327,16 +325,15 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
           y[kt * 4 + r] = tok < a.N ? fmaf(s[kt][r], sl2e, bias2) : RD_NEG;
         }
     } else {
+      // (the 16 gathers issued BEFORE the score MFMAs, to land behind them, was built: their 17 registers push address
+      // registers of this phase to scratch, and each reload waits for everything in flight -- 58 against 56 us)
+      float rbw[16];
+      unsigned vm = 0;
+      window_terms(key0, 0, rbw, vm);
+      window_terms(key0, 1, rbw, vm);
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        float rb[8];
-        window_terms(key0, half, rb);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float rbv = rb[e];
-          y[half * 8 + e] = rbv > -2.9e38f ? fmaf(s[half * 2 + (e >> 2)][e & 3], sl2e, rbv) : RD_NEG;
-        }
-      }
+      for (int e = 0; e < 16; ++e)
+        y[e] = ((vm >> e) & 1u) ? fmaf(s[e >> 2][e & 3], sl2e, rbw[e] * 1.44269504088896341f) : RD_NEG;
     }
     return t;
   };
@@ -643,13 +640,21 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
       if (it + 2 < n) tstep(t_v);
     }
     if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[3] += t1 - t0; t0 = t1; }
-    // Priority: the wave that is NOT in its P.V cluster goes first.  Both at priority 0, the partner's queued MFMAs sit
-    // at the head of the SIMD's vector issue and this wave's LDS reads / exp2 / conversions crawl beside them.
+    // Priorities.  (a) A wave that is NOT in its P.V cluster goes first (3): at equal priority the partner's queued
+    // MFMAs sit at the head of the SIMD's vector issue and this wave's LDS reads / exp2 / conversions crawl beside
+    // them.  (b) When the two P.V clusters of a SIMD collide, the wave that still has its SCORE part AFTER the cluster
+    // (P.V -> part 1) must win (1 against 0): it then scores beside the other wave's P.V.  Left to the hardware the
+    // older wave (0-3) wins every collision, and in every other interval the loser ends up with P.V and part 1 back
+    // to back while the winner waits at the barrier (measured: waves 4-7 6.4 k cycles per P.V against 3.5 k, waves
+    // 0-3 3.1 k per tile at the barrier).
     const bool second = ((it + 1) & 1) == grp;        // this wave owns tile it + 1: part 2 now, P.V after
     if (second && more) {
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(3);
       score_p2(t_p2, (it + 1) & 1);
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
+    }
+    if (!(VAR & 4)) {
+      if (second) __builtin_amdgcn_s_setprio(0);
+      else __builtin_amdgcn_s_setprio(1);
     }
     // (the logits are dead from here to part 1: said explicitly, or they keep 17 registers through the P.V cluster --
     // the compiler cannot see that a wave alternates between the two kinds of interval)
@@ -660,10 +665,10 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     pv_phase(it & 1, it & 3);
     if (TRACE) { const long long t1 = __builtin_readcyclecounter(); tacc[1] += t1 - t0; t0 = t1; }
     if (!second && it + 2 < n) {
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(1);
+      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(3);
       score_p1(t_p1, it + 2, it & 1);
-      if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
     }
+    if (!(VAR & 4)) __builtin_amdgcn_s_setprio(0);
     if (more) tstep(t_p2);
     if (it + 2 < n) tstep(t_p1);
     if (more) {
@@ -753,6 +758,15 @@ __device__ __forceinline__ void read64_body(const rmem_read_args& a, const int b
     trace[40 + wave] = tacc[3];
     trace[32 + wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave / SIMD / CU this wave ran on
   }
+}
+
+// mode 0 (bank: long-term / self) and mode 1 (window) are separate instantiations: the window arithmetic's state (query
+// coordinates, bias row pointer, the gathered biases) would otherwise hold registers of the bank read, which has none
+// to spare, and the bank read's (bias row, slot bookkeeping) registers of the windowed one
+template <int TRACE, int VAR = 0>
+__device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr) {
+  if (a.mode == 0) read64_mode<TRACE, VAR, 0>(a, blk, smem, trace_base);
+  else read64_mode<TRACE, VAR, 1>(a, blk, smem, trace_base);
 }
 
 __global__ __launch_bounds__(512) void read64_kernel(rmem_read_args a) {
