@@ -354,6 +354,11 @@ def main():
             out["roofline"]["frac_isolated"] = out["roofline"]["algorithmic_flops_per_launch"] / (iso * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS
         if out["roofline"] and C == 1:
             pmc_traffic(out["roofline"], (args.model, args.config, "one"))
+        if out["roofline"]:
+            # information only: what the peak means on this board under sustained matrix load
+            out["roofline"]["context"] = ("split-fp16: 3 MFMAs issued per algorithmic product; under this kernel the board is "
+                                          "power-limited (1300 W, shader clock 1.7-1.9 GHz of 2.4); hipBLASLt's fp16 8192^3 GEMM "
+                                          "sustains 1275 TFLOP/s = 0.51 of `peak` on the same box (profiles/r03_s_power_probe.json)")
         if dropin is not None:
             out["dropin"] = dropin
         if world == 1 and not args.no_cpu_baseline and args.model == "r50_deaotl":
