@@ -200,7 +200,7 @@ class DeAOTLSTT:
     def choose_splits(N: int, h: int, w: int, cap: int, clips: int = 1, cus: int = 256):
         """(ks_long, ks_win) of the paired long-term + windowed read launch: the pair that minimises the
         launch's makespan on `cus` CUs under a simple cost model measured on MI355X
-        (profiles/r03x_kbench_read.json, k cycles per 64-key tile: long-term 9.5, windowed 14.6 -- relative-bias
+        (profiles/r03f_kbench_read.json, k cycles per 64-key tile: long-term 9.5, windowed 14.6 -- relative-bias
         gathers and window arithmetic; ~14 per unit for the Q staging, the first tiles' scores, statistics and
         the flush; the measured sweep around the choice is profiles/r03y_split_sweep.txt).  Units are dispatched long-term first; with more units
         than CUs the surplus starts as the first units finish.  Several clips per launch share the CUs."""
