@@ -354,11 +354,13 @@ def _bank_case(rs, T, h, w, spike=False, rising=False):
 
 
 @pytest.mark.parametrize("ksplits", [1, 3, 9])
-@pytest.mark.parametrize("T,h,w", [(1, 9, 13), (3, 9, 13), (5, 12, 17), (4, 31, 54)])
+@pytest.mark.parametrize("T,h,w", [(1, 9, 13), (3, 9, 13), (5, 12, 17), (4, 31, 54), (16, 5, 7)])
 def test_read_bank(hip, ksplits, T, h, w):
     """Fused long-term / self read against fp64: softmax(scale*(Q.K^T + bias)) . V * U and the per-slot
     attention mass, with slot-map permutation and poisoned padding.  (4, 31, 54) is the full
-    BASELINE.json configs[1] size (N=1674, 6696 keys)."""
+    BASELINE.json configs[1] size (N=1674, 6696 keys); (16, 5, 7) is the largest bank the ABI takes on the smallest
+    golden geometry: one key tile per slot, so each slot is scored by ONE of the two wave groups and nine splits leave
+    units of one and two tiles."""
     if h * w > 1000 and ksplits == 1:
         pytest.skip("one split at full size only repeats the small cases")
     rs = np.random.RandomState(T * 100 + h)
@@ -453,7 +455,7 @@ def test_read_bank_logits_and_rescale(hip):
 
 
 @pytest.mark.parametrize("ksplits", [1, 4])
-@pytest.mark.parametrize("h,w", [(9, 13), (20, 23), (31, 54)])
+@pytest.mark.parametrize("h,w", [(5, 7), (9, 13), (20, 23), (31, 54)])
 def test_read_window(hip, ksplits, h, w):
     """Fused short-term 15x15 windowed read against the oracle's LocalGatedPropagation core."""
     from oracle import lstt_ref as R
