@@ -240,7 +240,14 @@ class DeAOTLSTT:
                 key = (round(span, 1), kl + kw)
                 if best is None or key < best[0]:
                     best = (key, kl, kw)
-        return best[1], best[2]
+        kl, kw = best[1], best[2]
+        # More units than CUs: the windowed units (last in dispatch order) queue on the few CUs per XCD the long-term
+        # units leave free and end up as the makespan (720p K=8: 8 units of up to 22 tiles on 2 CUs per XCD, at the
+        # throttled clock); halves of them pack better.  Measured (profiles/r03q_split_sweep_720p.txt): (4, 1) 743 us,
+        # (4, 2) 683, (4, 3) 675, (4, 4) 676 per launch; 193.8 -> 196.8 frames/s.
+        if nq * (kl + kw) * clips > cus and kw == 1 and band >= 8:
+            kw = 2
+        return kl, kw
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
