@@ -1,9 +1,10 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r03q; mkdir -p $O; rm -f $O/sweep_720p.txt
-for ks in 4,1,4 4,2,4 4,3,4 4,4,4 3,1,4 3,2,4; do
-  RMEM_KS=$ks timeout 300 python bench.py --config 720p_k8 --gap 2 --steps 30 --no-cpu-baseline --no-dropin 2>/dev/null | python -c "
+O=gpurun_out/r03q; mkdir -p $O
+timeout 1200 python -m pytest tests/test_hip_batched.py -q -m gpu -x > $O/pytest_batched.log 2>&1; tail -1 $O/pytest_batched.log
+for b in 8 4 2; do
+timeout 600 python bench.py --batched --clips-per-gpu $b --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().split('\n')[-1]); r=d['roofline']; print('$ks', round(d['value'],1), round(r['mean_us'],1), round(r.get('isolated_mean_us',0),1))" >> $O/sweep_720p.txt
+d=json.loads(sys.stdin.read().strip().split('\n')[-1]); r=d['roofline']; print('batched $b', round(d['value'],1), round(d['ms_per_step'],2), round(r['mean_us'],1), round(r['frac'],4))"
 done
