@@ -128,6 +128,11 @@ typedef struct {
   float *part;                             /* [ksplits][Npad][ncols] un-normalised partial O */
   float *ml;                               /* [ksplits][Npad][2]  (running max, row sum) */
   float *lslot;                            /* [ksplits][Npad][T][2] per-slot (sum, max at that time) or NULL */
+  int32_t *sched;                          /* NULL, or 2 device ints the caller zeroed ONCE (rmem_attn_read2, field of `a`): when the
+                                              launch holds more units than the device has CUs, one workgroup per CU takes its
+                                              first unit by index and every further one from this counter, longest first,
+                                              instead of leaving the surplus to the hardware's per-XCD dispatch order; the
+                                              last workgroup out zeroes the two ints again.  One launch at a time per buffer. */
 } rmem_read_args;
 
 int rmem_attn_read(const rmem_read_args *a, void *stream);

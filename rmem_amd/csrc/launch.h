@@ -33,6 +33,7 @@ struct RecOp {
   unsigned lds;     // dynamic LDS bytes
   unsigned off;     // offset of the argument block in the recorder's blob
   unsigned size;
+  void* aux;        // op-specific device pointer shared by the clips of a launch (the paired read's unit queue), or nullptr
 };
 
 struct Recorder {
@@ -53,6 +54,7 @@ inline void rec_push(Recorder* r, ManyFn fn, dim3 grid, dim3 block, unsigned lds
   op.lds = lds;
   op.off = off;
   op.size = size;
+  op.aux = nullptr;
   r->ops.push_back(op);
 }
 

@@ -828,6 +828,81 @@ __global__ __launch_bounds__(512) void read64x2_many_kernel(const char* __restri
   read64_body<0>(a, (which ? jj - cha : jj) * 8 + xcd, smem);
 }
 
+// ---- more units than CUs: one workgroup per CU, units taken from a counter, longest first.
+// Left to the hardware, block b of a grid larger than the device waits for a free CU of XCD b % 8 in index order:
+// 720p K=8 puts 30 long-term units and 8 windowed ones on each XCD's 32 CUs, and the windowed units queue on the
+// two CUs that are left (the makespan: 683 us for 630 us of long-term work); 8 clips per launch end with a tail of
+// long-term units on a few CUs.  Here workgroup w runs unit w, then unit ncu + (fetch-and-add of sched[0]), ... in
+// the launch's unit order (long-term first), whatever XCD it sits on.  sched[1] counts the workgroups that are done;
+// the last one zeroes both for the next launch.
+__device__ __forceinline__ int next_unit(int* sched, int base, char* smem) {
+  int* slot = reinterpret_cast<int*>(smem + R6_DUMMY);          // (any word nobody holds across units)
+  __syncthreads();                                     // every wave is done with the unit (LDS, its flush)
+  if (threadIdx.x == 0) *slot = base + atomicAdd(sched, 1);
+  __syncthreads();
+  const int u = *slot;
+  __syncthreads();                                     // read before the next unit's first request lands there
+  return __builtin_amdgcn_readfirstlane(u);
+}
+__device__ __forceinline__ void sched_done(int* sched) {
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(sched + 1, 1) == (int)gridDim.x - 1) {
+      sched[0] = 0;
+      sched[1] = 0;
+      __threadfence();
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void read64x2_pull_kernel(Read2Args g, int* sched) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int total = 8 * (g.cha + g.chb);
+  for (int b = blockIdx.x; b < total; b = next_unit(sched, gridDim.x, smem)) {
+    const int xcd = b & 7, jj = b >> 3;
+    const int which = jj < g.cha ? 0 : 1;
+    read64_body<0>(g.p[which], (which ? jj - g.cha : jj) * 8 + xcd, smem);
+  }
+  sched_done(sched);
+}
+
+__global__ __launch_bounds__(512) void read64x2_many_pull_kernel(const char* __restrict__ argv, long stride, int B, int* sched) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Read2Args& g0 = *reinterpret_cast<const Read2Args*>(argv);
+  const int cha = __builtin_amdgcn_readfirstlane(g0.cha), chb = __builtin_amdgcn_readfirstlane(g0.chb);
+  const int L = 8 * cha, W = 8 * chb, total = B * (L + W);
+  for (int u = blockIdx.x; u < total; u = next_unit(sched, gridDim.x, smem)) {
+    int b = u, clip, x;
+    if (b < B * L) {
+      clip = b / L;
+      x = b - clip * L;
+    } else {
+      b -= B * L;
+      clip = b / W;
+      x = L + (b - clip * W);
+    }
+    const Read2Args& g = *reinterpret_cast<const Read2Args*>(argv + (long)clip * stride);
+    const int xcd = x & 7, jj = x >> 3;
+    const int which = jj < cha ? 0 : 1;
+    const rmem_read_args a = rmem::uniform_copy(&g.p[which]);
+    read64_body<0>(a, (which ? jj - cha : jj) * 8 + xcd, smem);
+  }
+  sched_done(sched);
+}
+
+static int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
 template <class K>
 static int read_many_thunk(K kernel, const rmem::RecOp& op, const char* dev_args, long stride, int B, hipStream_t s) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
@@ -839,8 +914,15 @@ static int read_many(const rmem::RecOp& op, const char* d, long st, int B, hipSt
   return read_many_thunk(&read64_many_kernel, op, d, st, B, s);
 }
 static int read2_many(const rmem::RecOp& op, const char* d, long st, int B, hipStream_t s) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
-  hipLaunchKernelGGL(read64x2_many_kernel, dim3(op.grid.x * B), dim3(512), R6_LDS, s, d + op.off, st, B);
+  const int ncu = device_cus();
+  int* sched = static_cast<int*>(op.aux);              // (of the first clip's recording; one launch serves all clips)
+  if (sched && (int)op.grid.x * B > ncu) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_many_pull_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+    hipLaunchKernelGGL(read64x2_many_pull_kernel, dim3(ncu), dim3(512), R6_LDS, s, d + op.off, st, B, sched);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+    hipLaunchKernelGGL(read64x2_many_kernel, dim3(op.grid.x * B), dim3(512), R6_LDS, s, d + op.off, st, B);
+  }
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }
@@ -870,6 +952,14 @@ extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* b
   g.chb = chb;
   if (rmem::Recorder* r = rmem::current_recorder()) {
     rmem::rec_push(r, &read2_many, dim3(8 * (cha + chb)), dim3(512), R6_LDS, &g, (unsigned)sizeof(g));
+    r->ops.back().aux = ap->sched;
+    return RMEM_OK;
+  }
+  const int ncu = device_cus();
+  if (ap->sched && 8 * (cha + chb) > ncu) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_pull_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+    hipLaunchKernelGGL(read64x2_pull_kernel, dim3(ncu), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g, ap->sched);
+    RMEM_CHECK_LAUNCH();
     return RMEM_OK;
   }
   hipLaunchKernelGGL(read64x2_kernel, dim3(8 * (cha + chb)), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g);

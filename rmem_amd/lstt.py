@@ -254,6 +254,7 @@ class DeAOTLSTT:
         N, Np, dev = self.N, self.Npad, self.dev
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         self.tgt, self.tgt_id = z(N, 256), z(N, 256)
+        self.sched = None if os.environ.get("RMEM_NO_PULL") == "1" else z(2, dt=torch.int32)   # rmem_read_args.sched
         self.x_pl = Planes.empty((Np, 256), dev)
         self.z_pl = [Planes.empty((Np, 256), dev) for _ in range(self.L)]
         self.idemb_pl = Planes.empty((Np, 256), dev)
@@ -447,6 +448,9 @@ class DeAOTLSTT:
         ra.ksplits = ks
         ra.part, ra.ml = ws.part.data_ptr(), ws.ml.data_ptr()
         ra.lslot = ws.lslot.data_ptr() if want_mass else None
+        # unit queue of the paired read (used by the library only when a launch holds more units than the device has
+        # CUs: 720p K=8, several clips per launch); RMEM_NO_PULL=1 leaves the surplus to the hardware's dispatch order
+        ra.sched = self.sched.data_ptr() if (mode == 0 and self.sched is not None) else None
         ca = hip.ReadCombineArgs()
         ca.T, ca.N, ca.Npad, ca.ncols, ca.ksplits = T, self.N, Np, 1024, ks
         ca.part, ca.ml, ca.lslot = ws.part.data_ptr(), ws.ml.data_ptr(), (ws.lslot.data_ptr() if want_mass else None)

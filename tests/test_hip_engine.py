@@ -390,6 +390,48 @@ def test_paired_launches_bit_identical():
             assert torch.equal(o0, o1) and torch.equal(m0, m1), order
 
 
+def test_unit_queue_of_the_paired_read_bit_identical(monkeypatch):
+    """More units than CUs (here 11 query tiles x (20 + 6) splits = 286): the paired read runs one workgroup per CU that
+    pulls its further units from a counter (rmem_read_args.sched, read64x2_pull_kernel).  Which workgroup runs a unit
+    changes nothing the unit computes: LSTT output, attention mass and bank equal the hardware-dispatched launch
+    (RMEM_NO_PULL=1) bit for bit, and the two counters are back at zero after every launch."""
+    from rmem_amd.lstt import DeAOTLSTT
+    cfg, cpu_model, gpu_model, _ = _build()
+    h, w = 23, 30
+    N = h * w
+    H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
+    monkeypatch.setenv("RMEM_KS", "20,6,6")
+    outs = {}
+    for pull in (True, False):
+        if pull:
+            monkeypatch.delenv("RMEM_NO_PULL", raising=False)
+        else:
+            monkeypatch.setenv("RMEM_NO_PULL", "1")
+        lstt = DeAOTLSTT(gpu_model, h, w, DEV, nsplit=3)
+        assert (lstt.sched is not None) == pull
+        rs = np.random.RandomState(0)
+        rec = []
+        for t in range(5):
+            emb = torch.from_numpy(rs.standard_normal((N, 256)).astype(np.float32)).to(DEV)
+            label = torch.from_numpy(rs.randint(0, 4, (1, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
+            lab_u8 = F.interpolate(label, size=(H, W), mode="nearest")[0, 0].to(torch.uint8).to(DEV).contiguous()
+            if t == 0:
+                lstt.assign_identity(lab_u8)
+                out = lstt.forward(emb, ref_frame=True)
+            else:
+                out = lstt.forward(emb)
+                lstt.assign_identity(lab_u8)
+                lstt.update_short_memories(True)
+            torch.cuda.synchronize()
+            if pull:
+                assert int(lstt.sched.abs().sum()) == 0
+            rec.append((out.clone(), lstt.mass.clone()))
+        outs[pull] = rec
+    for (o0, m0), (o1, m1) in zip(outs[True], outs[False]):
+        assert torch.equal(o0, o1) and torch.equal(m0, m1)
+    assert float(outs[True][-1][0].abs().sum()) > 0
+
+
 def test_graph_caches_are_bounded_per_geometry(monkeypatch):
     """A caller that keeps changing the output size (a dataset with clips of different original
     sizes) must not accumulate frame / decoder graphs: at most RMEM_GRAPH_GEOMS geometries stay
