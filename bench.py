@@ -86,8 +86,8 @@ def parse():
 # (tools/jobs/gpujob_profile_r03.sh: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, mean per
 # launch), committed under profiles/.  (model, config, clips) -> (file, kernel-name prefix in that file)
 PMC_FILES = {("r50_deaotl", "480p_k4", "one"): ("r03f_pmc_x3.json", "read64x2_kernel"),
-             ("r50_deaotl", "720p_k8", "one"): ("r03f_pmc_720p_k8.json", "read64x2_kernel"),
-             ("r50_deaotl", "480p_k4", "batched8"): ("r03f_pmc_batched8.json", "read64x2_many_kernel"),
+             ("r50_deaotl", "720p_k8", "one"): ("r03g_pmc_720p_k8.json", "read64x2_pull_kernel"),
+             ("r50_deaotl", "480p_k4", "batched8"): ("r03g_pmc_batched8.json", "read64x2_many_pull_kernel"),
              ("r50_aotl", "480p_k4", "one"): ("r03f_pmc_aot.json", "mha_flash_kernel")}
 
 
@@ -445,7 +445,7 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
         iso = eng.lstt.time_read_isolated()
         flops = B * c0.read_flops(len(c0.bank))
         ach = flops / (iso * 1e-6) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": f"read64x2_many_kernel (fused long-term T={len(c0.bank)} + windowed memory read of {B} clips in one launch)",
+        out["roofline"] = {"bound": "mfma", "kernel": f"read64x2_many[_pull]_kernel (fused long-term T={len(c0.bank)} + windowed memory read of {B} clips in one launch)",
                            "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                            "traffic": None, "mean_us": iso, "algorithmic_flops_per_launch": flops,
                            "note": "isolated launches (HIP events, back to back); includes the upload of the clips' argument blocks"}

@@ -328,7 +328,7 @@ class DeAOTLSTT:
         flops = self.read_flops(T)
         mean_ms = sum(ms) / len(ms)
         ach = flops / (mean_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": f"read64x2_kernel (fused long-term T={T} + windowed memory read: Q.K^T, softmax, P.V)",
+        return {"bound": "mfma", "kernel": f"read64x2_kernel / read64x2_pull_kernel (fused long-term T={T} + windowed memory read: Q.K^T, softmax, P.V)",
                 "achieved": ach, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach / mfma_peak_tflops,
                 "traffic": None, "launches": len(ms), "mean_us": 1e3 * mean_ms,
                 "algorithmic_flops_per_launch": flops}

@@ -63,7 +63,7 @@ def from_trace(path, frames):
     # the dominant kernel of bench.py's roofline entry: the long-term P.V launches are the first
     # pv_kernel launch of every layer on the long chain = the longest third of the pv_kernel dispatches
     pv = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[start:end]
-                if r["Kernel_Name"].startswith(("read64x2_kernel", "read2_kernel")))
+                if r["Kernel_Name"].startswith(("read64x2_kernel", "read64x2_pull_kernel", "read2_kernel")))
     if pv:
         PV_LONG = (len(pv), sum(pv) / len(pv), min(pv), max(pv))
     return [(k, v[0], v[1], v[1] / v[0], 100 * v[1] / tot) for k, v in agg.items()]
