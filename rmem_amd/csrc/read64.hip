@@ -355,7 +355,10 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
     tstep(t01);
     if (n > 1) dma_k(t01, 1, true);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // Q and the first K tiles are in
+  // Q and K(0) are in (requests retire in order: at most the 4 pieces of K(1) may still be in flight -- its first
+  // reader runs behind the next barrier)
+  if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (trace && tid == 0) trace[1] = __builtin_readcyclecounter();
 
@@ -587,8 +590,8 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
   // prologue: SCORE(0) by parity 0; then K(2) requested, and part 1 of SCORE(1) by parity 1 beside part 2 of SCORE(0)
   if (grp == 0) score_p1(t_p1, 0, 0);
   tstep(t_p1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();                                    // m after tile 0 visible; K(0) read
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (K(1))
+  __syncthreads();                                    // m after tile 0 visible; K(0) read; K(1) in
   if (n > 2) {
     dma_k(t_dma, 0, true);
     if (lo + 3 < hi_t) tstep(t_dma);
