@@ -1,11 +1,10 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r03q; mkdir -p $O
-for rep in 1 2; do
-for np_ in 0 1; do
-RMEM_NO_PULL=$np_ timeout 600 python bench.py --config clips64 --batched 2>/dev/null | python -c "
+O=gpurun_out/r03q; mkdir -p $O; rm -f $O/mha_persist.txt
+for p in 0 1 2 3 4 6; do
+RMEM_MHA_PERSIST=$p timeout 300 python tools/kbench_mha.py 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('clips64 batched no_pull=$np_', round(d['value'],1), round(d['ms_per_step'],3))"
+d=json.load(sys.stdin); print('persist=$p', {k:v['us'] for k,v in d.items() if isinstance(v,dict)})" >> $O/mha_persist.txt
 done
-done
+RMEM_MHA_PERSIST=3 timeout 600 python -m pytest tests/test_hip_ops.py tests/test_hip_aot.py -q -m gpu -k "mha or aot" 2>&1 | tail -1 >> $O/mha_persist.txt
