@@ -210,6 +210,11 @@ def test_ragged_batch_and_run_dataset():
     assert torch.equal(res[0].masks, rag[0].masks) and torch.equal(res[1].masks, rag[1].masks)
     one = D.ClipDriver(model, cfg)
     assert torch.equal(res[3].masks, one.run_clip(d, num_frames=4).masks)
+    # a group whose remainder is two clips of a three-slot driver: one padded batch (the third slot repeats the first clip)
+    drv3 = D.BatchedClipDriver(model, 3, cfg)
+    res3 = drv3.run_dataset([a, b])
+    assert [r.batched for r in res3] == [True, True]
+    assert torch.equal(res3[0].masks, rag[0].masks) and torch.equal(res3[1].masks, rag[1].masks)
     # the flip-augmented clip: same path (ClipDriver, two engines), but a driver's engines carry their history (which
     # hipGraphs exist, what MIOpen tuned first), so a second driver is compared within the near-tie bound of the suite
     ref_c = D.ClipDriver(model, cfg).run_clip(c, num_frames=6).masks

@@ -458,11 +458,25 @@ def test_read_bank_logits_and_rescale(hip):
 @pytest.mark.parametrize("h,w", [(5, 7), (9, 13), (20, 23), (31, 54)])
 def test_read_window(hip, ksplits, h, w):
     """Fused short-term 15x15 windowed read against the oracle's LocalGatedPropagation core."""
+    _window_case(hip, ksplits, h, w, rising=False)
+
+
+@pytest.mark.parametrize("ksplits", [1, 3])
+def test_read_window_rising_logits(hip, ksplits):
+    """The windowed read with logits that rise by ~14 bits per 64-key tile (the online reference is raised and O rescaled on
+    every tile of the band, with masked keys and rows whose window has not started yet in the same tiles)."""
+    _window_case(hip, ksplits, 20, 23, rising=True)
+
+
+def _window_case(hip, ksplits, h, w, rising):
     from oracle import lstt_ref as R
     rs = np.random.RandomState(h * 10 + w)
     N = h * w
     Npad = (N + 127) // 128 * 128
     q, k = _rand(rs, N, 128, scale=1.5), _rand(rs, N, 128, scale=1.5)
+    if rising:
+        q = q + 1.0
+        k = k + 0.0134 * torch.arange(N, dtype=torch.float32)[:, None]
     v, u = _rand(rs, N, 1024), _rand(rs, N, 1024)
     rel_w, rel_b = _rand(rs, 225, 128, scale=0.15), _rand(rs, 225, scale=0.1)
     idx, inside = R.local_window_index(h, w)
