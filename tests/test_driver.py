@@ -275,3 +275,36 @@ def test_bench_gpus2_spawns_two_ranks_on_one_device():
     assert len(out["config"]["per_rank_frames_per_sec"]) == 2 and min(out["config"]["per_rank_frames_per_sec"]) > 0
     assert out["config"]["gathered_masks_shape"][0] == 2 and len(out["config"]["gathered_masks_sha256"]) == 64
     assert abs(out["value"] - 2 * 10 / (out["ms_per_step"] * 10 / 1e3)) < 1e-6 * out["value"]
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_single_gpu():
+    """The line the driver parses: `python bench.py --steps K --warmup W` prints ONE JSON object with BASELINE.json's
+    metric, whole-job frames/s consistent with ms_per_step, `roofline` for the dominant kernel (achieved = algorithmic
+    flops / HIP-event mean, frac = achieved / peak, traffic from the committed PMC summary) and `cpu_baseline` (the
+    oracle timed on the host cores, bounded sample), plus the parity fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "4", "--no-dropin"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert out["metric"] == base["metric"] and out["n_gpus"] == 1 and out["steps"] == 12 and out["warmup"] == 4
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None and out["data"] == "synthetic"
+    assert abs(out["value"] - 12 / (out["ms_per_step"] * 12 / 1e3)) < 1e-6 * out["value"]
+    assert "workload" in out["config"] and "model" not in out["config"]
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["mean_us"] * 1e-6) / 1e12) < 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.03 < r["frac"] < 0.5
+    assert r["traffic"] is not None and r["traffic"] > 1e7
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert max(out["mask_mismatch_px"]) <= 4 and out["eviction_sequence_equal"] is True and out["iou_vs_oracle"] > 0.9999
