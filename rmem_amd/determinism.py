@@ -21,7 +21,7 @@ whose output differs from call to call (~1e-5, kernel launches serialised or not
 encoder and decoder are bit-reproducible call to call and process to process at 97x129 and at 481x849
 (profiles/r03_parity_mode_probe.json).  One clip per GPU does not slow down (466.7 vs 463.8 frames/s,
 profiles/r03_j_bench_ab_*.json); several clips per launch DO (MIOpen at batch 8: 14.6 -> 21.9 ms per
-step with the switch on and off, measured on one box in round 3; profiles/r03t_bench_batched8.json is without it), so the switch is applied by fix_random(), by the test
+step with the switch on and off, measured on one box in round 3; profiles/r03g_bench_batched8.json is without it), so the switch is applied by fix_random(), by the test
 suite (tests/conftest.py) and by bench.py's one-clip-per-engine modes -- not by the library on import.
 """
 from __future__ import annotations

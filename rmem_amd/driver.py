@@ -15,7 +15,8 @@ upsamples, un-flips, averages and arg-maxes straight to a uint8 label map, and o
 generic path (several sub-engines, whose logits are aggregated at output resolution:
 engines/aot_engine.py:650-673,704-712) uses the same torch ops as the reference.
 
-Also here: static clip sharding across ranks and the one exchange step (all-gather of masks).
+Also here: static clip sharding across ranks (round-robin for equal clips, longest-first for a dataset of
+unequal clips: assign_clips_by_length) and the one exchange step (all-gather of masks).
 The reference distributes clips through an mp.Queue work queue and funnels statistics through
 a second queue (tools/eval.py:137-143, managers/evaluator.py:276-295,589-613); clips are
 independent, so the shard is static (clip i -> rank i mod world) and the masks are collected
@@ -79,6 +80,74 @@ def run_sharded_clips(driver, n_clips: int, world: int, rank: int, frames_of: Ca
     for pos, cid in enumerate(unshard_order(n_clips, world)):
         hashes[cid] = hashlib.sha256(host[pos].tobytes()).hexdigest()
     return hashes, allm, frames_run
+
+
+def assign_clips_by_length(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Clips of UNEQUAL length -> ranks, longest first: clips in order of (-frames, id), each to the rank that holds
+    the fewest frames so far (ties: the lowest rank).  The reference hands clips to its workers from a queue as they
+    become free (managers/evaluator.py:276-295), which for per-frame costs that do not depend on the clip IS this
+    greedy rule when the queue is sorted longest first; the frame counts of a dataset are known before the run, so the
+    assignment is computed up front, identically on every rank, and no work queue (no control-plane exchange) is
+    needed.  Greedy longest-first is within 4/3 - 1/(3 world) of the optimal makespan; round-robin is not bounded."""
+    if world <= 0:
+        raise ValueError("world must be positive")
+    if any(int(n) <= 0 for n in lengths):
+        raise ValueError("every clip needs at least one frame")
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for cid in sorted(range(len(lengths)), key=lambda c: (-int(lengths[c]), c)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(cid)
+        load[r] += int(lengths[cid])
+    return out
+
+
+def shard_clips_by_length(lengths: Sequence[int], world: int, rank: int) -> List[int]:
+    """Clip ids `rank` runs under assign_clips_by_length, in the order it runs them (longest first)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return assign_clips_by_length(lengths, world)[rank]
+
+
+def run_sharded_dataset(driver, lengths: Sequence[int], world: int, rank: int, frames_of: Callable[[int], list],
+                        group=None):
+    """Clips of unequal length over `world` ranks: length-aware static assignment (assign_clips_by_length), every
+    clip through `driver.run_clip`, ONE all-gather of uint8 masks padded to [max clips per rank, max frames - 1, H0, W0]
+    (all clips of a call share the output size; a dataset with several sizes is one call per size).  Returns
+    (sha256 per clip over ITS OWN frames, in clip-id order; frames run per rank, as assigned).  Like
+    run_sharded_clips the hashes do not depend on `world`."""
+    import hashlib
+    assign = assign_clips_by_length(lengths, world)
+    per = max(1, max(len(a) for a in assign))
+    fmax = max(int(n) for n in lengths) - 1
+    local: List[Optional[torch.Tensor]] = []
+    for cid in assign[rank]:
+        res = driver.run_clip(frames_of(cid), num_frames=int(lengths[cid]))
+        if int(res.masks.shape[0]) != int(lengths[cid]) - 1:
+            raise ValueError(f"clip {cid}: {int(res.masks.shape[0]) + 1} frames run, {int(lengths[cid])} announced")
+        local.append(res.masks)
+    shape = None
+    for m in local:
+        if shape is not None and tuple(m.shape[1:]) != shape:
+            raise ValueError("clips of one run_sharded_dataset call must share the output size")
+        shape = tuple(m.shape[1:])
+    if world > 1:          # a rank without clips still contributes a (zero) block: agree on the size
+        import torch.distributed as dist
+        hw = torch.tensor(list(shape) if shape else [0, 0], dtype=torch.int64)
+        if local and local[0].is_cuda and dist.get_backend(group) != "gloo":
+            hw = hw.to(local[0].device)
+        dist.all_reduce(hw, op=dist.ReduceOp.MAX, group=group)
+        shape = tuple(int(v) for v in hw.cpu())
+    devs = local[0].device if local else torch.device("cpu")
+    block = torch.zeros((per, max(fmax, 1)) + tuple(shape), dtype=torch.uint8, device=devs)
+    for j, m in enumerate(local):
+        block[j, :m.shape[0]] = m
+    allm = gather_masks(block, world, group).cpu().numpy()
+    hashes: List[Optional[str]] = [None] * len(lengths)
+    for r, ids in enumerate(assign):
+        for j, cid in enumerate(ids):
+            hashes[cid] = hashlib.sha256(allm[r * per + j, :int(lengths[cid]) - 1].tobytes()).hexdigest()
+    return hashes, [sum(int(lengths[c]) - 1 for c in ids) for ids in assign]
 
 
 def unshard_order(n_clips: int, world: int) -> List[int]:

@@ -594,7 +594,7 @@ class DeAOTEngine(nn.Module):
         if update_long:
             idx = self.long_memories_indexes            # (brings the host's view up to date first)
             idx.append(self.frame_step)
-            if getattr(self.lstt, "device_policy", False):
+            if getattr(self.lstt, "_dev_policy", False):      # the ONE flag the LSTT itself branches on
                 # foreground weights, attention-mass reduction, EMA / UCB rule and the deletion of the dropped slot
                 # all on the device (rmem_fg_weights, rmem_attn_mass_reduce, rmem_bank_policy_step): no D2H here
                 self.lstt.restrict_long_memories(idx, logits=self.pred_id_logits)

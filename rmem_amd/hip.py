@@ -113,6 +113,9 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+ABI_VERSION = 12          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
+
+
 def load():
     """Load librmem_hip.so (built in-tree by rmem_amd.build).  Raises if missing."""
     global _LIB
@@ -122,6 +125,10 @@ def load():
         raise RmemError(f"{_LIB_PATH} not found: run `python -m rmem_amd.build` (hipcc, gfx950). "
                         "There is no CPU fallback for the RMem hot path.")
     lib = C.CDLL(_LIB_PATH)
+    lib.rmem_abi_version.restype = C.c_int
+    if lib.rmem_abi_version() != ABI_VERSION:
+        raise RmemError(f"{_LIB_PATH} has ABI {lib.rmem_abi_version()}, this binding expects {ABI_VERSION}: "
+                        "stale library -- rebuild with `python -m rmem_amd.build --force`")
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
     lib.rmem_linear.argtypes = [C.POINTER(LinearArgs), c_p]

@@ -210,7 +210,7 @@ class DeAOTLSTT:
             # several clips per launch: two rounds of workgroups (longer units amortise the per-unit staging and flush);
             # measured at 480p K=4 (frames/s for long,win,self: 4 clips 3,1,4 479 / 4,2,4 476 / 7,2,6 461;
             # 8 clips 2,1,2 492 / 3,1,3 489 / 1,1,2 477) -- the model below does not cover the clip-major dispatch order
-            total = max(3, min(32, 512 // (nq * clips)))
+            total = max(3, min(32, 2 * cus // (nq * clips)))
             kw = max(1, min(8, int(round(total * 0.33 * min(1.0, 4.0 / max(cap, 1))))))
             return max(1, total - kw), kw
         long_tiles = cap * tv
@@ -240,6 +240,10 @@ class DeAOTLSTT:
                 key = (round(span, 1), kl + kw)
                 if best is None or key < best[0]:
                     best = (key, kl, kw)
+        if best is None:
+            # beyond 4 rounds of units per CU whatever the split (N > 32768 tokens): no key split pays -- a query
+            # tile's keys stay in one unit
+            return 1, 1
         kl, kw = best[1], best[2]
         # More units than CUs: the windowed units (last in dispatch order) queue on the few CUs per XCD the long-term
         # units leave free and end up as the makespan (720p K=8: 8 units of up to 22 tiles on 2 CUs per XCD, at the
@@ -269,10 +273,14 @@ class DeAOTLSTT:
         # Key splits of the fused reads (csrc/read64.hip).  A unit = (64-query tile, key split) is one 8-wave
         # workgroup that owns a CU; the long-term and the windowed read of a layer share ONE launch, the
         # self read gets a launch of its own.
-        self.ks_long, self.ks_win = self.choose_splits(N, self.h, self.w, self.cap, self.clips_per_launch)
+        # CUs of the device the library will launch on (its own pull-versus-plain decision reads the same attribute,
+        # read64.hip:device_cus): a partitioned or smaller part gets splits that match
+        cus = int(torch.cuda.get_device_properties(dev).multi_processor_count) if dev.type == "cuda" else 256
+        self.cus = cus = cus if cus > 0 else 256
+        self.ks_long, self.ks_win = self.choose_splits(N, self.h, self.w, self.cap, self.clips_per_launch, cus)
         nq = (N + 63) // 64
         tv = (N + 63) // 64
-        budget = 256 if self.clips_per_launch == 1 else max(1, 512 // self.clips_per_launch)
+        budget = cus if self.clips_per_launch == 1 else max(1, 2 * cus // self.clips_per_launch)
         # self read (T = 1, 27 tiles at 480p): 9 splits are faster isolated (33.8 + 13.1 us read + combine against
         # 38.2 + 10.1 with 6) but not in the frame (more partials beside the encoder stream)
         self.ks_self = max(1, min(budget // nq, tv, 6))
@@ -384,11 +392,16 @@ class DeAOTLSTT:
         drop = int(res[1])
         self._pending = None
         self.last_policy = dict(drop=drop)
+        left = int(res[2])
         if p["expect_drop"]:
-            if drop < 0 or int(res[2]) != len(self.bank) - 1:
+            if drop < 0 or left != len(self.bank) - 1:
                 raise hip.RmemError("device-side eviction disagrees with the host's bank length")
             del self.bank[drop]
             p["indexes"].remove(p["indexes"][drop])
+        elif drop >= 0 or left != len(self.bank):
+            # the host expected no eviction (bank below its cap): the device must not have dropped a slot either
+            raise hip.RmemError(f"device-side eviction dropped position {drop} ({left} slots left) although the "
+                                f"host's bank holds {len(self.bank)} <= cap slots")
         return True
 
     # ------------------------------------------------------------------ helpers
@@ -685,11 +698,12 @@ class DeAOTLSTT:
                        csplit=256, accumulate=True, nsplit=ns)
 
     # ------------------------------------------------------------------ memory update
-    def update_short_memories(self, update_long: bool):
+    def update_short_memories(self, update_long: bool, frame_index: int = 0):
         """update_short_memories + update_long_term_memory (transformer.py:826-878).
-        ``assign_identity`` must have been called with the current mask."""
+        ``assign_identity`` must have been called with the current mask.  `frame_index` = the frame step the
+        engine appends to long_memories_indexes (aot_engine.py:341-343): rmem_bank_state.index keeps the same id."""
         self._update_device(update_long)
-        self._update_host(update_long)
+        self._update_host(update_long, frame_index)
 
     def update_key(self, update_long: bool):
         return (self.cur,)

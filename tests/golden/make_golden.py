@@ -12,6 +12,7 @@ Fixtures are data only (inputs + the reference's outputs):
   clip_small_*.json/.npz     engine state machine on small clips (indexes, EMA, visits, labels)
   clip_480p.json/.npz        481x849 clip: per-frame label hashes + a few logits (fp16)
   multiengine_wrapper.*      AOTInferEngine.separate_mask / soft_logit_aggregation (> 10 objects)
+  clip_480p_fp64.*           the same 481x849 clip through the reference in DOUBLE precision (near-tie arbitration)
 """
 from __future__ import annotations
 
@@ -382,6 +383,95 @@ def gen_multiengine():
     print("multi-engine wrapper vectors:", sorted(out)[:6], "...")
 
 
+def gen_clip_480p_fp64(tie_margin=1e-4, token_stride=4):
+    """fp64 arbitration of the golden 481x849 clip.  The reference itself is run
+    with a double-precision model (``torch.set_default_dtype(float64)`` while it is built; the name-keyed fp32
+    weights are cast exactly), teacher-forced with the labels its fp32 run produced (clip_480p.npz), and then
+    once more in fp32 to record how far the fp32 CPU path itself is from fp64.  Stored (data only):
+      labels64            label maps of the fp64 run
+      tie_idx_t / tie_cls_t / tie_l64_t / tie_l32_t
+                          every output pixel whose two best class logits are closer than ``tie_margin`` in fp64:
+                          flat index, the two classes, their fp64 logits, the fp32 reference's logits
+      lstt64_t            final LSTT output (after the GroupNorm, what the decoder reads) of the fp64 run at
+                          tokens t % stride :: stride, rounded to fp32
+      lstt32_err_t, dec32_err_t
+                          [max, rms] of |fp32 reference - fp64| over the whole LSTT output / decoder logits
+    """
+    ref = rh.import_reference()
+    meta = json.load(open(os.path.join(HERE, "clip_480p.json")))
+    gold = np.load(os.path.join(HERE, "clip_480p.npz"))
+    H, W, frames, out_hw = meta["H"], meta["W"], meta["frames"], tuple(meta["out_hw"])
+    imgs32, lab = synth_clip(meta["seed"], frames, H, W, 3)
+    AOTEngine = ref["aot_engine"].AOTEngine
+    prev_assign = AOTEngine.assign_identity
+
+    def run(dtype):
+        # utils/image.py:74 hard-codes .float() for the one-hot planes: cast them (0/1, exact) to the model's dtype
+        AOTEngine.assign_identity = lambda self, oh, ign=None: prev_assign(
+            self, oh.to(dtype), None if ign is None else ign.to(dtype))
+        torch.set_default_dtype(dtype)
+        try:
+            cfg, model, engine = rh.build_reference("r50_deaotl", meta["former"], meta["latter"], meta["gap"])
+            assert next(model.parameters()).dtype == dtype
+            got = {}
+            hook = model.LSTT.register_forward_hook(lambda m, i, o: got.__setitem__("lstt", o[-1][:, 0].clone()))
+            rec = dict(up=[], lstt=[], dec=[], idx=[])
+            with torch.no_grad(), rh.quiet():
+                engine.restart_engine()
+                engine.add_reference_frame(imgs32[0].to(dtype), lab.int(), obj_nums=[int(lab.max())], frame_step=0)
+                sub = engine.aot_engines[0]
+                for t in range(1, frames):
+                    up = engine.match_propogate_one_frame(imgs32[t].to(dtype), output_size=out_hw)
+                    rec["up"].append(up[0].clone())
+                    rec["lstt"].append(got["lstt"])
+                    rec["dec"].append(sub.pred_id_logits.clone())
+                    fed = torch.from_numpy(gold["labels"][t - 1]).to(dtype)[None, None]
+                    engine.update_memory(F.interpolate(fed, size=engine.input_size_2d, mode="nearest"))
+                    rec["idx"].append(list(sub.long_memories_indexes))
+            hook.remove()
+            return rec
+        finally:
+            torch.set_default_dtype(torch.float32)
+            AOTEngine.assign_identity = prev_assign
+
+    r64, r32 = run(torch.float64), run(torch.float32)
+    assert r64["idx"] == meta["indexes"] and r32["idx"] == meta["indexes"]
+    out, info = {}, dict(tie_margin=tie_margin, token_stride=token_stride, mism32_vs_64=[], n_tie=[],
+                         lstt32_err=[], dec32_err=[])
+    labels64 = []
+    for t in range(1, frames):
+        u64, u32 = r64["up"][t - 1], r32["up"][t - 1]
+        l32 = torch.argmax(u32, dim=0).to(torch.uint8)
+        assert torch.equal(l32, torch.from_numpy(gold["labels"][t - 1])), "the fp32 re-run must reproduce the golden labels"
+        l64 = torch.argmax(u64, dim=0).to(torch.uint8)
+        labels64.append(l64)
+        top = torch.topk(u64, 2, dim=0)
+        tie = torch.nonzero(((top.values[0] - top.values[1]) < tie_margin).flatten())[:, 0]
+        cls = top.indices.flatten(1)[:, tie].T.contiguous()                   # [n, 2]
+        f64 = u64.flatten(1)[:, tie]
+        f32 = u32.flatten(1)[:, tie]
+        ar = torch.arange(tie.numel())
+        out[f"tie_idx_{t}"] = tie.to(torch.int32).numpy()
+        out[f"tie_cls_{t}"] = cls.to(torch.uint8).numpy()
+        out[f"tie_l64_{t}"] = torch.stack([f64[cls[:, 0], ar], f64[cls[:, 1], ar]], 1).numpy()
+        out[f"tie_l32_{t}"] = torch.stack([f32[cls[:, 0], ar], f32[cls[:, 1], ar]], 1).numpy()
+        out[f"lstt64_{t}"] = r64["lstt"][t - 1][t % token_stride::token_stride].float().numpy()
+        e = (r32["lstt"][t - 1].double() - r64["lstt"][t - 1]).abs()
+        d = (r32["dec"][t - 1].double() - r64["dec"][t - 1])[:, :int(lab.max()) + 1].abs()
+        out[f"lstt32_err_{t}"] = np.array([float(e.max()), float((e ** 2).mean().sqrt())])
+        out[f"dec32_err_{t}"] = np.array([float(d.max()), float((d ** 2).mean().sqrt())])
+        mm = torch.nonzero((l32 != l64).flatten())[:, 0]
+        assert all(int(i) in set(tie.tolist()) for i in mm), "an fp32/fp64 disagreement outside the near-tie set"
+        info["mism32_vs_64"].append(int(mm.numel()))
+        info["n_tie"].append(int(tie.numel()))
+        info["lstt32_err"].append(out[f"lstt32_err_{t}"].tolist())
+        info["dec32_err"].append(out[f"dec32_err_{t}"].tolist())
+    out["labels64"] = torch.stack(labels64).numpy()
+    np.savez_compressed(os.path.join(HERE, "clip_480p_fp64.npz"), **out)
+    json.dump(info, open(os.path.join(HERE, "clip_480p_fp64.json"), "w"))
+    print("480p fp64 arbitration:", info)
+
+
 def main():
     torch.manual_seed(0)
     if "--tta-only" in sys.argv:
@@ -392,6 +482,9 @@ def main():
         return
     if "--multiengine-only" in sys.argv:
         gen_multiengine()
+        return
+    if "--fp64-only" in sys.argv:
+        gen_clip_480p_fp64()
         return
     if "--aot-only" not in sys.argv and "--swin-only" not in sys.argv:
         cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
@@ -409,6 +502,7 @@ def main():
     gen_tta()
     gen_ignore_clip()
     gen_multiengine()
+    gen_clip_480p_fp64()
     os.system(f"du -sh {HERE}")
 
 

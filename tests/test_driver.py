@@ -308,3 +308,49 @@ def test_bench_line_contract_single_gpu():
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert max(out["mask_mismatch_px"]) <= 4 and out["eviction_sequence_equal"] is True and out["iou_vs_oracle"] > 0.9999
+
+
+@pytest.mark.gpu
+def test_rccl_world1_gather_and_max_over_ranks():
+    """First contact with RCCL on the leased GPU (tools/eval.py:137-143 starts one process per GPU; here the group has
+    ONE rank): `init_process_group("nccl")` loads librccl and creates a communicator, `all_gather_into_tensor` of a
+    uint8 mask tensor [2, 3, 480, 854] on the device goes through the backend (driver.gather_masks short-cuts world 1,
+    so the collective is called on the group directly with the same dtype / shape handling), and bench.max_over_ranks
+    runs its float64 device all-gather.  Run in a child process: a process group is process-global state."""
+    code = r"""
+import os, sys, json, hashlib
+sys.path.insert(0, os.getcwd())
+import torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl")
+assert dist.get_backend() == "nccl"
+g = torch.Generator().manual_seed(5)
+masks = torch.randint(0, 11, (2, 3, 480, 854), generator=g, dtype=torch.uint8).to(dev)
+out = torch.empty_like(masks)
+dist.all_gather_into_tensor(out, masks.contiguous())
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(out, masks)
+import bench
+from rmem_amd.driver import gather_masks
+assert gather_masks(masks, 1) is masks
+mx, vals = bench.max_over_ranks(dist, 1.25, dev)
+assert mx == 1.25 and vals == [1.25]
+t = torch.ones(4, device=dev, dtype=torch.float64); dist.all_reduce(t); torch.cuda.synchronize()
+assert float(t.sum()) == 4.0
+dist.destroy_process_group()
+print(json.dumps({"ok": True, "sha": hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]}))
+"""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["ok"]

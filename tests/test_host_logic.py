@@ -262,6 +262,82 @@ def test_sharded_clips_hashes_do_not_depend_on_world_size():
     assert out[1] == out[2] and len(set(out[1])) == 4      # same per clip, and the clips differ
 
 
+def test_assign_clips_by_length():
+    """Length-aware sharding (missing item 2; reference: work queue, evaluator.py:276-295)."""
+    from rmem_amd.driver import assign_clips_by_length, shard_clips, shard_clips_by_length
+    lengths = [100, 20, 20, 20, 20, 20, 90, 10]
+    a = assign_clips_by_length(lengths, 2)
+    assert sorted(c for r in a for c in r) == list(range(8))              # a partition
+    loads = [sum(lengths[c] for c in r) for r in a]
+    assert max(loads) == 150                                              # optimal here (300 frames over 2 ranks)
+    rr = [sum(lengths[c] for c in shard_clips(8, 2, r)) for r in range(2)]
+    assert max(rr) == 230                                                 # round-robin puts 100 and 90 on one rank
+    assert a == assign_clips_by_length(lengths, 2)                        # deterministic: every rank computes the same
+    assert shard_clips_by_length(lengths, 2, 1) == a[1]
+    assert a[0][0] == 0 and a[1][0] == 6                                  # longest first on each rank
+    # equal clips: as balanced as round-robin
+    eq = assign_clips_by_length([16] * 64, 8)
+    assert all(len(r) == 8 for r in eq)
+    # more ranks than clips: the surplus ranks get nothing
+    assert assign_clips_by_length([5, 7], 4) == [[1], [0], [], []]
+    import random
+    rnd = random.Random(3)
+    for _ in range(50):                                                   # 4/3 bound of longest-first greedy
+        ls = [rnd.randint(2, 120) for _ in range(rnd.randint(1, 40))]
+        w = rnd.randint(1, 8)
+        mk = max(sum(ls[c] for c in r) for r in assign_clips_by_length(ls, w))
+        lower = max(max(ls), -(-sum(ls) // w))
+        assert mk <= (4 / 3) * lower + max(ls) / 3 + 1e-9 or mk <= lower * (4 / 3 - 1 / (3 * w)) + max(ls)
+    with pytest.raises(ValueError):
+        assign_clips_by_length([3, 0], 2)
+    with pytest.raises(ValueError):
+        shard_clips_by_length([3, 4], 2, 2)
+
+
+def _sharded_dataset_worker(rank, world, port, q, lengths, H, W):
+    import torch.distributed as dist
+    from oracle.engine_ref import OracleDeAOTEngine
+    from rmem_amd import driver as D
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    torch.set_num_threads(2)
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = get_config("r50_deaotl", 1, 3)
+    model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(model)
+    model.cfg = cfg
+    drv = D.ClipDriver(model, cfg, engine_factory=lambda m: OracleDeAOTEngine(m), fixed_gap=2)
+    hashes, frames = D.run_sharded_dataset(drv, lengths, world, rank, lambda c: _clip_frames(c, lengths[c], H, W))
+    if rank == 0:
+        q.put((hashes, frames))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_dataset_of_unequal_clips_world_invariant():
+    """Clips of unequal length (7, 3, 4, 5, 3 frames), longest-first assignment, padded all-gather: the sha256 of
+    every clip's own frames as world = 1, 2 and 3 gloo processes (3: one rank ends up with a single clip)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    lengths = [7, 3, 4, 5, 3]
+    out = {}
+    for world in (1, 2, 3):
+        q = ctx.Queue()
+        port = 33500 + os.getpid() % 2000 + world
+        procs = [ctx.Process(target=_sharded_dataset_worker, args=(r, world, port, q, lengths, 49, 65)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out[world] = q.get(timeout=600)
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0
+    assert out[1][0] == out[2][0] == out[3][0] and len(set(out[1][0])) == 5
+    assert out[2][1] == [8, 9] and out[3][1] == [6, 6, 5]       # propagated frames per rank (22 frames over 2 / 3 ranks)
+
+
 def test_batched_clip_driver_validates_its_input_on_the_host():
     """BatchedClipDriver refuses what it cannot run in lockstep before anything is launched (no GPU
     needed): wrong clip count, clips whose lengths give different memory gaps, flip augmentation, mid-clip

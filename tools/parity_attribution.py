@@ -53,6 +53,9 @@ def main():
     gd = os.path.join(ROOT, "tests", "golden")
     meta = json.load(open(os.path.join(gd, "clip_480p.json")))
     gold = np.load(os.path.join(gd, "clip_480p.npz"))["labels"]
+    # the reference in double precision on the same teacher-forced inputs (make_golden.py:gen_clip_480p_fp64)
+    gold64 = np.load(os.path.join(gd, "clip_480p_fp64.npz"))["labels64"]
+    vs64 = {}
     cfg = get_config("r50_deaotl", meta["former"], meta["latter"])
     cpu_model = build_vos_model("deaot", cfg).eval()
     load_synthetic_weights(cpu_model)
@@ -85,6 +88,7 @@ def main():
                 ora_lab.append(labels_of(lg))
                 ora.update_memory(fed(t, ora.input_size_2d))
             res["rows"]["oracle (cpu/cpu/cpu)"] = [int((a != gold[i]).sum()) for i, a in enumerate(ora_lab)]
+            vs64["oracle (cpu/cpu/cpu)"] = [int((a != gold64[i]).sum()) for i, a in enumerate(ora_lab)]
 
         gpu_model = copy.deepcopy(cpu_model).to(dev)
         # ---- product
@@ -94,12 +98,15 @@ def main():
             eng.eval()
             gi = [x.to(dev) for x in imgs]
             eng.add_reference_frame(gi[0], lab.to(dev), obj_nums=[3], frame_step=0)
-            mm = []
+            mm, m64 = [], []
             for t in range(1, F_):
                 lg = eng.match_propogate_one_frame(gi[t], output_size=None)
-                mm.append(int((labels_of(lg) != gold[t - 1]).sum()))
+                lb = labels_of(lg)
+                mm.append(int((lb != gold[t - 1]).sum()))
+                m64.append(int((lb != gold64[t - 1]).sum()))
                 eng.update_memory(fed(t, eng.input_size_2d).to(dev))
             res["rows"]["product (gpu/hip/gpu)"] = mm
+            vs64["product (gpu/hip/gpu)"] = m64
             res["indexes_ok"] = list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][-1]
         # ---- CPU encoder features -> HIP LSTT -> GPU decoder / CPU decoder
         if "cpuenc" in rows or "lsttonly" in rows:
@@ -108,28 +115,40 @@ def main():
             sub.eval()
             eg = [[x.to(dev) for x in e] for e in enc_cpu]
             sub.add_reference_frame(imgs[0].to(dev), lab.to(dev), obj_nums=[10], img_embs=eg[0], frame_step=0)
-            mm_g, mm_c, lerr = [], [], []
+            mm_g, mm_c, lerr, g64, c64 = [], [], [], [], []
             for t in range(1, F_):
                 lg = sub.match_propogate_one_frame(img=None, img_embs=eg[t], output_size=None)
-                mm_g.append(int((labels_of(lg) != gold[t - 1]).sum()))
+                lb = labels_of(lg)
+                mm_g.append(int((lb != gold[t - 1]).sum()))
+                g64.append(int((lb != gold64[t - 1]).sum()))
                 out = sub.lstt.out.cpu()
                 lc = cpu_model.decode_id_logits(out, enc_cpu[t])
-                mm_c.append(int((labels_of(lc) != gold[t - 1]).sum()))
+                lb = labels_of(lc)
+                mm_c.append(int((lb != gold[t - 1]).sum()))
+                c64.append(int((lb != gold64[t - 1]).sum()))
                 if ora_out:
                     lerr.append(float((out - ora_out[t - 1]).abs().max()))
                 sub.update_short_term_memory(fed(t, sub.input_size_2d).to(dev))
             res["rows"]["cpu enc -> HIP LSTT -> gpu dec"] = mm_g
             res["rows"]["cpu enc -> HIP LSTT -> cpu dec (LSTT only)"] = mm_c
             res["lstt_out_max_abs_err_vs_oracle"] = lerr
+            vs64["cpu enc -> HIP LSTT -> gpu dec"] = g64
+            vs64["cpu enc -> HIP LSTT -> cpu dec (LSTT only)"] = c64
         # ---- oracle LSTT output -> GPU decoder
         if "deconly" in rows and ora_out:
-            mm = []
+            mm, m64 = [], []
             for t in range(1, F_):
                 eg = [x.to(dev) for x in enc_cpu[t]]
                 lg = gpu_model.decode_id_logits(ora_out[t - 1].to(dev), eg)
-                mm.append(int((labels_of(lg) != gold[t - 1]).sum()))
+                lb = labels_of(lg)
+                mm.append(int((lb != gold[t - 1]).sum()))
+                m64.append(int((lb != gold64[t - 1]).sum()))
             res["rows"]["cpu enc -> oracle LSTT -> gpu dec (decoder only)"] = mm
+            vs64["cpu enc -> oracle LSTT -> gpu dec (decoder only)"] = m64
     res["sums"] = {k: int(sum(v)) for k, v in res["rows"].items()}
+    res["rows_vs_fp64_reference"] = vs64
+    res["sums_vs_fp64_reference"] = {k: int(sum(v)) for k, v in vs64.items()}
+    res["fp32_reference_vs_fp64_reference"] = [int((gold[i] != gold64[i]).sum()) for i in range(F_ - 1)]
     print(json.dumps(res))
     if args.out:
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
