@@ -18,7 +18,8 @@ Frames are resident in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # same ranks, external launcher
 
 Environment: RMEM_DIST_BACKEND (default "nccl" = RCCL; "gloo" lets N ranks share ONE GPU for a launcher
-smoke test), RMEM_DEVICE_OVERRIDE=<index> (every rank uses that device instead of LOCAL_RANK).
+smoke test), RMEM_DEVICE_OVERRIDE=<index> (every rank uses that device instead of LOCAL_RANK), RMEM_FORCE_DIST=1
+(world 1 still initialises the process group and goes through every collective of the N > 1 path).
 
 Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the
 dominant kernel (HIP-event timed inside the timed region) and `cpu_baseline` (the
@@ -129,12 +130,32 @@ def rank_device(local_rank: int) -> int:
     return int(os.environ["RMEM_DEVICE_OVERRIDE"]) if os.environ.get("RMEM_DEVICE_OVERRIDE", "") != "" else local_rank
 
 
+def keep_stdout_for_the_json_line():
+    """Native libraries print to the C-level stdout (librccl: "Librccl path : ..." when its buffer is flushed at exit,
+    i.e. AFTER rank 0's JSON line; MIOpen warnings).  The driver reads ONE JSON line from stdout, so file descriptor 1 is
+    pointed at stderr for everything native and Python's sys.stdout keeps the real stdout."""
+    if getattr(keep_stdout_for_the_json_line, "done", False):
+        return
+    keep_stdout_for_the_json_line.done = True
+    try:
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(real, "w", buffering=1)
+    except OSError:
+        pass
+
+
 def init_dist(world: int):
     """None for one rank, else the initialised torch.distributed module (RCCL unless RMEM_DIST_BACKEND says gloo)."""
-    if world <= 1:
+    if world <= 1 and os.environ.get("RMEM_FORCE_DIST") != "1":
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world <= 1:             # RMEM_FORCE_DIST=1: a one-rank group, so that one leased GPU runs every RCCL call of the N > 1 path
+        os.environ.setdefault("MASTER_PORT", "29547")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     dist.init_process_group(backend=os.environ.get("RMEM_DIST_BACKEND", "nccl"))
     return dist
 
@@ -153,6 +174,8 @@ def max_over_ranks(dist, elapsed: float, dev):
 
 def main():
     args = parse()
+    if not (args.gpus > 1 and "WORLD_SIZE" not in os.environ):   # (the spawning parent passes its children's output through)
+        keep_stdout_for_the_json_line()
     if not args.batched:       # reproducible convolutions (rmem_amd/determinism.py): free for one clip per engine, so the
         from rmem_amd.determinism import reproducible_convolutions      # clip hashes of --config clips64 repeat run to run;
         reproducible_convolutions()                                     # MIOpen at batch B needs the solvers this disables
@@ -258,6 +281,11 @@ def main():
         t += 1
         cur = n_graphs()
         stable, last = (stable + 1, last) if cur == last else (0, cur)
+    sampled = hasattr(sub.lstt, "launch_read2_layer0") and sub.hoist_enabled and os.environ.get("RMEM_BENCH_EAGER_SAMPLE") != "1"
+    if sampled:                  # the `tail` graphs of the sampled frames (all slot variants) are captured here, not in the timed region
+        sub.lstt._sample_read = True
+        all_clips(t)
+        t += 1
     for _ in range(args.warmup):
         all_clips(t)
         t += 1
@@ -275,16 +303,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # steady-state frames replay hipGraphs; one frame in fifty of the timed region (at least one) is
-    # issued eagerly (~0.9 ms slower than a replayed frame) so that HIP events can bracket the
-    # dominant kernel on its launch stream
+    cpu0 = time.process_time()                # user + system time of every thread of this process (main + graph launcher)
+    # Steady-state frames replay hipGraphs.  The dominant kernel is timed by HIP events on its launch stream INSIDE
+    # replayed frames: on every fifth frame the LSTT is replayed as front graph | the fused read of layer 0 launched on
+    # its own between two events | tail graph (engine._graphed_frame) -- same kernels, same order, the prefetched
+    # encoder pass beside it as on every other frame.  (torch on ROCm refuses event nodes inside a graph; an eagerly
+    # issued frame, rounds 1-3, is host-bound and leaves the kernel the GPU to itself: 106 us against 119 in the trace.)
+    # Models without the front / tail split (AOT block) keep the eagerly issued frame, one in fifty.
     n_eager = max(1, args.steps // 50)
     eager_at = {(i * args.steps) // n_eager for i in range(n_eager)}
     for k in range(args.steps):
-        lstt._timing = (k in eager_at) and not os.environ.get("RMEM_BENCH_NOSYNC")
+        if sampled:
+            lstt._sample_read = (k % 5 == 2)
+        else:
+            lstt._timing = (k in eager_at) and not os.environ.get("RMEM_BENCH_NOSYNC")
         all_clips(t + k, masks)
     lstt._timing = False
     host_issue = time.perf_counter() - t0     # host-side launch time (GPU work still in flight)
+    host_cpu = time.process_time() - cpu0     # CPU seconds this rank burned while issuing (all threads)
     for st in streams[1:]:
         streams[0].wait_stream(st)
     if dist is not None:                      # collect per-clip masks (the only exchange step)
@@ -333,6 +369,7 @@ def main():
                                f"batch={C} clip{'s' if C > 1 else ''} per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
                    "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
                    "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
+                   "host_cpu_ms_per_step": 1e3 * host_cpu / args.steps,
                    "clips_per_gpu": C,
                    "parallelism": f"clips sharded {C}-per-GPU x{world}" + (" (one engine + HIP stream per clip)" if C > 1 else "")
                    + ", all-gather of masks"},
@@ -346,6 +383,10 @@ def main():
             out["config"]["gathered_masks_sha256"] = hashlib.sha256(gathered.cpu().numpy().tobytes()).hexdigest()
     if rank == 0:
         out["roofline"] = lstt.roofline_report(MFMA_PEAK_TFLOPS)
+        if out["roofline"]:
+            out["roofline"]["how"] = ("HIP events around the layer-0 launch of every 5th REPLAYED frame of the timed region "
+                                      "(front graph | launch | tail graph), beside the prefetched encoder pass") if sampled else \
+                "HIP events inside one eagerly issued frame in fifty"
         if out["roofline"] and hasattr(lstt, "time_read_isolated"):
             # information only: the same launch with the GPU to itself (in the frame it shares the
             # CUs with the prefetched encoder pass); `achieved` / `frac` above are the in-frame figures

@@ -44,9 +44,11 @@ def shard_clips(n_clips: int, world: int, rank: int) -> List[int]:
 def gather_masks(local_masks: torch.Tensor, world: int, group=None) -> torch.Tensor:
     """all-gather uint8 masks [clips_per_rank, F, H, W] -> [world*clips_per_rank, F, H, W]
     ordered by rank.  Every rank must contribute the same shape (pad short shards)."""
-    if world == 1:
-        return local_masks
     import torch.distributed as dist
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local_masks
+    # (a one-rank group that IS initialised goes through the collective: bench.py with RMEM_FORCE_DIST=1 runs the
+    # whole RCCL path -- communicator, uint8 all-gather, device-side timing exchange -- on a single leased GPU)
     if local_masks.dtype != torch.uint8:
         raise TypeError("masks are exchanged as uint8 label maps")
     src = local_masks.contiguous()

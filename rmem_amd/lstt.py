@@ -117,6 +117,8 @@ class DeAOTLSTT:
         self.nsplit = int(nsplit)
         self._timing = False
         self._events = []
+        self._sample_read = False          # bench.py: time the next replayed frame's layer-0 read (DeAOTEngine._graphed_frame)
+        self._skip_read2 = False
         self.scale = 1.0 / math.sqrt(self.DATT)
         if weights_from is not None:
             for k in ("cur_pe", "mem_pe", "id_ksize", "id_ncls", "id_stride", "id_pad", "id_wt", "id_bias", "id_gamma",
@@ -322,6 +324,24 @@ class DeAOTLSTT:
         if on:
             self._events = []
 
+    def launch_read2_layer0(self):
+        """The fused long-term + windowed read of layer 0 for the frame _prepare() set up, launched on its own between
+        two HIP events (appended to the list roofline_report() reads).  DeAOTEngine._graphed_frame uses it on sampled
+        frames between the replayed `front` graph and the `tail` graph (= `rest` without this launch): the kernel is
+        then timed inside a REPLAYED frame, beside the prefetched encoder pass, like every other frame of the timed
+        region (torch on ROCm refuses event-record nodes inside a hipGraph: profiles/r04a_graph_event_probe.json)."""
+        T, cur = self._T, self.cur
+        self._layer = 0
+        A = self._read_args(self.ws_main, 0, T, self.bankK[0], self.bankV[0], self.maps.data_ptr(), self.Qpe,
+                            self.bias_pe, self.Ucat0, True, self.ks_long)
+        B = self._read_args(self.ws_side, 1, 1, self.bankK[0], self.bankV[0], self.maps.data_ptr() + 16 * 4,
+                            self.bankK[0][cur], None, self.Ucat0, False, self.ks_win)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        hip.check(hip.load().rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), hip.stream_ptr()), "rmem_attn_read2")
+        e1.record()
+        self._events.append((e0, e1, T))
+
     def read_flops(self, T: int) -> float:
         """Algorithmic FLOPs of one read2 launch: Q.K^T and P.V of the
         long-term read over T*N keys plus the 225-key windowed read, unpadded, one product each."""
@@ -483,7 +503,10 @@ class DeAOTLSTT:
         if self._timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
+        if self._skip_read2:               # part "tail": this launch is issued separately (launch_read2_layer0)
+            self._skip_read2 = False
+        else:
+            hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
         if self._timing:
             e1.record()
             self._events.append((e0, e1, A[0].T))
@@ -588,7 +611,10 @@ class DeAOTLSTT:
         ID values written by the previous frame's memory update and the slot maps."""
         N, Np, ns = self.N, self.Npad, self.nsplit
         lib, st = hip.load(), hip.stream_ptr()
-        do_front, do_rest = part != "rest", part != "front"
+        # "tail" = "rest" without its first launch, the fused read of layer 0 (launch_read2_layer0 issues that one
+        # between HIP events on sampled frames of bench.py)
+        do_front, do_rest = part not in ("rest", "tail"), part != "front"
+        self._skip_read2 = part == "tail"
         if part != "all" and (ref_frame or self.branch_order != "serial"):
             raise hip.RmemError("front/rest split needs a propagation frame and the paired schedule")
         cur, T = self.cur, self._T

@@ -13,6 +13,7 @@ Fixtures are data only (inputs + the reference's outputs):
   clip_480p.json/.npz        481x849 clip: per-frame label hashes + a few logits (fp16)
   multiengine_wrapper.*      AOTInferEngine.separate_mask / soft_logit_aggregation (> 10 objects)
   clip_480p_fp64.*           the same 481x849 clip through the reference in DOUBLE precision (near-tie arbitration)
+  *_amp.json/.npz            golden clips through the reference under fp16 autocast (its --amp mode), teacher-forced
 """
 from __future__ import annotations
 
@@ -472,6 +473,52 @@ def gen_clip_480p_fp64(tie_margin=1e-4, token_stride=4):
     print("480p fp64 arbitration:", info)
 
 
+def gen_amp_clips():
+    """The reference's reduced-precision mode (`--amp`: tools/eval.py:45-47,90-92 wraps the whole evaluation in
+    torch.cuda.amp.autocast) on the golden clips, TEACHER-FORCED with the labels of its fp32 run (so that every frame
+    is a statement about one forward pass, not about the closed loop's chaos).
+
+    The container has no GPU, so the run is `torch.autocast("cpu", dtype=torch.float16)`.  CPU autocast does not
+    promote softmax to fp32 as CUDA autocast does, and the reference needs that promotion: `local2global`
+    (attention.py:390-396) index-puts the softmax output into an fp32 buffer and raises on CPU otherwise.  The
+    harness therefore wraps `torch.softmax` for the duration of the run to take its input as fp32 -- CUDA autocast's
+    rule for this op; nothing else is touched.  Stored: the autocast run's label maps, its mismatch count against
+    the fp32 golden maps per frame, the decoder logits of the last frame (fp16)."""
+    cases = [("clip_small_k4_gap2", None), ("clip_480p", None)]
+    orig_softmax = torch.softmax
+    torch.softmax = lambda x, dim, **kw: orig_softmax(x.float(), dim, **kw)
+    try:
+        for name, _ in cases:
+            meta = json.load(open(os.path.join(HERE, name + ".json")))
+            gold = np.load(os.path.join(HERE, name + ".npz"))
+            H, W, frames = meta["H"], meta["W"], meta["frames"]
+            out_hw = tuple(meta.get("out_hw", (H, W)))
+            imgs, lab = synth_clip(meta["seed"], frames, H, W, 3)
+            cfg, model, engine = rh.build_reference("r50_deaotl", meta["former"], meta["latter"], meta["gap"])
+            labels, mism, idx = [], [], []
+            with torch.no_grad(), rh.quiet(), torch.autocast("cpu", dtype=torch.float16):
+                engine.restart_engine()
+                engine.add_reference_frame(imgs[0], lab.int(), obj_nums=[int(lab.max())], frame_step=0)
+                sub = engine.aot_engines[0]
+                for t in range(1, frames):
+                    logit = engine.match_propogate_one_frame(imgs[t], output_size=out_hw)
+                    pred = torch.argmax(torch.softmax(logit, dim=1), dim=1)[0].to(torch.uint8)
+                    labels.append(pred)
+                    mism.append(int((pred.numpy() != gold["labels"][t - 1]).sum()))
+                    fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None]
+                    engine.update_memory(F.interpolate(fed, size=engine.input_size_2d, mode="nearest"))
+                    idx.append(list(sub.long_memories_indexes))
+                last = sub.pred_id_logits.float().clone()
+            np.savez_compressed(os.path.join(HERE, name + "_amp.npz"), labels_amp=torch.stack(labels).numpy(),
+                                last_logits_amp=last.numpy().astype(np.float16))
+            json.dump(dict(autocast="cpu/float16 + softmax taken in fp32 (CUDA autocast's rule)", mism_amp_vs_fp32=mism,
+                           indexes=idx, indexes_equal_fp32=bool(idx == meta["indexes"])),
+                      open(os.path.join(HERE, name + "_amp.json"), "w"))
+            print(name, "autocast fp16 vs fp32 golden, mismatching pixels per frame:", mism, "indexes equal:", idx == meta["indexes"])
+    finally:
+        torch.softmax = orig_softmax
+
+
 def main():
     torch.manual_seed(0)
     if "--tta-only" in sys.argv:
@@ -485,6 +532,9 @@ def main():
         return
     if "--fp64-only" in sys.argv:
         gen_clip_480p_fp64()
+        return
+    if "--amp-only" in sys.argv:
+        gen_amp_clips()
         return
     if "--aot-only" not in sys.argv and "--swin-only" not in sys.argv:
         cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
@@ -503,6 +553,7 @@ def main():
     gen_ignore_clip()
     gen_multiengine()
     gen_clip_480p_fp64()
+    gen_amp_clips()
     os.system(f"du -sh {HERE}")
 
 

@@ -278,6 +278,59 @@ def test_bench_gpus2_spawns_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+def test_bench_world1_over_rccl():
+    """bench.py's N > 1 code path on the ONE leased GPU with the real backend: RMEM_FORCE_DIST=1 makes a one-rank
+    RCCL group, so init_process_group("nccl"), the barriers, the uint8 all_gather_into_tensor of the masks and the
+    device-side float64 timing exchange (bench.max_over_ranks) all execute; the JSON line must be the only line on
+    stdout although librccl prints to the C-level stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RMEM_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-dropin"], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["dist_backend"] == "nccl"
+    assert out["config"]["gathered_masks_shape"] == [1, 10, 480, 854] and len(out["config"]["gathered_masks_sha256"]) == 64
+    assert len(out["config"]["per_rank_frames_per_sec"]) == 1 and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_clips64_two_ranks_equal_one_rank():
+    """BASELINE.json configs[3] in miniature through bench.py itself: `--config clips64` with 2 clips per rank x 6
+    frames as two ranks on the one device (gloo) and 4 clips per rank as one rank -- the same four clips; every clip's
+    sha256 must not depend on the rank count (tools/eval.py:137-143: which worker runs a clip changes nothing)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra, env_extra):
+        env = dict(os.environ, **env_extra)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "clips64", "--clip-frames", "6"] + extra,
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        return json.loads(lines[0])
+
+    two = run(["--gpus", "2", "--clips-per-rank", "2"], dict(RMEM_DEVICE_OVERRIDE="0", RMEM_DIST_BACKEND="gloo"))
+    one = run(["--gpus", "1", "--clips-per-rank", "4"], {})
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["clips"] == 4 and one["config"]["clips"] == 4
+    assert len(two["clip_sha256"]) == 4 and two["clip_sha256"] == one["clip_sha256"], (two["clip_sha256"], one["clip_sha256"])
+    assert len(two["config"]["per_rank_seconds"]) == 2
+
+
+@pytest.mark.gpu
 def test_bench_line_contract_single_gpu():
     """The line the driver parses: `python bench.py --steps K --warmup W` prints ONE JSON object with BASELINE.json's
     metric, whole-job frames/s consistent with ms_per_step, `roofline` for the dominant kernel (achieved = algorithmic
@@ -336,7 +389,8 @@ torch.cuda.synchronize()
 assert torch.equal(out, masks)
 import bench
 from rmem_amd.driver import gather_masks
-assert gather_masks(masks, 1) is masks
+got = gather_masks(masks, 1)          # an initialised one-rank group goes through the collective
+assert got is not masks and torch.equal(got, masks)
 mx, vals = bench.max_over_ranks(dist, 1.25, dev)
 assert mx == 1.25 and vals == [1.25]
 t = torch.ones(4, device=dev, dtype=torch.float64); dist.all_reduce(t); torch.cuda.synchronize()
@@ -353,4 +407,6 @@ print(json.dumps({"ok": True, "sha": hashlib.sha256(out.cpu().numpy().tobytes())
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert json.loads(r.stdout.strip().splitlines()[-1])["ok"]
+    # (librccl prints "Librccl path : ..." to the C-level stdout when its buffer is flushed at exit, after the JSON line)
+    line = next(ln for ln in r.stdout.splitlines() if ln.startswith("{"))
+    assert json.loads(line)["ok"]

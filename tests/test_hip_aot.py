@@ -278,14 +278,15 @@ def test_swin_aot_clip_teacher_forced(golden_dir):
 def test_swin_aot_480x848_vs_oracle():
     """BASELINE.json configs[4] at its full geometry: SwinB-AOTL + RMem, 480x848 (30x53 = 1590
     tokens), K=4, gap 1 -- the HIP engine against the CPU oracle (oracle/aot_ref.py, pinned by the
-    Swin golden clip at 128x160), teacher-forced with the oracle's labels for 3 frames."""
+    Swin golden clip at 128x160), teacher-forced with the oracle's labels for 9 frames: at gap 1 the bank fills at
+    frame 4 and every later frame reads a full bank (T = 4) and evicts one slot."""
     import copy
     from oracle.engine_ref import OracleAOTEngine
     from rmem_amd.config import get_config
     from rmem_amd.engine import build_engine
     from rmem_amd.model import build_vos_model
     from rmem_amd.synth import load_synthetic_weights, synth_clip
-    H, W, frames = 480, 848, 4
+    H, W, frames = 480, 848, 10
     cfg = get_config("swinb_aotl", 1, 3)
     model = build_vos_model("aot", cfg).eval()
     load_synthetic_weights(model)
@@ -296,7 +297,7 @@ def test_swin_aot_480x848_vs_oracle():
     eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
     ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
     assert eng.aot_engines[0].lstt.N == 30 * 53
-    mism, lerr = [], []
+    mism, lerr, hist = [], [], []
     for t in range(1, frames):
         lg = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(480, 854))
         lo = ora.match_propogate_one_frame(imgs[t], output_size=(480, 854))
@@ -307,5 +308,9 @@ def test_swin_aot_480x848_vs_oracle():
         eng.update_memory(fed.to(DEV))
         ora.update_memory(fed)
         assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.long_memories_indexes)
-    print("SwinB-AOTL 480x848 mismatching pixels per frame (of 409920):", mism, "decoder-logit max abs err:", lerr)
+        hist.append(list(ora.long_memories_indexes))
+    print("SwinB-AOTL 480x848 mismatching pixels per frame (of 409920):", mism, "decoder-logit max abs err:", lerr,
+          "kept frames:", hist[-1])
+    evictions = sum(1 for a, b in zip(hist, hist[1:]) if len(b) == len(a) and a != b)
+    assert len(hist[-1]) == 4 and evictions >= 4, hist          # the full-bank read and the eviction rule ran at 30x53
     assert max(mism) <= 4 and max(lerr) < 2e-3, (mism, lerr)

@@ -114,6 +114,39 @@ def test_small_clip(name, golden_dir):
             assert mism[0] <= 1
 
 
+def test_small_clip_reduced_precision_vs_reference_autocast(golden_dir):
+    """nsplit=1 (plain fp16 operands) on the small golden clip, teacher-forced, next to the reference's own
+    reduced-precision mode: tests/golden/clip_small_k4_gap2_amp.* holds the clip through the reference under
+    fp16 autocast (tools/eval.py:45-47; make_golden.py:gen_amp_clips), 8-28 of 12.5 k pixels per frame away from
+    its fp32 maps.  Asserted: the same eviction history, and on every frame no more mismatching pixels against the
+    fp32 maps than the reference's autocast run has."""
+    from rmem_amd.synth import synth_clip
+    meta = json.load(open(os.path.join(golden_dir, "clip_small_k4_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_small_k4_gap2.npz"))
+    amp = json.load(open(os.path.join(golden_dir, "clip_small_k4_gap2_amp.json")))
+    gamp = np.load(os.path.join(golden_dir, "clip_small_k4_gap2_amp.npz"))
+    cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"], nsplit=1)
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    eng.restart_engine()
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    idx_hist, mism, vs_amp = [], [], []
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(meta["H"], meta["W"]))
+        pred = torch.argmax(logit, dim=1)[0].cpu().numpy().astype(np.uint8)
+        mism.append(int((pred != gold["labels"][t - 1]).sum()))
+        vs_amp.append(int((pred != gamp["labels_amp"][t - 1]).sum()))
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        idx_hist.append(list(eng.aot_engines[0].long_memories_indexes))
+    lerr = np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max()
+    lerr_amp = np.abs(gamp["last_logits_amp"].astype(np.float32) - gold["last_logits"]).max()
+    print("nsplit=1 vs fp32 golden:", mism, "| reference autocast vs fp32 golden:", amp["mism_amp_vs_fp32"],
+          "| nsplit=1 vs reference autocast:", vs_amp, "| last-frame logit err:", lerr, "(autocast:", lerr_amp, ")")
+    assert idx_hist == meta["indexes"] and amp["indexes_equal_fp32"]
+    assert all(m <= a for m, a in zip(mism, amp["mism_amp_vs_fp32"])), (mism, amp["mism_amp_vs_fp32"])
+    assert lerr <= lerr_amp
+
+
 def test_reference_mask_with_ignore_label(golden_dir):
     """Reference mask with 255 pixels (golden clip from the reference's own add_reference_frame,
     which passes no ignore mask: aot_engine.py:304 -> :209-213): reference-frame decoder logits,
@@ -176,7 +209,14 @@ def test_480p_teacher_forced(nsplit, golden_dir):
         # between processes (tools/determinism_probe.py), each flip of a near-tie pixel counts one
         assert max(mism) <= 4, mism           # measured 0-3 per frame of 409,920 on every box (round 2): measured max + 1
     else:
-        assert max(mism) <= 600, mism         # plain fp16 (one plane per operand): measured 69-197
+        # plain fp16 operands (one plane each, fp32 accumulate) against the REFERENCE'S reduced-precision mode: the same
+        # clip through the reference under fp16 autocast (its --amp switch, tools/eval.py:45-47), teacher-forced the same
+        # way (tests/golden/clip_480p_amp.*, make_golden.py:gen_amp_clips): 271-790 pixels per frame away from its own
+        # fp32 label maps.  nsplit=1 must be no further from the fp32 maps than that on any frame.
+        amp = json.load(open(os.path.join(golden_dir, "clip_480p_amp.json")))["mism_amp_vs_fp32"]
+        print("reference under fp16 autocast vs its fp32 maps:", amp)
+        assert all(m <= a for m, a in zip(mism, amp)), (mism, amp)
+        assert max(mism) <= 198, mism         # measured 69-197 over the boxes of rounds 2-3: measured max + 1
     assert max(lerrs.values()) < (2e-2 if nsplit == 3 else 0.2)
 
 
