@@ -14,17 +14,39 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def timeit(fn, iters):
-    """Back-to-back launches between two events: per-launch time with the queue kept full
-    (includes the ~1.5 us kernel boundary, excludes host launch latency)."""
-    for _ in range(3):
+    """`iters` back-to-back launches captured in ONE hipGraph and replayed: per-launch time with the queue kept full
+    (includes the kernel boundary, excludes the Python / ctypes cost of a launch, which is 8-30 us -- more than the
+    small kernels themselves, and what the eagerly timed numbers of rounds 1-3 mostly measured for them).
+    RMEM_KBENCH_EAGER=1 times eager launches as before."""
+    for _ in range(2):
         fn()
+    torch.cuda.synchronize()
+    if os.environ.get("RMEM_KBENCH_EAGER") == "1":
+        best = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+        return best
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
     torch.cuda.synchronize()
     best = 1e30
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        g.replay()
         e1.record()
         e1.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / iters)

@@ -32,11 +32,18 @@ def from_csv(path):
     return rows
 
 
+def trace_rows_from_db(path):
+    """Dispatch rows of a rocpd database (rocprofv3's default output of this ROCm: `kernels` view)."""
+    cur = sqlite3.connect(path).cursor()
+    return [{"Kernel_Name": r[0], "Start_Timestamp": r[1], "End_Timestamp": r[2]}
+            for r in cur.execute("select name, start, end from kernels")]
+
+
 def from_trace(path, frames):
-    """Steady-state summary from a rocprofv3 kernel_trace CSV: only the dispatches of the last
+    """Steady-state summary from a rocprofv3 kernel trace (CSV or rocpd .db): only the dispatches of the last
     `frames` frames (delimited by the once-per-frame gn2_apply_kernel) are counted, which
     excludes MIOpen find-mode / first-call kernels of the warm-up."""
-    rows = list(csv.DictReader(open(path)))
+    rows = trace_rows_from_db(path) if path.endswith(".db") else list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     marks = [i for i, r in enumerate(rows) if "gn2_apply_kernel" in r["Kernel_Name"]]
     start = marks[-frames - 1] + 1 if len(marks) > frames else 0
@@ -75,7 +82,7 @@ PV_LONG = None
 
 def main():
     path, frames = sys.argv[1], int(sys.argv[2])
-    if path.endswith("kernel_trace.csv"):
+    if path.endswith("kernel_trace.csv") or (path.endswith(".db") and "--top" not in sys.argv):
         rows = from_trace(path, frames)
     else:
         rows = from_csv(path) if path.endswith(".csv") else from_db(path)
