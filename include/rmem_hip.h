@@ -67,7 +67,9 @@ typedef struct {
   int32_t nbatch;                          /* gridDim.z; strides below in elements    */
   int64_t bsx, bsy, bsd, bsbias, bspa;
   int32_t nsplit;                          /* 1 or 3                                   */
-  int32_t tile;                            /* 0 auto, 64 (64x64), 128 (128x128), 192 (64 rows x 128 cols) */
+  int32_t tile;                            /* 0 auto / 256: the streaming kernel (one persistent workgroup per CU, 64 x 128 tiles,
+                                              operands by LDS-DMA three stages deep); 64 (64x64), 128 (128x128), 192 (64 rows x
+                                              128 cols): the tile-per-workgroup kernels.  Results are bit-identical. */
   int32_t ksplits;                         /* >1: split K; raw partial sums (+bias in split 0) go to
                                               parts[split][M][N] instead of the outputs above; the
                                               consumer sums them in split order (rmem_layernorm_red) */
@@ -87,6 +89,11 @@ int rmem_linear(const rmem_linear_args *a, void *stream);
 /* Up to 8 independent problems (same nsplit, 64x64 tiles) in ONE launch: the small projections
  * of one LSTT stage share their input and individually cannot fill 256 CUs. */
 int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
+
+/* Debug aid (tools/kbench_gemm.py): the streaming kernel for `n` problems with shader-clock stamps of every workgroup's
+ * wave 0 written to trace[workgroup][64] ([0] start, [1] first requests out, [2 + 2 s] / [3 + 2 s] stage s landed / issued,
+ * [62] stages, [63] end).  trace must hold 64 int64 per CU.  Split precision (nsplit = 3) only. */
+int rmem_linear_trace(const rmem_linear_args *args, int32_t n, int64_t *trace, void *stream);
 
 /* ------------------------------------------------------------------ fused memory read
  * The memory read of GatedPropagation.forward / LocalGatedPropagation.forward (layers/attention.py:

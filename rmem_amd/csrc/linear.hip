@@ -3,6 +3,118 @@
 #include "../../include/rmem_hip.h"
 #include "gemm_core.h"
 #include "launch.h"
+#include <stdlib.h>
+
+// Epilogue of one output tile of problem `a` (bias, activation, the fp32 / plane / blocked-16 / split-K destinations).
+// Cfg gives the wave layout: wave (wr, wc) owns TM x TN accumulator tiles of 32 x 32 at rows wr * WM + tm * 32, columns
+// wc * WN + tn * 32 of the block tile at (m0, n0).  Shared by the 4-wave kernels (GemmCfg) and the 8-wave streaming
+// kernel (StreamCfg): the same instructions per element whatever kernel computed the accumulators.
+template <class Cfg>
+__device__ __forceinline__ void linear_epilogue(const rmem_linear_args& a, f32x16_t (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
+                                                int bzz, int wr, int wc, int lane) {
+  const bool splitk = a.ksplits > 1;
+  const int bz = splitk ? 0 : bzz;
+  if (splitk) {   // raw partials [split][M][N]; the consumer (rmem_layernorm_red) sums them in order
+    float* out = a.parts + (long)bzz * a.part_stride;
+    const float* b0 = (a.bias && bzz == 0) ? a.bias : nullptr;
+#pragma unroll
+    for (int tn = 0; tn < Cfg::TN; ++tn) {
+      const int col = n0 + frag_col<Cfg>(wc, tn, lane);
+      if (col >= a.N) continue;
+      const float bc = b0 ? b0[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + frag_row<Cfg>(wr, tm, r, lane);
+          if (row < a.M) out[(long)row * a.N + col] = acc[tm][tn][r] + bc;
+        }
+    }
+    return;
+  }
+  const float* bias = a.bias ? a.bias + bz * a.bsbias : nullptr;
+  float* d0 = a.d0 ? a.d0 + bz * a.bsd : nullptr;
+  float* d1 = a.d1 ? a.d1 + bz * a.bsd : nullptr;
+  h16_t* pah = a.pah ? a.pah + bz * a.bspa : nullptr;
+  h16_t* pal = a.pal ? a.pal + bz * a.bspa : nullptr;
+  h16_t* pbh = a.pbh ? a.pbh + bz * a.bspa : nullptr;
+  h16_t* pbl = a.pbl ? a.pbl + bz * a.bspa : nullptr;
+
+#pragma unroll
+  for (int tn = 0; tn < Cfg::TN; ++tn) {
+    const int col = n0 + frag_col<Cfg>(wc, tn, lane);
+    if (col >= a.N) continue;
+    const float bcol = (bias && !a.bias_per_row) ? bias[col] : 0.f;
+    const float addv = a.addvec ? a.addvec[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < Cfg::TM; ++tm) {
+      if (a.pa_blocked) {
+        // plane output in the "blocked-16" layout of the fused memory read (read64.hip): element
+        // (row, col) at ((row / 16) * ldpa + col) * 16 + row % 16.  Accumulator registers 4g..4g+3
+        // are 4 consecutive rows of one 16-row block: one 8-byte store per plane.
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row0 = m0 + frag_row<Cfg>(wr, tm, 4 * g, lane);
+          h16_t hh[4], ll[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[tm][tn][4 * g + e] + bcol;
+            if (bias && a.bias_per_row && row0 + e < a.M) v += bias[row0 + e];
+            if (a.act == 1) v = silu_f(v);
+            split_f16(v, hh[e], ll[e]);
+          }
+          const long off = ((long)(row0 >> 4) * a.ldpa + col) * 16 + (row0 & 15);
+          if (row0 + 3 < a.M) {
+            uint2 wh, wl;
+            wh.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+            wh.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+            wl.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
+            wl.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+            *reinterpret_cast<uint2*>(pah + off) = wh;
+            if (pal) *reinterpret_cast<uint2*>(pal + off) = wl;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (row0 + e < a.M) {
+                pah[off + e] = hh[e];
+                if (pal) pal[off + e] = ll[e];
+              }
+          }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + frag_row<Cfg>(wr, tm, r, lane);
+        if (row >= a.M) continue;
+        float v = acc[tm][tn][r] + bcol;
+        if (bias && a.bias_per_row) v += bias[row];
+        if (a.act == 1) v = silu_f(v);
+        if (col < a.csplit) {
+          if (d0) {
+            float* p = d0 + (long)row * a.ldd0 + (long)col * (a.d0_cs > 0 ? a.d0_cs : 1);
+            *p = a.accumulate ? (*p + v) : v;
+          }
+        } else if (d1) {
+          float* p = d1 + (long)row * a.ldd1 + (col - a.csplit);
+          *p = a.accumulate ? (*p + v) : v;
+        }
+        if (pah) {
+          h16_t hi, lo;
+          split_f16(v, hi, lo);
+          pah[(long)row * a.ldpa + col] = hi;
+          if (pal) pal[(long)row * a.ldpa + col] = lo;
+        }
+        if (pbh) {
+          h16_t hi, lo;
+          split_f16(v + addv, hi, lo);
+          pbh[(long)row * a.ldpb + col] = hi;
+          if (pbl) pbl[(long)row * a.ldpb + col] = lo;
+        }
+      }
+    }
+  }
+}
 
 // One BM x BN output tile of problem `a`.  bz = batch index (nbatch > 1) or K-split index
 // (ksplits > 1, raw partial sums to a.parts, bias added by split 0 only).
@@ -44,107 +156,7 @@ __device__ __forceinline__ void linear_body(const rmem_linear_args& a, int mx, i
   gemm_mainloop<Cfg>(f, lx, ly, kt0, kt1, smem);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  if (splitk) {   // raw partials [split][M][N]; the consumer (rmem_layernorm_red) sums them in order
-    float* out = a.parts + (long)bzz * a.part_stride;
-    const float* b0 = (a.bias && bzz == 0) ? a.bias : nullptr;
-#pragma unroll
-    for (int tn = 0; tn < Cfg::TN; ++tn) {
-      const int col = n0 + frag_col<Cfg>(wc, tn, lane);
-      if (col >= a.N) continue;
-      const float bc = b0 ? b0[col] : 0.f;
-#pragma unroll
-      for (int tm = 0; tm < Cfg::TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + frag_row<Cfg>(wr, tm, r, lane);
-          if (row < a.M) out[(long)row * a.N + col] = f.acc[tm][tn][r] + bc;
-        }
-    }
-    return;
-  }
-  const float* bias = a.bias ? a.bias + bz * a.bsbias : nullptr;
-  float* d0 = a.d0 ? a.d0 + bz * a.bsd : nullptr;
-  float* d1 = a.d1 ? a.d1 + bz * a.bsd : nullptr;
-  h16_t* pah = a.pah ? a.pah + bz * a.bspa : nullptr;
-  h16_t* pal = a.pal ? a.pal + bz * a.bspa : nullptr;
-  h16_t* pbh = a.pbh ? a.pbh + bz * a.bspa : nullptr;
-  h16_t* pbl = a.pbl ? a.pbl + bz * a.bspa : nullptr;
-
-#pragma unroll
-  for (int tn = 0; tn < Cfg::TN; ++tn) {
-    const int col = n0 + frag_col<Cfg>(wc, tn, lane);
-    if (col >= a.N) continue;
-    const float bcol = (bias && !a.bias_per_row) ? bias[col] : 0.f;
-    const float addv = a.addvec ? a.addvec[col] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < Cfg::TM; ++tm) {
-      if (a.pa_blocked) {
-        // plane output in the "blocked-16" layout of the fused memory read (read64.hip): element
-        // (row, col) at ((row / 16) * ldpa + col) * 16 + row % 16.  Accumulator registers 4g..4g+3
-        // are 4 consecutive rows of one 16-row block: one 8-byte store per plane.
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row0 = m0 + frag_row<Cfg>(wr, tm, 4 * g, lane);
-          h16_t hh[4], ll[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = f.acc[tm][tn][4 * g + e] + bcol;
-            if (bias && a.bias_per_row && row0 + e < a.M) v += bias[row0 + e];
-            if (a.act == 1) v = silu_f(v);
-            split_f16(v, hh[e], ll[e]);
-          }
-          const long off = ((long)(row0 >> 4) * a.ldpa + col) * 16 + (row0 & 15);
-          if (row0 + 3 < a.M) {
-            uint2 wh, wl;
-            wh.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
-            wh.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
-            wl.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
-            wl.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
-            *reinterpret_cast<uint2*>(pah + off) = wh;
-            if (pal) *reinterpret_cast<uint2*>(pal + off) = wl;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (row0 + e < a.M) {
-                pah[off + e] = hh[e];
-                if (pal) pal[off + e] = ll[e];
-              }
-          }
-        }
-        continue;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + frag_row<Cfg>(wr, tm, r, lane);
-        if (row >= a.M) continue;
-        float v = f.acc[tm][tn][r] + bcol;
-        if (bias && a.bias_per_row) v += bias[row];
-        if (a.act == 1) v = silu_f(v);
-        if (col < a.csplit) {
-          if (d0) {
-            float* p = d0 + (long)row * a.ldd0 + (long)col * (a.d0_cs > 0 ? a.d0_cs : 1);
-            *p = a.accumulate ? (*p + v) : v;
-          }
-        } else if (d1) {
-          float* p = d1 + (long)row * a.ldd1 + (col - a.csplit);
-          *p = a.accumulate ? (*p + v) : v;
-        }
-        if (pah) {
-          h16_t hi, lo;
-          split_f16(v, hi, lo);
-          pah[(long)row * a.ldpa + col] = hi;
-          if (pal) pal[(long)row * a.ldpa + col] = lo;
-        }
-        if (pbh) {
-          h16_t hi, lo;
-          split_f16(v + addv, hi, lo);
-          pbh[(long)row * a.ldpb + col] = hi;
-          if (pbl) pbl[(long)row * a.ldpb + col] = lo;
-        }
-      }
-    }
-  }
+  linear_epilogue<Cfg>(a, f.acc, m0, n0, bzz, wave >> 1, wave & 1, lane);
 }
 
 template <int BM, int BN, int NS>
@@ -184,6 +196,25 @@ __device__ void linear_grouped_kernel(const GroupedLinear& g, int) { linear_grou
 template <int NS>
 __device__ void linear_grouped_many(const GroupedLinear& g, int) { linear_grouped_body<NS, true>(g); }
 
+static int validate_linear(rmem_linear_args& a);
+
+#include "linear_stream.h"
+
+// Debug aid: the streaming kernel with cycle stamps (see linear_stream_kernel); trace must hold 64 int64 per workgroup
+// (at most one per CU).  nsplit = 3 only.
+extern "C" int rmem_linear_trace(const rmem_linear_args* args, int32_t n, int64_t* trace, void* stream) {
+  if (!args || n <= 0 || n > 8 || !trace) return RMEM_ERR_INVALID;
+  rmem_linear_args v[8];
+  for (int i = 0; i < n; ++i) {
+    v[i] = args[i];
+    if (validate_linear(v[i]) != RMEM_OK || v[i].nsplit != 3) return RMEM_ERR_INVALID;
+  }
+  if (!use_stream(v, n)) return RMEM_ERR_INVALID;
+  StreamGroup g;
+  const int total = stream_group(v, n, g);
+  return launch_stream<3, 1>(g, total, reinterpret_cast<long long*>(trace), static_cast<hipStream_t>(stream));
+}
+
 template <int BM, int BN, int NS>
 static int launch_linear(const rmem_linear_args& a, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, NS>;
@@ -220,6 +251,11 @@ extern "C" int rmem_linear_grouped(const rmem_linear_args* args, int32_t n, void
   }
   g.tile_start[n] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (use_stream(g.p, n)) {
+    StreamGroup gs;
+    const int tot = stream_group(g.p, n, gs);
+    return args[0].nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
+  }
   if (args[0].nsplit == 3)
     return rmem::launch<GroupedLinear, linear_grouped_kernel<3>, 256, linear_grouped_many<3>>(
         g, dim3(total), dim3(256), GemmCfg<64, 64, 3>::LDS_BYTES, s);
@@ -232,7 +268,12 @@ extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
   rmem_linear_args a = *ap;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (validate_linear(a) != RMEM_OK) return RMEM_ERR_INVALID;
-  int tile = a.tile;
+  if (use_stream(&a, 1)) {
+    StreamGroup gs;
+    const int tot = stream_group(&a, 1, gs);
+    return a.nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
+  }
+  int tile = a.tile == 256 ? 0 : a.tile;
   if (tile == 0) {
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) *
                            (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));

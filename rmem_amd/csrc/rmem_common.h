@@ -92,7 +92,24 @@ __device__ __forceinline__ float dec_ordered(uint32_t u) {
 // -3e38 sentinels overflow to -inf and give exactly 0.
 __device__ __forceinline__ float exp_weight(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// SiLU x / (1 + e^-x) in ten instructions (the correctly rounded expf + IEEE division form is ~50, sixteen times per
+// lane in the epilogue of every V / U projection: 3 k of the 6 k cycles of such an epilogue, profiles/r04f_stream_trace.json).
+// e^-x = 2^(t + tl): t = fl(-x log2 e), tl = the rounding error of that product + the low part of log2 e, applied as the
+// factor (1 + tl ln 2) behind v_exp_f32 (1 ulp); 1 / d by v_rcp_f32 + one Newton step.  ~3 ulp (2e-7 relative) against
+// ~1.5 ulp before -- inside the 2^-21 of one split-fp16 product.  t is clamped so that d stays finite (x < -83: the true
+// value is below 1e-34 in magnitude either way).
+__device__ __forceinline__ float silu_f(float x) {
+  const float nx = -x;
+  const float tu = nx * 1.44269504088896341f;
+  const float tl = fmaf(nx, 1.92596299112661746e-8f, fmaf(nx, 1.44269504088896341f, -tu));
+  const float t = fminf(tu, 120.0f);
+  float e = __builtin_amdgcn_exp2f(t);
+  e = fmaf(e, tl * 0.693147180559945f, e);
+  const float d = 1.0f + e;
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);
+  return x * r;
+}
 
 // exact floor(k / w) for 0 <= k < 2^20, 1 <= w ((k+0.5)/w is never
 // closer than 0.5/w to an integer, far above fp32 rounding).

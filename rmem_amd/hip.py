@@ -92,7 +92,7 @@ class LabelSrc(C.Structure):
 
 
 EXPORTS = [
-    "rmem_abi_version", "rmem_linear",
+    "rmem_abi_version", "rmem_linear", "rmem_linear_trace",
     "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_fg_weights", "rmem_bank_reset", "rmem_bank_append",
     "rmem_bank_policy_step", "rmem_split_planes", "rmem_groupnorm_nchw",
@@ -113,7 +113,7 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 12          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
+ABI_VERSION = 13          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
 
 
 def load():
@@ -133,6 +133,7 @@ def load():
         getattr(lib, name).restype = C.c_int
     lib.rmem_linear.argtypes = [C.POINTER(LinearArgs), c_p]
     lib.rmem_linear_grouped.argtypes = [C.POINTER(LinearArgs), i32, c_p]
+    lib.rmem_linear_trace.argtypes = [C.POINTER(LinearArgs), i32, c_p, c_p]
     lib.rmem_layernorm_red.argtypes = [c_p, i64, c_p, i32, i64, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64,
                                        c_p, i64, c_p]
     lib.rmem_bias_act_nchw.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p]

@@ -117,6 +117,7 @@ class DeAOTLSTT:
         self.nsplit = int(nsplit)
         self._timing = False
         self._events = []
+        self._force_tiles = os.environ.get("RMEM_LINEAR", "") == "tiles"
         self._sample_read = False          # bench.py: time the next replayed frame's layer-0 read (DeAOTEngine._graphed_frame)
         self._skip_read2 = False
         self.scale = 1.0 / math.sqrt(self.DATT)
@@ -432,6 +433,13 @@ class DeAOTLSTT:
         m[16] = self.short if self.short is not None else 0
         self.maps.copy_(m, non_blocking=False)
 
+    def _tile(self, tiles: int) -> int:
+        """rmem_linear_args.tile of a projection: 0 = the streaming kernel (csrc/linear.hip: one persistent workgroup per
+        CU, operands by LDS-DMA) for launches issued directly; recorded launches (several clips per launch,
+        rmem_amd.batched) keep the tile-per-workgroup kernel `tiles`.  Bit-identical either way
+        (tests/test_hip_ops.py::test_linear_stream_equals_tile_kernels); RMEM_LINEAR=tiles forces the tile kernels."""
+        return tiles if (self._batched or self._force_tiles) else 0
+
     def _free_slot(self) -> int:
         used = set(self.bank)
         if self.short is not None:
@@ -524,11 +532,11 @@ class DeAOTLSTT:
         dst = self.bankV[l][slot]
         if l == 0:
             return hip.linear(self.idemb_pl, W.Widv, N, 512, 256, ldx=256, ldy=256, bias=W.bidv, act=1,
-                              pa=dst, ldpa=1024, pa_blocked=True, pa_off=512 * 16, nsplit=self.nsplit, tile=64,
+                              pa=dst, ldpa=1024, pa_blocked=True, pa_off=512 * 16, nsplit=self.nsplit, tile=self._tile(64),
                               launch=launch)
         return hip.linear(self.z_pl[l], W.Widv, N, 512, 512, ldx=256, ldy=512, x2=self.idemb_pl, ldx2=256,
                           kx_split=256, bias=W.bidv, act=1, pa=dst, ldpa=1024, pa_blocked=True, pa_off=512 * 16,
-                          nsplit=self.nsplit, tile=64, launch=launch)
+                          nsplit=self.nsplit, tile=self._tile(64), launch=launch)
 
     # ------------------------------------------------------------------ ID assignment
     def assign_identity(self, label_u8: torch.Tensor, ignore: bool = True):
@@ -654,21 +662,21 @@ class DeAOTLSTT:
             pe = W.pe_x[T]
             grp = [
                 hip.linear(self.x_pl, W.Wq, N, 128, 256, ldx=256, ldy=256, bias=W.bq, pa=curK, ldpa=128,
-                           pb=self.Qpe, ldpb=128, addvec=self.cur_pe, nsplit=ns, tile=64, launch=False),
+                           pb=self.Qpe, ldpb=128, addvec=self.cur_pe, nsplit=ns, tile=self._tile(64), launch=False),
                 # relative-position bias of the windowed read, anti-diagonal layout (rmem_read_args.rcs)
                 hip.linear(self.x_pl, W.Wrel_x, N, self.WIN, 256, ldx=256, ldy=256, bias=W.brel_x,
-                           d0=self.R.data_ptr(), ldd0=self.ldr, d0_cs=self.rcs, nsplit=ns, tile=64, launch=False),
+                           d0=self.R.data_ptr(), ldd0=self.ldr, d0_cs=self.rcs, nsplit=ns, tile=self._tile(64), launch=False),
                 # temporal-PE bias of the long-term read: bias_pe[q][t] = (Q[q] + cur_pe) . mem_pe[row(t, T)]
                 hip.linear(self.x_pl, pe[0], N, T, 256, ldx=256, ldy=256, bias=pe[1],
-                           d0=self.bias_pe.data_ptr(), ldd0=T, nsplit=ns, tile=64, launch=False),
+                           d0=self.bias_pe.data_ptr(), ldd0=T, nsplit=ns, tile=self._tile(64), launch=False),
                 # V = silu(linear_V(x)) -> columns 0..511 of the current slot's blocked-16 V planes
                 hip.linear(self.x_pl, W.Wv, N, 512, 256, ldx=256, ldy=256, bias=W.bv, act=1,
-                           pa=curV, ldpa=1024, pa_blocked=True, nsplit=ns, tile=64, launch=False),
+                           pa=curV, ldpa=1024, pa_blocked=True, nsplit=ns, tile=self._tile(64), launch=False),
                 hip.linear(self.x_pl, W.Wu, N, 512, 256, ldx=256, ldy=256, bias=W.bu, act=1,
-                           d0=Ucat.data_ptr(), ldd0=1024, nsplit=ns, tile=64, launch=False)]
+                           d0=Ucat.data_ptr(), ldd0=1024, nsplit=ns, tile=self._tile(64), launch=False)]
             if l > 0:
                 grp.append(hip.linear(self.z_pl[l], W.Widu, N, 512, 256, ldx=256, ldy=256, bias=W.bidu, act=1,
-                                      d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns, tile=64,
+                                      d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns, tile=self._tile(64),
                                       launch=False))
             hip.linear_grouped(grp)
             if ref_frame:
@@ -697,27 +705,27 @@ class DeAOTLSTT:
         # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
         #    adds happen in the norms that follow (rmem_layernorm_red)
         hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
-                   kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=192, ksplits=self.KS, parts=self.parts,
+                   kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=self._tile(192), ksplits=self.KS, parts=self.parts,
                    part_stride=N * 512)       # 64 x 128 tiles: 27.5 -> 21.2 us (L2 -> LDS traffic -25 %)
         # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
         self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
         sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
         hip.linear_grouped([
             hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
-                       nsplit=ns, tile=64, launch=False),
+                       nsplit=ns, tile=self._tile(64), launch=False),
             # V = silu([V1(s[:256]) | V2(s[256:])]) -> blocked-16 planes (two diagonal blocks)
             hip.linear(self.s_pl, W.Wv12, N, 512, 256, ldx=512, ldy=256, bias=W.bv12, act=1,
                        pa=self.selfV, ldpa=1024, pa_blocked=True, nbatch=2, bsx=256, bsy=512 * 256, bsbias=512,
-                       bspa=512 * 16, nsplit=ns, tile=64, launch=False),
+                       bspa=512 * 16, nsplit=ns, tile=self._tile(64), launch=False),
             hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
                        d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
-                       bsbias=512, bsd=512, nsplit=ns, tile=64, launch=False)])
+                       bsbias=512, bsd=512, nsplit=ns, tile=self._tile(64), launch=False)])
         self._read(self._read_args(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
                                    False, self.ks_self))
         self._dwconv(self.ws_main, W.dw_self, self.Ylt)
         if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
-                       tile=192, ksplits=self.KS, parts=self.parts, part_stride=N * 512)
+                       tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
         else:                  # last layer: the GroupNorm reads tgt / tgt_id directly
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
                        d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,

@@ -39,7 +39,7 @@ def _tol(nsplit):
 
 
 @pytest.mark.parametrize("nsplit", [3, 1])
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [0, 64, 128])
 @pytest.mark.parametrize("M,N,K", [(200, 130, 256), (64, 64, 64), (333, 225, 128)])
 def test_linear_basic(hip, nsplit, tile, M, N, K):
     rs = np.random.RandomState(M + N + K)
@@ -532,6 +532,70 @@ def test_linear_blocked_output(hip):
                      _silu(S[:, 256:].double() @ W2[512:].double().t() + b2[512:].double())], 1)
     got = dst.float().cpu().permute(0, 2, 1).reshape(Np, 1024)
     assert (got[:ntok].double() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+def test_linear_stream_equals_tile_kernels(hip, nsplit):
+    """The streaming kernel (tile 0: one persistent workgroup per CU, 64 x 128 tiles, LDS-DMA ring) against the
+    tile-per-workgroup kernels (tile 64) on the launch shapes of the memory path -- bias / SiLU, two K segments,
+    nbatch, split-K partials, blocked-16 planes, plane + addvec outputs, the anti-diagonal column stride, accumulate
+    with two destinations, ragged M / N, one grouped launch of six problems: every output bit for bit (each element
+    sees the same MFMAs in the same order), and nothing written outside the outputs."""
+    rs = np.random.RandomState(17)
+    P = lambda x: _planes(hip, x)
+
+    def run(tile):
+        out = {}
+        # (a) grouped launch in the shape of a layer's front projections: shared X, ragged N, four epilogues
+        M, K = 333, 256
+        X, X2 = P(_rand(rs0, M, K)), P(_rand(rs0, M, K))
+        Wq, Wr, Wpe, Wv, Wu = (P(_rand(rs0, n, K, scale=0.1)) for n in (128, 225, 5, 512, 512))
+        bq, br, bpe, bv, bu, addv = (_rand(rs0, n).to(DEV) for n in (128, 225, 5, 512, 512, 128))
+        Mp = (M + 15) // 16 * 16
+        pa, pb = hip.Planes.empty((M, 128), DEV), hip.Planes.empty((M, 128), DEV)
+        R = torch.full((M * 225 + 225 * 226 + 7,), 3.0, device=DEV)
+        pe = torch.full((M, 5), 3.0, device=DEV)
+        vb = hip.Planes.empty((Mp // 16, 1024, 16), DEV)
+        U = torch.full((M, 1024), 3.0, device=DEV)
+        hip.linear_grouped([
+            hip.linear(X, Wq, M, 128, K, ldx=K, ldy=K, bias=bq, pa=pa, ldpa=128, pb=pb, ldpb=128, addvec=addv,
+                       nsplit=nsplit, tile=tile, launch=False),
+            hip.linear(X, Wr, M, 225, K, ldx=K, ldy=K, bias=br, d0=R.data_ptr(), ldd0=225, d0_cs=226, nsplit=nsplit,
+                       tile=tile, launch=False),
+            hip.linear(X, Wpe, M, 5, K, ldx=K, ldy=K, bias=bpe, d0=pe.data_ptr(), ldd0=5, nsplit=nsplit, tile=tile,
+                       launch=False),
+            hip.linear(X, Wv, M, 512, K, ldx=K, ldy=K, bias=bv, act=1, pa=vb, ldpa=1024, pa_blocked=True, nsplit=nsplit,
+                       tile=tile, launch=False),
+            hip.linear(X, Wu, M, 512, K, ldx=K, ldy=K, bias=bu, act=1, d0=U.data_ptr(), ldd0=1024, nsplit=nsplit,
+                       tile=tile, launch=False),
+            hip.linear(X2, Wu, M, 512, K, ldx=K, ldy=K, bias=bv, act=1, d0=U.data_ptr() + 512 * 4, ldd0=1024,
+                       nsplit=nsplit, tile=tile, launch=False)])
+        out.update(pa_hi=pa.hi, pa_lo=pa.lo, pb_hi=pb.hi, pb_lo=pb.lo, R=R, pe=pe, vb_hi=vb.hi, vb_lo=vb.lo, U=U)
+        # (b) split-K over two K segments -> partials; (c) nbatch = 2 block-diagonal; (d) accumulate into two destinations
+        M2, K2 = 150, 1024
+        Ya, Yb, Wp = P(_rand(rs0, M2, 512)), P(_rand(rs0, M2, 512)), P(_rand(rs0, 200, K2, scale=0.1))
+        bp = _rand(rs0, 200).to(DEV)
+        parts = torch.full((4, M2, 200), 3.0, device=DEV)
+        hip.linear(Ya, Wp, M2, 200, K2, ldx=512, ldy=K2, x2=Yb, ldx2=512, kx_split=512, bias=bp, nsplit=nsplit, tile=tile,
+                   ksplits=4, parts=parts, part_stride=M2 * 200)
+        S_, W12, b12 = P(_rand(rs0, M2, 512)), P(_rand(rs0, 2 * 192, 256, scale=0.1)), _rand(rs0, 2 * 192).to(DEV)
+        D12 = torch.full((M2, 2 * 192), 3.0, device=DEV)
+        hip.linear(S_, W12, M2, 192, 256, ldx=512, ldy=256, bias=b12, act=1, d0=D12.data_ptr(), ldd0=2 * 192, nbatch=2,
+                   bsx=256, bsy=192 * 256, bsbias=192, bsd=192, nsplit=nsplit, tile=tile)
+        t0, t1 = _rand(rs0, M2, 96).to(DEV), _rand(rs0, M2, 104).to(DEV)
+        hip.linear(Ya, Wp, M2, 200, 512, ldx=512, ldy=K2, bias=bp, d0=t0.data_ptr(), ldd0=96, d1=t1.data_ptr(), ldd1=104,
+                   csplit=96, accumulate=True, nsplit=nsplit, tile=tile)
+        out.update(parts=parts, D12=D12, t0=t0, t1=t1)
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in out.items()}
+
+    rs0 = np.random.RandomState(17)
+    a = run(64)
+    rs0 = np.random.RandomState(17)
+    b = run(0)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.all(a["R"][-7:] == 3.0) and torch.all(b["R"][-7:] == 3.0)
 
 
 def test_fg_weights_vs_torch(hip):
