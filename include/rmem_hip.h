@@ -220,6 +220,13 @@ int rmem_layernorm_red(float *x, int64_t ldx, const float *parts, int32_t nparts
                        float eps, rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, float *of32, int64_t ldof,
                        void *stream);
 
+/* LayerNorm of the first layer straight from the encoder feature map (replaces bchw_2_lbc + norm1 of layer 0,
+ * utils/tensor.py:3-6 + layers/transformer.py:1104): src_cn is channel-major [C = 256][ld_src >= N] fp32; writes the
+ * token-major residual stream x [N][256], zeroes `zero` [N][256] when given (the ID stream starts a frame at 0,
+ * transformer.py:779) and the normalised planes oh / ol [N][ldo].  Per row the arithmetic of rmem_layernorm_red. */
+int rmem_layernorm_cn(const float *src_cn, int64_t ld_src, float *x, float *zero, const float *gamma, const float *beta,
+                      int32_t N, int32_t C, float eps, rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, void *stream);
+
 /* Two such problems of the same shape in one launch: norm1 / id_norm1 and norm2 / id_norm2 of a
  * GPM layer (layers/transformer.py:1104, 1120, 1223-1224), each with its own residual stream,
  * partials, affine parameters and output planes. */

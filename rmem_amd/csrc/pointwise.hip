@@ -67,6 +67,39 @@ extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, i
   return RMEM_OK;
 }
 
+// LayerNorm of one row of 256 held as a float4 per lane -> planes (and optionally fp32): ONE definition for every kernel
+// that normalises a row, so that they agree bit for bit (same expression tree, same contraction).
+__device__ __forceinline__ void ln_row256(const float4 v, const float* gamma, const float* beta, float eps, int lane, long row,
+                                          h16_t* oh, h16_t* ol, long ldo, float* of32, long ldof) {
+  float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / 256.0f);
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  // (every multiply-add spelled as fmaf: left to the compiler the contraction depends on whether the SLP vectoriser got
+  // to the products first -- the single-row kernel came out with separately rounded squares, the paired one with fma chains)
+  float ss = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(fmaf(ss, 1.0f / 256.0f, eps));
+  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  const float4 b = *reinterpret_cast<const float4*>(beta + lane * 4);
+  const float y[4] = {fmaf(d0 * rstd, g.x, b.x), fmaf(d1 * rstd, g.y, b.y), fmaf(d2 * rstd, g.z, b.z), fmaf(d3 * rstd, g.w, b.w)};
+  if (of32) *reinterpret_cast<float4*>(of32 + row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
+  if (oh) {
+    h16_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_f16(y[e], hi[e], lo[e]);
+    uint2 vh, vl;
+    vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+    vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+    vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+    *reinterpret_cast<uint2*>(oh + row * ldo + lane * 4) = vh;
+    if (ol) *reinterpret_cast<uint2*>(ol + row * ldo + lane * 4) = vl;
+  }
+}
+
 // residual reduce (split-K partials, fixed order) + LayerNorm
 __device__ __forceinline__ void layernorm_red_body(float* x, long ldx, const float* parts, int nparts,
                                                    long part_stride, long ldpart, const float* gamma,
@@ -81,31 +114,7 @@ __device__ __forceinline__ void layernorm_red_body(float* x, long ldx, const flo
     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
   }
   if (nparts > 0) *reinterpret_cast<float4*>(x + (long)row * ldx + lane * 4) = v;
-  float s = v.x + v.y + v.z + v.w;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.0f / 256.0f);
-  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-  float ss = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
-  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
-  const float4 b = *reinterpret_cast<const float4*>(beta + lane * 4);
-  const float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
-  if (of32) *reinterpret_cast<float4*>(of32 + (long)row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
-  if (oh) {
-    h16_t hi[4], lo[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split_f16(y[e], hi[e], lo[e]);
-    uint2 vh, vl;
-    vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
-    vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
-    vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
-    vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
-    *reinterpret_cast<uint2*>(oh + (long)row * ldo + lane * 4) = vh;
-    if (ol) *reinterpret_cast<uint2*>(ol + (long)row * ldo + lane * 4) = vl;
-  }
+  ln_row256(v, gamma, beta, eps, lane, row, oh, ol, ldo, of32, ldof);
 }
 
 struct LnRedArgs {
@@ -128,6 +137,47 @@ extern "C" int rmem_layernorm_red(float* x, int64_t ldx, const float* parts, int
               (long)ldof};
   return rmem::launch<LnRedArgs, layernorm_red_kernel, 256>(a, dim3((N + 3) / 4), dim3(256), 0,
                                                              static_cast<hipStream_t>(stream));
+}
+
+// LayerNorm of the FIRST layer straight from the encoder's feature map: src is channel-major [256][N] (NCHW, batch 1);
+// one launch transposes 16 tokens through LDS, writes the token-major residual stream x [N][256], zeroes the second
+// stream (tgt_id starts every frame at 0) and emits the normalised planes -- instead of a transposing copy kernel, a
+// fill kernel and the LayerNorm launch (the arithmetic per row is layernorm_red_body's: same values, same order).
+struct LnCnArgs {
+  const float* src; long lds_; float* x; float* zero; const float* gamma; const float* beta; int N; float eps;
+  h16_t* oh; h16_t* ol; long ldo;
+};
+__device__ void layernorm_cn_kernel(const LnCnArgs& a, int) {
+  __shared__ float tile[16][256 + 4];
+  const int t0 = blockIdx.x * 16, tid = threadIdx.x;
+  {                                            // thread = channel: 16 consecutive tokens of its row (64 B), clamped
+    const float* row = a.src + (long)tid * a.lds_;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = t0 + i < a.N ? t0 + i : a.N - 1;
+      tile[i][tid] = row[t];
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {                // (rolled: the rows' arithmetic must not be merged into vector operations)
+    const int tl = w * 4 + j, row = t0 + tl;
+    if (row >= a.N) continue;
+    const float4 v = *reinterpret_cast<const float4*>(&tile[tl][lane * 4]);
+    *reinterpret_cast<float4*>(a.x + (long)row * 256 + lane * 4) = v;
+    if (a.zero) *reinterpret_cast<float4*>(a.zero + (long)row * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    ln_row256(v, a.gamma, a.beta, a.eps, lane, row, a.oh, a.ol, a.ldo, nullptr, 0);
+  }
+}
+
+extern "C" int rmem_layernorm_cn(const float* src_cn, int64_t ld_src, float* x, float* zero, const float* gamma,
+                                 const float* beta, int32_t N, int32_t C, float eps, rmem_f16* oh, rmem_f16* ol,
+                                 int64_t ldo, void* stream) {
+  if (!src_cn || !x || !gamma || !beta || !oh || N <= 0 || C != 256 || ld_src < N || (ldo % 4)) return RMEM_ERR_INVALID;
+  LnCnArgs a{src_cn, (long)ld_src, x, zero, gamma, beta, N, eps, oh, ol, (long)ldo};
+  return rmem::launch<LnCnArgs, layernorm_cn_kernel, 256>(a, dim3((N + 15) / 16), dim3(256), 0,
+                                                           static_cast<hipStream_t>(stream));
 }
 
 // two independent rows-of-256 problems of the same shape in one launch (blockIdx.y selects):
@@ -168,28 +218,7 @@ __device__ void layernorm_red2_kernel(const LnRed2Args& a, int) {
       if (z0 + i < nparts) { v.x += w[i].x; v.y += w[i].y; v.z += w[i].z; v.w += w[i].w; }
   }
   if (nparts > 0) *reinterpret_cast<float4*>(p.x + (long)row * ldx + lane * 4) = v;
-  float s = v.x + v.y + v.z + v.w;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.0f / 256.0f);
-  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-  float ss = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
-  const float4 g = *reinterpret_cast<const float4*>(p.gamma + lane * 4);
-  const float4 b = *reinterpret_cast<const float4*>(p.beta + lane * 4);
-  const float y[4] = {d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
-  h16_t hi[4], lo[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) split_f16(y[e], hi[e], lo[e]);
-  uint2 vh, vl;
-  vh.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
-  vh.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
-  vl.x = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
-  vl.y = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
-  *reinterpret_cast<uint2*>(p.oh + (long)row * p.ldo + lane * 4) = vh;
-  if (p.ol) *reinterpret_cast<uint2*>(p.ol + (long)row * p.ldo + lane * 4) = vl;
+  ln_row256(v, p.gamma, p.beta, eps, lane, row, p.oh, p.ol, p.ldo, nullptr, 0);
 }
 
 extern "C" int rmem_layernorm_red2(float* x0, float* x1, int64_t ldx, const float* parts0, const float* parts1,
@@ -232,9 +261,9 @@ template <> struct DwVec<1> { typedef float T; };
 
 template <int RX, int V>
 __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const float* wt, int h, int w, int C,
-                                               h16_t* oh, h16_t* ol, long ldo, int bz) {
+                                               h16_t* oh, h16_t* ol, long ldo, int bx, int y, int bz) {
   typedef typename DwVec<V>::T VT;
-  const int x0 = blockIdx.x * RX, y = blockIdx.y;
+  const int x0 = bx * RX;
   const int c = (bz * 256 + threadIdx.x) * V;
   if (c >= C) return;
   // every load of the thread is issued before the first use (clamped addresses; out-of-image taps are
@@ -295,15 +324,29 @@ __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const f
 
 // one map (p[0], nmaps = 1) or two maps of the same geometry (the gated long-term and short-term
 // aggregates of a layer) in one launch: z = map * nz + channel block
+// Block order.  The work items are (z = map x 256-channel block, row y, run of RX tokens); a thread's 5 x (RX + 4) input
+// window overlaps its neighbours' (each input is read 7.2 times), and those re-reads only hit in L2 when the neighbours
+// run on the SAME XCD -- the eight L2s are separate, and workgroup b goes to XCD b % 8.  In (x, y, z) grid order
+// neighbouring runs land on different XCDs and every XCD pulls nearly the whole input from the memory side (8 x 13.7 MB
+// for a layer's two maps).  Here XCD k = b % 8 takes the k-th eighth of the items in z-major order: with two maps x four
+// channel blocks exactly one z slice each, with one map half the rows of a slice.
 struct DwArgs {
   DwOne p[2];
   long ldg; int h, w, C; long ldo; int nz;
+  int gx, cap, total, xcd;     // runs per row; items per XCD; items; 0 = plain grid order (RMEM_DW_ORDER=grid, the A/B switch)
 };
 template <int RX, int V>
-__device__ void dwconv5x5_split_kernel(const DwArgs& a, int bz) {
+__device__ void dwconv5x5_split_kernel(const DwArgs& a, int) {
+  const int b = blockIdx.x;
+  const int wid = a.xcd ? (b & 7) * a.cap + (b >> 3) : b;
+  if (wid >= a.total) return;
+  const int per_z = a.gx * a.h;
+  const int bz = wid / per_z;
+  const int r = wid - bz * per_z;
+  const int y = r / a.gx, bx = r - y * a.gx;
   const int which = bz < a.nz ? 0 : 1;
   const DwOne& p = a.p[which];
-  dwconv5x5_body<RX, V>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, which ? bz - a.nz : bz);
+  dwconv5x5_body<RX, V>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, bx, y, which ? bz - a.nz : bz);
 }
 
 // (RX, V) chosen by measurement; RMEM_DW="rx,v" overrides (tuning aid)
@@ -313,7 +356,12 @@ static int launch_dwconv(DwArgs& a, int nmaps, hipStream_t s) {
   if (env) sscanf(env, "%d,%d", &rx, &v);
   if (a.C % (256 * v)) rx = 6, v = 4;
   a.nz = (a.C + 256 * v - 1) / (256 * v);
-  const dim3 grid((a.w + rx - 1) / rx, a.h, nmaps * a.nz);
+  a.gx = (a.w + rx - 1) / rx;
+  a.total = a.gx * a.h * nmaps * a.nz;
+  a.cap = (a.total + 7) / 8;
+  static const char* ord = getenv("RMEM_DW_ORDER");
+  a.xcd = (ord && ord[0] == 'g') ? 0 : 1;
+  const dim3 grid(8 * a.cap);
 #define RMEM_DW_CASE(RX_, V_) \
   if (rx == RX_ && v == V_) return rmem::launch<DwArgs, dwconv5x5_split_kernel<RX_, V_>, 256>(a, grid, dim3(256), 0, s);
   RMEM_DW_CASE(9, 1) RMEM_DW_CASE(6, 4) RMEM_DW_CASE(6, 1) RMEM_DW_CASE(8, 1) RMEM_DW_CASE(12, 1) RMEM_DW_CASE(6, 2)
@@ -326,14 +374,14 @@ extern "C" int rmem_dwconv5x5_split2(const float* g0, const float* g1, int64_t l
                                      rmem_f16* ol1, int64_t ldo, void* stream) {
   if (!g0 || !g1 || !wt0 || !wt1 || !oh0 || !oh1 || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4))
     return RMEM_ERR_INVALID;
-  DwArgs a{{{g0, wt0, oh0, ol0}, {g1, wt1, oh1, ol1}}, (long)ldg, h, w, C, (long)ldo, 0};
+  DwArgs a{{{g0, wt0, oh0, ol0}, {g1, wt1, oh1, ol1}}, (long)ldg, h, w, C, (long)ldo, 0, 0, 0, 0, 1};
   return launch_dwconv(a, 2, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt, int32_t h, int32_t w,
                                     int32_t C, rmem_f16* oh, rmem_f16* ol, int64_t ldo, void* stream) {
   if (!g || !wt || !oh || h <= 0 || w <= 0 || (C % 4) || (ldg % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
-  DwArgs a{{{g, wt, oh, ol}, {g, wt, oh, ol}}, (long)ldg, h, w, C, (long)ldo, 0};
+  DwArgs a{{{g, wt, oh, ol}, {g, wt, oh, ol}}, (long)ldg, h, w, C, (long)ldo, 0, 0, 0, 0, 1};
   return launch_dwconv(a, 1, static_cast<hipStream_t>(stream));
 }
 

@@ -455,15 +455,23 @@ class DeAOTEngine(nn.Module):
                 for k, v in var.items():
                     setattr(l, k, v)
                 g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                fused_in = isinstance(l, DeAOTLSTT) and os.environ.get("RMEM_LN_CN", "1") == "1"          # norm1 of layer 0 reads the feature map itself (rmem_layernorm_cn)
+                src_cn = enc[-1][0].flatten(1) if fused_in else None
                 with torch.cuda.graph(g):
-                    l.tgt.copy_(enc[-1][0].flatten(1).t())
-                    l._forward_device(False)
+                    if not fused_in:
+                        l.tgt.copy_(enc[-1][0].flatten(1).t())
+                        l._forward_device(False)
+                    else:
+                        l._forward_device(False, src_cn=src_cn)
                 gf = gr = None
                 if self.hoist_enabled and getattr(l, "branch_order", "") == "serial":
                     gf, gr = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gf):
-                        l.tgt.copy_(enc[-1][0].flatten(1).t())
-                        l._forward_device(False, "front")
+                        if not fused_in:
+                            l.tgt.copy_(enc[-1][0].flatten(1).t())
+                            l._forward_device(False, "front")
+                        else:
+                            l._forward_device(False, "front", src_cn=src_cn)
                     with torch.cuda.graph(gr):
                         l._forward_device(False, "rest")
                 # the decoder (+ upsample) graph reads the LSTT's static output buffer and this feature

@@ -99,7 +99,7 @@ EXPORTS = [
     "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_transpose_planes", "rmem_add_split",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
-    "rmem_upsample_add_nchw_out", "rmem_layernorm_red2",
+    "rmem_upsample_add_nchw_out", "rmem_layernorm_red2", "rmem_layernorm_cn",
     "rmem_bias_act_nchw_batched", "rmem_dwconv5x5_split2",
     "rmem_attn_read", "rmem_attn_read_trace", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
     "rmem_rec_end", "rmem_launch_recorded",
@@ -140,6 +140,7 @@ def load():
     lib.rmem_bias_act_nchw_batched.argtypes = [c_p, c_p, c_p, i32, i32, i64, i32, c_p]
     lib.rmem_layernorm_red2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i64, i64, c_p, c_p, c_p, c_p, i32, i32, f32,
                                         c_p, c_p, i64, c_p, c_p, i64, c_p]
+    lib.rmem_layernorm_cn.argtypes = [c_p, i64, c_p, c_p, c_p, c_p, i32, i32, f32, c_p, c_p, i64, c_p]
     lib.rmem_set_ints.argtypes = [c_p, C.POINTER(i32), i32, c_p]
     lib.rmem_dwconv5x5_split2.argtypes = [c_p, c_p, i64, c_p, c_p, i32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p]
     lib.rmem_attn_read.argtypes = [C.POINTER(ReadArgs), c_p]

@@ -607,7 +607,7 @@ class DeAOTLSTT:
         all of them are captured together the first time one is needed."""
         return [{"cur": c} for c in range(self.S)]
 
-    def _forward_device(self, ref_frame: bool = False, part: str = "all"):
+    def _forward_device(self, ref_frame: bool = False, part: str = "all", src_cn: Optional[torch.Tensor] = None):
         """Device part of a forward pass (reads self.tgt, writes self.out): kernel launches and
         device-side memsets only -- hipGraph-capturable; depends on the host only through
         graph_key() = (T, cur).
@@ -629,7 +629,11 @@ class DeAOTLSTT:
         map_bank = self.maps.data_ptr()
         map_short = self.maps.data_ptr() + 16 * 4
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
-        if do_front and not self._batched:     # batched: the shared buffer is cleared once for all clips
+        # src_cn: the encoder's last feature map [256][h*w] (channel-major, contiguous): layer 0's norm1 then reads it
+        # directly (rmem_layernorm_cn: transpose + residual stream + zeroed ID stream + planes in ONE launch) instead of
+        # the caller's transposing copy into self.tgt, the fill of self.tgt_id and the LayerNorm launch
+        self._src_cn = src_cn if (src_cn is not None and do_front and not self._batched) else None
+        if do_front and not self._batched and self._src_cn is None:     # batched: the shared buffer is cleared once for all clips
             self.tgt_id.zero_()
 
         for l in range(self.L):
@@ -657,6 +661,12 @@ class DeAOTLSTT:
             #    split-K partials of the previous layer's self-attention projection
             if l > 0:
                 self._ln2(W.ln1, self.x_pl, 256, 0, W.lnid1, self.z_pl[l], 256, 0, parts=True)
+            elif getattr(self, "_src_cn", None) is not None:
+                src = self._src_cn
+                hip.check(lib.rmem_layernorm_cn(src.data_ptr(), src.stride(0), self.tgt.data_ptr(), self.tgt_id.data_ptr(),
+                                                W.ln1[0].data_ptr(), W.ln1[1].data_ptr(), N, 256, 1e-5,
+                                                self.x_pl.hi.data_ptr(), self.x_pl.lo.data_ptr(), 256, hip.stream_ptr()),
+                          "rmem_layernorm_cn")
             else:
                 self._ln(self.tgt, W.ln1, self.x_pl, 256, parts_col=None)
             pe = W.pe_x[T]

@@ -598,6 +598,31 @@ def test_linear_stream_equals_tile_kernels(hip, nsplit):
     assert torch.all(a["R"][-7:] == 3.0) and torch.all(b["R"][-7:] == 3.0)
 
 
+@pytest.mark.parametrize("N", [35, 1674])
+def test_layernorm_from_channel_major_features(hip, N):
+    """rmem_layernorm_cn (norm1 of layer 0 straight from the encoder's [256][N] feature map: transpose + residual stream
+    + zeroed ID stream + planes in one launch) against the transposing copy + rmem_layernorm_red it replaces: every
+    output bit for bit."""
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(N)
+    src = (_rand(rs, 256, N, scale=2.0) + 0.3).to(DEV).contiguous()
+    gm, bt = (_rand(rs, 256) * 0.2 + 1).to(DEV), (_rand(rs, 256) * 0.1).to(DEV)
+    x_ref = src.t().contiguous()
+    pl_ref = hip.Planes.empty((N, 256), DEV)
+    hip.check(lib.rmem_layernorm_red(x_ref.data_ptr(), 256, None, 0, 0, 0, gm.data_ptr(), bt.data_ptr(), N, 256, 1e-5,
+                                     pl_ref.hi.data_ptr(), pl_ref.lo.data_ptr(), 256, None, 0, st), "ln_red")
+    x = torch.full((N + 1, 256), 7.0, device=DEV)
+    z = torch.full((N + 1, 256), 7.0, device=DEV)
+    pl = hip.Planes.empty((N + 1, 256), DEV)
+    hip.check(lib.rmem_layernorm_cn(src.data_ptr(), N, x.data_ptr(), z.data_ptr(), gm.data_ptr(), bt.data_ptr(), N, 256,
+                                    1e-5, pl.hi.data_ptr(), pl.lo.data_ptr(), 256, st), "ln_cn")
+    torch.cuda.synchronize()
+    assert torch.equal(x[:N], x_ref) and torch.all(x[N] == 7.0)
+    assert torch.all(z[:N] == 0) and torch.all(z[N] == 7.0)
+    assert torch.equal(pl.hi[:N], pl_ref.hi) and torch.equal(pl.lo[:N], pl_ref.lo)
+    assert torch.all(pl.hi[N] == 0) and torch.all(pl.lo[N] == 0)
+
+
 def test_fg_weights_vs_torch(hip):
     """rmem_fg_weights = 1 - softmax(bilinear align_corners resize of the decoder logits to the token grid)[0]
     (engines/aot_engine.py:350-356) against the torch ops of the reference, on the CPU and on the GPU."""
