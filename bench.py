@@ -84,7 +84,7 @@ def parse():
 
 
 # HBM traffic of the dominant kernel: from separate rocprofv3 --pmc passes of the same bench command
-# (tools/jobs/gpujob_profile_r03.sh: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, mean per
+# (research/jobs/gpujob_profile_r03.sh: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, mean per
 # launch), committed under profiles/.  (model, config, clips) -> (file, kernel-name prefix in that file)
 PMC_FILES = {("r50_deaotl", "480p_k4", "one"): ("r03f_pmc_x3.json", "read64x2_kernel"),
              ("r50_deaotl", "720p_k8", "one"): ("r03g_pmc_720p_k8.json", "read64x2_pull_kernel"),

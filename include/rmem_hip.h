@@ -68,7 +68,7 @@ typedef struct {
   int64_t bsx, bsy, bsd, bsbias, bspa;
   int32_t nsplit;                          /* 1 or 3                                   */
   int32_t tile;                            /* 0 auto / 256: the streaming kernel (one persistent workgroup per CU, 64 x 128 tiles,
-                                              operands by LDS-DMA three stages deep); 64 (64x64), 128 (128x128), 192 (64 rows x
+                                              operands by LDS-DMA three stages deep); 64 (64x64; 128 is accepted as 64), 192 (64 rows x
                                               128 cols): the tile-per-workgroup kernels.  Results are bit-identical. */
   int32_t ksplits;                         /* >1: split K; raw partial sums (+bias in split 0) go to
                                               parts[split][M][N] instead of the outputs above; the

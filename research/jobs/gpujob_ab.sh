@@ -1,4 +1,4 @@
-# generic A/B: bash tools/jobs/gpujob_ab.sh "<ENV=.. ENV=..>" "<ENV=..>" ...   (each variant benched twice, interleaved)
+# generic A/B: bash research/jobs/gpujob_ab.sh "<ENV=.. ENV=..>" "<ENV=..>" ...   (each variant benched twice, interleaved)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for rep in 1 2; do
 for v in "$@"; do

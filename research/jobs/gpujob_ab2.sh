@@ -1,4 +1,4 @@
-# A/B with bench flags: bash tools/jobs/gpujob_ab2.sh "<ENV=.. -- flags>" ...
+# A/B with bench flags: bash research/jobs/gpujob_ab2.sh "<ENV=.. -- flags>" ...
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for rep in 1 2; do
 for v in "$@"; do

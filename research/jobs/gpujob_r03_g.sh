@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 TAG=r03g
 O=gpurun_out/$TAG; mkdir -p $O
-source <(sed -n '/^SETS=/,/^}/p' tools/jobs/gpujob_profile_r03.sh)
+source <(sed -n '/^SETS=/,/^}/p' research/jobs/gpujob_profile_r03.sh)
 pmc 720p_k8 python bench.py --config 720p_k8 --gap 2 --steps 6 --warmup 2 --no-cpu-baseline --no-dropin
 pmc batched8 python bench.py --batched --clips-per-gpu 8 --steps 4 --warmup 1 --no-cpu-baseline
 timeout 600 python bench.py --config 720p_k8 --gap 2 --no-cpu-baseline --no-dropin > $O/${TAG}_bench_720p_k8.json 2> $O/bench_720.err

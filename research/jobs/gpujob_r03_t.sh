@@ -1,10 +1,10 @@
 #!/bin/bash
-# final round-3 evidence run: whole GPU suite, then the profile set (tools/jobs/gpujob_profile_r03.sh), kernel micro-benches
+# final round-3 evidence run: whole GPU suite, then the profile set (research/jobs/gpujob_profile_r03.sh), kernel micro-benches
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 O=gpurun_out/r03f; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
-bash tools/jobs/gpujob_profile_r03.sh r03f > $O/profile_job.log 2>&1
+bash research/jobs/gpujob_profile_r03.sh r03f > $O/profile_job.log 2>&1
 timeout 300 python tools/kbench.py > $O/r03f_kbench.json 2> $O/kbench.err
 timeout 300 python tools/kbench_read.py > $O/r03f_kbench_read.json 2> $O/kbench_read.err
 timeout 600 python bench.py --batched --clips-per-gpu 2 --no-cpu-baseline > $O/r03f_bench_batched2.json 2> $O/bench_b2.err

@@ -7,6 +7,6 @@ timeout 300 python tools/kbench_mha.py > $O/r03u_kbench_mha.json 2> $O/kbench_mh
 timeout 600 python bench.py --model r50_aotl --no-cpu-baseline --no-dropin > $O/r03u_bench_aot.json 2> $O/bench_aot.err
 timeout 600 python bench.py --batched --clips-per-gpu 4 --no-cpu-baseline > $O/r03u_bench_batched4.json 2> $O/bench_b4.err
 RMEM_DIST_BACKEND=gloo RMEM_DEVICE_OVERRIDE=0 timeout 600 python bench.py --gpus 2 --steps 10 --no-cpu-baseline --no-dropin > $O/r03u_bench_gpus2_one_device.json 2> $O/bench_g2.err
-source <(sed -n '/^SETS=/,/^}/p' tools/jobs/gpujob_profile_r03.sh)
+source <(sed -n '/^SETS=/,/^}/p' research/jobs/gpujob_profile_r03.sh)
 TAG=r03u
 pmc aot python bench.py --model r50_aotl --steps 6 --warmup 2 --no-cpu-baseline --no-dropin

@@ -1,7 +1,7 @@
 // pv_trace.hip -- standalone micro-benchmark of the long-term P.V kernel (480p K=4 problem) with
 // per-k-step shader-clock stamps of wave 0 of a few blocks.  Shows where a k-step's cycles go
 // (barrier waits, global-load landing, LDS staging, fragment reads + MFMA).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/pv_trace.hip -o tools/ubench/pv_trace
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 research/ubench/pv_trace.hip -o research/ubench/pv_trace
 #include "../../rmem_amd/csrc/attn.hip"
 #include <cstdio>
 #include <cstdlib>

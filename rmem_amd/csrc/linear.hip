@@ -273,13 +273,9 @@ extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
     const int tot = stream_group(&a, 1, gs);
     return a.nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
   }
-  int tile = a.tile == 256 ? 0 : a.tile;
-  if (tile == 0) {
-    const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) *
-                           (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
-    tile = blocks128 >= 256 ? 128 : 64;
-  }
-  if (tile == 128) return a.nsplit == 3 ? launch_linear<128, 128, 3>(a, s) : launch_linear<128, 128, 1>(a, s);
+  // tile-per-workgroup kernels: 64 x 64 unless 64 rows x 128 columns is asked for (the 128 x 128 instantiation -- 248
+  // registers + 64 accumulator registers, 336 B of scratch, one wave per SIMD, never selected by the memory path -- is gone)
+  const int tile = (a.tile == 0 || a.tile == 256 || a.tile == 128) ? 64 : a.tile;
   if (tile == 64) return a.nsplit == 3 ? launch_linear<64, 64, 3>(a, s) : launch_linear<64, 64, 1>(a, s);
   if (tile == 192) return a.nsplit == 3 ? launch_linear<64, 128, 3>(a, s) : launch_linear<64, 128, 1>(a, s);   // 64 rows x 128 columns
   return RMEM_ERR_INVALID;

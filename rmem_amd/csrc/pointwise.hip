@@ -391,22 +391,37 @@ struct Gn2Args {
   const float* tgt; const float* tgt_id; int N, C; const float* gamma; const float* beta; float eps; double* ws;
   int nblk; float* out; long ldo;
 };
+// (Both passes are 27 workgroups at 480p -- a latency-bound launch each.  1024 threads per 64 tokens with every load of a
+// thread issued before its first use, and the per-block partial sums reduced by a wave instead of one thread walking them:
+// 12.5 + 12.3 us -> see DESIGN.md section 8.)
 __device__ void gn2_stats_kernel(const Gn2Args& a, int) {
-  const float* tgt = a.tgt; const float* tgt_id = a.tgt_id; const int N = a.N, C = a.C; double* ws = a.ws;
-  __shared__ double red[2][2][4];
+  const float* __restrict__ tgt = a.tgt; const float* __restrict__ tgt_id = a.tgt_id; const int N = a.N, C = a.C; double* ws = a.ws;
+  __shared__ double red[2][2][16];
   const int t0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = C / 4, n = 64 * per;         // float4 per token / per block (C = 256: 4096 = 4 per thread)
   double s[2] = {0, 0}, q[2] = {0, 0};
-  for (int i = tid; i < 64 * (C / 4); i += 256) {
-    const int tok = t0 + i / (C / 4);
-    const int c = (i % (C / 4)) * 4;
-    if (tok >= N) continue;
-    const float4 a = *reinterpret_cast<const float4*>(tgt + (long)tok * C + c);
-    const float4 b = *reinterpret_cast<const float4*>(tgt_id + (long)tok * C + c);
-    s[0] += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
-    q[0] += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
-    s[1] += (double)b.x + (double)b.y + (double)b.z + (double)b.w;
-    q[1] += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
+  for (int i0 = tid; i0 < n; i0 += 4096) {
+    float4 va[4], vb[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * 1024;
+      const int tok = t0 + i / per, c = (i % per) * 4;
+      ok[k] = i < n && tok < N;
+      const long off = ok[k] ? (long)tok * C + c : 0;
+      va[k] = *reinterpret_cast<const float4*>(tgt + off);
+      vb[k] = *reinterpret_cast<const float4*>(tgt_id + off);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!ok[k]) continue;
+      const float4 x = va[k], y = vb[k];
+      s[0] += (double)x.x + (double)x.y + (double)x.z + (double)x.w;
+      q[0] += (double)x.x * x.x + (double)x.y * x.y + (double)x.z * x.z + (double)x.w * x.w;
+      s[1] += (double)y.x + (double)y.y + (double)y.z + (double)y.w;
+      q[1] += (double)y.x * y.x + (double)y.y * y.y + (double)y.z * y.z + (double)y.w * y.w;
+    }
   }
 #pragma unroll
   for (int gidx = 0; gidx < 2; ++gidx) {
@@ -423,48 +438,70 @@ __device__ void gn2_stats_kernel(const Gn2Args& a, int) {
   __syncthreads();
   if (tid < 4) {
     const int gidx = tid >> 1, k = tid & 1;
-    ws[(long)blockIdx.x * 4 + tid] = red[gidx][k][0] + red[gidx][k][1] + red[gidx][k][2] + red[gidx][k][3];
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[gidx][k][w];
+    ws[(long)blockIdx.x * 4 + tid] = t;
   }
 }
 
 __device__ void gn2_apply_kernel(const Gn2Args& a, int) {
-  const float* tgt = a.tgt; const float* tgt_id = a.tgt_id; const int N = a.N, C = a.C; const double* ws = a.ws;
-  const float* gamma = a.gamma; const float* beta = a.beta; const float eps = a.eps; const int nblk = a.nblk;
-  float* out = a.out; const long ldo = a.ldo;
+  const float* __restrict__ tgt = a.tgt; const float* __restrict__ tgt_id = a.tgt_id; const int N = a.N, C = a.C;
+  const double* __restrict__ ws = a.ws;
+  const float* __restrict__ gamma = a.gamma; const float* __restrict__ beta = a.beta; const float eps = a.eps; const int nblk = a.nblk;
+  float* __restrict__ out = a.out; const long ldo = a.ldo;
   __shared__ float stat[4];  // mean0, rstd0, mean1, rstd1
   const int tid = threadIdx.x;
-  if (tid < 2) {
-    double s = 0, q = 0;
-    for (int b = 0; b < nblk; ++b) {
-      s += ws[(long)b * 4 + tid * 2 + 0];
-      q += ws[(long)b * 4 + tid * 2 + 1];
+  if (tid < 64) {                              // the per-block partial sums, a strided share per lane, then a butterfly
+    double p[4] = {0, 0, 0, 0};
+    for (int b = tid; b < nblk; b += 64) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] += ws[(long)b * 4 + j];
     }
-    const double cnt = (double)N * C;
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
-    if (var < 0) var = 0;
-    stat[tid * 2 + 0] = (float)mean;
-    stat[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) p[j] += __shfl_xor(p[j], o);
+    if (tid < 2) {
+      const double cnt = (double)N * C;
+      const double mean = p[tid * 2] / cnt;
+      double var = p[tid * 2 + 1] / cnt - mean * mean;
+      if (var < 0) var = 0;
+      stat[tid * 2 + 0] = (float)mean;
+      stat[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
   __syncthreads();
   const int t0 = blockIdx.x * 64;
-  for (int i = tid; i < 64 * (C / 4); i += 256) {
-    const int tok = t0 + i / (C / 4);
-    const int c = (i % (C / 4)) * 4;
-    if (tok >= N) continue;
+  const int per = C / 4, n = 64 * per;
+  for (int i0 = tid; i0 < n; i0 += 4096) {
 #pragma unroll
     for (int gidx = 0; gidx < 2; ++gidx) {
-      const float* src = gidx ? tgt_id : tgt;
-      const float4 v = *reinterpret_cast<const float4*>(src + (long)tok * C + c);
-      const float4 g = *reinterpret_cast<const float4*>(gamma + gidx * C + c);
-      const float4 b = *reinterpret_cast<const float4*>(beta + gidx * C + c);
+      const float* __restrict__ src = gidx ? tgt_id : tgt;
       const float m = stat[gidx * 2], r = stat[gidx * 2 + 1];
-      float4 o;
-      o.x = (v.x - m) * r * g.x + b.x;
-      o.y = (v.y - m) * r * g.y + b.y;
-      o.z = (v.z - m) * r * g.z + b.z;
-      o.w = (v.w - m) * r * g.w + b.w;
-      *reinterpret_cast<float4*>(out + (long)tok * ldo + gidx * C + c) = o;
+      float4 v[4], g[4], b[4];
+      bool ok[4];
+      long offo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 1024;
+        const int tok = t0 + i / per, c = (i % per) * 4;
+        ok[k] = i < n && tok < N;
+        v[k] = *reinterpret_cast<const float4*>(src + (ok[k] ? (long)tok * C + c : 0));
+        g[k] = *reinterpret_cast<const float4*>(gamma + gidx * C + c);
+        b[k] = *reinterpret_cast<const float4*>(beta + gidx * C + c);
+        offo[k] = (long)tok * ldo + gidx * C + c;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        float4 o;
+        o.x = (v[k].x - m) * r * g[k].x + b[k].x;
+        o.y = (v[k].y - m) * r * g[k].y + b[k].y;
+        o.z = (v[k].z - m) * r * g[k].z + b[k].z;
+        o.w = (v[k].w - m) * r * g[k].w + b[k].w;
+        *reinterpret_cast<float4*>(out + offo[k]) = o;
+      }
     }
   }
 }
@@ -475,9 +512,9 @@ extern "C" int rmem_groupnorm2(const float* tgt, const float* tgt_id, int32_t N,
   const int nblk = (N + 63) / 64;
   hipStream_t s = static_cast<hipStream_t>(stream);
   Gn2Args a{tgt, tgt_id, N, C, gamma, beta, eps, ws, nblk, out, (long)ldo};
-  const int rc = rmem::launch<Gn2Args, gn2_stats_kernel, 256>(a, dim3(nblk), dim3(256), 0, s);
+  const int rc = rmem::launch<Gn2Args, gn2_stats_kernel, 1024>(a, dim3(nblk), dim3(1024), 0, s);
   if (rc != RMEM_OK) return rc;
-  return rmem::launch<Gn2Args, gn2_apply_kernel, 256>(a, dim3(nblk), dim3(256), 0, s);
+  return rmem::launch<Gn2Args, gn2_apply_kernel, 1024>(a, dim3(nblk), dim3(1024), 0, s);
 }
 
 // ------------------------------------------------------------------ ID assignment

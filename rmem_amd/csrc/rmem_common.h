@@ -2,7 +2,7 @@
 //
 // Numeric convention ("split-fp16"): an fp32 value x is carried as two fp16 planes
 // hi = fp16(x), lo = fp16(x - hi): 22 significant bits (fp16 subnormals are kept by the
-// conversions and by the MFMA, tools/ubench/f16_denorm.hip).  A product of two such values
+// conversions and by the MFMA, research/ubench/f16_denorm.hip).  A product of two such values
 // evaluated on the 16-bit MFMA pipe as  hi*lo' + lo*hi' + hi*hi'  (NSPLIT = 3) has a relative
 // error of ~2^-21 per product, i.e. fp32-class, at 3 MFMA issues; NSPLIT = 1 uses hi*hi' only
 // (plain fp16).  All accumulation is fp32 in the MFMA accumulators.  (bf16 hi/lo planes carry 16

@@ -39,7 +39,7 @@ def _tol(nsplit):
 
 
 @pytest.mark.parametrize("nsplit", [3, 1])
-@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("tile", [0, 64, 192])
 @pytest.mark.parametrize("M,N,K", [(200, 130, 256), (64, 64, 64), (333, 225, 128)])
 def test_linear_basic(hip, nsplit, tile, M, N, K):
     rs = np.random.RandomState(M + N + K)

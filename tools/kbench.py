@@ -137,7 +137,7 @@ def main():
     res["gemm_proj_self(512x1024)"] = timeit(lambda: hip.linear(
         L.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, d0=L.tgt.data_ptr(), ldd0=256,
         d1=L.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns), args.iters)
-    for tile, ks in ((64, 4), (192, 4), (192, 2), (192, 8), (128, 4)):
+    for tile, ks in ((0, 4), (64, 4), (192, 4), (0, 2), (0, 8)):
         parts = torch.zeros(ks, N, 512, device=dev)
         res[f"proj_ls_splitk(tile{tile},ks{ks})"] = timeit(lambda: hip.linear(
             L.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=L.Yst, ldx2=1024, kx_split=1024, bias=W.bp_ls,
