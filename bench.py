@@ -86,10 +86,10 @@ def parse():
 # HBM traffic of the dominant kernel: from separate rocprofv3 --pmc passes of the same bench command
 # (research/jobs/gpujob_profile_r03.sh: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, mean per
 # launch), committed under profiles/.  (model, config, clips) -> (file, kernel-name prefix in that file)
-PMC_FILES = {("r50_deaotl", "480p_k4", "one"): ("r03f_pmc_x3.json", "read64x2_kernel"),
-             ("r50_deaotl", "720p_k8", "one"): ("r03g_pmc_720p_k8.json", "read64x2_pull_kernel"),
-             ("r50_deaotl", "480p_k4", "batched8"): ("r03g_pmc_batched8.json", "read64x2_many_pull_kernel"),
-             ("r50_aotl", "480p_k4", "one"): ("r03f_pmc_aot.json", "mha_flash_kernel")}
+PMC_FILES = {("r50_deaotl", "480p_k4", "one"): ("r04m_pmc_x3.json", "read64x2_kernel"),
+             ("r50_deaotl", "720p_k8", "one"): ("r04m_pmc_720p_k8.json", "read64x2_pull_kernel"),
+             ("r50_deaotl", "480p_k4", "batched8"): ("r04m_pmc_batched8.json", "read64x2_many_pull_kernel"),
+             ("r50_aotl", "480p_k4", "one"): ("r04m_pmc_aot.json", "mha_flash_kernel")}
 
 
 def pmc_traffic(roofline: dict, key) -> None:

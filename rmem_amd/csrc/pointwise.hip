@@ -1289,4 +1289,4 @@ extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 13; }   // 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_abi_version(void) { return 14; }   // 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

@@ -66,8 +66,9 @@ constexpr float RD_BUMP = 12.0f;            // log2 domain: weights up to 2^12 =
 
 // VAR (experiments, tracing kernel only): 4 = no s_setprio at all; 8 = never wait for V fragments (timing only:
 // results are wrong).
+// zwin: the key splits this launch class serves -- z0 = zwin & 0xffff first split, nz = zwin >> 16 how many (0 = all of them)
 template <int TRACE, int VAR, int MODE>
-__device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int blk, char* smem, long long* trace_base) {
+__device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int blk, char* smem, long long* trace_base, const int zwin) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,13 +80,14 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
   // observed placement, used for speed only) owns a contiguous chunk, so the units of one XCD share a
   // key split, i.e. the same K / V bytes in that XCD's L2.
   const int nq = (a.N + 63) / 64;
-  const int nunits = nq * a.ksplits;
+  const int z0 = zwin & 0xffff, nz = (zwin >> 16) ? (zwin >> 16) : a.ksplits;
+  const int nunits = nq * nz;
   const int chunk = (nunits + 7) / 8;
   const int jj = blk >> 3;
   const int u = (blk & 7) * chunk + jj;
   if (jj >= chunk || u >= nunits) return;
   const int qtile = u % nq;
-  const int z = u / nq;
+  const int z = z0 + u / nq;
 
   const int tv = (a.N + 63) / 64;            // 64-key tiles of a slot that hold valid keys
   int k_lo, k_hi;
@@ -101,9 +103,25 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
     k_lo = (y_lo * a.w) / 64;
     k_hi = ((y_hi + 1) * a.w + 63) / 64;
   }
-  const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
-  const int lo = k_lo + z * per;
-  const int hi_t = lo + per < k_hi ? lo + per : k_hi;
+  // Even split, or (mode 0, a.nfull > 0) UNEVEN: the first nfull splits hold a.pf key tiles each, the remaining ones share
+  // the rest evenly.  The short pieces are launched LAST (rmem_attn_read2) and run behind the windowed units of the same
+  // launch on the CUs those leave early: 27 x (7 x 14 + 2 x 5) tiles instead of 27 x (6 x 16 + 12) at 480p K=4.
+  int lo, hi_t;
+  if (MODE == 0 && a.nfull > 0) {
+    if (z < a.nfull) {
+      lo = k_lo + z * a.pf;
+      hi_t = lo + a.pf < k_hi ? lo + a.pf : k_hi;
+    } else {
+      const int base = k_lo + a.nfull * a.pf, nr = a.ksplits - a.nfull;
+      const int pr = (k_hi - base + nr - 1) / nr;
+      lo = base + (z - a.nfull) * pr;
+      hi_t = lo + pr < k_hi ? lo + pr : k_hi;
+    }
+  } else {
+    const int per = (k_hi - k_lo + a.ksplits - 1) / a.ksplits;
+    lo = k_lo + z * per;
+    hi_t = lo + per < k_hi ? lo + per : k_hi;
+  }
   const int n = hi_t - lo;
 
   const int q = qtile * 64 + qg * 16 + jq;            // this lane's query in the score phase
@@ -767,9 +785,10 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
 // coordinates, bias row pointer, the gathered biases) would otherwise hold registers of the bank read, which has none
 // to spare, and the bank read's (bias row, slot bookkeeping) registers of the windowed one
 template <int TRACE, int VAR = 0>
-__device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr) {
-  if (a.mode == 0) read64_mode<TRACE, VAR, 0>(a, blk, smem, trace_base);
-  else read64_mode<TRACE, VAR, 1>(a, blk, smem, trace_base);
+__device__ __forceinline__ void read64_body(const rmem_read_args& a, const int blk, char* smem, long long* trace_base = nullptr,
+                                            const int zwin = 0) {
+  if (a.mode == 0) read64_mode<TRACE, VAR, 0>(a, blk, smem, trace_base, zwin);
+  else read64_mode<TRACE, VAR, 1>(a, blk, smem, trace_base, 0);
 }
 
 __global__ __launch_bounds__(512) void read64_kernel(rmem_read_args a) {
@@ -785,16 +804,38 @@ __global__ __launch_bounds__(512) void read64_trace_kernel(rmem_read_args a, lon
 
 // The bank read (p[0], mode 0) and the windowed read (p[1], mode 1) of one layer in ONE launch.  Per
 // XCD (block % 8) the first cha blocks serve p[0]'s units, the next chb blocks p[1]'s.
+// With uneven long-term splits (p[0].nfull > 0) a third class follows: the SHORT long-term pieces (chs chunks), so that
+// the dispatch / queue order is long pieces, windowed units, short pieces -- longest first.
 struct Read2Args {
   rmem_read_args p[2];
-  int cha, chb;
+  int cha, chb, chs;
 };
+
+// block index of the paired launch (x = index inside the launch, already XCD-major: xcd = x & 7) -> (argument block, unit
+// index inside its class, split window)
+__device__ __forceinline__ void read2_class(const Read2Args& g, int x, int& which, int& blk, int& zwin) {
+  const int xcd = x & 7, jj = x >> 3;
+  const int nfull = g.p[0].nfull;
+  if (jj < g.cha) {
+    which = 0;
+    blk = jj * 8 + xcd;
+    zwin = nfull > 0 ? (nfull << 16) : 0;
+  } else if (jj < g.cha + g.chb) {
+    which = 1;
+    blk = (jj - g.cha) * 8 + xcd;
+    zwin = 0;
+  } else {
+    which = 0;
+    blk = (jj - g.cha - g.chb) * 8 + xcd;
+    zwin = ((g.p[0].ksplits - nfull) << 16) | nfull;
+  }
+}
 
 __global__ __launch_bounds__(512) void read64x2_kernel(Read2Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int which = jj < g.cha ? 0 : 1;
-  read64_body<0>(g.p[which], (which ? jj - g.cha : jj) * 8 + xcd, smem);
+  int which, blk, zwin;
+  read2_class(g, blockIdx.x, which, blk, zwin);
+  read64_body<0>(g.p[which], blk, smem, nullptr, zwin);
 }
 
 // the same two kernels for several clips in one launch (launch.h): block z = clip, whose argument
@@ -860,11 +901,11 @@ __device__ __forceinline__ void sched_done(int* sched) {
 
 __global__ __launch_bounds__(512) void read64x2_pull_kernel(Read2Args g, int* sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int total = 8 * (g.cha + g.chb);
+  const int total = 8 * (g.cha + g.chb + g.chs);
   for (int b = blockIdx.x; b < total; b = next_unit(sched, gridDim.x, smem)) {
-    const int xcd = b & 7, jj = b >> 3;
-    const int which = jj < g.cha ? 0 : 1;
-    read64_body<0>(g.p[which], (which ? jj - g.cha : jj) * 8 + xcd, smem);
+    int which, blk, zwin;
+    read2_class(g, b, which, blk, zwin);
+    read64_body<0>(g.p[which], blk, smem, nullptr, zwin);
   }
   sched_done(sched);
 }
@@ -936,6 +977,11 @@ static int read_args_ok(const rmem_read_args& a) {
   if (a.ncols != 1024) return 0;                      // eight waves x 128 columns of [V | ID_V]
   if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1 || a.w < 1 || a.ldr < 1)) return 0;
   if (a.mode != 0 && a.mode != 1) return 0;
+  if (a.nfull < 0 || a.pf < 0) return 0;
+  if (a.nfull > 0) {        // uneven splits: mode 0 only, at least one short split, the full pieces must leave keys for the rest
+    const int tiles = a.T * ((a.N + 63) / 64);
+    if (a.mode != 0 || a.nfull >= a.ksplits || a.pf <= 0 || a.nfull * a.pf >= tiles) return 0;
+  }
   return 1;
 }
 
@@ -945,7 +991,11 @@ static int read_chunk(const rmem_read_args& a) {
 
 extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* bp, void* stream) {
   if (!ap || !bp || !read_args_ok(*ap) || !read_args_ok(*bp) || ap->mode != 0 || bp->mode != 1) return RMEM_ERR_INVALID;
-  const int cha = read_chunk(*ap), chb = read_chunk(*bp);
+  const int nq = (ap->N + 63) / 64;
+  const bool uneven = ap->nfull > 0;
+  if (uneven && rmem::current_recorder()) return RMEM_ERR_INVALID;      // (several clips per launch: even splits only)
+  const int cha = uneven ? (nq * ap->nfull + 7) / 8 : read_chunk(*ap), chb = read_chunk(*bp);
+  const int chs = uneven ? (nq * (ap->ksplits - ap->nfull) + 7) / 8 : 0;
   // per launch: the attribute belongs to the (device, function) pair; no process-wide "already set" flag
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
   Read2Args g;
@@ -953,19 +1003,20 @@ extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* b
   g.p[1] = *bp;
   g.cha = cha;
   g.chb = chb;
+  g.chs = chs;
   if (rmem::Recorder* r = rmem::current_recorder()) {
     rmem::rec_push(r, &read2_many, dim3(8 * (cha + chb)), dim3(512), R6_LDS, &g, (unsigned)sizeof(g));
     r->ops.back().aux = ap->sched;
     return RMEM_OK;
   }
   const int ncu = device_cus();
-  if (ap->sched && 8 * (cha + chb) > ncu) {
+  if (ap->sched && 8 * (cha + chb + chs) > ncu) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_pull_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
     hipLaunchKernelGGL(read64x2_pull_kernel, dim3(ncu), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g, ap->sched);
     RMEM_CHECK_LAUNCH();
     return RMEM_OK;
   }
-  hipLaunchKernelGGL(read64x2_kernel, dim3(8 * (cha + chb)), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g);
+  hipLaunchKernelGGL(read64x2_kernel, dim3(8 * (cha + chb + chs)), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }

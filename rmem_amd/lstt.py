@@ -256,6 +256,71 @@ class DeAOTLSTT:
             kw = 2
         return kl, kw
 
+    @staticmethod
+    def window_unit_tiles(N: int, h: int, w: int, kw: int):
+        """Key tiles of every windowed unit (query tile x split), computed as read64.hip does (15 x 15 window)."""
+        out = []
+        for qt in range((N + 63) // 64):
+            q_lo, q_hi = qt * 64, min(qt * 64 + 63, N - 1)
+            y_lo, y_hi = max(q_lo // w - 7, 0), min(q_hi // w + 7, h - 1)
+            k_lo, k_hi = (y_lo * w) // 64, ((y_hi + 1) * w + 63) // 64
+            per = -(-(k_hi - k_lo) // kw)
+            for z in range(kw):
+                out.append(max(0, min(k_lo + z * per + per, k_hi) - (k_lo + z * per)))
+        return out
+
+    @staticmethod
+    def choose_uneven(N: int, h: int, w: int, T: int, kl: int, kw: int, cus: int = 256):
+        """Uneven long-term splits for the paired read of a bank of T slots (rmem_read_args.nfull / pf), or None when the
+        even pair (kl, kw) is as good.  With an even split the launch lasts as long as its longest unit while the
+        windowed units (4-8 key tiles against 16) leave their CUs early and a few CUs get no unit at all (480p K=4: 189 +
+        54 units on 256 CUs, 15 % of the CU-time idle).  Here the first `nfull` splits of a query tile hold `pf` key tiles
+        each and `ns` short splits share the rest; rmem_attn_read2 queues long pieces, windowed units, short pieces in
+        that order (longest first), so the short pieces land on the CUs the windowed units free.  Cost model in k cycles,
+        from the per-unit stamps of profiles/r03f_kbench_read.json: 9.0 per long-term tile + 13.3 per unit, 13.3 per
+        windowed tile + 9.3 per unit (the windowed units' tile counts are exact: window_unit_tiles), + 3 per extra partial
+        for the combine's traffic; the candidate must beat the even pair by 4 %."""
+        import heapq
+        nq = tv = (N + 63) // 64
+        long_tiles = T * tv
+        LONG, FIXL, WIN, FIXW, PART = 9.0, 13.3, 13.3, 9.3, 3.0
+        win_units = sorted((t * WIN + FIXW for t in DeAOTLSTT.window_unit_tiles(N, h, w, kw) if t > 0), reverse=True)
+
+        def span(units):                                   # list scheduling in queue order
+            if len(units) <= cus:
+                return max(units)
+            free = [0.0] * cus
+            heapq.heapify(free)
+            m = 0.0
+            for c in units:
+                t0 = heapq.heappop(free)
+                heapq.heappush(free, t0 + c)
+                m = max(m, t0 + c)
+            return m
+
+        per = -(-long_tiles // kl)
+        even = span([min(per, long_tiles - z * per) * LONG + FIXL for z in range(kl) for _ in range(nq)] + win_units)
+        best = None
+        for nfull in range(1, 17):
+            for pf in range(2, long_tiles):
+                rest = long_tiles - nfull * pf
+                if rest <= 0:
+                    break
+                for ns in range(1, 5):
+                    if nfull + ns > 16 or nq * (nfull + ns + kw) > 3 * cus:
+                        continue
+                    ps = -(-rest // ns)
+                    if ps >= pf or (ns - 1) * ps >= rest:      # short pieces are the short ones; none of them empty
+                        continue
+                    short = [min(ps, rest - z * ps) * LONG + FIXL for z in range(ns) for _ in range(nq)]
+                    units = [pf * LONG + FIXL] * (nq * nfull) + win_units + short
+                    cost = span(units) + PART * (nfull + ns - kl)
+                    if best is None or cost < best[0]:
+                        best = (cost, nfull + ns, nfull, pf)
+        if best is None or best[0] > 0.96 * even:
+            return None
+        return best[1], best[2], best[3]
+
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
         N, Np, dev = self.N, self.Npad, self.dev
@@ -287,10 +352,19 @@ class DeAOTLSTT:
         # self read (T = 1, 27 tiles at 480p): 9 splits are faster isolated (33.8 + 13.1 us read + combine against
         # 38.2 + 10.1 with 6) but not in the frame (more partials beside the encoder stream)
         self.ks_self = max(1, min(budget // nq, tv, 6))
-        if os.environ.get("RMEM_KS"):                             # tuning override: "long,win,self"
-            self.ks_long, self.ks_win, self.ks_self = (int(x) for x in os.environ["RMEM_KS"].split(","))
-        self.ksplits_max = max(self.ks_long, self.ks_win, self.ks_self)
-        self.ws_main = _AttnWS(self.Tmax, N, Np, max(self.ks_long, self.ks_self), dev)
+        # uneven long-term splits of the paired read, per bank depth T (one clip per launch; RMEM_UNEVEN=0: even splits)
+        self.uneven: Dict[int, tuple] = {}
+        if self.clips_per_launch == 1 and os.environ.get("RMEM_UNEVEN", "1") == "1":
+            for T in range(1, self.Tmax + 1):
+                u = self.choose_uneven(N, self.h, self.w, T, min(self.ks_long, T * tv), self.ks_win, cus)
+                if u is not None:
+                    self.uneven[T] = u
+        if os.environ.get("RMEM_KS"):                             # tuning override: "long,win,self[,nfull,pf]" (uneven: every T)
+            v = [int(x) for x in os.environ["RMEM_KS"].split(",")]
+            self.ks_long, self.ks_win, self.ks_self = v[:3]
+            self.uneven = {T: (v[0], v[3], v[4]) for T in range(1, self.Tmax + 1) if v[3] * v[4] < T * tv} if len(v) >= 5 else {}
+        self.ksplits_max = max([self.ks_long, self.ks_win, self.ks_self] + [u[0] for u in self.uneven.values()])
+        self.ws_main = _AttnWS(self.Tmax, N, Np, max([self.ks_long, self.ks_self] + [u[0] for u in self.uneven.values()]), dev)
         self.ws_side = _AttnWS(1, N, Np, self.ks_win, dev)
         self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "serial")   # serial (paired launches) | serial_unpaired
         self.Ylt = Planes.empty((Np, 1024), dev)
@@ -334,7 +408,7 @@ class DeAOTLSTT:
         T, cur = self._T, self.cur
         self._layer = 0
         A = self._read_args(self.ws_main, 0, T, self.bankK[0], self.bankV[0], self.maps.data_ptr(), self.Qpe,
-                            self.bias_pe, self.Ucat0, True, self.ks_long)
+                            self.bias_pe, self.Ucat0, True, self.ks_long, uneven=True)
         B = self._read_args(self.ws_side, 1, 1, self.bankK[0], self.bankV[0], self.maps.data_ptr() + 16 * 4,
                             self.bankK[0][cur], None, self.Ucat0, False, self.ks_win)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -368,7 +442,7 @@ class DeAOTLSTT:
         T = len(self.bank)
         self._layer = 0
         A = self._read_args(self.ws_main, 0, T, self.bankK[0], self.bankV[0], self.maps.data_ptr(), self.Qpe,
-                            self.bias_pe, self.Ucat0, True, self.ks_long)
+                            self.bias_pe, self.Ucat0, True, self.ks_long, uneven=True)
         B = self._read_args(self.ws_side, 1, 1, self.bankK[0], self.bankV[0], self.maps.data_ptr() + 64,
                             Planes(self.bankK[0].hi[self.cur], self.bankK[0].lo[self.cur]), None, self.Ucat0, False,
                             self.ks_win)
@@ -472,7 +546,7 @@ class DeAOTLSTT:
         hip.check(rc, "rmem_layernorm_red2")
 
     def _read_args(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
-                   qpl: Planes, bias, U, want_mass: bool, ksplits: int):
+                   qpl: Planes, bias, U, want_mass: bool, ksplits: int, uneven: bool = False):
         """Argument blocks (fused read, combine) of one read into workspace `ws`."""
         Np = self.Npad
         ra = hip.ReadArgs()
@@ -486,6 +560,8 @@ class DeAOTLSTT:
         ra.rcs = self.rcs
         tiles = T * ((self.N + 63) // 64)
         ks = max(1, min(ksplits, tiles))
+        if uneven and mode == 0 and T in self.uneven and not self._batched:
+            ks, ra.nfull, ra.pf = self.uneven[T]
         ra.ksplits = ks
         ra.part, ra.ml = ws.part.data_ptr(), ws.ml.data_ptr()
         ra.lslot = ws.lslot.data_ptr() if want_mass else None
@@ -698,7 +774,7 @@ class DeAOTLSTT:
         #    projection; ONE fused-read launch, one combine and one depth-wise-conv launch for both
         #    ("serial_unpaired": one launch each, bit-identical, kept for the equivalence test)
         A = self._read_args(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
-                            self.bias_pe, Ucat, l == 0, self.ks_long)
+                            self.bias_pe, Ucat, l == 0, self.ks_long, uneven=True)
         B = self._read_args(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
                             Ucat, False, self.ks_win)
         if self.branch_order == "serial":

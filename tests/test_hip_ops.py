@@ -285,7 +285,8 @@ def _block16(Vf):
     return Vf.permute(0, 2, 1).reshape(S, Np // 16, 16, Cn).permute(0, 1, 3, 2).contiguous()
 
 
-def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, ksplits, want_mass=True, ldr=None, rcs=0):
+def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, ksplits, want_mass=True, ldr=None, rcs=0,
+              uneven=None):
     """K: [S][Npad][128] planes, Vb: blocked-16 planes [S][Npad/16][1024][16], Q planes [Npad][128]."""
     lib, st = hip.load(), hip.stream_ptr()
     part = torch.full((ksplits, Npad, 1024), float("nan"), device=DEV)     # every valid row must be written
@@ -304,6 +305,8 @@ def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, kspli
     if R is not None:
         ra.R, ra.ldr, ra.rcs = R.data_ptr(), (ldr if ldr is not None else R.shape[1]), rcs
     ra.h, ra.w, ra.ksplits = h, w, ksplits
+    if uneven is not None:
+        ra.nfull, ra.pf = uneven
     ra.part, ra.ml = part.data_ptr(), ml.data_ptr()
     ra.lslot = lslot.data_ptr() if want_mass else None
     hip.check(lib.rmem_attn_read(C.byref(ra), st), "read")
@@ -374,6 +377,30 @@ def test_read_bank(hip, ksplits, T, h, w):
     assert torch.isfinite(ml[:, :N]).all()
     live = ml[:, :N, 1] > 0                      # splits without a key tile leave their partial unwritten
     assert torch.isfinite(part[:, :N][live]).all()
+
+
+@pytest.mark.parametrize("T,h,w,ks,nfull,pf", [(4, 31, 54, 9, 7, 14), (4, 31, 54, 8, 7, 15), (3, 9, 13, 4, 2, 2),
+                                              (5, 12, 17, 6, 3, 4), (2, 9, 13, 3, 1, 1)])
+def test_read_bank_uneven_splits(hip, T, h, w, ks, nfull, pf):
+    """rmem_read_args.nfull / pf: the first nfull key splits hold pf tiles each, the others share the rest.  Against
+    fp64 like test_read_bank (output, attention mass), every partial of a live split written; and invalid geometries
+    (no short split, full pieces covering every tile, mode 1) are refused."""
+    rs = np.random.RandomState(T * 100 + h + ks)
+    N, Npad, slot_map, Kf, Vf, Qf, bias, U, A, ref, _ = _bank_case(rs, T, h, w)
+    G, mass, part, ml = _run_read(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, _block16(Vf)), slot_map,
+                                  _planes(hip, Qf), bias.to(DEV), U.to(DEV), h, w, None, ks, uneven=(nfull, pf))
+    err = (G.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    merr = (mass.cpu().double() - A.sum(dim=2)).abs().max().item()
+    print(f"uneven splits T={T} {h}x{w} ks={ks} nfull={nfull} pf={pf}: G rel err {err:.2e}, mass err {merr:.2e}")
+    assert err < 5e-5 and merr < 1e-5, (err, merr)
+    assert (ml[:, :N, 1] > 0).all()              # every split holds keys
+    assert torch.isfinite(part[:, :N]).all()
+    lib, st = hip.load(), hip.stream_ptr()
+    tiles = T * ((N + 63) // 64)
+    for bad in ((ks, pf), (nfull, tiles), (-1, pf)):
+        with pytest.raises(hip.RmemError):
+            _run_read(hip, 0, T, N, Npad, _planes(hip, Kf), _planes(hip, _block16(Vf)), slot_map, _planes(hip, Qf),
+                      bias.to(DEV), U.to(DEV), h, w, None, ks, uneven=bad)
 
 
 @pytest.mark.parametrize("ksplits", [1, 3])

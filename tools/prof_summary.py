@@ -89,7 +89,7 @@ def main():
     rows.sort(key=lambda r: -r[2])
     rows = [(short_name(r[0]),) + tuple(r[1:]) for r in rows]
     tot = sum(r[2] for r in rows)
-    ours = ("read64", "fg_weights", "bank_policy", "bank_edit", "read2_kernel", "read_kernel", "read_combine", "linear_kernel", "linear_grouped", "pv_kernel", "pv16_kernel", "scores_kernel", "scores2_kernel",
+    ours = ("read64", "fg_weights", "bank_policy", "bank_edit", "read2_kernel", "read_kernel", "read_combine", "linear_kernel", "linear_grouped", "linear_stream", "pv_kernel", "pv16_kernel", "scores_kernel", "scores2_kernel",
             "combine_kernel", "combine2_kernel", "dwconv5x5",
             "layernorm_", "gn2_", "gn_nchw", "gn_tok", "id_assign", "pe_bias", "mass_reduce", "split_planes",
             "bias_act_nchw", "upsample_add", "labels_kernel", "label_resize", "set_ints", "mha_", "transpose_planes",
