@@ -352,9 +352,12 @@ class DeAOTLSTT:
         # self read (T = 1, 27 tiles at 480p): 9 splits are faster isolated (33.8 + 13.1 us read + combine against
         # 38.2 + 10.1 with 6) but not in the frame (more partials beside the encoder stream)
         self.ks_self = max(1, min(budget // nq, tv, 6))
-        # uneven long-term splits of the paired read, per bank depth T (one clip per launch; RMEM_UNEVEN=0: even splits)
+        # Uneven long-term splits of the paired read, per bank depth T: OFF by default (RMEM_UNEVEN=1 turns the chooser
+        # on).  Measured at 480p K=4 (profiles/r04n_split_sweep.txt): (7 x 15 + 3) 110.5 us, (7 x 14 + 2 x 5) 123.0 us
+        # against 101.6 us for the even (7, 2) -- with more units than CUs the launch goes through the unit queue, and the
+        # extra partials and per-unit fixed costs outweigh the idle CU-time the model promised to recover.
         self.uneven: Dict[int, tuple] = {}
-        if self.clips_per_launch == 1 and os.environ.get("RMEM_UNEVEN", "1") == "1":
+        if self.clips_per_launch == 1 and os.environ.get("RMEM_UNEVEN", "0") == "1":
             for T in range(1, self.Tmax + 1):
                 u = self.choose_uneven(N, self.h, self.w, T, min(self.ks_long, T * tv), self.ks_win, cus)
                 if u is not None:
