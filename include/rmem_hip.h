@@ -139,7 +139,8 @@ typedef struct {
                                               launch holds more units than the device has CUs, one workgroup per CU takes its
                                               first unit by index and every further one from this counter, longest first,
                                               instead of leaving the surplus to the hardware's per-XCD dispatch order; the
-                                              last workgroup out zeroes the two ints again.  One launch at a time per buffer. */
+                                              last workgroup out zeroes the two ints again, and the library zeroes them on the launch stream in front of every such
+                                              launch.  One launch at a time per buffer. */
   int32_t nfull, pf;                       /* mode 0, rmem_attn_read2 / rmem_attn_read: nfull > 0 = UNEVEN key splits: the first nfull splits
                                               hold pf 64-key tiles each, the other ksplits - nfull share the rest evenly (0 = even).
                                               rmem_attn_read2 launches the short pieces last, behind the windowed units, so that

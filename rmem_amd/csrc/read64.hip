@@ -962,6 +962,7 @@ static int read2_many(const rmem::RecOp& op, const char* d, long st, int B, hipS
   int* sched = static_cast<int*>(op.aux);              // (of the first clip's recording; one launch serves all clips)
   if (sched && (int)op.grid.x * B > ncu) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_many_pull_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+    if (hipMemsetAsync(sched, 0, 2 * sizeof(int), s) != hipSuccess) return RMEM_ERR_LAUNCH;   // (see rmem_attn_read2)
     hipLaunchKernelGGL(read64x2_many_pull_kernel, dim3(ncu), dim3(512), R6_LDS, s, d + op.off, st, B, sched);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
@@ -1012,6 +1013,10 @@ extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* b
   const int ncu = device_cus();
   if (ap->sched && 8 * (cha + chb + chs) > ncu) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_pull_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
+    // The queue counters are zeroed on the launch stream in front of every pull launch (a memset node under capture):
+    // the last workgroup out also zeroes them, but a faulted or aborted launch would otherwise leave the next read
+    // skipping units silently.
+    if (hipMemsetAsync(ap->sched, 0, 2 * sizeof(int), static_cast<hipStream_t>(stream)) != hipSuccess) return RMEM_ERR_LAUNCH;
     hipLaunchKernelGGL(read64x2_pull_kernel, dim3(ncu), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g, ap->sched);
     RMEM_CHECK_LAUNCH();
     return RMEM_OK;
