@@ -444,3 +444,31 @@ def test_multi_engine_wrapper_vs_reference_vectors(which, golden_dir, deaot_mode
     m1, l1 = torch.zeros(1, 1, 4, 4), torch.zeros(1, 11, 4, 4)
     assert w.separate_mask(m1)[0] is m1 and w.soft_logit_aggregation([l1]) is l1
     setattr(w, attr, [])
+
+
+def test_uneven_split_chooser_returns_valid_geometries():
+    """DeAOTLSTT.choose_uneven (off by default, RMEM_UNEVEN=1): whatever it proposes must be a geometry rmem_attn_read2
+    accepts -- at least one short split, the full pieces leave key tiles for the short ones, no empty split -- and the
+    windowed units' tile counts it models must be what read64.hip computes (15 x 15 window, clipped rows)."""
+    from rmem_amd.lstt import DeAOTLSTT as D
+    for (h, w, cap) in ((31, 54, 4), (46, 81, 8), (12, 17, 4), (30, 53, 4), (7, 9, 4)):
+        N = h * w
+        tv = (N + 63) // 64
+        kl, kw = D.choose_splits(N, h, w, cap)
+        wt = D.window_unit_tiles(N, h, w, kw)
+        assert len(wt) == tv * kw and all(0 <= t <= tv for t in wt)
+        # every key tile a query tile can see is covered by exactly its kw units
+        for qt in range(tv):
+            q_lo, q_hi = qt * 64, min(qt * 64 + 63, N - 1)
+            y_lo, y_hi = max(q_lo // w - 7, 0), min(q_hi // w + 7, h - 1)
+            assert sum(wt[qt * kw:(qt + 1) * kw]) == ((y_hi + 1) * w + 63) // 64 - (y_lo * w) // 64
+        for T in range(1, cap + 2):
+            u = D.choose_uneven(N, h, w, T, min(kl, T * tv), kw)
+            if u is None:
+                continue
+            ks, nfull, pf = u
+            tiles = T * tv
+            assert 0 < nfull < ks <= 16 and pf >= 1 and nfull * pf < tiles
+            rest, ns = tiles - nfull * pf, ks - nfull
+            pr = -(-rest // ns)
+            assert (ns - 1) * pr < rest and pr < pf
