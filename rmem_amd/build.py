@@ -37,7 +37,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, src), "-o", obj] + EXTRA_FLAGS.get(src, [])
+               os.path.join(CSRC, src), "-o", obj] + EXTRA_FLAGS.get(src, []) + os.environ.get("RMEM_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
