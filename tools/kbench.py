@@ -100,20 +100,19 @@ def main():
     A = L._read_args(L.ws_main, 0, T, L.bankK[1], L.bankV[1], map_bank, L.Qpe, L.bias_pe, L.Ucat, True, L.ks_long)
     B = L._read_args(L.ws_side, 1, 1, L.bankK[1], L.bankV[1], map_short, curK, None, L.Ucat, False, L.ks_win)
     S = L._read_args(L.ws_main, 0, 1, L.selfQK, L.selfV, None, sQK, None, L.Uself, False, L.ks_self)
-    st = hip.stream_ptr()
     if args.only == "pv":       # for --pmc runs: only the fused read launches
         for _ in range(args.iters):
-            hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "read2")
-            hip.check(lib.rmem_attn_read(C.byref(S[0]), st), "read")
+            hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), hip.stream_ptr()), "read2")
+            hip.check(lib.rmem_attn_read(C.byref(S[0]), hip.stream_ptr()), "read")
         torch.cuda.synchronize()
         return
     res["ks_long"], res["ks_win"], res["ks_self"] = L.ks_long, L.ks_win, L.ks_self
-    res["read2_long+window"] = timeit(lambda: hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "r2"), args.iters)
-    res["read_combine2"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "c2"), args.iters)
-    res["read_long_alone"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "r"), args.iters)
-    res["read_window_alone"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(B[0]), st), "r"), args.iters)
-    res["read_self"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(S[0]), st), "r"), args.iters)
-    res["read_combine_self"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine(C.byref(S[1]), st), "c"), args.iters)
+    res["read2_long+window"] = timeit(lambda: hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), hip.stream_ptr()), "r2"), args.iters)
+    res["read_combine2"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), hip.stream_ptr()), "c2"), args.iters)
+    res["read_long_alone"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(A[0]), hip.stream_ptr()), "r"), args.iters)
+    res["read_window_alone"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(B[0]), hip.stream_ptr()), "r"), args.iters)
+    res["read_self"] = timeit(lambda: hip.check(lib.rmem_attn_read(C.byref(S[0]), hip.stream_ptr()), "r"), args.iters)
+    res["read_combine_self"] = timeit(lambda: hip.check(lib.rmem_attn_read_combine(C.byref(S[1]), hip.stream_ptr()), "c"), args.iters)
     res["read2_TFLOPs_algorithmic"] = L.read_flops(T) / res["read2_long+window"] / 1e6
     if args.only == "reads":
         print(json.dumps({k: round(v, 2) for k, v in res.items()}, indent=1))
