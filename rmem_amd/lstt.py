@@ -372,7 +372,13 @@ class DeAOTLSTT:
         self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "serial")   # serial (paired launches) | serial_unpaired
         self.Ylt = Planes.empty((Np, 1024), dev)
         self.Yst = Planes.empty((Np, 1024), dev)
-        self.KS = 4                                                # split-K of the projection GEMMs
+        # split-K of the projection GEMMs.  Under the streaming kernel two splits are one round of 216 items (19.1 / 12.9 us
+        # for the two projections against 22.3 / 15.6 with four, profiles/r04y_kbench.json) and half the partials for
+        # the LayerNorm that folds them; the tile-per-workgroup kernels (recorded launches, RMEM_LINEAR=tiles) are
+        # fastest with four (21.2 against 27.4 us)
+        self.KS = 2 if (self.clips_per_launch == 1 and not self._force_tiles) else 4
+        if os.environ.get("RMEM_PROJ_KS"):                       # tuning override
+            self.KS = int(os.environ["RMEM_PROJ_KS"])
         self.parts = z(self.KS, N, 512)
         # relative bias of the windowed read, stored by anti-diagonals: element (q, o) at 225*(q+o) + o
         # = q*ldr + o*rcs with ldr = 225, rcs = 226 (rmem_read_args.rcs: coalesced gathers)
@@ -815,7 +821,14 @@ class DeAOTLSTT:
         if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
                        tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
-        else:                  # last layer: the GroupNorm reads tgt / tgt_id directly
+        elif self.clips_per_launch == 1 and not self._force_tiles:
+            # last layer: the same split-K launch; its partials are folded into tgt / tgt_id by the LayerNorm kernel
+            # (planes into the free self-attention input buffer, unused) -- 12.9 + 6.3 us against 24.7 us for the
+            # read-modify-write epilogue of a full-K launch -- and the GroupNorm reads tgt / tgt_id
+            hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
+                       tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
+            self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
+        else:                  # (recorded launches) last layer: accumulate straight into tgt / tgt_id
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
                        d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,
                        csplit=256, accumulate=True, nsplit=ns)

@@ -331,6 +331,32 @@ def test_bench_clips64_two_ranks_equal_one_rank():
 
 
 @pytest.mark.gpu
+def test_bench_clips64_world1_over_rccl():
+    """BASELINE.json configs[3] in miniature through RCCL: `--config clips64` (2 clips x 6 frames through the clip
+    driver) with a one-rank RCCL group (RMEM_FORCE_DIST=1) -- run_sharded_clips' uint8 all-gather and the timing exchange
+    go through the backend -- gives the clip hashes of the same run without a process group."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "clips64", "--clips-per-rank", "2",
+                            "--clip-frames", "6"], env=env, capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+        return json.loads(lines[0])
+
+    a, b = run({"RMEM_FORCE_DIST": "1"}), run({})
+    assert a["config"]["dist_backend"] == "nccl" and b["config"]["dist_backend"] is None
+    assert len(a["clip_sha256"]) == 2 and a["clip_sha256"] == b["clip_sha256"] and a["masks_sha256"] == b["masks_sha256"]
+
+
+@pytest.mark.gpu
 def test_bench_line_contract_single_gpu():
     """The line the driver parses: `python bench.py --steps K --warmup W` prints ONE JSON object with BASELINE.json's
     metric, whole-job frames/s consistent with ms_per_step, `roofline` for the dominant kernel (achieved = algorithmic
