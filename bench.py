@@ -536,13 +536,17 @@ def clips64(args, world, rank, local_rank, dev, dist):
     t0 = time.perf_counter()
     if args.batched:       # this rank's clips in lockstep, one launch per kernel for all of them
         res = drv.run_clips([cache[c] for c in mine], num_frames=F_)
+        t_issue = time.perf_counter() - t0             # host time to issue the clips (the GPU may still be running)
         allm = D.gather_masks(torch.stack([r.masks for r in res]), world)
         host = allm.cpu().numpy()
+        t_masks = time.perf_counter() - t0             # masks of every rank in host memory
         hashes = [None] * n_clips
         for pos, cid in enumerate(D.unshard_order(n_clips, world)):
             hashes[cid] = hashlib.sha256(host[pos].tobytes()).hexdigest()
+        sections = {"issued": round(t_issue, 4), "masks_on_host": round(t_masks, 4)}
     else:
         hashes, allm, frames_run = D.run_sharded_clips(drv, n_clips, world, rank, lambda c: cache[c], F_)
+        sections = None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -560,7 +564,7 @@ def clips64(args, world, rank, local_rank, dev, dist):
                                    f"(clip i -> rank i mod {world}), evaluator gap rule (gap {D.memory_gap(F_)}), reference frame + bank fill timed",
                        "clips": n_clips, "frames_per_clip": F_, "frames_per_sec_per_gpu": total_frames / elapsed / world,
                        "batched": bool(args.batched),
-                       "per_rank_seconds": per_rank_s,
+                       "per_rank_seconds": per_rank_s, "rank0_sections_s": sections,
                        "dist_backend": dist.get_backend() if dist is not None else None,
                        "parallelism": f"clips sharded {args.clips_per_rank}-per-GPU x{world}"
                                       + (" in lockstep (one launch per kernel for all clips of a rank)" if args.batched else "")
