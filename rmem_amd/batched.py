@@ -88,6 +88,8 @@ class BatchedLSTT:
         self._labels: Dict[tuple, torch.Tensor] = {}
         self._recs: Dict[tuple, hip.Recording] = {}
         self._chan: Dict[tuple, _Upload] = {}
+        self._maps_host: Optional[np.ndarray] = None      # what the clips last published (slot maps), all clips
+        self.groups_last = 0         # launch groups of the last pass (1 = every active clip in the same state)
         self.launches = 0            # recorded ops issued (each ONE launch for all clips)
 
     # ------------------------------------------------------------------ recorder plumbing
@@ -100,23 +102,34 @@ class BatchedLSTT:
             self._recs[k] = r
         return r
 
-    def _run(self, kind: str, keys: List[tuple], fn):
-        """Record (or look up) `fn(clip)` for every clip, upload the B argument blobs, launch."""
-        recs = [self._record(kind, i, keys[i], fn) for i in range(self.B)]
-        sig, n = recs[0].signature, len(recs[0].blob)
-        if any(r.signature != sig or len(r.blob) != n for r in recs):
-            raise hip.RmemError(f"batched '{kind}': the clips recorded different launch sequences "
-                                "(clips of one batch must share geometry and bank depth)")
-        stride = (n + 255) // 256 * 256
-        ch = self._chan.get((kind, n))
-        if ch is None:
-            ch = self._chan[(kind, n)] = _Upload(self.B * stride, self.dev)
-        buf = ch.stage()
-        for i, r in enumerate(recs):
-            buf[i * stride:i * stride + n] = np.frombuffer(r.blob, dtype=np.uint8)
-        ch.send()
-        recs[0].launch(ch.dev, stride, self.B)
-        self.launches += recs[0].count
+    def _run(self, kind: str, keys: List[tuple], fn, active: Optional[List[bool]] = None):
+        """Record (or look up) `fn(clip)` for every active clip, upload the argument blobs, launch.  Clips whose
+        recordings share a signature (same kernels, grids, argument-block offsets: same pass at the same bank
+        depth) share ONE launch per kernel; a clip in another state (a slot that has just taken the next clip of
+        the queue: reference frame, shallower bank) gets launches of its own group.  keys[i] is ignored for an
+        inactive clip."""
+        idx = [i for i in range(self.B) if active is None or active[i]]
+        groups: Dict[tuple, List[int]] = {}
+        recs = {}
+        for i in idx:
+            r = recs[i] = self._record(kind, i, keys[i], fn)
+            groups.setdefault((r.signature, len(r.blob)), []).append(i)
+        for (sig, n), members in groups.items():
+            stride = (n + 255) // 256 * 256
+            ch = self._chan.get((kind, n))
+            if ch is None:
+                ch = self._chan[(kind, n)] = _Upload(self.B * stride, self.dev)
+            buf = ch.stage()
+            for pos, i in enumerate(members):
+                buf[pos * stride:pos * stride + n] = np.frombuffer(recs[i].blob, dtype=np.uint8)
+            ch.send()
+            recs[members[0]].launch(ch.dev, stride, len(members))
+            self.launches += recs[members[0]].count
+        self.groups_last = len(groups)
+
+    @staticmethod
+    def _per_clip(v, B: int) -> list:
+        return list(v) if isinstance(v, (list, tuple)) else [v] * B
 
     # ------------------------------------------------------------------ passes
     def label_buffer(self, H: int, W: int) -> torch.Tensor:
@@ -126,35 +139,42 @@ class BatchedLSTT:
             buf = self._labels[(H, W)] = torch.zeros(self.B, H, W, dtype=torch.uint8, device=self.dev)
         return buf
 
-    def clear_memory(self):
-        for c in self.clips:
+    def clear_memory(self, clip: Optional[int] = None):
+        for c in (self.clips if clip is None else [self.clips[clip]]):
             c.clear_memory()
 
-    def assign_identity(self, labels_u8: torch.Tensor, ignore: bool = True):
-        """labels_u8: the label_buffer() of its shape (or a tensor copied into it)."""
+    def assign_identity(self, labels_u8: torch.Tensor, ignore=True, active: Optional[List[bool]] = None):
+        """labels_u8: the label_buffer() of its shape (or a tensor copied into it).  `ignore`: one flag or one per
+        clip; `active`: the clips that take part (None = all)."""
         B, H, W = labels_u8.shape
         lab = self.label_buffer(H, W)
         if labels_u8.data_ptr() != lab.data_ptr():
             lab.copy_(labels_u8)
-        self._run("id", [(H, W, bool(ignore))] * self.B,
-                  lambda c: c.assign_identity(lab[self.clips.index(c)], ignore=ignore))
+        ign = [bool(g) for g in self._per_clip(ignore, self.B)]
+        self._run("id", [(H, W, ign[i]) for i in range(self.B)],
+                  lambda c: c.assign_identity(lab[self.clips.index(c)], ignore=ign[self.clips.index(c)]), active)
 
-    def forward(self, emb_bnc: torch.Tensor, ref_frame: bool = False) -> torch.Tensor:
-        """DualBranchGPM.forward for every clip.  emb_bnc: [B,N,256] fp32 -> [B,N,512]."""
+    def forward(self, emb_bnc: torch.Tensor, ref_frame=False, active: Optional[List[bool]] = None) -> torch.Tensor:
+        """DualBranchGPM.forward for every (active) clip.  emb_bnc: [B,N,256] fp32 -> [B,N,512].  `ref_frame`: one
+        flag or one per clip -- a slot may add the reference frame of its next clip while the others propagate."""
+        ref = [bool(r) for r in self._per_clip(ref_frame, self.B)]
+        on = [True] * self.B if active is None else [bool(a) for a in active]
         self.tgt.copy_(emb_bnc)
         self.tgt_id.zero_()
         stage = self.maps_up.stage().view(np.int32).reshape(self.B, 32)
+        if self._maps_host is not None:
+            stage[:] = self._maps_host                 # (inactive clips keep what they published last)
         for i, c in enumerate(self.clips):
-            c._prepare(ref_frame)
-            stage[i, :18] = c._map_vals
+            if on[i]:
+                c._prepare(ref[i])
+                stage[i, :18] = c._map_vals
+        self._maps_host = stage.copy()
         self.maps_up.send()
-        T = self.clips[0]._T
-        if any(c._T != T for c in self.clips):
-            raise hip.RmemError("batched clips must hold banks of the same depth (lockstep schedule)")
-        self._run("fwd", [(c.cur, c._T, bool(ref_frame)) for c in self.clips],
-                  lambda c: c._forward_device(ref_frame))
-        for c in self.clips:
-            c._finish(ref_frame)
+        self._run("fwd", [(c.cur, c._T, ref[i]) if on[i] else () for i, c in enumerate(self.clips)],
+                  lambda c: c._forward_device(ref[self.clips.index(c)]), on)
+        for i, c in enumerate(self.clips):
+            if on[i]:
+                c._finish(ref[i])
         return self.out
 
     def time_read_isolated(self, iters: int = 20) -> float:
@@ -182,20 +202,27 @@ class BatchedLSTT:
         e1.synchronize()
         return 1e3 * e0.elapsed_time(e1) / iters
 
-    def update_short_memories(self, update_long: bool):
-        self._run("upd", [(c.cur,) for c in self.clips], lambda c: c._update_device(update_long))
-        for c in self.clips:
-            c._update_host(update_long)
+    def update_short_memories(self, update_long, active: Optional[List[bool]] = None):
+        """`update_long`: one flag or one per clip (clips of different lengths follow different gap schedules)."""
+        upd = [bool(u) for u in self._per_clip(update_long, self.B)]
+        self._run("upd", [(c.cur,) for c in self.clips], lambda c: c._update_device(upd[self.clips.index(c)]), active)
+        for i, c in enumerate(self.clips):
+            if active is None or active[i]:
+                c._update_host(upd[i])
 
-    def restrict_long_memories(self, indexes: List[List[int]], fg_bn: torch.Tensor):
-        """restrict_long_memories (transformer.py:880-991) for every clip: one reduce launch, ONE
-        device-to-host copy, the EMA + UCB rule per clip on the host."""
+    def restrict_long_memories(self, indexes: List[List[int]], fg_bn: torch.Tensor, active: Optional[List[bool]] = None):
+        """restrict_long_memories (transformer.py:880-991) for every (active) clip: one reduce launch per group of
+        clips with the same bank depth, ONE device-to-host copy, the EMA + UCB rule per clip on the host.  Returns
+        the dropped position (or None) per clip; None for an inactive clip."""
+        on = [True] * self.B if active is None else [bool(a) for a in active]
+        if not any(on):
+            return [None] * self.B
         self.fg.copy_(fg_bn)
-        T = self.clips[0].mass_T
         self._run("mass", [(c.mass_T,) for c in self.clips],
-                  lambda c: c._mass_reduce_device(self.fg[self.clips.index(c)]))
+                  lambda c: c._mass_reduce_device(self.fg[self.clips.index(c)]), on)
+        T = max(c.mass_T for i, c in enumerate(self.clips) if on[i])
         w = self.w_out[:, :T].cpu().numpy().astype(np.float32)
-        return [c._restrict_host(indexes[i], w[i]) for i, c in enumerate(self.clips)]
+        return [c._restrict_host(indexes[i], w[i, :c.mass_T]) if on[i] else None for i, c in enumerate(self.clips)]
 
 
 class BatchedDeAOTEngine:
@@ -226,8 +253,11 @@ class BatchedDeAOTEngine:
         self.restart_engine()
 
     def restart_engine(self):                                   # aot_engine.py:533-563
-        self.frame_step = 0
-        self.last_mem_step = -1
+        self.frame_steps = [0] * self.B           # per slot: a slot that takes the next clip of a queue starts over
+        self.last_mem_steps = [-1] * self.B
+        self.slot_gaps: List[Optional[int]] = [None] * self.B      # per-slot gap (None: long_term_mem_gap)
+        self.active = [True] * self.B             # slots that hold a clip (an idle slot takes part in no launch of the memory path)
+        self._ref_now: set = set()                # slots whose current frame is a reference frame (no memory update follows)
         self.obj_nums = None
         self.input_size_2d = self.enc_size_2d = self.enc_hw = None
         self.long_memories_indexes: List[List[int]] = [[] for _ in range(self.B)]
@@ -242,6 +272,32 @@ class BatchedDeAOTEngine:
             self.lstt, self._eg, self._dg = None, {}, {}
         if self.lstt is not None:
             self.lstt.clear_memory()
+
+    # lockstep callers (every slot on the same frame) read and write one counter
+    @property
+    def frame_step(self) -> int:
+        return self.frame_steps[0]
+
+    @frame_step.setter
+    def frame_step(self, v: int):
+        self.frame_steps = [int(v)] * self.B
+
+    @property
+    def last_mem_step(self) -> int:
+        return self.last_mem_steps[0]
+
+    @last_mem_step.setter
+    def last_mem_step(self, v: int):
+        self.last_mem_steps = [int(v)] * self.B
+
+    def restart_slot(self, i: int, gap: Optional[int] = None):
+        """restart_engine (aot_engine.py:533-563) for ONE slot: the reference's worker takes the next clip of the
+        queue when its clip ends (managers/evaluator.py:287-295); here the slot does, while the others carry on."""
+        self.frame_steps[i], self.last_mem_steps[i] = 0, -1
+        self.slot_gaps[i] = gap
+        self.long_memories_indexes[i] = []
+        self.active[i] = True
+        self.lstt.clear_memory(i)
 
     def _stale_weights(self) -> bool:
         return self._lstt_wv != self.AOT.__dict__.get("_weights_version", 0)
@@ -372,6 +428,7 @@ class BatchedDeAOTEngine:
         enc = self._encode(imgs)
         if self.input_size_2d is None or self._stale_weights():
             self.update_size(imgs.shape[2:], enc[-1].shape[2:])
+        self.active, self._ref_now = [True] * self.B, set()
         # no ignore channel on reference frames (aot_engine.py:304 -> :209-213)
         self.lstt.assign_identity(self._labels_u8(masks), ignore=False)
         self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=True)
@@ -380,30 +437,69 @@ class BatchedDeAOTEngine:
         self.pred_id_logits, _ = self._decode(enc, None, imgs.is_cuda)
 
     @torch.no_grad()
-    def match_propogate_one_frame(self, imgs, output_size=None, next_imgs=None):
+    def match_propogate_one_frame(self, imgs, output_size=None, next_imgs=None, ref_slots: Optional[Dict] = None,
+                                  idle_slots=()):
         """aot_engine.py:398-436 for B clips -> logits [B,C,H,W].  `next_imgs` (extension, optional):
         the tensor that will be passed to the NEXT call; its encoder pass then runs on a second
-        stream beside this frame's LSTT and decoder (the encoder does not depend on the memory)."""
-        self.frame_step += 1
+        stream beside this frame's LSTT and decoder (the encoder does not depend on the memory).
+
+        `ref_slots` (extension): {slot: (label map [H,W] / [1,1,H,W] at the network size, object count, gap or None)}
+        -- imgs[slot] is the reference frame of the NEXT clip of that slot: the slot starts over
+        (restart_slot + add_reference_frame, aot_engine.py:241-325) inside this step while the other slots
+        propagate; its row of the returned logits means nothing and update_memory() skips it.  `idle_slots`: slots
+        without a clip (queue empty): their images still pass the encoder / decoder at batch B, the memory path
+        skips them."""
+        ref_slots = ref_slots or {}
         enc = self._encode(imgs)
         self._prefetch(next_imgs)
-        self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=False)
+        if self.input_size_2d is None or self._stale_weights():
+            self.update_size(imgs.shape[2:], enc[-1].shape[2:])
+        for i in idle_slots:
+            self.active[i] = False
+        if ref_slots:
+            if self.obj_nums is None:
+                self.obj_nums = [int(self.AOT.max_obj_num)] * self.B
+            lab = self.lstt.label_buffer(*self.input_size_2d)
+            for i, (m, n, gap) in ref_slots.items():
+                if int(n) > self.AOT.max_obj_num:
+                    raise NotImplementedError(f"more than {self.AOT.max_obj_num} objects per clip: use DeAOTInferEngine")
+                if int(n) != self.obj_nums[i]:
+                    self.obj_nums = self.obj_nums[:i] + [int(n)] + self.obj_nums[i + 1:]
+                self.restart_slot(i, gap)
+                lab[i].copy_(m.reshape(lab.shape[1:]).to(torch.uint8))
+                self.last_mem_steps[i] = 0
+                self.long_memories_indexes[i] = [0]
+            self.lstt.assign_identity(lab, ignore=False, active=[i in ref_slots for i in range(self.B)])
+        self._ref_now = set(ref_slots)
+        for i in range(self.B):
+            if self.active[i] and i not in ref_slots:
+                self.frame_steps[i] += 1
+        self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=[i in ref_slots for i in range(self.B)],
+                          active=self.active)
         self.pred_id_logits, up = self._decode(enc, output_size, imgs.is_cuda)
         return up
 
     @torch.no_grad()
     def update_memory(self, masks):
-        """update_short_term_memory (aot_engine.py:327-369) for B clips; the long-term update and the
-        RMem eviction follow the shared gap schedule."""
-        update_long = False
-        if (not self.cfg.NO_LONG_MEMORY) and self.frame_step - self.last_mem_step >= self.long_term_mem_gap:
-            update_long = True
-            self.last_mem_step = self.frame_step
-        self.lstt.assign_identity(self._labels_u8(masks), ignore=True)
-        self.lstt.update_short_memories(update_long)
-        if update_long:
-            for idx in self.long_memories_indexes:
-                idx.append(self.frame_step)
+        """update_short_term_memory (aot_engine.py:327-369) for B clips; the long-term update and the RMem eviction
+        follow each slot's gap schedule (one shared schedule for clips in lockstep).  Slots that added a reference
+        frame in this step, and idle slots, are skipped."""
+        on = [self.active[i] and i not in self._ref_now for i in range(self.B)]
+        if not any(on):
+            return
+        upd = [False] * self.B
+        if not self.cfg.NO_LONG_MEMORY:
+            for i in range(self.B):
+                gap = self.slot_gaps[i] if self.slot_gaps[i] is not None else self.long_term_mem_gap
+                if on[i] and self.frame_steps[i] - self.last_mem_steps[i] >= gap:
+                    upd[i] = True
+                    self.last_mem_steps[i] = self.frame_steps[i]
+        self.lstt.assign_identity(self._labels_u8(masks), ignore=True, active=on)
+        self.lstt.update_short_memories(upd, active=on)
+        if any(upd):
+            for i, idx in enumerate(self.long_memories_indexes):
+                if upd[i]:
+                    idx.append(self.frame_steps[i])
             lg = F.interpolate(self.pred_id_logits, size=self.enc_size_2d, mode="bilinear", align_corners=True)
             fg = (1 - torch.softmax(lg, dim=1)[:, 0]).reshape(self.B, -1).contiguous()
-            self.lstt.restrict_long_memories(self.long_memories_indexes, fg)
+            self.lstt.restrict_long_memories(self.long_memories_indexes, fg, active=upd)

@@ -49,8 +49,8 @@ def load_network(net: torch.nn.Module, path_or_ckpt, device=None):
     net.load_state_dict(sd)
     if device is not None:
         net = net.to(device)
-    if net.__dict__.get("_enc_infer") is not None:      # folded inference encoder is stale now
-        net.optimize_for_inference(True)
     # engines pack the LSTT / ID-bank weights into planes when they are built: tell them to re-pack
     object.__setattr__(net, "_weights_version", net.__dict__.get("_weights_version", 0) + 1)
+    if net.__dict__.get("_enc_infer") is not None:      # folded inference encoder is stale now (folds again: new version)
+        net.optimize_for_inference(True)
     return net, removed

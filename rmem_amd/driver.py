@@ -473,6 +473,41 @@ def plan_ragged_batches(clips_info: Sequence[Dict], B: int, no_memory_gap: bool 
     return {"batches": batches, "singles": sorted(singles)}
 
 
+def plan_slot_queue(lengths: Sequence[int], B: int, order: str = "longest_first") -> List[List[Optional[tuple]]]:
+    """Schedule of a clip queue served by B slots (host logic only).  The reference's workers take the next clip of
+    the queue when theirs ends (managers/evaluator.py:276-295); here a SLOT of the batch does: steps[k][s] =
+    (clip id, frame index) of slot s at step k, or None when the queue has run dry for that slot.  Frame 0 of a clip is
+    its reference frame (the slot restarts inside that step), so a slot never idles between clips.
+    order: "longest_first" (shortest makespan: the long clips cannot end up alone at the tail) or "given"."""
+    B = int(B)
+    if B < 1:
+        raise ValueError("B must be >= 1")
+    if any(int(n) < 1 for n in lengths):
+        raise ValueError("empty clip")
+    if order not in ("longest_first", "given"):
+        raise ValueError("order: longest_first | given")
+    ids = list(range(len(lengths)))
+    if order == "longest_first":
+        ids.sort(key=lambda i: (-int(lengths[i]), i))
+    slot_clip: List[Optional[int]] = [None] * B
+    pos = [0] * B
+    steps: List[List[Optional[tuple]]] = []
+    while True:
+        row: List[Optional[tuple]] = []
+        for s_ in range(B):
+            if slot_clip[s_] is None or pos[s_] >= int(lengths[slot_clip[s_]]):
+                slot_clip[s_] = ids.pop(0) if ids else None
+                pos[s_] = 0
+            if slot_clip[s_] is None:
+                row.append(None)
+            else:
+                row.append((slot_clip[s_], pos[s_]))
+                pos[s_] += 1
+        if all(e is None for e in row):
+            return steps
+        steps.append(row)
+
+
 class BatchedClipDriver:
     """B clips of one frame size and one memory-gap schedule in lockstep through
     rmem_amd.batched.BatchedDeAOTEngine: ONE launch per kernel of the memory path for all clips,
@@ -568,6 +603,89 @@ class BatchedClipDriver:
             results.append(r)
         return results
 
+    def _check_objects(self, clip, lab_net: torch.Tensor, i: int) -> None:
+        """A clip with more than max_obj_num objects needs one sub-engine per 10 ids (engines/aot_engine.py:675-702):
+        the batched engine has none, and rmem_id_assign drops ids above max_obj_num."""
+        maxo = int(self.engine.AOT.max_obj_num)
+        n = clip[0][0]["meta"].get("obj_num")
+        n = int(n[0] if isinstance(n, (list, tuple)) else n) if n is not None else None
+        if n is None:
+            ids = lab_net[lab_net != 255]
+            n = int(ids.max().item()) if ids.numel() else 0
+        if n > maxo:
+            raise NotImplementedError(f"clip {i} holds {n} objects (> {maxo}): use ClipDriver (one sub-engine per "
+                                      f"{maxo} objects, engines/aot_engine.py:675-702)")
+
+    @torch.no_grad()
+    def run_queue(self, clips: Sequence[Sequence[List[Dict]]], order: str = "longest_first") -> List[ClipResult]:
+        """Any number of clips of ONE frame size through the B slots of the batch, each slot taking the next clip of
+        the queue the moment its clip ends (plan_slot_queue; the reference's worker queue,
+        managers/evaluator.py:276-295).  Lengths and memory gaps may differ per clip: every slot follows its own
+        clip's schedule, and the launches of the memory path are shared by the slots that are in the same state
+        (BatchedLSTT._run groups them) -- a slot that has just restarted (reference frame, bank still filling) costs a
+        few extra launches, not an idle slot until the longest clip of a lockstep batch ends.  Per clip the results
+        are those of run_clips / ClipDriver.run_clip: nothing a clip computes depends on its neighbours."""
+        from . import hip
+        B, eng = self.B, self.engine
+        if not clips:
+            return []
+        if any(len(c) < 1 for c in clips):
+            raise ValueError("empty clip")
+        if any(len(c[0]) != 1 for c in clips):
+            raise ValueError("batched clips take one augmentation: use ClipDriver for test-time augmentation")
+        if any(s[0].get("current_label") is not None for c in clips for s in c[1:]):
+            raise NotImplementedError("mid-clip new objects: use ClipDriver")
+        meta = [c[0][0]["meta"] for c in clips]
+        ori_hw = (int(meta[0]["height"]), int(meta[0]["width"]))
+        size = tuple(clips[0][0][0]["current_img"].shape[2:])
+        if any((int(m["height"]), int(m["width"])) != ori_hw for m in meta) or \
+                any(tuple(c[0][0]["current_img"].shape[2:]) != size for c in clips):
+            raise ValueError("the clips of a queue must share the frame size (run_dataset groups them)")
+        lens = [len(c) for c in clips]
+        gaps = [self._gap_of(n) for n in lens]
+        maxo = int(eng.AOT.max_obj_num)
+        # reference labels at the network size (nearest, as run_clips) and the object-count check, before the loop
+        ref_lab = []
+        for i, c in enumerate(clips):
+            lab = F.interpolate(c[0][0]["current_label"].float(), size=size, mode="nearest").to(torch.uint8)[0, 0]
+            self._check_objects(c, lab, i)
+            ref_lab.append(lab)
+        steps = plan_slot_queue(lens, B, order)
+        dev = clips[0][0][0]["current_img"].device
+        out = [torch.zeros(max(n - 1, 0), ori_hw[0], ori_hw[1], dtype=torch.uint8, device=dev) for n in lens]
+        filler = clips[steps[0][0][0]][0][0]["current_img"]        # an idle slot still holds a row of the encoder batch
+
+        def stack(row):
+            return torch.cat([filler if e is None else clips[e[0]][e[1]][0]["current_img"] for e in row])
+
+        eng.restart_engine()
+        lab_in = None
+        nxt = stack(steps[0])
+        self.queue_stats = {"steps": len(steps), "slot_steps": B * len(steps),
+                            "busy_slot_steps": sum(e is not None for row in steps for e in row), "launch_groups": 0}
+        for k, row in enumerate(steps):
+            cur, nxt = nxt, (stack(steps[k + 1]) if k + 1 < len(steps) else None)
+            ref = {s_: (ref_lab[e[0]], maxo, gaps[e[0]]) for s_, e in enumerate(row) if e is not None and e[1] == 0}
+            idle = [s_ for s_, e in enumerate(row) if e is None]
+            logit = eng.match_propogate_one_frame(cur, output_size=None, next_imgs=nxt, ref_slots=ref, idle_slots=idle)
+            self.queue_stats["launch_groups"] += eng.lstt.groups_last
+            if lab_in is None:
+                lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
+            for s_, e in enumerate(row):
+                if e is None or e[1] == 0:
+                    continue
+                lab = hip.labels_from_logits([logit[s_:s_ + 1]], [False], ori_hw, self.align_corners, out=out[e[0]][e[1] - 1])
+                hip.label_resize_nearest(lab, eng.input_size_2d, False, out=lab_in[s_])
+            eng.update_memory(lab_in)
+        results = []
+        for i, c in enumerate(clips):
+            r = ClipResult()
+            r.gap, r.masks, r.obj_idx = gaps[i], out[i], meta[i].get("obj_idx")
+            r.names = [str(s[0]["meta"].get("current_name", "")) for s in c[1:]]
+            r.batched = True
+            results.append(r)
+        return results
+
     @staticmethod
     def clip_info(clip: Sequence[List[Dict]]) -> Dict:
         """The facts plan_ragged_batches() needs about one clip (see there)."""
@@ -580,26 +698,49 @@ class BatchedClipDriver:
                 "mid_labels": any(s[0].get("current_label") is not None for s in clip[1:]), "obj_num": n}
 
     @torch.no_grad()
-    def run_dataset(self, clips: Sequence[Sequence[List[Dict]]]) -> List[ClipResult]:
-        """Any list of clips -> one ClipResult per clip, in order.  plan_ragged_batches() decides which
-        clips share a lockstep batch; the rest (test-time augmentation, mid-clip labels, > 10 objects, a
-        lone clip of its (gap, size) group) run through ClipDriver.run_clip -- the reference's one-clip
-        loop.  ClipResult.batched tells which way a clip went."""
+    def run_dataset(self, clips: Sequence[Sequence[List[Dict]]], mode: str = "queue") -> List[ClipResult]:
+        """Any list of clips -> one ClipResult per clip, in order.
+
+        mode "queue" (default): the clips of one frame size share the B slots through run_queue() -- a slot takes
+        the next clip when its clip ends, whatever the lengths and gaps.  mode "lockstep": plan_ragged_batches()
+        groups clips by (gap, size) into batches that run for their longest clip (run_clips).  Either way test-time
+        augmentation, mid-clip labels, > 10 objects and a lone clip of its group run through ClipDriver.run_clip --
+        the reference's one-clip loop.  ClipResult.batched tells which way a clip went."""
+        if mode not in ("queue", "lockstep"):
+            raise ValueError("mode: queue | lockstep")
         info = [self.clip_info(c) for c in clips]
-        plan = plan_ragged_batches(info, self.B, max_obj_num=int(self.engine.AOT.max_obj_num), gap_of=self._gap_of)
         results: List[Optional[ClipResult]] = [None] * len(clips)
-        for batch in plan["batches"]:
-            real = [i for i in batch if i >= 0]
-            res = self.run_clips([clips[i if i >= 0 else real[0]] for i in batch])
-            for slot, i in enumerate(batch):
-                if i >= 0:
-                    res[slot].batched = True
-                    results[i] = res[slot]
-        if plan["singles"]:
+        singles: List[int] = []
+        if mode == "lockstep":
+            plan = plan_ragged_batches(info, self.B, max_obj_num=int(self.engine.AOT.max_obj_num), gap_of=self._gap_of)
+            for batch in plan["batches"]:
+                real = [i for i in batch if i >= 0]
+                res = self.run_clips([clips[i if i >= 0 else real[0]] for i in batch])
+                for slot, i in enumerate(batch):
+                    if i >= 0:
+                        res[slot].batched = True
+                        results[i] = res[slot]
+            singles = plan["singles"]
+        else:
+            maxo = int(self.engine.AOT.max_obj_num)
+            groups: Dict[tuple, List[int]] = {}
+            for i, c in enumerate(info):
+                if int(c.get("n_aug", 1)) != 1 or bool(c.get("mid_labels", False)) or int(c.get("obj_num", 1)) > maxo:
+                    singles.append(i)
+                else:
+                    groups.setdefault((tuple(c["size"]), tuple(c["ori_size"])), []).append(i)
+            for key in sorted(groups):
+                ids = groups[key]
+                if len(ids) < 2:
+                    singles.extend(ids)
+                    continue
+                for i, r in zip(ids, self.run_queue([clips[i] for i in ids])):
+                    results[i] = r
+        if singles:
             if self._single is None:
                 self._single = ClipDriver(self.model, self.cfg, gpu_id=self.gpu_id, no_memory_gap=self.no_memory_gap,
                                           fixed_gap=self.fixed_gap)
-            for i in plan["singles"]:
+            for i in sorted(singles):
                 r = self._single.run_clip(clips[i], num_frames=len(clips[i]))
                 r.batched = False
                 results[i] = r

@@ -120,11 +120,26 @@ class DeAOT(nn.Module):
         self.cur_pos_emb = nn.Parameter(torch.zeros(1, d // 2))
         self.mem_pos_emb = nn.Parameter(torch.zeros(4, d // 2))
 
-    def optimize_for_inference(self, fold_bn: bool = True):
-        """Build the inference-time encoder (FrozenBN folded into the convs).  Call after the
-        weights are loaded; call again if they change."""
+    def optimize_for_inference(self, fold_bn: bool = True, force: bool = False):
+        """Build the inference-time encoder (FrozenBN folded into the convs).  Call after the weights are loaded.
+
+        Idempotent per (fold_bn, weights version, device): every engine calls it when it is built, and an engine
+        built EARLIER holds hipGraphs that replay the folded tensors -- folding again would free the memory those
+        graphs read (a second driver on the same model used to corrupt the first one's encoder that way).  It folds
+        again when the weights changed: rmem_amd.checkpoint.load_network() bumps `_weights_version`; after changing
+        weights by hand pass force=True, which bumps the version itself so that existing engines re-pack their LSTT
+        planes and re-capture their graphs (engine.py / batched.py: _stale_weights)."""
+        wv = self.__dict__.get("_weights_version", 0)
+        dev = str(next(self.parameters()).device)
+        have = self.__dict__.get("_enc_infer_state")
+        if not force and have == (bool(fold_bn), wv, dev):
+            return self
+        if force and have is not None:
+            wv += 1
+            object.__setattr__(self, "_weights_version", wv)
         # kept out of nn.Module registration so that state_dict() keeps the reference's keys
         object.__setattr__(self, "_enc_infer", self.encoder.folded() if fold_bn else None)
+        object.__setattr__(self, "_enc_infer_state", (bool(fold_bn), wv, dev))
         return self
 
     # -- pass-throughs to PyTorch (models/aot.py:116-134, deaot.py:57-63)

@@ -51,3 +51,32 @@ def test_load_network_bumps_the_weights_version():
     m, _ = load_network(m, {k: v.clone() for k, v in m.state_dict().items()})
     assert m.__dict__["_weights_version"] == v0 + 1
     assert "_weights_version" not in m.state_dict()
+
+
+def test_folding_is_idempotent_until_the_weights_change():
+    """Every engine calls optimize_for_inference() when it is built.  An engine built earlier holds hipGraphs that
+    replay the folded tensors, so a second call must NOT fold again (it used to: the second driver on one model freed
+    what the first one's encoder graph read).  load_network() -- a new weights version -- and force=True fold again."""
+    m = build_vos_model("deaot", get_config("r50_deaotl")).eval()
+    load_synthetic_weights(m)
+    m.optimize_for_inference(True)
+    first = m.__dict__["_enc_infer"]
+    ptr = first.conv1.weight.data_ptr() if hasattr(first, "conv1") else next(first.parameters()).data_ptr()
+    m.optimize_for_inference(True)
+    assert m.__dict__["_enc_infer"] is first
+    again = m.__dict__["_enc_infer"]
+    assert (again.conv1.weight.data_ptr() if hasattr(again, "conv1") else next(again.parameters()).data_ptr()) == ptr
+    v0 = m.__dict__.get("_weights_version", 0)
+    sd = {k: v.clone() * (0.5 if k.endswith("layer1.0.conv1.weight") else 1) for k, v in m.state_dict().items()}
+    m, _ = load_network(m, sd)
+    assert m.__dict__["_enc_infer"] is not first and m.__dict__["_weights_version"] == v0 + 1
+    x = torch.randn(1, 3, 33, 49)
+    with torch.no_grad():
+        a, b = m.__dict__["_enc_infer"](x), m.encoder(x)
+    assert all(torch.allclose(p, q, atol=1e-4, rtol=1e-4) for p, q in zip(a, b))      # folded from the NEW weights
+    second = m.__dict__["_enc_infer"]
+    m.optimize_for_inference(True, force=True)
+    assert m.__dict__["_enc_infer"] is not second and m.__dict__["_weights_version"] == v0 + 2
+    m.optimize_for_inference(False)
+    assert m.__dict__["_enc_infer"] is None
+    assert "_enc_infer_state" not in m.state_dict()

@@ -472,3 +472,41 @@ def test_uneven_split_chooser_returns_valid_geometries():
             rest, ns = tiles - nfull * pf, ks - nfull
             pr = -(-rest // ns)
             assert (ns - 1) * pr < rest and pr < pf
+
+
+def test_slot_queue_plan_serves_every_frame_once_without_idle_slots():
+    """plan_slot_queue (the reference's worker queue, managers/evaluator.py:276-295, for the slots of a batch)."""
+    from rmem_amd.driver import plan_slot_queue, plan_ragged_batches
+    import numpy as np
+    rs = np.random.RandomState(0)
+    for B in (1, 2, 3, 8):
+        for trial in range(20):
+            lens = [int(x) for x in rs.randint(1, 40, size=rs.randint(1, 30))]
+            for order in ("longest_first", "given"):
+                steps = plan_slot_queue(lens, B, order)
+                seen = {}
+                for k, row in enumerate(steps):
+                    assert len(row) == B
+                    for s, e in enumerate(row):
+                        if e is not None:
+                            assert e not in seen
+                            seen[e] = (k, s)
+                assert sorted(seen) == [(c, t) for c in range(len(lens)) for t in range(lens[c])]
+                for c, n in enumerate(lens):               # a clip stays in its slot, one frame per step
+                    k0, s0 = seen[(c, 0)]
+                    assert all(seen[(c, t)] == (k0 + t, s0) for t in range(n))
+                for s in range(B):                          # a slot that went idle never works again (queue empty)
+                    col = [row[s] is None for row in steps]
+                    assert col == sorted(col)
+                if order == "given":                        # clips start in queue order
+                    starts = [seen[(c, 0)][0] for c in range(len(lens))]
+                    assert starts == sorted(starts)
+                # never longer than lockstep batches of the same clips (longest first, B per batch)
+                ordered = sorted(lens, reverse=True)
+                lockstep = sum(ordered[i] for i in range(0, len(ordered), B))
+                if order == "longest_first":
+                    assert len(steps) <= lockstep
+    assert plan_slot_queue([3], 2) == [[(0, 0), None], [(0, 1), None], [(0, 2), None]]
+    import pytest
+    with pytest.raises(ValueError):
+        plan_slot_queue([3, 0], 2)
