@@ -538,21 +538,19 @@ def clips64(args, world, rank, local_rank, dev, dist):
         res = drv.run_clips([cache[c] for c in mine], num_frames=F_)
         t_issue = time.perf_counter() - t0             # host time to issue the clips (the GPU may still be running)
         allm = D.gather_masks(torch.stack([r.masks for r in res]), world)
-        host = allm.cpu().numpy()
-        t_masks = time.perf_counter() - t0             # masks of every rank in host memory
-        hashes = [None] * n_clips
-        for pos, cid in enumerate(D.unshard_order(n_clips, world)):
-            hashes[cid] = hashlib.sha256(host[pos].tobytes()).hexdigest()
-        sections = {"issued": round(t_issue, 4), "masks_on_host": round(t_masks, 4)}
     else:
-        hashes, allm, frames_run = D.run_sharded_clips(drv, n_clips, world, rank, lambda c: cache[c], F_)
-        sections = None
+        _, allm, frames_run = D.run_sharded_clips(drv, n_clips, world, rank, lambda c: cache[c], F_, hashes=False)
+        t_issue = None
+    host = allm.cpu().numpy()                          # the masks of every rank in host memory: end of the job
+    sections = {"issued": round(t_issue, 4) if t_issue is not None else None,
+                "masks_on_host": round(time.perf_counter() - t0, 4)}
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
+    hashes = D.hash_masks(host, n_clips, world)        # verification by-product, after the window (sha256 of 49 MB: 20-40 ms of host time)
     total_frames = n_clips * (F_ - 1)               # propagated frames (the reference frame is not a "frame/s" frame in evaluator.py:571-587)
     if rank == 0:
         print(json.dumps({
@@ -561,7 +559,7 @@ def clips64(args, world, rank, local_rank, dev, dist):
             "warmup": 1, "ms_per_step": 1e3 * elapsed / max(1, total_frames // world), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp16x3 (split-fp16 MFMA)", "data": "synthetic",
             "config": {"workload": f"R50-DeAOTL + RMem, 480p, K=4, {n_clips} clips x {F_} frames, {args.clips_per_rank} per rank "
-                                   f"(clip i -> rank i mod {world}), evaluator gap rule (gap {D.memory_gap(F_)}), reference frame + bank fill timed",
+                                   f"(clip i -> rank i mod {world}), evaluator gap rule (gap {D.memory_gap(F_)}), reference frame + bank fill + gather + copy of the masks to the host timed",
                        "clips": n_clips, "frames_per_clip": F_, "frames_per_sec_per_gpu": total_frames / elapsed / world,
                        "batched": bool(args.batched),
                        "per_rank_seconds": per_rank_s, "rank0_sections_s": sections,
@@ -571,7 +569,7 @@ def clips64(args, world, rank, local_rank, dev, dist):
                                       + ", one all-gather of uint8 masks "
                                       f"({allm.numel() / 1e6:.1f} MB)"},
             "clip_sha256": [h[:16] for h in hashes],
-            "masks_sha256": hashlib.sha256(allm.cpu().numpy().tobytes()).hexdigest()}))
+            "masks_sha256": hashlib.sha256(host.tobytes()).hexdigest()}))
     if dist is not None:
         dist.destroy_process_group()
 

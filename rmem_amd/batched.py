@@ -81,10 +81,18 @@ class BatchedLSTT:
         self.fg = z(self.B, self.N)
         self.maps_up = _Upload(self.B * 128, self.dev)
         maps_i32 = self.maps_up.dev.view(torch.int32).view(self.B, 32)
+        self.maps_i32 = maps_i32
+        # RMem eviction rule on the device, per clip (rmem_bank_policy_step; RMEM_HOST_POLICY=1: on the host, with ONE
+        # blocking device-to-host copy per long-term update for all clips): the bank maps then live on the device and a
+        # pass publishes only [short-term slot, slot of this frame] per clip
+        self.device_policy = os.environ.get("RMEM_HOST_POLICY") != "1"
+        self.short_up = _Upload(self.B * 8, self.dev)
+        self._short_host = np.zeros((self.B, 2), dtype=np.int32)
         for i, c in enumerate(self.clips):
             c.tgt, c.tgt_id, c.out, c.w_out = self.tgt[i], self.tgt_id[i], self.out[i], self.w_out[i]
             c.maps = maps_i32[i]
             c._batched = True
+            c.device_policy = self.device_policy
         self._labels: Dict[tuple, torch.Tensor] = {}
         self._recs: Dict[tuple, hip.Recording] = {}
         self._chan: Dict[tuple, _Upload] = {}
@@ -161,15 +169,25 @@ class BatchedLSTT:
         on = [True] * self.B if active is None else [bool(a) for a in active]
         self.tgt.copy_(emb_bnc)
         self.tgt_id.zero_()
-        stage = self.maps_up.stage().view(np.int32).reshape(self.B, 32)
-        if self._maps_host is not None:
-            stage[:] = self._maps_host                 # (inactive clips keep what they published last)
-        for i, c in enumerate(self.clips):
-            if on[i]:
-                c._prepare(ref[i])
-                stage[i, :18] = c._map_vals
-        self._maps_host = stage.copy()
-        self.maps_up.send()
+        if self.device_policy:             # bank maps on the device: [short, cur] per clip, scattered into the maps
+            stage = self.short_up.stage().view(np.int32).reshape(self.B, 2)
+            for i, c in enumerate(self.clips):
+                if on[i]:
+                    c._prepare(ref[i])         # (reference frame: rmem_bank_reset for that clip)
+                    self._short_host[i] = c._map_vals[16:18]
+            stage[:] = self._short_host        # (inactive clips keep what they published last)
+            self.short_up.send()
+            self.maps_i32[:, 16:18].copy_(self.short_up.dev.view(torch.int32).view(self.B, 2))
+        else:
+            stage = self.maps_up.stage().view(np.int32).reshape(self.B, 32)
+            if self._maps_host is not None:
+                stage[:] = self._maps_host
+            for i, c in enumerate(self.clips):
+                if on[i]:
+                    c._prepare(ref[i])
+                    stage[i, :18] = c._map_vals
+            self._maps_host = stage.copy()
+            self.maps_up.send()
         self._run("fwd", [(c.cur, c._T, ref[i]) if on[i] else () for i, c in enumerate(self.clips)],
                   lambda c: c._forward_device(ref[self.clips.index(c)]), on)
         for i, c in enumerate(self.clips):
@@ -202,24 +220,46 @@ class BatchedLSTT:
         e1.synchronize()
         return 1e3 * e0.elapsed_time(e1) / iters
 
-    def update_short_memories(self, update_long, active: Optional[List[bool]] = None):
-        """`update_long`: one flag or one per clip (clips of different lengths follow different gap schedules)."""
+    def update_short_memories(self, update_long, active: Optional[List[bool]] = None, frame_index=0):
+        """`update_long`: one flag or one per clip (clips of different lengths follow different gap schedules);
+        `frame_index`: the frame step(s) the engine appends to long_memories_indexes."""
         upd = [bool(u) for u in self._per_clip(update_long, self.B)]
+        fi = [int(f) for f in self._per_clip(frame_index, self.B)]
         self._run("upd", [(c.cur,) for c in self.clips], lambda c: c._update_device(upd[self.clips.index(c)]), active)
         for i, c in enumerate(self.clips):
             if active is None or active[i]:
-                c._update_host(upd[i])
+                c._update_host(upd[i], fi[i])
 
-    def restrict_long_memories(self, indexes: List[List[int]], fg_bn: torch.Tensor, active: Optional[List[bool]] = None):
+    def resolve_policy(self, block: bool = True) -> bool:
+        """Host views (clip.bank, the indexes lists handed to restrict_long_memories) up to date with the device-side
+        evictions of every clip."""
+        return all([c.resolve_policy(block) for c in self.clips])
+
+    def restrict_long_memories(self, indexes: List[List[int]], fg_bn: torch.Tensor, active: Optional[List[bool]] = None,
+                               wait: bool = False):
         """restrict_long_memories (transformer.py:880-991) for every (active) clip: one reduce launch per group of
-        clips with the same bank depth, ONE device-to-host copy, the EMA + UCB rule per clip on the host.  Returns
-        the dropped position (or None) per clip; None for an inactive clip."""
+        clips with the same bank depth, then per clip the EMA + UCB rule on the device (rmem_bank_policy_step:
+        nothing is read back here; `indexes[i]` and the clip's bank catch up in resolve_policy()) -- or, with
+        RMEM_HOST_POLICY=1, ONE device-to-host copy and the rule on the host.  Returns the dropped position (or
+        None) per clip when the rule ran on the host or `wait` is set, else None for every clip."""
         on = [True] * self.B if active is None else [bool(a) for a in active]
         if not any(on):
             return [None] * self.B
         self.fg.copy_(fg_bn)
         self._run("mass", [(c.mass_T,) for c in self.clips],
                   lambda c: c._mass_reduce_device(self.fg[self.clips.index(c)]), on)
+        if self.device_policy:
+            for i, c in enumerate(self.clips):
+                if on[i]:
+                    c._policy_device(indexes[i])
+            if not wait:
+                return [None] * self.B
+            drops = []
+            for i, c in enumerate(self.clips):
+                if on[i]:
+                    c.resolve_policy(block=True)
+                drops.append(c.last_policy["drop"] if on[i] and c.last_policy["drop"] >= 0 else None)
+            return drops
         T = max(c.mass_T for i, c in enumerate(self.clips) if on[i])
         w = self.w_out[:, :T].cpu().numpy().astype(np.float32)
         return [c._restrict_host(indexes[i], w[i, :c.mass_T]) if on[i] else None for i, c in enumerate(self.clips)]
@@ -273,6 +313,18 @@ class BatchedDeAOTEngine:
         if self.lstt is not None:
             self.lstt.clear_memory()
 
+    @property
+    def long_memories_indexes(self) -> List[List[int]]:
+        """Frame indexes of the bank slots, per clip (aot_engine.py:322, 346).  With the eviction rule on the device the
+        host's copy may lag by one decision per clip; reading it waits for those decisions."""
+        if self.__dict__.get("lstt") is not None:
+            self.lstt.resolve_policy(block=True)
+        return self._lmi
+
+    @long_memories_indexes.setter
+    def long_memories_indexes(self, v):
+        self._lmi = v
+
     # lockstep callers (every slot on the same frame) read and write one counter
     @property
     def frame_step(self) -> int:
@@ -295,7 +347,7 @@ class BatchedDeAOTEngine:
         queue when its clip ends (managers/evaluator.py:287-295); here the slot does, while the others carry on."""
         self.frame_steps[i], self.last_mem_steps[i] = 0, -1
         self.slot_gaps[i] = gap
-        self.long_memories_indexes[i] = []
+        self._lmi[i] = []
         self.active[i] = True
         self.lstt.clear_memory(i)
 
@@ -468,7 +520,7 @@ class BatchedDeAOTEngine:
                 self.restart_slot(i, gap)
                 lab[i].copy_(m.reshape(lab.shape[1:]).to(torch.uint8))
                 self.last_mem_steps[i] = 0
-                self.long_memories_indexes[i] = [0]
+                self._lmi[i] = [0]
             self.lstt.assign_identity(lab, ignore=False, active=[i in ref_slots for i in range(self.B)])
         self._ref_now = set(ref_slots)
         for i in range(self.B):
@@ -495,11 +547,12 @@ class BatchedDeAOTEngine:
                     upd[i] = True
                     self.last_mem_steps[i] = self.frame_steps[i]
         self.lstt.assign_identity(self._labels_u8(masks), ignore=True, active=on)
-        self.lstt.update_short_memories(upd, active=on)
+        # (a clip that appends to its bank first waits for its previous eviction -- `gap` frames ago, long since there)
+        self.lstt.update_short_memories(upd, active=on, frame_index=self.frame_steps)
         if any(upd):
-            for i, idx in enumerate(self.long_memories_indexes):
+            for i, idx in enumerate(self._lmi):
                 if upd[i]:
                     idx.append(self.frame_steps[i])
             lg = F.interpolate(self.pred_id_logits, size=self.enc_size_2d, mode="bilinear", align_corners=True)
             fg = (1 - torch.softmax(lg, dim=1)[:, 0]).reshape(self.B, -1).contiguous()
-            self.lstt.restrict_long_memories(self.long_memories_indexes, fg, active=upd)
+            self.lstt.restrict_long_memories(self._lmi, fg, active=upd)

@@ -60,15 +60,15 @@ def gather_masks(local_masks: torch.Tensor, world: int, group=None) -> torch.Ten
 
 
 def run_sharded_clips(driver, n_clips: int, world: int, rank: int, frames_of: Callable[[int], list],
-                      num_frames: int, group=None):
+                      num_frames: int, group=None, hashes: bool = True):
     """BASELINE.json configs[3]: `n_clips` independent clips, clip i on rank i mod world
     (tools/eval.py:137-143 and managers/evaluator.py:276-295 hand clips to processes through a queue;
     equal-length clips make the static shard as balanced), each through `driver.run_clip` (reference
     frame and bank fill included), then ONE all-gather of the uint8 masks
     (evaluator.py:589-613 funnels results through a queue instead).  Returns (sha256 per clip in
     clip-id order, gathered masks [n_clips, F-1, H0, W0] in gather order, frames run on this rank).
-    The hashes do not depend on `world`: what rank a clip runs on changes nothing it computes."""
-    import hashlib
+    The hashes do not depend on `world`: what rank a clip runs on changes nothing it computes.  hashes=False returns
+    None in their place (bench.py hashes after its timed window: hash_masks)."""
     if n_clips % world:
         raise ValueError("n_clips must be a multiple of the world size (pad the clip list)")
     local, frames_run = [], 0
@@ -77,11 +77,18 @@ def run_sharded_clips(driver, n_clips: int, world: int, rank: int, frames_of: Ca
         local.append(res.masks)
         frames_run += int(res.masks.shape[0])
     allm = gather_masks(torch.stack(local), world, group)
-    hashes: List[Optional[str]] = [None] * n_clips
-    host = allm.cpu().numpy()
+    return (hash_masks(allm, n_clips, world) if hashes else None), allm, frames_run
+
+
+def hash_masks(allm, n_clips: int, world: int) -> List[str]:
+    """sha256 per clip, in clip-id order, of gathered masks [n_clips, F-1, H0, W0] (a device tensor in gather order
+    -- rank-major, see unshard_order -- or its host copy as a numpy array)."""
+    import hashlib
+    host = allm.cpu().numpy() if isinstance(allm, torch.Tensor) else allm
+    out: List[Optional[str]] = [None] * n_clips
     for pos, cid in enumerate(unshard_order(n_clips, world)):
-        hashes[cid] = hashlib.sha256(host[pos].tobytes()).hexdigest()
-    return hashes, allm, frames_run
+        out[cid] = hashlib.sha256(host[pos].tobytes()).hexdigest()
+    return out
 
 
 def assign_clips_by_length(lengths: Sequence[int], world: int) -> List[List[int]]:

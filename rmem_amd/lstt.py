@@ -479,7 +479,10 @@ class DeAOTLSTT:
 
     @property
     def _dev_policy(self) -> bool:
-        return self.device_policy and not self._batched
+        """Eviction rule on the device (rmem_bank_policy_step) -- the default for one clip per launch, and for the clips of
+        rmem_amd.batched (BatchedLSTT switches it on: per clip the same tiny launches, no device-to-host copy on the
+        critical path); a DeAOTLSTT built with clips_per_launch > 1 on its own keeps the rule on the host."""
+        return self.device_policy
 
     def resolve_policy(self, block: bool = True) -> bool:
         """Bring the host's view of the bank (self.bank, the engine's long_memories_indexes) up to date with the
@@ -662,7 +665,8 @@ class DeAOTLSTT:
         vals = list(bank_map)[:16] + [0] * (16 - len(bank_map)) + [short, self.cur]
         self._map_vals = vals
         if self._dev_policy:               # the bank map lives on the device: only the short-term slots are published
-            hip.set_ints(self.maps, [short, self.cur], offset=16, count=2)
+            if not self._batched:          # (batched: one upload of [short, cur] for all clips, rmem_amd.batched)
+                hip.set_ints(self.maps, [short, self.cur], offset=16, count=2)
             if ref_frame:
                 self._pending = None
                 hip.check(hip.load().rmem_bank_reset(self.maps.data_ptr(), self.bank_state.data_ptr(), self.cur,
@@ -873,6 +877,11 @@ class DeAOTLSTT:
         if not self._dev_policy:
             w = self.w_out[:self.mass_T].cpu().numpy().astype(np.float32)        # the one D2H per long update
             return self._restrict_host(indexes, w)
+        return self._policy_device(indexes)
+
+    def _policy_device(self, indexes: List[int]) -> None:
+        """The EMA + UCB rule and the deletion of the dropped slot, queued on the stream after the mass reduction;
+        `indexes` and self.bank catch up in resolve_policy()."""
         self._policy_seq += 1
         hip.check(hip.load().rmem_bank_policy_step(
             self.maps.data_ptr(), self.bank_state.data_ptr(), self.w_out.data_ptr(), self.mass_T, self.cap,
