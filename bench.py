@@ -189,6 +189,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     local_rank = rank_device(local_rank)
+    from rmem_amd import hip as _hip
+    _hip.set_host_wait(local_rank)       # before this process touches the device: host waits sleep instead of spinning (RMEM_SPIN_WAIT=1: default)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = init_dist(world)
@@ -304,6 +306,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     cpu0 = time.process_time()                # user + system time of every thread of this process (main + graph launcher)
+    thr0 = thread_cpu_seconds()
     # Steady-state frames replay hipGraphs.  The dominant kernel is timed by HIP events on its launch stream INSIDE
     # replayed frames: on every fifth frame the LSTT is replayed as front graph | the fused read of layer 0 launched on
     # its own between two events | tail graph (engine._graphed_frame) -- same kernels, same order, the prefetched
@@ -321,6 +324,9 @@ def main():
     lstt._timing = False
     host_issue = time.perf_counter() - t0     # host-side launch time (GPU work still in flight)
     host_cpu = time.process_time() - cpu0     # CPU seconds this rank burned while issuing (all threads)
+    thr1 = thread_cpu_seconds()
+    host_threads = sorted(((1e3 * (v - thr0.get(k, 0.0)) / args.steps, k) for k, v in thr1.items()), reverse=True)
+    host_threads = {f"{name}#{i}": round(ms, 3) for i, (ms, name) in enumerate(host_threads[:6]) if ms > 0.005}
     for st in streams[1:]:
         streams[0].wait_stream(st)
     if dist is not None:                      # collect per-clip masks (the only exchange step)
@@ -369,7 +375,7 @@ def main():
                                f"batch={C} clip{'s' if C > 1 else ''} per GPU, long_term_mem_gap={args.gap}, steady-state bank (T={mem_k})",
                    "frames_per_sec_per_gpu": fps / world, "precision_nsplit": args.nsplit,
                    "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
-                   "host_cpu_ms_per_step": 1e3 * host_cpu / args.steps,
+                   "host_cpu_ms_per_step": 1e3 * host_cpu / args.steps, "host_cpu_ms_per_step_by_thread": host_threads,
                    "clips_per_gpu": C,
                    "parallelism": f"clips sharded {C}-per-GPU x{world}" + (" (one engine + HIP stream per clip)" if C > 1 else "")
                    + ", all-gather of masks"},
@@ -494,6 +500,24 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def thread_cpu_seconds():
+    """user + system CPU seconds of every thread of this process, keyed by (tid, name) (Linux /proc; {} elsewhere)."""
+    import threading
+    names = {t.native_id: t.name for t in threading.enumerate()}
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            with open(f"/proc/self/task/{tid}/stat") as f:
+                st = f.read()
+            comm = st[st.index("(") + 1:st.rindex(")")]
+            fields = st[st.rindex(")") + 2:].split()
+            out[f"{names.get(int(tid), comm)}:{tid}"] = (int(fields[11]) + int(fields[12])) / tick
+    except (OSError, ValueError):
+        return {}
+    return out
 
 
 def clips64(args, world, rank, local_rank, dev, dist):

@@ -37,6 +37,15 @@ typedef uint16_t rmem_f16;
 /* ABI version (bumped on any signature change). */
 int rmem_abi_version(void);
 
+/* How host threads of this process wait for `device` (hipSetDeviceFlags): blocking != 0 = sleep on the interrupt
+ * (hipDeviceScheduleBlockingSync), 0 = the runtime's default, which spins on a core.  The engine's host thread runs up
+ * to `long_term_mem_gap` frames ahead of the GPU and waits for it at every long-term memory update
+ * (the reference waits in every frame: `.item()` / `.cpu()` in engines/aot_engine.py:350-356 and
+ * networks/layers/transformer.py:880-991) -- with the default that wait costs one core per rank, all the time.
+ * Call before the process first touches the device for the full effect (later calls reach only streams created
+ * afterwards).  Leaves the calling thread's current device unchanged. */
+int rmem_set_host_wait(int32_t device, int32_t blocking);
+
 /* ------------------------------------------------------------------ linear layers
  * D = act(X . Y^T + bias) on the fp16 MFMA pipe (v_mfma_f32_32x32x16_f16).  X is [M][K], Y is [N][K] (both
  * K-contiguous planes), D is [M][N].  Either operand may be continued along K by a

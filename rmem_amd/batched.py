@@ -58,7 +58,7 @@ class _Upload:
 
     def send(self):
         self.dev.copy_(self.pin[self.k], non_blocking=True)
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(blocking=True)          # (a host that waits for a ring slot sleeps instead of spinning)
         ev.record(torch.cuda.current_stream())
         self.done[self.k] = ev
 
@@ -282,6 +282,8 @@ class BatchedDeAOTEngine:
         if use_graphs is None:
             use_graphs = os.environ.get("RMEM_NO_GRAPHS") is None
         self.use_graphs = bool(use_graphs)
+        if next(aot_model.parameters()).is_cuda:
+            hip.set_host_wait(next(aot_model.parameters()).device.index or 0)    # host waits sleep instead of spinning
         if fold_bn and next(aot_model.parameters()).is_cuda:
             aot_model.optimize_for_inference(True)
         self.lstt: Optional[BatchedLSTT] = None

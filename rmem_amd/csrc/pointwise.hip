@@ -1289,4 +1289,18 @@ extern "C" int rmem_set_ints(int32_t* dst, const int32_t* host_vals, int32_t n, 
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 14; }   // 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_set_host_wait(int32_t device, int32_t blocking) {
+  int n = 0, prev = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RMEM_ERR_INVALID;
+  const bool had = hipGetDevice(&prev) == hipSuccess;
+  if (hipSetDevice(device) != hipSuccess) return RMEM_ERR_INVALID;
+  const hipError_t e = hipSetDeviceFlags(blocking ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
+  if (had && prev != device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return RMEM_ERR_LAUNCH;
+  }
+  return RMEM_OK;
+}
+
+extern "C" int rmem_abi_version(void) { return 15; }   // 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

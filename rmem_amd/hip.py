@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from typing import Optional
 
 import torch
 
@@ -93,7 +94,7 @@ class LabelSrc(C.Structure):
 
 
 EXPORTS = [
-    "rmem_abi_version", "rmem_linear", "rmem_linear_trace",
+    "rmem_abi_version", "rmem_set_host_wait", "rmem_linear", "rmem_linear_trace",
     "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_fg_weights", "rmem_bank_reset", "rmem_bank_append",
     "rmem_bank_policy_step", "rmem_split_planes", "rmem_groupnorm_nchw",
@@ -114,7 +115,7 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 14          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
+ABI_VERSION = 15          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
 
 
 def load():
@@ -188,6 +189,29 @@ def load():
 
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+_HOST_WAIT: dict = {}
+
+
+def set_host_wait(device_index: int = 0, blocking: Optional[bool] = None) -> bool:
+    """Host threads that wait for `device_index` sleep instead of spinning (rmem_set_host_wait, include/rmem_hip.h).
+    The engine thread runs ahead of the GPU and waits for it at every long-term memory update; the runtime's default
+    turns that into one busy core per rank (bench.py: 3.7 ms of CPU per 1.9 ms frame before, see
+    profiles/r04_host_cpu_blocking_wait.txt).  blocking=None: on unless RMEM_SPIN_WAIT=1.  Full effect when called
+    before the process first touches the device (bench.py does; the engines call it when they are built, which
+    reaches the streams created from then on).  Returns whether the flag was set."""
+    if blocking is None:
+        blocking = os.environ.get("RMEM_SPIN_WAIT") != "1"
+    key = int(device_index)
+    if _HOST_WAIT.get(key) == bool(blocking):
+        return True
+    lib = load()
+    lib.rmem_set_host_wait.argtypes = [i32, i32]
+    ok = lib.rmem_set_host_wait(key, int(bool(blocking))) == 0
+    if ok:
+        _HOST_WAIT[key] = bool(blocking)
+    return ok
 
 
 def ptr(t):
