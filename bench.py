@@ -190,7 +190,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     local_rank = rank_device(local_rank)
     from rmem_amd import hip as _hip
-    _hip.set_host_wait(local_rank)       # before this process touches the device: host waits sleep instead of spinning (RMEM_SPIN_WAIT=1: default)
+    _hip.set_host_wait(local_rank)       # RMEM_BLOCKING_WAIT=1 only (opt-in, before this process touches the device): see rmem_amd.hip.set_host_wait
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = init_dist(world)
@@ -300,6 +300,11 @@ def main():
     lstt = sub.lstt
     lstt.enable_kernel_timing(True)       # clears the event list
     lstt._timing = False
+    if dist is not None:                  # warm-up of the exchange step too: the first all-gather of a shape sets up RCCL's
+        from rmem_amd.driver import gather_masks      # channels and buffers (the timed region ends with the same call)
+        del_me = gather_masks(masks, world)
+        torch.cuda.synchronize()
+        del del_me
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -450,6 +455,11 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
         step(t)
         t += 1
     masks = torch.zeros(B, args.steps, H_OUT, W_OUT, dtype=torch.uint8, device=dev)
+    if dist is not None:                  # warm-up of the exchange step (RCCL channels / buffers of this shape)
+        from rmem_amd.driver import gather_masks
+        del_me = gather_masks(masks, world)
+        torch.cuda.synchronize()
+        del del_me
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -558,6 +568,10 @@ def clips64(args, world, rank, local_rank, dev, dist):
     host_pin = torch.empty((n_clips, F_ - 1, H_OUT, W_OUT), dtype=torch.uint8)
     if dev.type == "cuda":
         host_pin = host_pin.pin_memory()
+    if dist is not None:                  # warm-up of the exchange step (RCCL channels / buffers of this shape)
+        del_me = D.gather_masks(torch.zeros((len(mine), F_ - 1, H_OUT, W_OUT), dtype=torch.uint8, device=dev), world)
+        torch.cuda.synchronize()
+        del del_me
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -43,7 +43,9 @@ int rmem_abi_version(void);
  * (the reference waits in every frame: `.item()` / `.cpu()` in engines/aot_engine.py:350-356 and
  * networks/layers/transformer.py:880-991) -- with the default that wait costs one core per rank, all the time.
  * Call before the process first touches the device for the full effect (later calls reach only streams created
- * afterwards).  Leaves the calling thread's current device unchanged. */
+ * afterwards).  Leaves the calling thread's current device unchanged.  OPT-IN (the Python host calls it only with
+ * RMEM_BLOCKING_WAIT=1): with two processes sharing one GPU the first MIOpen convolution never returned under this flag
+ * on ROCm 7.2; the host side's one long wait polls with a 0.2 ms sleep instead (rmem_amd/hip.py: wait_event). */
 int rmem_set_host_wait(int32_t device, int32_t blocking);
 
 /* ------------------------------------------------------------------ linear layers

@@ -53,12 +53,12 @@ class _Upload:
         """The pinned buffer to fill next (waits until the copy that last read it has run)."""
         self.k = (self.k + 1) % self.RING
         if self.done[self.k] is not None:
-            self.done[self.k].synchronize()
+            hip.wait_event(self.done[self.k])
         return self.np[self.k]
 
     def send(self):
         self.dev.copy_(self.pin[self.k], non_blocking=True)
-        ev = torch.cuda.Event(blocking=True)          # (a host that waits for a ring slot sleeps instead of spinning)
+        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.done[self.k] = ev
 
@@ -283,7 +283,7 @@ class BatchedDeAOTEngine:
             use_graphs = os.environ.get("RMEM_NO_GRAPHS") is None
         self.use_graphs = bool(use_graphs)
         if next(aot_model.parameters()).is_cuda:
-            hip.set_host_wait(next(aot_model.parameters()).device.index or 0)    # host waits sleep instead of spinning
+            hip.set_host_wait(next(aot_model.parameters()).device.index or 0)     # (RMEM_BLOCKING_WAIT=1 only: opt-in, hip.set_host_wait)
         if fold_bn and next(aot_model.parameters()).is_cuda:
             aot_model.optimize_for_inference(True)
         self.lstt: Optional[BatchedLSTT] = None

@@ -665,7 +665,7 @@ class DeAOTInferEngine(nn.Module):
         self.AOT = aot_model
         if next(aot_model.parameters()).is_cuda:
             from . import hip
-            hip.set_host_wait(next(aot_model.parameters()).device.index or 0)     # host waits for the GPU sleep instead of spinning (hip.set_host_wait)
+            hip.set_host_wait(next(aot_model.parameters()).device.index or 0)     # (RMEM_BLOCKING_WAIT=1 only: opt-in, hip.set_host_wait)
         if fold_bn and hasattr(aot_model, "optimize_for_inference") and \
                 next(aot_model.parameters()).is_cuda:
             aot_model.optimize_for_inference(True)     # weights must already be loaded / on device

@@ -195,14 +195,15 @@ _HOST_WAIT: dict = {}
 
 
 def set_host_wait(device_index: int = 0, blocking: Optional[bool] = None) -> bool:
-    """Host threads that wait for `device_index` sleep instead of spinning (rmem_set_host_wait, include/rmem_hip.h).
-    The engine thread runs ahead of the GPU and waits for it at every long-term memory update; the runtime's default
-    turns that into one busy core per rank (bench.py: 3.7 ms of CPU per 1.9 ms frame before, see
-    profiles/r04_host_cpu_blocking_wait.txt).  blocking=None: on unless RMEM_SPIN_WAIT=1.  Full effect when called
-    before the process first touches the device (bench.py does; the engines call it when they are built, which
-    reaches the streams created from then on).  Returns whether the flag was set."""
+    """rmem_set_host_wait (include/rmem_hip.h): every host wait for `device_index` sleeps on the interrupt
+    (hipDeviceScheduleBlockingSync) instead of spinning.  OPT-IN (blocking=None: only with RMEM_BLOCKING_WAIT=1):
+    with two processes sharing one GPU the first MIOpen convolution never returns under this flag
+    (profiles/r04_host_cpu_blocking_wait.md), and the one long wait of the frame loop is handled without it
+    (wait_event below).  Returns whether the flag was set."""
     if blocking is None:
-        blocking = os.environ.get("RMEM_SPIN_WAIT") != "1"
+        blocking = os.environ.get("RMEM_BLOCKING_WAIT") == "1"
+        if not blocking:
+            return False
     key = int(device_index)
     if _HOST_WAIT.get(key) == bool(blocking):
         return True
@@ -212,6 +213,22 @@ def set_host_wait(device_index: int = 0, blocking: Optional[bool] = None) -> boo
     if ok:
         _HOST_WAIT[key] = bool(blocking)
     return ok
+
+
+def wait_event(ev) -> None:
+    """Wait for a HIP event WITHOUT burning a core: poll + sleep 0.2 ms.  The engine thread runs up to
+    `long_term_mem_gap` frames ahead of the GPU and waits for it once per long-term update (resolve_policy); the
+    runtime's hipEventSynchronize spins for the whole wait -- 0.88 of every 1.12 s of the bench loop -- and
+    torch.cuda.Event(blocking=True) does not change that on this ROCm.  The sleep's latency (< 0.3 ms) is hidden: the
+    host is frames ahead.  RMEM_SPIN_WAIT=1: the runtime's wait."""
+    if ev.query():
+        return
+    if os.environ.get("RMEM_SPIN_WAIT") == "1":
+        ev.synchronize()
+        return
+    import time
+    while not ev.query():
+        time.sleep(2e-4)
 
 
 def ptr(t):

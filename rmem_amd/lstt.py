@@ -492,7 +492,7 @@ class DeAOTLSTT:
             return True
         if not block and not p["event"].query():
             return False
-        p["event"].synchronize()
+        hip.wait_event(p["event"])        # (the host is up to `gap` frames ahead: the one long wait of the frame loop; sleeps, does not spin)
         res = self.policy_result
         if int(res[0]) != p["seq"]:
             raise hip.RmemError(f"eviction result out of sequence ({int(res[0])} != {p['seq']})")
@@ -886,10 +886,7 @@ class DeAOTLSTT:
         hip.check(hip.load().rmem_bank_policy_step(
             self.maps.data_ptr(), self.bank_state.data_ptr(), self.w_out.data_ptr(), self.mass_T, self.cap,
             self.cfg.FORMER_MEM_LEN, self.policy_result.data_ptr(), hip.stream_ptr()), "rmem_bank_policy_step")
-        # blocking=True (hipEventBlockingSync): the host runs up to `gap` frames ahead of the GPU and waits HERE for it at
-        # every long-term update (resolve_policy from _update_host); a default event makes that wait a spin on a core
-        # (measured: 0.88 of every 1.12 s of the bench loop, one more core in the runtime's helper thread)
-        ev = torch.cuda.Event(blocking=os.environ.get("RMEM_SPIN_WAIT") != "1")
+        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._pending = dict(event=ev, seq=self._policy_seq, indexes=indexes, expect_drop=len(self.bank) > self.cap)
         return None

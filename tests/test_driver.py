@@ -180,6 +180,9 @@ def _sharded_hip_worker(rank, world, port, q, n_clips, frames, H, W, product=Fal
     from rmem_amd.model import build_vos_model
     from rmem_amd.synth import load_synthetic_weights
     from sandwich import SandwichInferEngine
+    import faulthandler
+    # a worker that hangs dumps every thread's stack and exits instead of running into the parent's queue timeout
+    faulthandler.dump_traceback_later(int(os.environ.get("RMEM_TEST_WATCHDOG", "600")), exit=True)
     torch.cuda.set_device(0)
     torch.set_num_threads(4)
     if world > 1:
@@ -204,6 +207,7 @@ def _sharded_hip_worker(rank, world, port, q, n_clips, frames, H, W, product=Fal
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 @pytest.mark.gpu
