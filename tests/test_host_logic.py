@@ -510,3 +510,47 @@ def test_slot_queue_plan_serves_every_frame_once_without_idle_slots():
     import pytest
     with pytest.raises(ValueError):
         plan_slot_queue([3, 0], 2)
+
+
+def test_wait_event_polls_without_the_runtime_wait(monkeypatch):
+    """hip.wait_event: the engine thread's long wait (resolve_policy) polls event.query() with a short sleep instead of
+    the runtime's spinning hipEventSynchronize; RMEM_SPIN_WAIT=1 selects the runtime's wait."""
+    from rmem_amd import hip
+
+    class Ev:
+        def __init__(self, ready_after):
+            self.n, self.ready_after, self.synced = 0, ready_after, 0
+
+        def query(self):
+            self.n += 1
+            return self.n > self.ready_after
+
+        def synchronize(self):
+            self.synced += 1
+
+    monkeypatch.delenv("RMEM_SPIN_WAIT", raising=False)
+    e = Ev(0)
+    hip.wait_event(e)
+    assert e.n == 1 and e.synced == 0                # already complete: one query, no wait
+    e = Ev(5)
+    hip.wait_event(e)
+    assert e.n == 6 and e.synced == 0
+    monkeypatch.setenv("RMEM_SPIN_WAIT", "1")
+    e = Ev(5)
+    hip.wait_event(e)
+    assert e.synced == 1 and e.n == 1
+
+
+def test_hash_masks_follows_the_gather_order():
+    """driver.hash_masks: sha256 per clip in clip-id order from masks in gather order (rank-major, unshard_order)."""
+    import hashlib
+    import numpy as np
+    import torch
+    from rmem_amd import driver as D
+    n, world = 6, 3
+    rs = np.random.RandomState(0)
+    per_clip = [rs.randint(0, 4, (2, 5, 7)).astype(np.uint8) for _ in range(n)]
+    gathered = np.stack([per_clip[c] for r in range(world) for c in D.shard_clips(n, world, r)])
+    want = [hashlib.sha256(m.tobytes()).hexdigest() for m in per_clip]
+    assert D.hash_masks(gathered, n, world) == want
+    assert D.hash_masks(torch.from_numpy(gathered), n, world) == want
