@@ -427,6 +427,14 @@ class BatchedDeAOTEngine:
     def _decode_eager(self, enc, osz):
         h, w = self.enc_size_2d
         emb = self.lstt.out.view(self.B, h, w, 512).permute(0, 3, 1, 2)
+        if enc[-1].shape[0] == 1 and self.B > 1:
+            # ONE image shared by all slots (the sub-engines of a many-object clip): the encoder ran at batch 1; the
+            # decoder's inputs get the clip axis here (views; the skip-adapter outputs are read by a HIP kernel: copies)
+            from .model import FeatureList
+            shared = enc
+            enc = FeatureList([e.expand(self.B, -1, -1, -1) for e in shared])
+            if getattr(shared, "adapters", None) is not None:
+                enc.adapters = [a.expand(self.B, -1, -1, -1).contiguous() for a in shared.adapters]
         logits = self.AOT.decoder([enc[-1], emb], enc)
         for b, obj_num in enumerate(self.obj_nums):
             logits[b, (obj_num + 1):] = -1e10
@@ -467,14 +475,13 @@ class BatchedDeAOTEngine:
     @torch.no_grad()
     def add_reference_frame(self, imgs, masks, obj_nums, frame_step: int = -1):
         """aot_engine.py:241-325 for B clips.  obj_nums: one object count per clip."""
-        if len(obj_nums) != self.B or imgs.shape[0] != self.B:
-            raise ValueError("one image, mask and object count per clip")
+        if len(obj_nums) != self.B or imgs.shape[0] not in (1, self.B):
+            raise ValueError("one mask and object count per clip; one image per clip, or ONE image shared by all slots "
+                             "(the sub-engines of a clip with more than 10 objects, DeAOTInferEngine)")
         self.obj_nums = [int(n) for n in obj_nums]
         if any(n > self.AOT.max_obj_num for n in self.obj_nums):
             raise NotImplementedError(f"more than {self.AOT.max_obj_num} objects per clip: use DeAOTInferEngine (one sub-engine "
                                       "per 10 objects, engines/aot_engine.py:675-702)")
-        if frame_step == -1:
-            frame_step = self.frame_step
         self._drop_pending()
         if self._stale_weights() and (self._eg or self._dg):    # load_network() since the graphs were captured
             torch.cuda.synchronize()
@@ -486,8 +493,10 @@ class BatchedDeAOTEngine:
         # no ignore channel on reference frames (aot_engine.py:304 -> :209-213)
         self.lstt.assign_identity(self._labels_u8(masks), ignore=False)
         self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=True)
-        self.last_mem_step = frame_step
-        self.long_memories_indexes = [[self.frame_step] for _ in range(self.B)]
+        # per slot, as every engine of the reference does for itself (aot_engine.py:241-325: last_mem_step := the
+        # frame_step argument, or the engine's own counter; long_memories_indexes := [its own counter])
+        self.last_mem_steps = list(self.frame_steps) if frame_step == -1 else [int(frame_step)] * self.B
+        self.long_memories_indexes = [[fs] for fs in self.frame_steps]
         self.pred_id_logits, _ = self._decode(enc, None, imgs.is_cuda)
 
     @torch.no_grad()

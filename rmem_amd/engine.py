@@ -644,8 +644,39 @@ class DeAOTEngine(nn.Module):
                 self.lstt.restrict_long_memories(idx, fg)
 
 
+class _SubEngineView:
+    """What callers read from `DeAOTInferEngine.aot_engines[i]` when the sub-engines of a many-object clip are the
+    slots of ONE rmem_amd.batched.BatchedDeAOTEngine (shared launches of the memory path)."""
+
+    def __init__(self, bat, i: int):
+        self.bat, self.i = bat, i
+
+    long_memories_indexes = property(lambda self: self.bat.long_memories_indexes[self.i])
+    pred_id_logits = property(lambda self: self.bat.pred_id_logits[self.i:self.i + 1])
+    frame_step = property(lambda self: self.bat.frame_steps[self.i])
+    last_mem_step = property(lambda self: self.bat.last_mem_steps[self.i])
+    input_size_2d = property(lambda self: self.bat.input_size_2d)
+    enc_size_2d = property(lambda self: self.bat.enc_size_2d)
+    enc_hw = property(lambda self: self.bat.enc_hw)
+    obj_nums = property(lambda self: [self.bat.obj_nums[self.i]])
+
+    @property
+    def lstt(self):
+        return self.bat.lstt.clips[self.i]
+
+    def restart_engine(self):
+        if self.i == 0:
+            self.bat.restart_engine()
+
+
 class DeAOTInferEngine(nn.Module):
-    """Multi-object wrapper (engines/aot_engine.py:571-725, deaot_engine.py:20-56)."""
+    """Multi-object wrapper (engines/aot_engine.py:571-725, deaot_engine.py:20-56).
+
+    More than `max_aot_obj_num` objects -> one sub-engine per 10 ids (aot_engine.py:675-702).  On the GPU with the DeAOT
+    block the sub-engines are the slots of ONE BatchedDeAOTEngine: the image is encoded once, every launch of the memory
+    path serves all sub-engines, the decoder runs at batch = number of sub-engines and the frame replays hipGraphs
+    (RMEM_MULTI_ENGINE=serial: one DeAOTEngine after the other, eagerly issued, as before round 4
+    -- also what the AOT block and substituted engines use)."""
 
     supports_prefetch = True      # match_propogate_one_frame accepts next_img
 
@@ -679,14 +710,50 @@ class DeAOTInferEngine(nn.Module):
         self.nsplit = nsplit
         self.aot_engines: List[DeAOTEngine] = []
         self._pool: List[DeAOTEngine] = []     # engines (and their HBM buffers) are reused across clips
+        self._bat = None                       # the BatchedDeAOTEngine whose slots are the sub-engines (> 10 objects), or None
+        self._bat_pool: dict = {}              # number of sub-engines -> BatchedDeAOTEngine, reused across clips
         self.restart_engine()
 
     def restart_engine(self):                                   # aot_engine.py:598-602
         for e in self.aot_engines:
             e.restart_engine()
-        self._pool = self.aot_engines + [e for e in self._pool if e not in self.aot_engines]
+        singles = [e for e in self.aot_engines if isinstance(e, DeAOTEngine)]
+        self._pool = singles + [e for e in self._pool if e not in singles]
         self.aot_engines = []
+        self._bat = None
         self.obj_nums = None
+
+    def _batched_ok(self, n: int) -> bool:
+        """Sub-engines as slots of one batched engine: DeAOT block on the GPU, product sub-engines (tests substitute
+        theirs through _new_engine), not switched off."""
+        return (n > 1 and self.cfg.MODEL_VOS == "deaot" and next(self.AOT.parameters()).is_cuda
+                and type(self)._new_engine is DeAOTInferEngine._new_engine
+                and os.environ.get("RMEM_MULTI_ENGINE", "batched") != "serial")
+
+    def _add_reference_batched(self, img, mask, aot_num: int, frame_step: int):
+        from .batched import BatchedDeAOTEngine
+        # every engine of the reference keeps its own frame counter: those that exist carry on, new ones start at 0
+        counters = [int(e.frame_step) for e in self.aot_engines][:aot_num]
+        counters += [0] * (aot_num - len(counters))
+        bat = self._bat
+        if bat is None or bat.B != aot_num:
+            singles = [e for e in self.aot_engines if isinstance(e, DeAOTEngine)]      # (a clip that grows past 10 objects)
+            for e in singles:
+                e.restart_engine()
+            self._pool = singles + [e for e in self._pool if e not in singles]
+            bat = self._bat_pool.get(aot_num)
+            if bat is None:
+                bat = self._bat_pool[aot_num] = BatchedDeAOTEngine(
+                    self.AOT, aot_num, gpu_id=self.gpu_id, long_term_mem_gap=self.long_term_mem_gap, nsplit=self.nsplit,
+                    use_graphs=self.use_graphs)
+            bat.restart_engine()
+        bat.long_term_mem_gap = self.long_term_mem_gap
+        bat.frame_steps = counters
+        self._bat = bat
+        self.aot_engines = [_SubEngineView(bat, i) for i in range(aot_num)]
+        masks = torch.cat([m.reshape(1, 1, *m.shape[-2:]) for m in self.separate_mask(mask)])
+        bat.add_reference_frame(img, masks, obj_nums=[self.max_aot_obj_num] * aot_num, frame_step=frame_step)
+        self.update_size()
 
     def _new_engine(self) -> DeAOTEngine:
         """One sub-engine (<= max_aot_obj_num objects); tests substitute engines that run the encoder and
@@ -726,6 +793,9 @@ class DeAOTInferEngine(nn.Module):
             obj_nums = obj_nums[0]
         self.obj_nums = obj_nums
         aot_num = max(int(np.ceil(obj_nums / self.max_aot_obj_num)), 1)
+        aot_num = max(aot_num, len(self.aot_engines))           # (engines are never dropped inside a clip: `while aot_num > len`)
+        if self._batched_ok(aot_num):
+            return self._add_reference_batched(img, mask, aot_num, frame_step)
         while aot_num > len(self.aot_engines):
             if self._pool:
                 eng = self._pool.pop(0)
@@ -748,12 +818,20 @@ class DeAOTInferEngine(nn.Module):
         if len(self.aot_engines) == 1:
             return self.aot_engines[0].match_propogate_one_frame(img, mask=mask, output_size=output_size,
                                                                  next_img=next_img)
+        if self._bat is not None:
+            nxt = next_img[0] if isinstance(next_img, (list, tuple)) and next_img else next_img
+            lg = self._bat.match_propogate_one_frame(img, output_size=output_size,
+                                                     next_imgs=nxt if torch.is_tensor(nxt) else None)
+            return self.soft_logit_aggregation([lg[i:i + 1] for i in range(self._bat.B)])
         img_embs = self.AOT.encode_image(img)
         all_logits = [e.match_propogate_one_frame(img, img_embs=img_embs, mask=mask, output_size=output_size)
                       for e in self.aot_engines]
         return self.soft_logit_aggregation(all_logits)
 
     def update_memory(self, curr_mask):                         # aot_engine.py:714-720
+        if self._bat is not None:
+            return self._bat.update_memory(torch.cat([m.reshape(1, 1, *m.shape[-2:])
+                                                      for m in self.separate_mask(curr_mask)]))
         for eng, m in zip(self.aot_engines, self.separate_mask(curr_mask)):
             eng.update_short_term_memory(m)
 

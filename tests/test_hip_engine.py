@@ -296,8 +296,11 @@ def test_480p_lstt_isolated_from_miopen(golden_dir):
     assert max(lerr.values()) < 2e-2
 
 
-def test_multi_object_engines():
-    """12 objects -> two sub-engines (engines/aot_engine.py:604-712).  The reference cannot run
+@pytest.mark.parametrize("mode", ["batched", "serial"])
+def test_multi_object_engines(mode, monkeypatch):
+    """mode: the sub-engines as slots of ONE BatchedDeAOTEngine (default: image encoded once, shared launches of the
+    memory path, hipGraph replay) or one DeAOTEngine after the other (RMEM_MULTI_ENGINE=serial).
+    12 objects -> two sub-engines (engines/aot_engine.py:604-712).  The reference cannot run
     this case (its sub-engines share one LSTT memory state and crash, see
     tests/golden/make_golden.py), so the HIP wrapper is compared with the oracle's restatement of
     the wrapper with per-engine state (oracle.engine_ref.OracleDeAOTInferEngine: separate_mask,
@@ -306,6 +309,7 @@ def test_multi_object_engines():
     from inputs import multiobj_label
     from oracle.engine_ref import OracleDeAOTInferEngine
     from rmem_amd.synth import synth_clip
+    monkeypatch.setenv("RMEM_MULTI_ENGINE", mode)
     H, W, frames = 97, 129, 7
     imgs, _ = synth_clip(21, frames, H, W, 3)
     lab = multiobj_label(H, W, 12)
@@ -315,6 +319,7 @@ def test_multi_object_engines():
     eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[12], frame_step=0)
     ora.add_reference_frame(imgs[0], lab, obj_nums=[12], frame_step=0)
     assert len(eng.aot_engines) == 2 and len(ora.engines) == 2
+    assert (eng._bat is not None) == (mode == "batched")
     mism, lerr = [], []
     for t in range(1, frames):
         logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(H, W))
@@ -333,6 +338,59 @@ def test_multi_object_engines():
     print("12 objects / 2 engines: mismatching pixels per frame (of %d):" % (H * W), mism, "logit err:", lerr)
     assert int(torch.argmax(lo, dim=1).max()) > 10          # ids of the second engine do appear
     assert max(mism) <= 2 and max(lerr) < 5e-3, (mism, lerr)
+
+
+def test_clip_that_grows_past_ten_objects_batched_equals_serial():
+    """A clip that starts with 3 objects (one engine) and is re-referenced with 12 at frame 3 (aot_engine.py:675-702: a
+    second sub-engine appears; the first keeps its frame counter, the new one starts at 0), then with 23 at frame 6
+    (three sub-engines).  The batched wrapper (sub-engines = slots of one BatchedDeAOTEngine, rebuilt at the new size
+    on each growth) against the serial one, teacher-forced with the serial run's labels: eviction bookkeeping equal per
+    sub-engine and frame, aggregated logits within 5e-3 where the 1e-5 probability clamp is not active, label maps
+    within two near-tie pixels."""
+    from inputs import multiobj_label
+    from rmem_amd.synth import synth_clip
+    H, W, frames = 97, 129, 10
+    imgs, lab3 = synth_clip(23, frames, H, W, 3)
+    imgs = [x.to(DEV) for x in imgs]
+    refs = {0: (lab3.to(DEV), 3), 3: (multiobj_label(H, W, 12).to(DEV), 12), 6: (multiobj_label(H, W, 23).to(DEV), 23)}
+
+    def run(mode, fed):
+        os.environ["RMEM_MULTI_ENGINE"] = mode
+        try:
+            _, _, _, eng = _build(1, 3, 2)
+            out = []
+            for t in range(frames):
+                if t in refs and t > 0:
+                    # (the driver re-references AFTER propagating the frame: evaluator.py:484-508)
+                    lg = eng.match_propogate_one_frame(imgs[t], output_size=(H, W))
+                    eng.add_reference_frame(imgs[t], refs[t][0], obj_nums=[refs[t][1]], frame_step=t)
+                    out.append((lg.clone(), [list(e.long_memories_indexes) for e in eng.aot_engines], len(eng.aot_engines)))
+                    continue
+                if t == 0:
+                    eng.add_reference_frame(imgs[0], refs[0][0], obj_nums=[3], frame_step=0)
+                    continue
+                lg = eng.match_propogate_one_frame(imgs[t], output_size=(H, W))
+                lab = torch.argmax(lg, dim=1, keepdim=True).float() if fed is None else fed[t]
+                cur = F.interpolate(lab, size=eng.input_size_2d, mode="nearest")
+                eng.update_memory(cur)
+                out.append((lg.clone(), [list(e.long_memories_indexes) for e in eng.aot_engines], len(eng.aot_engines), lab))
+            return out, eng
+        finally:
+            os.environ.pop("RMEM_MULTI_ENGINE", None)
+    ser, eng_s = run("serial", None)
+    fed = {t + 1: o[3] for t, o in enumerate(ser) if len(o) == 4}
+    bat, eng_b = run("batched", fed)
+    assert eng_s._bat is None and eng_b._bat is not None and eng_b._bat.B == 3
+    assert [o[2] for o in ser] == [o[2] for o in bat] == [1, 1, 2, 2, 2, 3, 3, 3, 3]
+    mism, lerr = [], []
+    for t, (a, b) in enumerate(zip(ser, bat)):
+        assert a[1] == b[1], (t, a[1], b[1])
+        act = a[0].abs() < 11.0
+        lerr.append(float((a[0] - b[0])[act].abs().max()))
+        mism.append(int((a[0].argmax(1) != b[0].argmax(1)).sum()))
+    print("grow 3 -> 12 -> 23 objects, batched vs serial: mismatching pixels", mism, "logit err", lerr)
+    assert max(mism) <= 2 and max(lerr) < 5e-3, (mism, lerr)
+    assert int(ser[-1][0].argmax(1).max()) > 10
 
 
 def test_prefetch_lookahead_ring():
