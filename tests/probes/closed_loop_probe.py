@@ -5,11 +5,11 @@ scaled by s.  With the default synthetic weights the loop amplifies a single nea
 (tests/test_oracle_golden.py); this probe looks for a gain at which the loop is stable AND the
 memory still moves the masks (labels differ from a run whose memory never sees the labels).
 
-    python tools/closed_loop_probe.py [--frames 16] [--scales 1,0.5,0.25,0.1]
+    python tests/probes/closed_loop_probe.py [--frames 16] [--scales 1,0.5,0.25,0.1]
 """
 import argparse, copy, os, sys
 import numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def run(engine, imgs, lab, dev, H, W, frames, feed_zero=False):

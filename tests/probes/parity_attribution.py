@@ -17,7 +17,7 @@ Environment switches are applied by the caller (one process per setting):
   MIOPEN_DEBUG_CONV_WINOGRAD=0   no Winograd solvers
   RMEM_P16=1                     bank reads with P as one fp16 plane
 
-    python tools/parity_attribution.py --tag base --out gpurun_out/parity_base.json
+    python tests/probes/parity_attribution.py --tag base --out gpurun_out/parity_base.json
 """
 from __future__ import annotations
 
@@ -31,7 +31,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 

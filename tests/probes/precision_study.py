@@ -4,7 +4,7 @@ probabilities P and/or the values V (and optionally Q/K of the score GEMM) are r
 given MFMA operand plan would carry them; the clip is run teacher-forced like
 tests/test_oracle_golden.py::test_480p_clip and mismatching pixels per frame are printed.
 
-  python tools/precision_study.py p16_v16x2 p16_v16 pbf_vbf p16@long p16_v16@self,win ...
+  python tests/probes/precision_study.py p16_v16x2 p16_v16 pbf_vbf p16@long p16_v16@self,win ...
   (@long / @self / @win restricts a plan to the long-term, self or windowed short-term read)
 
 plan tokens:  p16 = P as one fp16 plane        pbf = P as one bf16 plane     pbfx2 = bf16 hi+lo
@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
