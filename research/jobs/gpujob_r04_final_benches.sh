@@ -2,9 +2,9 @@
 # the bench lines of every configuration on the final kernels (one box)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-TAG=r04f
+TAG=${TAG:-r04g}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 600 python bench.py > $O/${TAG}_bench_x3.json 2> $O/bench_x3.err
+timeout 600 python bench.py --no-cpu-baseline > $O/${TAG}_bench_x3.json 2> $O/bench_x3.err
 timeout 600 python bench.py --config 720p_k8 --gap 2 --no-cpu-baseline --no-dropin > $O/${TAG}_bench_720p_k8.json 2> $O/bench_720.err
 timeout 600 python bench.py --batched --clips-per-gpu 8 --no-cpu-baseline > $O/${TAG}_bench_batched8.json 2> $O/bench_b8.err
 timeout 600 python bench.py --batched --clips-per-gpu 4 --no-cpu-baseline > $O/${TAG}_bench_batched4.json 2> $O/bench_b4.err
