@@ -130,8 +130,14 @@ def run_sharded_dataset(driver, lengths: Sequence[int], world: int, rank: int, f
     per = max(1, max(len(a) for a in assign))
     fmax = max(int(n) for n in lengths) - 1
     local: List[Optional[torch.Tensor]] = []
-    for cid in assign[rank]:
-        res = driver.run_clip(frames_of(cid), num_frames=int(lengths[cid]))
+    if hasattr(driver, "run_dataset"):
+        # BatchedClipDriver: this rank's clips share its B slots through the clip queue (run_dataset -> run_queue: a
+        # slot takes the next clip when its clip ends) -- the reference's worker queue twice over, ranks x slots
+        clips = [frames_of(cid)[:int(lengths[cid])] for cid in assign[rank]]
+        results = driver.run_dataset(clips) if clips else []
+    else:
+        results = [driver.run_clip(frames_of(cid), num_frames=int(lengths[cid])) for cid in assign[rank]]
+    for cid, res in zip(assign[rank], results):
         if int(res.masks.shape[0]) != int(lengths[cid]) - 1:
             raise ValueError(f"clip {cid}: {int(res.masks.shape[0]) + 1} frames run, {int(lengths[cid])} announced")
         local.append(res.masks)
