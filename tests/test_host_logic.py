@@ -554,3 +554,23 @@ def test_hash_masks_follows_the_gather_order():
     want = [hashlib.sha256(m.tobytes()).hexdigest() for m in per_clip]
     assert D.hash_masks(gathered, n, world) == want
     assert D.hash_masks(torch.from_numpy(gathered), n, world) == want
+
+
+def test_set_host_wait_rejects_a_device_that_does_not_exist_and_is_opt_in(monkeypatch):
+    """rmem_set_host_wait (include/rmem_hip.h): an out-of-range device is refused without touching anything; the Python
+    host calls it only when RMEM_BLOCKING_WAIT=1 (two processes sharing a GPU hung in MIOpen under the flag)."""
+    import ctypes as C
+    from rmem_amd import hip
+    lib = hip.load()
+    lib.rmem_set_host_wait.argtypes = [C.c_int32, C.c_int32]
+    assert lib.rmem_set_host_wait(9999, 1) == -1           # RMEM_ERR_INVALID
+    assert lib.rmem_set_host_wait(-1, 1) == -1
+    monkeypatch.delenv("RMEM_BLOCKING_WAIT", raising=False)
+    assert hip.set_host_wait(0) is False                   # opt-in: nothing is called without the switch
+
+
+def test_slot_queue_of_nothing_and_of_one_frame_clips():
+    from rmem_amd.driver import plan_slot_queue
+    assert plan_slot_queue([], 4) == []
+    # clips of one frame (a reference frame only): every step restarts slots, nothing is propagated
+    assert plan_slot_queue([1, 1, 1], 2) == [[(0, 0), (1, 0)], [(2, 0), None]]
