@@ -272,6 +272,10 @@ def test_queue_refill_equals_lockstep_runs_per_clip():
     # a queue shorter than the batch: the second slot idles, the clip's result is unchanged
     lone = drv.run_queue([clips[3]])
     assert torch.equal(lone[0].masks, res[3].masks)
+    # a clip that is its reference frame only (nothing to propagate) beside a real one, and an empty queue
+    tiny = drv.run_queue([clip(9, 1), clips[4]])
+    assert tuple(tiny[0].masks.shape) == (0, Hh, Ww) and tiny[0].names == [] and torch.equal(tiny[1].masks, res[4].masks)
+    assert drv.run_queue([]) == []
 
 
 def test_batched_clip_driver_vs_clip_driver():
