@@ -73,11 +73,19 @@ def from_trace(path, frames):
                 if r["Kernel_Name"].startswith(("read64x2_kernel", "read64x2_pull_kernel", "read2_kernel")))
     if pv:
         PV_LONG = (len(pv), sum(pv) / len(pv), min(pv), max(pv))
+        # per layer: the launches of a frame in time order are layers 0, 1, 2 (bench.py's HIP events sample layer 0)
+        global PV_LAYER
+        seq = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows[start:end]
+               if r["Kernel_Name"].startswith(("read64x2_kernel", "read64x2_pull_kernel", "read2_kernel"))]
+        seq.sort()
+        if len(seq) % 3 == 0:
+            PV_LAYER = [sum(d for _, d in seq[l::3]) / (len(seq) // 3) for l in range(3)]
     return [(k, v[0], v[1], v[1] / v[0], 100 * v[1] / tot) for k, v in agg.items()]
 
 
 SPAN = None
 PV_LONG = None
+PV_LAYER = None
 
 
 def main():
@@ -105,7 +113,9 @@ def main():
     if PV_LONG:
         print(f"`read64x2_kernel` launches (bench.py roofline kernel: fused long-term + windowed memory read of a layer): "
               f"{PV_LONG[0]} launches, mean {PV_LONG[1]:.1f} us (min {PV_LONG[2]:.1f}, max {PV_LONG[3]:.1f}) "
-              f"-- inside a frame, beside the encoder stream\n")
+              f"-- inside a frame, beside the encoder stream"
+              + (f"; per layer (launch order within a frame) {PV_LAYER[0]:.1f} / {PV_LAYER[1]:.1f} / {PV_LAYER[2]:.1f} us -- bench.py's events "
+                 f"bracket the layer-0 launch of sampled frames" if PV_LAYER else "") + "\n")
     print("| kernel | calls | calls/frame | total us | avg us | % |")
     print("|---|---|---|---|---|---|")
     for n, c, t, a, p in rows[:40]:
