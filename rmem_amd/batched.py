@@ -2,25 +2,31 @@
 
 The reference serves one clip per process: its attention asserts batch 1
 (/root/reference/aot_plus/networks/layers/transformer.py:641,1190) and the evaluator walks the clips
-one after the other (managers/evaluator.py:344-523).  Here B clips of one geometry advance in
-lockstep (same frame index, same memory schedule -- config 4 of BASELINE.json: equal-length clips,
-one gap rule) and share every launch of the memory path:
+one after the other (managers/evaluator.py:344-523).  Here B clips of one geometry -- the slots of a
+batch -- share the launches of the memory path:
 
-  * each clip keeps its own ``DeAOTLSTT`` state (bank ring, slot map, EMA / visit dictionaries);
+  * each clip keeps its own ``DeAOTLSTT`` state (bank ring, slot map, eviction bookkeeping);
     their packed weights are shared;
   * the host code of a pass is RECORDED once per (clip, slot, bank depth) -- librmem_hip's launch
     recorder (include/rmem_hip.h, csrc/launch.h) turns every entry point into "append the
-    argument block" -- and the B argument blobs are uploaded (one pinned-memory copy) and replayed
-    by ``rmem_launch_recorded``: per kernel ONE launch whose grid covers all clips, each block
+    argument block" -- and the argument blobs are uploaded (one pinned-memory copy) and replayed
+    by ``rmem_launch_recorded``: per kernel ONE launch whose grid covers the clips, each block
     reading its clip's arguments from device memory.  Per clip the arithmetic is the single-clip
     kernel's, bit for bit (tests/test_hip_batched.py);
+  * clips in the SAME state (same pass, same bank depth) share a launch; a clip in another state -- a
+    slot that has just taken the next clip of a queue (reference frame, bank still filling), a clip on
+    another gap schedule -- gets launches of its own group (``BatchedLSTT._run`` groups by recording
+    signature), an idle slot takes part in none.  Equal-length clips in lockstep (config 4 of
+    BASELINE.json) are one group throughout;
   * encoder and decoder run through MIOpen at batch B (hipGraphs keyed by the shapes only: nothing
-    clip-specific is baked in, the per-clip state lives in the uploaded argument blocks);
-  * the RMem eviction needs ONE device-to-host copy per long-term update for all clips.
+    clip-specific is baked in, the per-clip state lives in the uploaded argument blocks); ONE image may
+    be shared by all slots (the sub-engines of a clip with more than 10 objects: encoder at batch 1);
+  * the RMem eviction runs on the device per clip (rmem_bank_policy_step; RMEM_HOST_POLICY=1: one
+    device-to-host copy per long-term update for all clips and the rule on the host).
 
 ``BatchedDeAOTEngine`` mirrors the engine API of engines/aot_engine.py with a leading clip axis:
 ``add_reference_frame(imgs [B,3,H,W], masks [B,1,H,W], obj_nums=[n_0..n_B-1])``,
-``match_propogate_one_frame(imgs)`` -> logits [B,C,H,W], ``update_memory(masks)``.
+``match_propogate_one_frame(imgs, ref_slots=..., idle_slots=...)`` -> logits [B,C,H,W], ``update_memory(masks)``.
 """
 from __future__ import annotations
 
