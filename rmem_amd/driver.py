@@ -527,9 +527,11 @@ class BatchedClipDriver:
     encoder / decoder at batch B (BASELINE.json configs[3] runs 8 such clips per GPU).
     Per clip the protocol is ClipDriver.run_clip's for one augmentation without mid-clip new objects
     (managers/evaluator.py:344-523): gap rule, reference frame, per frame decoder logits -> label map at
-    the original size -> nearest resize to the network size -> update_memory.  Clips may differ in
-    length as long as the gap rule gives them the same gap (run_clips); run_dataset() takes any list of
-    clips and sends what cannot share a batch through the one-clip driver."""
+    the original size -> nearest resize to the network size -> update_memory.  run_clips(): B clips in
+    lockstep (lengths may differ as long as the gap rule gives them the same gap); run_queue(): any number
+    of clips of one frame size through the B slots, a slot taking the next clip when its clip ends, every
+    clip on its own gap schedule; run_dataset(): any list of clips -- one queue per frame size, the rest
+    (augmentation, mid-clip labels, > 10 objects, a lone clip) through the one-clip driver."""
 
     def __init__(self, model, B: int, cfg=None, gpu_id: int = 0, no_memory_gap: Optional[bool] = None,
                  fixed_gap: Optional[int] = None):
