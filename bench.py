@@ -34,6 +34,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -60,6 +62,10 @@ def parse():
                          "and bank fill inside the timed window), static shard + all-gather of masks, sha256 per clip")
     ap.add_argument("--clips-per-rank", type=int, default=8, help="clips64 mode: clips per rank (64 clips at 8 GPUs)")
     ap.add_argument("--clip-frames", type=int, default=16, help="clips64 mode: frames per clip")
+    ap.add_argument("--ragged", action="store_true",
+                    help="clips64 mode: clips of DIFFERENT lengths (uniform in [clip_frames/2, 2*clip_frames], 3 clips per "
+                         "slot): longest-first assignment to ranks, and with --batched each rank's clips through the slot "
+                         "queue of its BatchedClipDriver (a slot takes the next clip when its clip ends)")
     ap.add_argument("--model", choices=["r50_deaotl", "r50_aotl", "swinb_aotl"], default="r50_deaotl",
                     help="r50_deaotl = headline metric; r50_aotl = AOT block (BASELINE.json configs[0] on GPU)")
     ap.add_argument("--clips-per-gpu", type=int, default=1,
@@ -530,6 +536,65 @@ def thread_cpu_seconds():
     return out
 
 
+def clips_ragged(args, world, rank, dev, dist, drv, D):
+    """`--config clips64 --ragged`: a dataset of clips of unequal length -- what the reference's worker queue is for
+    (managers/evaluator.py:276-295).  3 clips per slot, lengths uniform in [clip_frames/2, 2*clip_frames]; ranks get
+    clips longest-first (driver.assign_clips_by_length), and a BatchedClipDriver serves its share through the slot queue
+    (driver.run_sharded_dataset).  One untimed pass over a short dataset of the same geometry first; the timed window
+    ends with the gathered masks in pinned host memory; their sha256 per clip is taken after it."""
+    from rmem_amd.synth import synth_clip
+    F_ = args.clip_frames
+    n_clips = 3 * args.clips_per_rank * world
+    rs = np.random.RandomState(7)
+    lengths = [int(x) for x in rs.randint(max(2, F_ // 2), 2 * F_ + 1, size=n_clips)]
+
+    def frames_of_len(cid, n):
+        imgs, lab = synth_clip(cid, n, H_IN, W_IN, 3)
+        lab0 = F.interpolate(lab, size=(H_OUT, W_OUT), mode="nearest").to(dev)
+        return [D.make_samples(imgs[t].to(dev), lab0 if t == 0 else None, (H_OUT, W_OUT), 3, name=f"{t:05d}.jpg")
+                for t in range(n)]
+    # warm-up: every bank depth and slot state once (recordings, hipGraph captures, MIOpen search)
+    wl = [F_, F_ // 2 + 1, F_, F_ // 2 + 2][:max(2, min(4, args.clips_per_rank + 1))]
+    warm = {i: frames_of_len(10 ** 6 + i, n) for i, n in enumerate(wl)}
+    D.run_sharded_dataset(drv, wl, 1, 0, lambda c: warm[c])
+    assign = D.assign_clips_by_length(lengths, world)
+    mine = assign[rank]
+    cache = {c: frames_of_len(c, lengths[c]) for c in mine}
+    per = max(1, max(len(a) for a in assign))
+    host_pin = torch.empty((world * per, max(lengths) - 1, H_OUT, W_OUT), dtype=torch.uint8)     # destination of the masks: pinned,
+    if dev.type == "cuda":                                                                       # allocated before the window
+        host_pin = host_pin.pin_memory()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    allm, frames_per_rank = D.run_sharded_dataset(drv, lengths, world, rank, lambda c: cache[c], hashes=False, host_out=host_pin)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
+    hashes = D.hash_dataset_masks(allm, lengths, world)       # (after the window, as in clips64)
+    total = sum(lengths) - n_clips
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec (480p, K=4) R50-DeAOTL+RMem, clips of unequal length over ranks and slots, masks all-gathered",
+            "value": total / elapsed, "unit": "frames/s (whole job)", "n_gpus": world, "steps": total // world, "warmup": 1,
+            "ms_per_step": 1e3 * elapsed / max(1, total // world), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16x3 (split-fp16 MFMA)", "data": "synthetic",
+            "config": {"workload": f"R50-DeAOTL + RMem, 480p, K=4, {n_clips} clips of {min(lengths)}-{max(lengths)} frames "
+                                   f"({total} propagated), longest-first over {world} rank(s)"
+                                   + (f", {args.clips_per_rank} slots per rank with the slot queue" if args.batched else ", one clip at a time"),
+                       "lengths": lengths, "frames_per_rank": frames_per_rank, "per_rank_seconds": per_rank_s,
+                       "batched": bool(args.batched), "queue_stats_rank0": getattr(drv, "queue_stats", None),
+                       "dist_backend": dist.get_backend() if dist is not None else None},
+            "clip_sha256": [h[:16] for h in hashes]}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def clips64(args, world, rank, local_rank, dev, dist):
     """BASELINE.json configs[3]: R50-DeAOTL + RMem, 480p, K=4, `clips_per_rank` x world independent
     synthetic clips of `clip_frames` frames, clip i on rank i mod world, every clip through
@@ -548,6 +613,8 @@ def clips64(args, world, rank, local_rank, dev, dist):
     n_clips, F_ = args.clips_per_rank * world, args.clip_frames
     drv = D.ClipDriver(model, cfg, gpu_id=local_rank) if not args.batched else \
         D.BatchedClipDriver(model, args.clips_per_rank, cfg, gpu_id=local_rank)
+    if args.ragged:
+        return clips_ragged(args, world, rank, dev, dist, drv, D)
 
     def frames_of(cid):          # frames are resident in HBM before they are consumed; generated per clip
         imgs, lab = synth_clip(cid, F_, H_IN, W_IN, 3)

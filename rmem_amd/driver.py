@@ -118,14 +118,28 @@ def shard_clips_by_length(lengths: Sequence[int], world: int, rank: int) -> List
     return assign_clips_by_length(lengths, world)[rank]
 
 
+def hash_dataset_masks(allm, lengths: Sequence[int], world: int) -> List[str]:
+    """sha256 per clip over ITS OWN frames, in clip-id order, from the padded gather of run_sharded_dataset
+    (`allm`: numpy [world * clips per rank, max frames - 1, H0, W0] in rank-major order)."""
+    import hashlib
+    assign = assign_clips_by_length(lengths, world)
+    per = max(1, max(len(a) for a in assign))
+    out: List[Optional[str]] = [None] * len(lengths)
+    for r, ids in enumerate(assign):
+        for j, cid in enumerate(ids):
+            out[cid] = hashlib.sha256(allm[r * per + j, :int(lengths[cid]) - 1].tobytes()).hexdigest()
+    return out
+
+
 def run_sharded_dataset(driver, lengths: Sequence[int], world: int, rank: int, frames_of: Callable[[int], list],
-                        group=None):
+                        group=None, hashes: bool = True, host_out: Optional[torch.Tensor] = None):
     """Clips of unequal length over `world` ranks: length-aware static assignment (assign_clips_by_length), every
     clip through `driver.run_clip`, ONE all-gather of uint8 masks padded to [max clips per rank, max frames - 1, H0, W0]
     (all clips of a call share the output size; a dataset with several sizes is one call per size).  Returns
     (sha256 per clip over ITS OWN frames, in clip-id order; frames run per rank, as assigned).  Like
-    run_sharded_clips the hashes do not depend on `world`."""
-    import hashlib
+    run_sharded_clips the hashes do not depend on `world`.  hashes=False: returns the gathered masks on the host (numpy,
+    rank-major, padded) in place of the hashes -- hash_dataset_masks() turns them into the same list later (bench.py
+    hashes after its timed window); `host_out`: a (pinned) uint8 tensor of the gathered shape to copy them into."""
     assign = assign_clips_by_length(lengths, world)
     per = max(1, max(len(a) for a in assign))
     fmax = max(int(n) for n in lengths) - 1
@@ -157,12 +171,16 @@ def run_sharded_dataset(driver, lengths: Sequence[int], world: int, rank: int, f
     block = torch.zeros((per, max(fmax, 1)) + tuple(shape), dtype=torch.uint8, device=devs)
     for j, m in enumerate(local):
         block[j, :m.shape[0]] = m
-    allm = gather_masks(block, world, group).cpu().numpy()
-    hashes: List[Optional[str]] = [None] * len(lengths)
-    for r, ids in enumerate(assign):
-        for j, cid in enumerate(ids):
-            hashes[cid] = hashlib.sha256(allm[r * per + j, :int(lengths[cid]) - 1].tobytes()).hexdigest()
-    return hashes, [sum(int(lengths[c]) - 1 for c in ids) for ids in assign]
+    gathered = gather_masks(block, world, group)
+    if host_out is not None and tuple(host_out.shape) == tuple(gathered.shape):
+        host_out.copy_(gathered, non_blocking=True)
+        if gathered.is_cuda:
+            torch.cuda.synchronize()
+        allm = host_out.numpy()
+    else:
+        allm = gathered.cpu().numpy()
+    frames_run = [sum(int(lengths[c]) - 1 for c in ids) for ids in assign]
+    return (hash_dataset_masks(allm, lengths, world) if hashes else allm), frames_run
 
 
 def unshard_order(n_clips: int, world: int) -> List[int]:

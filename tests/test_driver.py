@@ -507,3 +507,30 @@ def test_sharded_dataset_through_batched_drivers_world_invariant():
     same = [a == b for a, b in zip(h1, h0)]
     print("clips whose masks equal the one-clip driver's:", same)
     assert sum(same) >= len(lengths) - 2, same
+
+
+@pytest.mark.gpu
+def test_bench_ragged_dataset_through_the_slot_queue():
+    """`bench.py --config clips64 --ragged --batched`: clips of unequal length, longest-first over ranks, each rank's
+    share through the slot queue of its BatchedClipDriver, here with a one-rank RCCL group (RMEM_FORCE_DIST=1) so that
+    the padded all-gather runs over the real backend.  One JSON line; the queue served every frame of every clip."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RMEM_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "clips64", "--ragged", "--batched",
+                        "--clips-per-rank", "2", "--clip-frames", "6"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    n = len(cfg["lengths"])
+    assert n == 6 and all(3 <= x <= 12 for x in cfg["lengths"]) and len(set(cfg["lengths"])) > 1
+    assert cfg["batched"] and cfg["dist_backend"] == "nccl" and out["n_gpus"] == 1
+    assert cfg["frames_per_rank"] == [sum(cfg["lengths"]) - n]
+    assert cfg["queue_stats_rank0"]["busy_slot_steps"] == sum(cfg["lengths"])
+    assert len(out["clip_sha256"]) == n and len(set(out["clip_sha256"])) == n and out["value"] > 0
