@@ -313,8 +313,26 @@ class ClipDriver:
             else no_memory_gap
         self.fixed_gap = fixed_gap
         self.align_corners = bool(self.cfg.MODEL_ALIGN_CORNERS)
+        self._aug_bat: Dict[int, object] = {}          # number of augmentations -> BatchedDeAOTEngine (see _aug_batched_ok)
 
     # -- engines
+    def _aug_batched_ok(self, samples) -> bool:
+        """Test-time augmentation (managers/evaluator.py:337-353: one engine per augmentation, here the flipped copy)
+        as the slots of ONE BatchedDeAOTEngine: the augmented images of a frame are one encoder / decoder batch and
+        every launch of the memory path serves all of them -- the augmentations of a clip are in lockstep by
+        construction.  DeAOT block on the GPU, product engines, augmentations of one image size (flip, not
+        multi-scale), <= 10 objects; RMEM_TTA=serial keeps one engine after the other."""
+        if len(samples) < 2 or self._factory is not None or self.fused_post is False:
+            return False
+        if os.environ.get("RMEM_TTA", "batched") == "serial" or getattr(self.cfg, "MODEL_VOS", "") != "deaot":
+            return False
+        img0 = samples[0]["current_img"]
+        if not img0.is_cuda or any(tuple(s["current_img"].shape) != tuple(img0.shape) for s in samples):
+            return False
+        n = samples[0]["meta"]["obj_num"]
+        n = int(n[0] if isinstance(n, (list, tuple)) else n)
+        return n <= int(self.model.max_obj_num)
+
     def _engine(self, aug_idx: int):
         while len(self.engines) <= aug_idx:
             if self._factory is not None:
@@ -378,6 +396,8 @@ class ClipDriver:
             f = next(it, None)
             if f is not None:
                 ahead.append(f)
+        if ahead and self._aug_batched_ok(ahead[0]):
+            return self._run_clip_batched_aug(ahead, it, gap, res, save_dir, on_frame)
         frame_idx = -1
         while ahead:
             samples, ahead = ahead[0], ahead[1:]
@@ -458,6 +478,107 @@ class ClipDriver:
                 th.join()
         res.masks = torch.stack(labels_out) if labels_out else None
         return res
+
+
+class _AugEngineView:
+    """One augmentation's engine as `on_frame` callbacks see it (the multi-object wrapper's attributes) when the
+    augmentations are the slots of one BatchedDeAOTEngine."""
+
+    def __init__(self, bat, i: int):
+        from .engine import _SubEngineView
+        self.bat, self.i = bat, i
+        self.aot_engines = [_SubEngineView(bat, i)]
+
+    long_memories_indexes = property(lambda self: self.bat.long_memories_indexes[self.i])
+    input_size_2d = property(lambda self: self.bat.input_size_2d)
+    enc_size_2d = property(lambda self: self.bat.enc_size_2d)
+
+
+def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
+    """ClipDriver.run_clip for a clip with test-time augmentation through ONE BatchedDeAOTEngine whose slots are the
+    augmentations (ClipDriver._aug_batched_ok).  Same protocol per frame as the loop of run_clip: logits of every
+    augmentation -> un-flip, softmax, mean, argmax at the original size (rmem_labels_from_logits) -> per augmentation
+    flip + nearest resize -> update_memory; a mid-clip label re-references every slot (evaluator.py:484-508)."""
+    from . import hip
+    from .batched import BatchedDeAOTEngine
+    B = len(ahead[0])
+    eng = self._aug_bat.get(B)
+    if eng is None:
+        eng = self._aug_bat[B] = BatchedDeAOTEngine(self.model, B, gpu_id=self.gpu_id,
+                                                    long_term_mem_gap=getattr(self.cfg, "TEST_LONG_TERM_MEM_GAP", 9999))
+    eng.restart_engine()
+    eng.long_term_mem_gap = gap
+    maxo = int(self.model.max_obj_num)
+    views = [_AugEngineView(eng, i) for i in range(B)]        # what on_frame callbacks read per augmentation
+    labels_out, timers, writers = [], [], []
+    cat = lambda samples: torch.cat([s_["current_img"] for s_ in samples])
+    pending = None                                            # (frame's sample list, its concatenated images): the prefetched batch
+    frame_idx = -1
+    while ahead:
+        samples, ahead = ahead[0], ahead[1:]
+        f = next(it, None)
+        if f is not None:
+            ahead.append(f)
+        frame_idx += 1
+        if len(samples) != B:
+            raise ValueError("the number of augmentations changed inside a clip")
+        flips = [bool(s_["meta"]["flip"]) for s_ in samples]
+        meta0 = samples[0]["meta"]
+        ori_hw = (int(meta0["height"]), int(meta0["width"]))
+        imgs = pending[1] if pending is not None and pending[0] is samples else cat(samples)
+        pending = None
+        if frame_idx == 0:
+            res.obj_idx = meta0.get("obj_idx")
+            labs = torch.cat([F.interpolate(s_["current_label"].float(), size=imgs.shape[2:], mode="nearest").int()
+                              for s_ in samples])
+            eng.add_reference_frame(imgs, labs, obj_nums=[maxo] * B, frame_step=0)
+            continue
+        t0 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        nxt = None
+        if ahead and len(ahead[0]) == B:
+            nxt = cat(ahead[0])
+            pending = (ahead[0], nxt)
+        lg = eng.match_propogate_one_frame(imgs, output_size=None, next_imgs=nxt)
+        label = hip.labels_from_logits([lg[i:i + 1] for i in range(B)], flips, ori_hw, self.align_corners)
+        new_obj_label = next((s_["current_label"] for s_, fl in zip(samples, flips)
+                              if (not fl) and s_.get("current_label") is not None), None)
+        lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
+        if new_obj_label is not None:                          # evaluator.py:484-508
+            new = new_obj_label.to(lg.device).float()[0, 0].to(torch.uint8)
+            label = torch.where(new == 0, label, new)
+            n_new = int(label.max().item())
+            if n_new > maxo:
+                raise NotImplementedError(f"{n_new} objects after a mid-clip label: RMEM_TTA=serial (one sub-engine per "
+                                          f"{maxo} objects per augmentation)")
+            cur = torch.cat([ClipDriver._resize_generic(label, eng.input_size_2d, fl) for fl in flips])
+            eng.add_reference_frame(imgs, cur, obj_nums=[maxo] * B, frame_step=frame_idx)
+        else:                                                  # evaluator.py:509-523
+            for i, fl in enumerate(flips):
+                hip.label_resize_nearest(label, eng.input_size_2d, fl, out=lab_in[i])
+            eng.update_memory(lab_in)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t1.record()
+        timers.append((t0, t1))
+        labels_out.append(label)
+        if on_frame is not None:
+            on_frame(frame_idx, label, views)
+        name = meta0.get("current_name", f"{frame_idx:05d}")
+        name = name[0] if isinstance(name, (list, tuple)) else name
+        res.names.append(str(name))
+        if save_dir is not None:
+            writers.append(save_mask(label, os.path.join(save_dir, str(name).split(".")[0] + ".png"), res.obj_idx))
+    torch.cuda.synchronize()
+    res.frame_ms = [a.elapsed_time(b) for a, b in timers]
+    for th in writers:
+        if th is not None:
+            th.join()
+    res.masks = torch.stack(labels_out) if labels_out else None
+    res.batched = True
+    return res
+
+
+ClipDriver._run_clip_batched_aug = _run_clip_batched_aug
 
 
 def plan_ragged_batches(clips_info: Sequence[Dict], B: int, no_memory_gap: bool = False,

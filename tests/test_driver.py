@@ -137,10 +137,12 @@ def test_c_abi_rejects_bad_postproc_args():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [True, False])
-def test_driver_hip_vs_reference_golden(fused, golden_dir):
+@pytest.mark.parametrize("fused,tta", [(True, "batched"), (True, "serial"), (False, "serial")])
+def test_driver_hip_vs_reference_golden(fused, tta, golden_dir, monkeypatch):
     """The driver on the HIP engines against the reference-driven golden clip (closed loop, flip
-    TTA, new object at frame 10).  Closed loops with synthetic weights amplify a near-tie flip
+    TTA, new object at frame 10).  tta: the two augmentations as the slots of ONE batched engine (the default with fused
+    post-processing: one encoder / decoder batch, shared launches of the memory path) or one engine after the other
+    (RMEM_TTA=serial).  Closed loops with synthetic weights amplify a near-tie flip
     (tests/test_oracle_golden.py), so pixel agreement is asserted for the first frames and for
     the frames right after the re-reference; the bank index sequence for the whole clip."""
     from rmem_amd.config import get_config
@@ -152,6 +154,7 @@ def test_driver_hip_vs_reference_golden(fused, golden_dir):
     model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
     load_synthetic_weights(model)
     model = model.to(DEV)
+    monkeypatch.setenv("RMEM_TTA", tta)
     drv = D.ClipDriver(model, cfg, fused_post=fused, fixed_gap=meta["gap"])
     idx = []
     res = drv.run_clip(_tta_frames(meta, DEV), num_frames=meta["frames"],
@@ -159,8 +162,9 @@ def test_driver_hip_vs_reference_golden(fused, golden_dir):
                                                                  for e in engs]))
     assert res.masks.dtype == torch.uint8 and tuple(res.masks.shape) == gold.shape
     mism = [int((res.masks[i].cpu().numpy() != gold[i]).sum()) for i in range(len(gold))]
-    print("fused" if fused else "generic", "mismatching pixels per frame (of %d):" % gold[0].size, mism,
+    print("fused" if fused else "generic", tta, "mismatching pixels per frame (of %d):" % gold[0].size, mism,
           "fps %.1f" % res.fps)
+    assert bool(res.batched) == (tta == "batched")
     assert max(mism[:3]) <= 2, mism
     # after the re-reference the engines restart from the merged label, which contains the new
     # object's rectangle verbatim
