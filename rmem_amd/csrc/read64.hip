@@ -65,7 +65,8 @@ constexpr float RD_BUMP = 12.0f;            // log2 domain: weights up to 2^12 =
 #define R6_OPAQUE(x) asm volatile("" : "+v"(x))
 
 // VAR (experiments, tracing kernel only): 4 = no s_setprio at all; 8 = never wait for V fragments (timing only:
-// results are wrong).
+// results are wrong); 16 = one MFMA per product instead of three (hi . hi only; every plane is still staged: what the
+// exactness of split-fp16 costs in matrix-pipe time, profiles/r04_read_one_product_probe.md).
 // zwin: the key splits this launch class serves -- z0 = zwin & 0xffff first split, nz = zwin >> 16 how many (0 = all of them)
 template <int TRACE, int VAR, int MODE>
 __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int blk, char* smem, long long* trace_base, const int zwin) {
@@ -323,8 +324,10 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
       __builtin_amdgcn_sched_barrier(0);
       frag8_t (&fqc)[2] = fq[k4 & 1];
       frag8_t (&fkc)[2] = fk[i & 1];
-      s[kt] = RMEM_MFMA16(fkc[0], fqc[1], s[kt]);     // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
-      s[kt] = RMEM_MFMA16(fkc[1], fqc[0], s[kt]);
+      if constexpr (!(VAR & 16)) {                    // (VAR 16, timing only: the hi . hi product alone, operands still loaded)
+        s[kt] = RMEM_MFMA16(fkc[0], fqc[1], s[kt]);   // small terms first: K hi . Q lo, K lo . Q hi, K hi . Q hi
+        s[kt] = RMEM_MFMA16(fkc[1], fqc[0], s[kt]);
+      }
       s[kt] = RMEM_MFMA16(fkc[0], fqc[0], s[kt]);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -584,8 +587,10 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
       const frag8_t vl = __builtin_bit_cast(frag8_t, vr[sidx & 3][1]);
 #pragma unroll
       for (int qi = 0; qi < 2; ++qi) {                // small terms first
-        o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vl, o[qi][ci]);
-        o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 1], vh, o[qi][ci]);
+        if constexpr (!(VAR & 16)) {
+          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vl, o[qi][ci]);
+          o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 1], vh, o[qi][ci]);
+        }
         o[qi][ci] = RMEM_MFMA(pc[qi * 2 + 0], vh, o[qi][ci]);
       }
       vreq(std::integral_constant<int, sidx + 4>{});  // (steps 16-19: the next tile's first four, see vwait)
@@ -1049,7 +1054,7 @@ extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, vo
   if (!ap || !trace || !read_args_ok(*ap) || rmem::current_recorder()) return RMEM_ERR_INVALID;
   const int chunk = read_chunk(*ap);
   const char* ev = getenv("RMEM_READ_VAR");           // experiments (see read64_body)
-  const int var = ev ? atoi(ev) & 15 : 0;
+  const int var = ev ? atoi(ev) & 31 : 0;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
     hipLaunchKernelGGL(kern, dim3(8 * chunk), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), *ap,
@@ -1057,6 +1062,7 @@ extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, vo
   };
   if (var == 4) go(&read64_trace_kernel<4>);
   else if (var == 8) go(&read64_trace_kernel<8>);
+  else if (var == 16) go(&read64_trace_kernel<16>);
   else go(&read64_trace_kernel<0>);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--win-splits", default="1,2")
     ap.add_argument("--only", default="")
     ap.add_argument("--no-trace", action="store_true", help="timing only (for rocprofv3 --pmc runs)")
+    ap.add_argument("--time-vars", default="", help="RMEM_READ_VAR values whose tracing-kernel launch is timed as well, e.g. 16")
     ap.add_argument("--old", action="store_true", help="also time the round-2 kernel if the library still has it (rmem_attn_read_v128)")
     args = ap.parse_args()
     from rmem_amd import hip
@@ -130,6 +131,10 @@ def main():
                     ntv = tt[:, 28:29].clamp(min=1)
                     ent[f"var{var}_top_score_pv_barrier_w0_w4"] = [[round(float((tt[:, o + w] / ntv[:, 0]).mean())) for o in (40, 4, 12, 20)] for w in (0, 4)]
             ent["trace_kernel_us"] = round(timeit(lambda: hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace"), args.iters), 2)
+            for var in [v for v in args.time_vars.split(",") if v]:      # whole-launch time of an experiment variant (16: one MFMA per product)
+                os.environ["RMEM_READ_VAR"] = var
+                ent[f"trace_kernel_us_var{var}"] = round(timeit(lambda: hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace"), args.iters), 2)
+            os.environ["RMEM_READ_VAR"] = "0"
             t = tr.cpu().double()
             t = t[t[:, 3] > 0]
             if t.shape[0]:
