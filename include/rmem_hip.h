@@ -101,6 +101,43 @@ int rmem_linear(const rmem_linear_args *a, void *stream);
  * of one LSTT stage share their input and individually cannot fill 256 CUs. */
 int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
 
+/* LayerNorm fused with the grouped projections that read the normalised rows (one launch, row tile resident in LDS):
+ * norm1 / id_norm1 + linear_QV / linear_U / linear_ID_U / relative_emb_k / temporal-PE bias, and norm2 / id_norm2 +
+ * self_attn.linear_QK / V1 / V2 / U1 / U2 of GatedPropagationModule.forward (layers/transformer.py:1104-1123,1223-1232,
+ * layers/attention.py:151-172,314).  Replaces rmem_layernorm_red[2] followed by rmem_linear_grouped; results are
+ * bit-identical to that sequence.
+ *
+ * Up to two residual streams of 256 channels (tgt, tgt_id); the normalised row seen by the problems is the 512-wide
+ * concatenation [LN(stream 0) | LN(stream 1)].  mode 0: stream s is LayerNorm(x + sum_z parts[z]) with the partials summed in
+ * split order; when nparts > 0 the folded stream is written to xo, which must differ from x (the workgroups of a row tile
+ * read x concurrently); oh/ol (optional) receive the normalised planes.  mode 1: the planes oh/ol already hold the
+ * normalised rows (rmem_layernorm_cn wrote them) and are read.
+ * Problem i computes D = act(Xn[:, xk0 + b*bxk : +K] . W_b^T + bias) for its batches b; lin gives M (= N rows), N, K
+ * (128, 256, 384 or 512), bias, act, the destinations and batch strides exactly as for rmem_linear (xh/xl/yh/yl are ignored,
+ * ksplits must be <= 1); wpk = the weight planes packed in MFMA fragment order:
+ *   wpk[(((b * ceil(N/32) + u) * (K/16) + ks) * 2 + plane) * 512 + lane * 8 + e]
+ *     = plane (0 hi, 1 lo) of W_b[u*32 + (lane & 31)][ks*16 + (lane >> 5)*8 + e]     (rows >= N: zero)
+ * Not recordable (rmem_rec_begin): returns RMEM_ERR_INVALID while the thread records, and with RMEM_ROWRES=0. */
+typedef struct {
+  const float *x; float *xo; const float *parts;
+  const float *gamma, *beta;
+  rmem_f16 *oh, *ol; int64_t ldo;
+} rmem_rowres_stream;
+typedef struct {
+  rmem_linear_args lin;
+  const rmem_f16 *wpk;
+  int32_t xk0, bxk;
+} rmem_rowres_problem;
+int rmem_ln_linear_grouped(const rmem_rowres_stream *streams, int32_t nstreams, int32_t mode, int32_t N, int32_t nparts,
+                           int64_t part_stride, int64_t ldpart, float eps, const rmem_rowres_problem *probs, int32_t n,
+                           void *stream);
+/* Debug aid (tools/kbench_rowres.py): the same launch with shader-clock stamps per wave in trace[(workgroup * 8 + wave) * 8 + k]
+ * ([0] start, [1] first weight fragments requested, [2] LayerNorm done, [3] barrier passed, [4] MFMAs issued, [5] end);
+ * trace holds 64 int64 per workgroup (at most 8 * ceil(N / 512) * 16 workgroups), zeroed by the caller. */
+int rmem_ln_linear_grouped_trace(const rmem_rowres_stream *streams, int32_t nstreams, int32_t mode, int32_t N, int32_t nparts,
+                                 int64_t part_stride, int64_t ldpart, float eps, const rmem_rowres_problem *probs, int32_t n,
+                                 int64_t *trace, void *stream);
+
 /* Debug aid (tools/kbench_gemm.py): the streaming kernel for `n` problems with shader-clock stamps of every workgroup's
  * wave 0 written to trace[workgroup][64] ([0] start, [1] first requests out, [2 + 2 s] / [3 + 2 s] stage s landed / issued,
  * [62] stages, [63] end).  trace must hold 64 int64 per CU.  Split precision (nsplit = 3) only. */

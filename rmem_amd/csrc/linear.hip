@@ -4,6 +4,7 @@
 #include "gemm_core.h"
 #include "launch.h"
 #include <stdlib.h>
+#include <string.h>
 
 // Epilogue of one output tile of problem `a` (bias, activation, the fp32 / plane / blocked-16 / split-K destinations).
 // Cfg gives the wave layout: wave (wr, wc) owns TM x TN accumulator tiles of 32 x 32 at rows wr * WM + tm * 32, columns
@@ -199,6 +200,7 @@ __device__ void linear_grouped_many(const GroupedLinear& g, int) { linear_groupe
 static int validate_linear(rmem_linear_args& a);
 
 #include "linear_stream.h"
+#include "linear_rowres.h"
 
 // Debug aid: the streaming kernel with cycle stamps (see linear_stream_kernel); trace must hold 64 int64 per workgroup
 // (at most one per CU).  nsplit = 3 only.

@@ -489,8 +489,8 @@ static int launch_stream(const StreamGroup& g, int total, long long* trace, hipS
 
 // The streaming kernel serves a launch issued directly whose problems ask for tile 0 (auto) or 256; tile 64 / 128 / 192
 // select the tile-per-workgroup kernels (kept for the recorded launches of several clips -- launch.h -- and as the
-// bit-identical cross-check), as does RMEM_LINEAR=tiles for every launch.  Stays with the tile kernels as well: a split-K
-// problem whose last split would be empty (ceil division; the stream counts one stage per k-tile of every item), leading
+// bit-identical cross-check), as does RMEM_LINEAR=tiles for every launch.  Stays with the tile kernels as well: items of a
+// single stage (see below), a split-K problem whose last split would be empty (ceil division; the stream counts one stage per k-tile of every item), leading
 // dimensions or item counts beyond what the packed descriptor holds.
 static bool use_stream(const rmem_linear_args* args, int n) {
   static const char* e = getenv("RMEM_LINEAR");
@@ -501,9 +501,14 @@ static bool use_stream(const rmem_linear_args* args, int n) {
     if (a.tile != 0 && a.tile != 256) return false;
     if (a.ldx >= (1L << 30) || a.ldy >= (1L << 30) || a.ldx2 >= (1L << 30) || a.ldy2 >= (1L << 30)) return false;
     if (a.M > 65535 * 64 || a.N > 32767 * 128) return false;
+    // an item of ONE stage: the load side runs up to four stages ahead and would publish the descriptor of item i + 4
+    // into the four-entry item ring before the epilogue of item i has read its slot (a workgroup with five or more
+    // items); such shapes (K = 64, or split-K down to one k-tile per split) stay with the tile kernels
+    if (a.K / 64 < 2) return false;
     if (a.ksplits > 1) {
       const int kt = a.K / 64, per = (kt + a.ksplits - 1) / a.ksplits;
       if ((a.ksplits - 1) * per >= kt) return false;
+      if (per < 2 || kt - (a.ksplits - 1) * per < 2) return false;
     }
     items += (long)((a.M + 63) / 64) * ((a.N + 127) / 128) * (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
   }

@@ -71,20 +71,8 @@ extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, i
 // that normalises a row, so that they agree bit for bit (same expression tree, same contraction).
 __device__ __forceinline__ void ln_row256(const float4 v, const float* gamma, const float* beta, float eps, int lane, long row,
                                           h16_t* oh, h16_t* ol, long ldo, float* of32, long ldof) {
-  float s = v.x + v.y + v.z + v.w;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.0f / 256.0f);
-  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-  // (every multiply-add spelled as fmaf: left to the compiler the contraction depends on whether the SLP vectoriser got
-  // to the products first -- the single-row kernel came out with separately rounded squares, the paired one with fma chains)
-  float ss = fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0)));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float rstd = 1.0f / sqrtf(fmaf(ss, 1.0f / 256.0f, eps));
-  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
-  const float4 b = *reinterpret_cast<const float4*>(beta + lane * 4);
-  const float y[4] = {fmaf(d0 * rstd, g.x, b.x), fmaf(d1 * rstd, g.y, b.y), fmaf(d2 * rstd, g.z, b.z), fmaf(d3 * rstd, g.w, b.w)};
+  float y[4];
+  ln_row256_vals(v, gamma, beta, eps, lane, y);     // (rmem_common.h: the one row function, shared with linear_rowres.h)
   if (of32) *reinterpret_cast<float4*>(of32 + row * ldof + lane * 4) = make_float4(y[0], y[1], y[2], y[3]);
   if (oh) {
     h16_t hi[4], lo[4];
@@ -1303,4 +1291,4 @@ extern "C" int rmem_set_host_wait(int32_t device, int32_t blocking) {
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 15; }   // 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_abi_version(void) { return 16; }   // 16: rmem_ln_linear_grouped (LayerNorm + grouped projections, row tile resident in LDS); 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

@@ -72,6 +72,41 @@ __device__ __forceinline__ void xor32_pair(float x, float& lo, float& hi) {
   hi = __builtin_bit_cast(float, r1);
 }
 
+// the same for lanes L and L ^ 16 (v_permlane16_swap: odd 16-lane rows of one operand against even rows of the other):
+// lo = x of the pair's copy in the even row, hi = in the odd row, the same pair in both lanes
+__device__ __forceinline__ void xor16_pair(float x, float& lo, float& hi) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const uint32_t r0 = r[0], r1 = r[1];
+  lo = __builtin_bit_cast(float, r0);
+  hi = __builtin_bit_cast(float, r1);
+}
+
+// x of another lane of the 16-lane row through the DPP crossbar (a VALU move the compiler folds into the consuming add;
+// no LDS round trip): CTRL = 0x128 row_ror:8 (lane ^ 8), 0x141 row_half_mirror (7 - lane % 8), quad_perm 0x1B [3,2,1,0]
+// (lane ^ 3), 0x4E [2,3,0,1] (lane ^ 2), 0xB1 [1,0,3,2] (lane ^ 1)
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
+// Sum over the 64 lanes, every lane gets it: the butterfly  s += s[lane ^ o]  for o = 32, 16, 8, 4, 2, 1 -- bit for bit
+// the chain of __shfl_xor steps it replaces (fp32 addition is commutative; the partner at every step is the same lane) --
+// on lane-swap and DPP instructions instead of twelve dependent ds_bpermute round trips per row (~1.5 k cycles per
+// LayerNorm row, the whole cost of the small normalisation kernels: profiles/r05b_kbench_rowres.json).
+__device__ __forceinline__ float wave_sum_xor(float s) {
+  float lo, hi;
+  xor32_pair(s, lo, hi);
+  s = lo + hi;
+  xor16_pair(s, lo, hi);
+  s = lo + hi;
+  s += dpp_lane<0x128>(s);
+  s += dpp_lane<0x1B>(dpp_lane<0x141>(s));    // lane ^ 4 = (lane ^ 7) ^ 3
+  s += dpp_lane<0x4E>(s);
+  s += dpp_lane<0xB1>(s);
+  return s;
+}
+
 #define RMEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 // Monotone float <-> uint encoding so that atomicMax on the uint orders like the
@@ -109,6 +144,26 @@ __device__ __forceinline__ float silu_f(float x) {
   float r = __builtin_amdgcn_rcpf(d);
   r = fmaf(fmaf(-d, r, 1.0f), r, r);
   return x * r;
+}
+
+// LayerNorm of one row of 256 held as a float4 per lane (64 lanes): the normalised values of the lane's four columns.  ONE
+// definition for every kernel that normalises a row (pointwise.hip: ln_row256; linear_rowres.h), so that they agree bit for
+// bit: every multiply-add is spelled as fmaf (left to the compiler the contraction depended on whether the SLP vectoriser
+// got to the products first), the mean is a product with a power of two (exact, contraction cannot change it).
+__device__ __forceinline__ void ln_row256_gb(const float4 v, const float4 g, const float4 b, float eps, float (&y)[4]) {
+  const float s = wave_sum_xor(v.x + v.y + v.z + v.w);
+  const float mean = s * (1.0f / 256.0f);
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  const float ss = wave_sum_xor(fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0))));
+  const float rstd = 1.0f / sqrtf(fmaf(ss, 1.0f / 256.0f, eps));
+  y[0] = fmaf(d0 * rstd, g.x, b.x);
+  y[1] = fmaf(d1 * rstd, g.y, b.y);
+  y[2] = fmaf(d2 * rstd, g.z, b.z);
+  y[3] = fmaf(d3 * rstd, g.w, b.w);
+}
+__device__ __forceinline__ void ln_row256_vals(const float4 v, const float* gamma, const float* beta, float eps, int lane,
+                                               float (&y)[4]) {
+  ln_row256_gb(v, *reinterpret_cast<const float4*>(gamma + lane * 4), *reinterpret_cast<const float4*>(beta + lane * 4), eps, y);
 }
 
 // exact floor(k / w) for 0 <= k < 2^20, 1 <= w ((k+0.5)/w is never

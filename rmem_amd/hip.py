@@ -44,6 +44,15 @@ class LinearArgs(C.Structure):
     ]
 
 
+class RowresStream(C.Structure):
+    _fields_ = [("x", c_p), ("xo", c_p), ("parts", c_p), ("gamma", c_p), ("beta", c_p),
+                ("oh", c_p), ("ol", c_p), ("ldo", i64)]
+
+
+class RowresProblem(C.Structure):
+    _fields_ = [("lin", LinearArgs), ("wpk", c_p), ("xk0", i32), ("bxk", i32)]
+
+
 class ReadArgs(C.Structure):
     _fields_ = [
         ("mode", i32),
@@ -104,7 +113,7 @@ EXPORTS = [
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2", "rmem_layernorm_cn",
     "rmem_bias_act_nchw_batched", "rmem_dwconv5x5_split2",
     "rmem_attn_read", "rmem_attn_read_trace", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
-    "rmem_rec_end", "rmem_launch_recorded",
+    "rmem_rec_end", "rmem_launch_recorded", "rmem_ln_linear_grouped", "rmem_ln_linear_grouped_trace",
 ]
 # exports with a non-int return type
 EXPORTS_OTHER = ["rmem_rec_begin", "rmem_rec_free", "rmem_rec_count", "rmem_rec_size", "rmem_rec_data",
@@ -115,7 +124,7 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 15          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
+ABI_VERSION = 16          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
 
 
 def load():
@@ -136,6 +145,10 @@ def load():
     lib.rmem_linear.argtypes = [C.POINTER(LinearArgs), c_p]
     lib.rmem_linear_grouped.argtypes = [C.POINTER(LinearArgs), i32, c_p]
     lib.rmem_linear_trace.argtypes = [C.POINTER(LinearArgs), i32, c_p, c_p]
+    lib.rmem_ln_linear_grouped.argtypes = [C.POINTER(RowresStream), i32, i32, i32, i32, i64, i64, f32,
+                                           C.POINTER(RowresProblem), i32, c_p]
+    lib.rmem_ln_linear_grouped_trace.argtypes = [C.POINTER(RowresStream), i32, i32, i32, i32, i64, i64, f32,
+                                                 C.POINTER(RowresProblem), i32, c_p, c_p]
     lib.rmem_layernorm_red.argtypes = [c_p, i64, c_p, i32, i64, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64,
                                        c_p, i64, c_p]
     lib.rmem_bias_act_nchw.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p]
@@ -311,6 +324,46 @@ def linear_grouped(args):
     """One launch for up to 8 problems built with linear(..., launch=False)."""
     arr = (LinearArgs * len(args))(*args)
     check(load().rmem_linear_grouped(arr, len(args), stream_ptr()), "rmem_linear_grouped")
+
+
+def pack_frag(w: Planes) -> torch.Tensor:
+    """Weight planes [N][K] (or [batch][N][K]) -> the MFMA-fragment order rmem_ln_linear_grouped streams straight into
+    registers (include/rmem_hip.h): [batch][ceil(N/32)][K/16][plane][lane = (k / 8 % 2) * 32 + col % 32][8 halves]; rows
+    beyond N are zero."""
+    hi, lo = w.hi, w.lo
+    if hi.dim() == 2:
+        hi, lo = hi[None], lo[None]
+    nb, n, k = hi.shape
+    if k % 16:
+        raise RmemError("pack_frag: K must be a multiple of 16")
+    u = (n + 31) // 32
+    t = torch.zeros(2, nb, u * 32, k, dtype=torch.float16, device=hi.device)
+    t[0, :, :n], t[1, :, :n] = hi, lo
+    t = t.view(2, nb, u, 32, k // 16, 2, 8)              # plane, batch, unit, col, k-step, k-group, e
+    return t.permute(1, 2, 4, 0, 5, 3, 6).contiguous()   # batch, unit, k-step, plane, k-group, col, e
+
+
+def rowres_stream(x=None, xo=None, parts=None, gamma=None, beta=None, planes: Planes = None, ldo=256, plane_off=0):
+    st = RowresStream()
+    st.x, st.xo, st.parts, st.gamma, st.beta = ptr(x), ptr(xo), parts, ptr(gamma), ptr(beta)
+    if planes is not None:
+        st.oh, st.ol, st.ldo = planes.hi.data_ptr() + 2 * plane_off, planes.lo.data_ptr() + 2 * plane_off, ldo
+    return st
+
+
+def ln_linear_grouped(streams, mode, N, nparts, part_stride, ldpart, eps, probs, trace=None):
+    """rmem_ln_linear_grouped: `probs` = [(LinearArgs, packed weights tensor, xk0, bxk), ...]; trace = int64 device
+    tensor for the cycle-stamp variant (debug)."""
+    sa = (RowresStream * len(streams))(*streams)
+    pa = (RowresProblem * len(probs))()
+    for i, (lin, wpk, xk0, bxk) in enumerate(probs):
+        pa[i].lin, pa[i].wpk, pa[i].xk0, pa[i].bxk = lin, wpk.data_ptr(), xk0, bxk
+    if trace is not None:
+        check(load().rmem_ln_linear_grouped_trace(sa, len(streams), mode, N, nparts, part_stride, ldpart, eps, pa,
+                                                  len(probs), trace.data_ptr(), stream_ptr()), "rmem_ln_linear_grouped_trace")
+        return
+    check(load().rmem_ln_linear_grouped(sa, len(streams), mode, N, nparts, part_stride, ldpart, eps, pa, len(probs),
+                                        stream_ptr()), "rmem_ln_linear_grouped")
 
 
 def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool, conv_bias=None) -> torch.Tensor:

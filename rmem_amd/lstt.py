@@ -196,6 +196,15 @@ class DeAOTLSTT:
             W.bu12 = self._f(torch.cat([g("self_attn.linear_U1.bias"), g("self_attn.linear_U2.bias")], 0))
             W.Wp_self, W.bp_self = (self._pl(g("self_attn.projection.weight")),
                                     self._f(g("self_attn.projection.bias")))
+            # the weights of the projections that read the normalised rows, in MFMA-fragment order for
+            # rmem_ln_linear_grouped (LayerNorm + grouped projections in one launch, csrc/linear_rowres.h)
+            W.Wq_f, W.Wrel_f, W.Wv_f, W.Wu_f = (hip.pack_frag(x) for x in (W.Wq, W.Wrel_x, W.Wv, W.Wu))
+            W.pe_f = {T: hip.pack_frag(v[0]) for T, v in W.pe_x.items()}
+            if l > 0:
+                W.Widu_f = hip.pack_frag(W.Widu)
+            W.Wqk_f = hip.pack_frag(W.Wqk)
+            W.Wv12_f = hip.pack_frag(Planes(W.Wv12.hi.view(2, 512, 256), W.Wv12.lo.view(2, 512, 256)))
+            W.Wu12_f = hip.pack_frag(Planes(W.Wu12.hi.view(2, 512, 256), W.Wu12.lo.view(2, 512, 256)))
             self.lw.append(W)
 
     # ------------------------------------------------------------------ key splits
@@ -326,6 +335,21 @@ class DeAOTLSTT:
         N, Np, dev = self.N, self.Npad, self.dev
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         self.tgt, self.tgt_id = z(N, 256), z(N, 256)
+        # LayerNorm + grouped projections as one launch (rmem_ln_linear_grouped): the workgroups of a row tile fold the
+        # split-K partials of the preceding projection while others still read the unfolded rows, so the folded residual
+        # streams go to a second pair of buffers and the two pairs alternate (self._tg / self._tgi = the current pair)
+        # RMEM_ROWRES: "fused" = the LayerNorm inside the launch (mode 0); "planes" = the LayerNorm launch stays and the
+        # row-tile-resident kernel reads its planes (mode 1); "0" (default) = LayerNorm launch + streaming kernel.
+        # All three are bit-identical (tests/test_hip_ops.py::test_ln_linear_grouped_equals_separate_launches) and, measured
+        # on one box in alternation (profiles/r05e_bench_ab_rowres.txt, r05c_lstt_modes.txt), equally fast: 523.6 / 521.2 /
+        # 521.0 frames/s, LSTT isolated 855.6 / 859.6 / 854.5 us -- the LayerNorm a workgroup repeats for its row tile is
+        # VALU-issue-bound (~9.6 k cycles per 64 rows: 150 instructions per row on two waves per SIMD) and eats what the
+        # single fetch of the activations saves; see DESIGN.md section 5.
+        rr = os.environ.get("RMEM_ROWRES", "0")
+        self.rowres = (self.clips_per_launch == 1 and os.environ.get("RMEM_LINEAR", "") != "tiles" and rr != "0")
+        self.rowres_fused = self.rowres and rr == "fused"
+        self.tgt_b, self.tgt_id_b = (z(N, 256), z(N, 256)) if self.rowres_fused else (None, None)
+        self._tg, self._tgi = self.tgt, self.tgt_id
         self.sched = None if os.environ.get("RMEM_NO_PULL") == "1" else z(2, dt=torch.int32)   # rmem_read_args.sched
         self.x_pl = Planes.empty((Np, 256), dev)
         self.z_pl = [Planes.empty((Np, 256), dev) for _ in range(self.L)]
@@ -551,11 +575,15 @@ class DeAOTLSTT:
         pp0 = self.parts.data_ptr() if parts else None
         pp1 = self.parts.data_ptr() + 256 * 4 if parts else None
         rc = hip.load().rmem_layernorm_red2(
-            self.tgt.data_ptr(), self.tgt_id.data_ptr(), 256, pp0, pp1, np_, self.N * 512, 512,
+            self._tg.data_ptr(), self._tgi.data_ptr(), 256, pp0, pp1, np_, self.N * 512, 512,
             gb0[0].data_ptr(), gb0[1].data_ptr(), gb1[0].data_ptr(), gb1[1].data_ptr(), self.N, 256, 1e-5,
             out0.hi.data_ptr() + off0 * 2, out0.lo.data_ptr() + off0 * 2, ldo0,
             out1.hi.data_ptr() + off1 * 2, out1.lo.data_ptr() + off1 * 2, ldo1, hip.stream_ptr())
         hip.check(rc, "rmem_layernorm_red2")
+
+    def _other_pair(self):
+        """The residual-stream pair the next fused LayerNorm launch folds into (not the current one)."""
+        return (self.tgt_b, self.tgt_id_b) if self._tg is self.tgt else (self.tgt, self.tgt_id)
 
     def _read_args(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
                    qpl: Planes, bias, U, want_mass: bool, ksplits: int, uneven: bool = False):
@@ -715,6 +743,7 @@ class DeAOTLSTT:
         if part != "all" and (ref_frame or self.branch_order != "serial"):
             raise hip.RmemError("front/rest split needs a propagation frame and the paired schedule")
         cur, T = self.cur, self._T
+        self._tg, self._tgi = self.tgt, self.tgt_id        # (the front part folds nothing: every part starts on the first pair)
         map_bank = self.maps.data_ptr()
         map_short = self.maps.data_ptr() + 16 * 4
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
@@ -736,7 +765,7 @@ class DeAOTLSTT:
             self._forward_layer(l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short)
         if do_rest:
             # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
-            hip.check(lib.rmem_groupnorm2(self.tgt.data_ptr(), self.tgt_id.data_ptr(), N, 256,
+            hip.check(lib.rmem_groupnorm2(self._tg.data_ptr(), self._tgi.data_ptr(), N, 256,
                                           self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
                                           self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
                       "rmem_groupnorm2")
@@ -748,8 +777,11 @@ class DeAOTLSTT:
         if seg_a:
             # -- norms + projections (transformer.py:1104-1123); the norms first fold in the
             #    split-K partials of the previous layer's self-attention projection
+            fused = self.rowres and not self._batched
+            ln_inside = fused and self.rowres_fused
             if l > 0:
-                self._ln2(W.ln1, self.x_pl, 256, 0, W.lnid1, self.z_pl[l], 256, 0, parts=True)
+                if not ln_inside:
+                    self._ln2(W.ln1, self.x_pl, 256, 0, W.lnid1, self.z_pl[l], 256, 0, parts=True)
             elif getattr(self, "_src_cn", None) is not None:
                 src = self._src_cn
                 hip.check(lib.rmem_layernorm_cn(src.data_ptr(), src.stride(0), self.tgt.data_ptr(), self.tgt_id.data_ptr(),
@@ -777,7 +809,27 @@ class DeAOTLSTT:
                 grp.append(hip.linear(self.z_pl[l], W.Widu, N, 512, 256, ldx=256, ldy=256, bias=W.bidu, act=1,
                                       d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns, tile=self._tile(64),
                                       launch=False))
-            hip.linear_grouped(grp)
+            if not fused:
+                hip.linear_grouped(grp)
+            else:
+                # ONE launch: (layers >= 1) norm1 / id_norm1 with the split-K fold, then every projection above from the
+                # row tile in LDS; layer 0: the planes rmem_layernorm_cn wrote are the tile (no fold, tgt_id = 0)
+                fr = [W.Wq_f, W.Wrel_f, W.pe_f[T], W.Wv_f, W.Wu_f] + ([W.Widu_f] if l > 0 else [])
+                probs = [(a, f, 256 if i == 5 else 0, 0) for i, (a, f) in enumerate(zip(grp, fr))]
+                if l == 0:
+                    hip.ln_linear_grouped([hip.rowres_stream(planes=self.x_pl, ldo=256)], 1, N, 0, 0, 0, 1e-5, probs)
+                elif not ln_inside:
+                    hip.ln_linear_grouped([hip.rowres_stream(planes=self.x_pl, ldo=256),
+                                           hip.rowres_stream(planes=self.z_pl[l], ldo=256)], 1, N, 0, 0, 0, 1e-5, probs)
+                else:
+                    to, tio = self._other_pair()
+                    pp = self.parts.data_ptr()
+                    hip.ln_linear_grouped(
+                        [hip.rowres_stream(x=self._tg, xo=to, parts=pp, gamma=W.ln1[0], beta=W.ln1[1]),
+                         hip.rowres_stream(x=self._tgi, xo=tio, parts=pp + 256 * 4, gamma=W.lnid1[0], beta=W.lnid1[1],
+                                           planes=self.z_pl[l], ldo=256)],
+                        0, N, self.KS, N * 512, 512, 1e-5, probs)
+                    self._tg, self._tgi = to, tio
             if ref_frame:
                 self._idv(l, cur)
         if not seg_b:
@@ -807,9 +859,12 @@ class DeAOTLSTT:
                    kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=self._tile(192), ksplits=self.KS, parts=self.parts,
                    part_stride=N * 512)       # 64 x 128 tiles: 27.5 -> 21.2 us (L2 -> LDS traffic -25 %)
         # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
-        self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
+        fused = self.rowres and not self._batched
+        ln_inside = fused and self.rowres_fused
+        if not ln_inside:
+            self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
         sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
-        hip.linear_grouped([
+        grp = [
             hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
                        nsplit=ns, tile=self._tile(64), launch=False),
             # V = silu([V1(s[:256]) | V2(s[256:])]) -> blocked-16 planes (two diagonal blocks)
@@ -818,7 +873,21 @@ class DeAOTLSTT:
                        bspa=512 * 16, nsplit=ns, tile=self._tile(64), launch=False),
             hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
                        d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
-                       bsbias=512, bsd=512, nsplit=ns, tile=self._tile(64), launch=False)])
+                       bsbias=512, bsd=512, nsplit=ns, tile=self._tile(64), launch=False)]
+        sprobs = [(grp[0], W.Wqk_f, 0, 0), (grp[1], W.Wv12_f, 0, 256), (grp[2], W.Wu12_f, 0, 256)]
+        if not fused:
+            hip.linear_grouped(grp)
+        elif not ln_inside:    # the planes of [norm2(tgt) | id_norm2(tgt_id)] exist: two 256-wide streams of s_pl
+            hip.ln_linear_grouped([hip.rowres_stream(planes=self.s_pl, ldo=512),
+                                   hip.rowres_stream(planes=self.s_pl, ldo=512, plane_off=256)], 1, N, 0, 0, 0, 1e-5, sprobs)
+        else:              # norm2 / id_norm2 (+ the split-K fold of the projection above) and the three projections: one launch
+            to, tio = self._other_pair()
+            pp = self.parts.data_ptr()
+            hip.ln_linear_grouped(
+                [hip.rowres_stream(x=self._tg, xo=to, parts=pp, gamma=W.ln2[0], beta=W.ln2[1]),
+                 hip.rowres_stream(x=self._tgi, xo=tio, parts=pp + 256 * 4, gamma=W.lnid2[0], beta=W.lnid2[1])],
+                0, N, self.KS, N * 512, 512, 1e-5, sprobs)
+            self._tg, self._tgi = to, tio
         self._read(self._read_args(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
                                    False, self.ks_self))
         self._dwconv(self.ws_main, W.dw_self, self.Ylt)

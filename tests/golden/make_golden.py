@@ -13,6 +13,7 @@ Fixtures are data only (inputs + the reference's outputs):
   clip_480p.json/.npz        481x849 clip: per-frame label hashes + a few logits (fp16)
   multiengine_wrapper.*      AOTInferEngine.separate_mask / soft_logit_aggregation (> 10 objects)
   clip_480p_fp64.*           the same 481x849 clip through the reference in DOUBLE precision (near-tie arbitration)
+  clip_480p_long*.json/.npz  the 481x849 clip at the evaluator's gap 5 over 46 frames (six evictions) + its fp64 tie lists
   *_amp.json/.npz            golden clips through the reference under fp16 autocast (its --amp mode), teacher-forced
 """
 from __future__ import annotations
@@ -473,6 +474,101 @@ def gen_clip_480p_fp64(tie_margin=1e-4, token_stride=4):
     print("480p fp64 arbitration:", info)
 
 
+def gen_clip_480p_long(frames=46, tie_margin=1e-4, resume=False):
+    """BASELINE.json configs[1] at the evaluator's own schedule (managers/evaluator.py:331-332: gap 5), K = 4,
+    481x849, long enough for the benchmarked steady state: the bank fills at frame 15 and every long-term update
+    from frame 20 on evicts (frames 20, 25, 30, 35, 40, 45 -> six evictions in 46 frames).
+      clip_480p_long.json/.npz   the reference's closed-loop fp32 run: label maps, long_memories_indexes /
+                                 EMA / visit dictionaries / layer-0 attention mass after every frame, decoder
+                                 logits (fp16) of frames 1, 20 (first eviction) and the last frame
+      clip_480p_long_fp64.npz    the same clip through the reference in DOUBLE precision, teacher-forced with those
+                                 labels: per frame the near-tie list (flat pixel index, the two best classes, their
+                                 fp64 logits and the fp32 re-run's logits) and the pixels on which the fp32
+                                 reference's own label differs from the fp64 one (always inside the tie list)
+    """
+    ref = rh.import_reference()
+    H, W, out_hw, gap, former, latter, seed = 481, 849, (480, 854), 5, 1, 3, 0
+    imgs32, lab = synth_clip(seed, frames, H, W, 3)
+    if resume:             # (--long-fp64-only: the closed-loop run is on disk, redo the arbitration only)
+        meta = json.load(open(os.path.join(HERE, "clip_480p_long.json")))
+        gold_labels = np.load(os.path.join(HERE, "clip_480p_long.npz"))["labels"]
+        assert meta["frames"] == frames
+    else:
+        cfg, model, engine = rh.build_reference("r50_deaotl", former, latter, gap)
+        cap = (1, 20, frames - 1)
+        rec = run_reference_clip(engine, imgs32, lab, out_hw, capture_logits=cap)
+        n_evict = sum(1 for a, b in zip(rec["indexes"][:-1], rec["indexes"][1:]) if a != b and len(b) <= len(a))
+        meta = dict(H=H, W=W, out_hw=list(out_hw), frames=frames, gap=gap, former=former, latter=latter, seed=seed,
+                    indexes=rec["indexes"], ema=rec["ema"], visits=rec["visits"], hist=rec["hist"], mass0=rec["mass0"],
+                    label_sha=[sha(l) for l in rec["labels"]], evictions=n_evict, logit_frames=list(cap))
+        json.dump(meta, open(os.path.join(HERE, "clip_480p_long.json"), "w"))
+        gold_labels = torch.stack(rec["labels"]).numpy()
+        np.savez_compressed(os.path.join(HERE, "clip_480p_long.npz"),
+                            **{f"logits_{t}": v.numpy().astype(np.float16) for t, v in rec["logits"].items()},
+                            labels=gold_labels)
+        print("clip 480p long: evictions", n_evict, "indexes", rec["indexes"][-1], flush=True)
+
+    AOTEngine = ref["aot_engine"].AOTEngine
+    prev_assign = AOTEngine.assign_identity
+
+    def run(dtype):
+        AOTEngine.assign_identity = lambda self, oh, ign=None: prev_assign(
+            self, oh.to(dtype), None if ign is None else ign.to(dtype))
+        torch.set_default_dtype(dtype)
+        try:
+            cfg, model, engine = rh.build_reference("r50_deaotl", former, latter, gap)
+            ups, idx = [], []
+            with torch.no_grad(), rh.quiet():
+                engine.restart_engine()
+                engine.add_reference_frame(imgs32[0].to(dtype), lab.int(), obj_nums=[int(lab.max())], frame_step=0)
+                sub = engine.aot_engines[0]
+                for t in range(1, frames):
+                    up = engine.match_propogate_one_frame(imgs32[t].to(dtype), output_size=out_hw)
+                    ups.append(up[0].clone())
+                    fed = torch.from_numpy(gold_labels[t - 1]).to(dtype)[None, None]
+                    engine.update_memory(F.interpolate(fed, size=engine.input_size_2d, mode="nearest"))
+                    idx.append(list(sub.long_memories_indexes))
+            return ups, idx
+        finally:
+            torch.set_default_dtype(torch.float32)
+            AOTEngine.assign_identity = prev_assign
+
+    u64s, idx64 = run(torch.float64)
+    assert idx64 == meta["indexes"], "the fp64 run must evict the same slots"
+    # (the fp32 side is the closed-loop run above: its own labels are what it was fed, so a teacher-forced fp32 re-run
+    # reproduces it frame by frame; its full-size logits are recomputed here only for the tie pixels)
+    u32s, idx32 = run(torch.float32)
+    assert idx32 == meta["indexes"]
+    out, info = {}, dict(tie_margin=tie_margin, mism32_vs_64=[], n_tie=[])
+    for t in range(1, frames):
+        u64, u32 = u64s[t - 1], u32s[t - 1]
+        # the label the evaluator takes is argmax(softmax(logit)) (managers/evaluator.py:430-441): in fp32 the softmax can
+        # round two near-tied logits to one probability, and argmax then takes the lower id
+        l32 = torch.argmax(torch.softmax(u32, dim=0), dim=0).to(torch.uint8)
+        n_bad = int((l32 != torch.from_numpy(gold_labels[t - 1])).sum())
+        assert n_bad == 0, f"frame {t}: the fp32 re-run must reproduce the golden labels ({n_bad} pixels differ)"
+        l64 = torch.argmax(u64, dim=0).to(torch.uint8)
+        top = torch.topk(u64, 2, dim=0)
+        tie = torch.nonzero(((top.values[0] - top.values[1]) < tie_margin).flatten())[:, 0]
+        cls = top.indices.flatten(1)[:, tie].T.contiguous()
+        f64 = u64.flatten(1)[:, tie]
+        f32 = u32.flatten(1)[:, tie]
+        ar = torch.arange(tie.numel())
+        out[f"tie_idx_{t}"] = tie.to(torch.int32).numpy()
+        out[f"tie_cls_{t}"] = cls.to(torch.uint8).numpy()
+        out[f"tie_l64_{t}"] = torch.stack([f64[cls[:, 0], ar], f64[cls[:, 1], ar]], 1).numpy()
+        out[f"tie_l32_{t}"] = torch.stack([f32[cls[:, 0], ar], f32[cls[:, 1], ar]], 1).numpy()
+        mm = torch.nonzero((l32 != l64).flatten())[:, 0]
+        assert all(int(i) in set(tie.tolist()) for i in mm), "an fp32/fp64 disagreement outside the near-tie set"
+        out[f"mism32_idx_{t}"] = mm.to(torch.int32).numpy()
+        out[f"mism32_l64_{t}"] = l64.flatten()[mm].numpy()
+        info["mism32_vs_64"].append(int(mm.numel()))
+        info["n_tie"].append(int(tie.numel()))
+    np.savez_compressed(os.path.join(HERE, "clip_480p_long_fp64.npz"), **out)
+    json.dump(info, open(os.path.join(HERE, "clip_480p_long_fp64.json"), "w"))
+    print("480p long fp64 arbitration:", info, flush=True)
+
+
 def gen_amp_clips():
     """The reference's reduced-precision mode (`--amp`: tools/eval.py:45-47,90-92 wraps the whole evaluation in
     torch.cuda.amp.autocast) on the golden clips, TEACHER-FORCED with the labels of its fp32 run (so that every frame
@@ -533,6 +629,9 @@ def main():
     if "--fp64-only" in sys.argv:
         gen_clip_480p_fp64()
         return
+    if "--long-only" in sys.argv or "--long-fp64-only" in sys.argv:
+        gen_clip_480p_long(resume="--long-fp64-only" in sys.argv)
+        return
     if "--amp-only" in sys.argv:
         gen_amp_clips()
         return
@@ -553,6 +652,7 @@ def main():
     gen_ignore_clip()
     gen_multiengine()
     gen_clip_480p_fp64()
+    gen_clip_480p_long()
     gen_amp_clips()
     os.system(f"du -sh {HERE}")
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/rmem_hip.h but not exported"
     assert declared == set(hip.EXPORTS)
     assert every - declared == set(hip.EXPORTS_OTHER)
-    assert lib.rmem_abi_version() == 15
+    assert lib.rmem_abi_version() == 16
 
 
 def test_launch_recorder_records_without_a_gpu():
@@ -63,9 +63,9 @@ def test_ctypes_struct_sizes_match_header_layout():
     src = r'''
     #include "rmem_hip.h"
     #include <stdio.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_mha_args),
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_mha_args),
                        sizeof(rmem_mha_combine_args), sizeof(rmem_read_args), sizeof(rmem_read_combine_args),
-                       sizeof(rmem_bank_state)); return 0; }'''
+                       sizeof(rmem_bank_state), sizeof(rmem_rowres_stream), sizeof(rmem_rowres_problem)); return 0; }'''
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
@@ -74,7 +74,7 @@ def test_ctypes_struct_sizes_match_header_layout():
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     assert sizes == [ctypes.sizeof(hip.LinearArgs), ctypes.sizeof(hip.MHAArgs),
                      ctypes.sizeof(hip.MHACombineArgs), ctypes.sizeof(hip.ReadArgs), ctypes.sizeof(hip.ReadCombineArgs),
-                     ctypes.sizeof(hip.BankState)]
+                     ctypes.sizeof(hip.BankState), ctypes.sizeof(hip.RowresStream), ctypes.sizeof(hip.RowresProblem)]
 
 
 def test_product_path_never_imports_oracle():
