@@ -110,6 +110,25 @@ def pmc_traffic(roofline: dict, key) -> None:
             return
 
 
+def pmc_kernel_traffic(entry: dict, key) -> None:
+    """HBM-side bytes per launch of a kernel class from the committed PMC file of this configuration (separate rocprofv3
+    --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes) and its ratio to the class's algorithmic bytes."""
+    name, _ = PMC_FILES.get(key, (None, None))
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
+        return
+    want = entry["kernel"].split(" ")[0].split("_kernel")[0]
+    alias = {"read_combine2": "_ZN4rmem5k_oneI12Combine2Args", "read_combine": "_ZN4rmem5k_oneI22rmem_read_combine_args",
+             "layernorm_red2": "_ZN4rmem5k_oneI10LnRed2Args"}
+    for k, v in json.load(open(path)).items():
+        if isinstance(v, dict) and "hbm_bytes_per_launch" in v and (k.startswith(want + "_kernel") or k.startswith(alias.get(want, "\0"))):
+            entry["traffic"] = v["hbm_bytes_per_launch"]
+            entry["traffic_source"] = f"profiles/{name}"
+            if entry.get("algorithmic_mb_per_launch"):
+                entry["traffic_over_algorithmic"] = v["hbm_bytes_per_launch"] / (entry["algorithmic_mb_per_launch"] * 1e6)
+            return
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec this script as N ranks of one node through
     torch.distributed.run (one process per GPU, LOCAL_RANK -> device), the role mp.spawn(main_worker,
@@ -166,6 +185,17 @@ def init_dist(world: int):
     return dist
 
 
+def gather_rank_vectors(dist, vec, dev):
+    """Every rank's list of floats -> [world][len] (one all-gather; the values themselves are host-side statistics)."""
+    if dist is None:
+        return [list(map(float, vec))]
+    on = dev if dist.get_backend() != "gloo" else torch.device("cpu")
+    mine = torch.tensor(list(map(float, vec)), dtype=torch.float64, device=on)
+    every = torch.zeros(dist.get_world_size() * len(vec), dtype=torch.float64, device=on)
+    dist.all_gather_into_tensor(every, mine)
+    return [[float(v) for v in row] for row in every.cpu().view(dist.get_world_size(), len(vec))]
+
+
 def max_over_ranks(dist, elapsed: float, dev):
     """(max over ranks, list of every rank's value): the job takes as long as its slowest rank."""
     if dist is None:
@@ -194,6 +224,11 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus = {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # host placement: this rank's threads on its share of the NUMA node its GPU hangs off (rmem_amd/affinity.py), before
+    # any thread pool exists; external launchers (torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset) included
+    from rmem_amd.affinity import pin_rank
+    PIN = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), rank_device)
+    args._pin = PIN
     local_rank = rank_device(local_rank)
     from rmem_amd import hip as _hip
     _hip.set_host_wait(local_rank)       # RMEM_BLOCKING_WAIT=1 only (opt-in, before this process touches the device): see rmem_amd.hip.set_host_wait
@@ -371,6 +406,21 @@ def main():
                   "flags": "--no-prefetch --reference-postproc (match_propogate_one_frame(img, output_size) -> torch "
                            "softmax/argmax/nearest -> update_memory, nothing announced ahead)"}
         PREFETCH, args.reference_postproc = PREFETCH_SAVE, POST_SAVE
+    # ---- per-kernel roofline sample (outside the timed window, same steady state and announcements): every fourth frame
+    # of a short extra run issues the LSTT's `rest` part eagerly with HIP events around each launch
+    # (DeAOTEngine._graphed_frame, lstt._ev); the host is frames ahead of the GPU, so the launches queue like replayed ones
+    kernels = None
+    if rank == 0 and C == 1 and sampled and os.environ.get("RMEM_BENCH_KERNELS", "1") == "1":
+        tk = t + args.steps + 200
+        lstt._kev_store, lstt._kev_frames = [], 0
+        for k in range(8):
+            all_clips(tk + k)
+        for k in range(48):
+            lstt._sample_kernels = (k % 4 == 2)
+            all_clips(tk + 8 + k)
+        lstt._sample_kernels = False
+        torch.cuda.synchronize()
+        kernels = lstt.kernel_report(MFMA_PEAK_TFLOPS)
     out = {
         "metric": "frames/sec/GPU (480p, K=4 memory) R50-DeAOTL+RMem; mask IoU vs ref"
         if (args.config == "480p_k4" and args.model == "r50_deaotl") else f"frames/sec/GPU ({args.config}) {args.model}+RMem"
@@ -391,9 +441,17 @@ def main():
                    "parallelism": f"clips sharded {C}-per-GPU x{world}" + (" (one engine + HIP stream per clip)" if C > 1 else "")
                    + ", all-gather of masks"},
     }
+    # every rank's host side (one small all-gather after the timed window): CPU ms per step of the process and of its
+    # three busiest threads, where it is pinned
+    top3 = (sorted(host_threads.values(), reverse=True) + [0.0, 0.0, 0.0])[:3]
+    rows = gather_rank_vectors(dist, [1e3 * host_cpu / args.steps] + top3 +
+                               [1.0 if PIN.get("pinned") else 0.0, float(PIN.get("numa_node") if PIN.get("numa_node") is not None else -1),
+                                float(PIN.get("cpus", 0)), float(PIN.get("first_cpu", -1))], dev)
+    out["config"]["per_rank_frames_per_sec"] = [C * args.steps / t_ for t_ in per_rank_s]
+    out["config"]["per_rank_host"] = [{"host_cpu_ms_per_step": round(r[0], 3), "busiest_threads_ms_per_step": [round(v, 3) for v in r[1:4]],
+                                       "pinned": bool(r[4]), "numa_node": int(r[5]), "cpus": int(r[6]), "first_cpu": int(r[7])} for r in rows]
     if dist is not None:
         import hashlib
-        out["config"]["per_rank_frames_per_sec"] = [C * args.steps / t_ for t_ in per_rank_s]
         out["config"]["dist_backend"] = dist.get_backend()
         if rank == 0:      # outside the timed region: what the exchange step delivered, [world*C, steps, H, W] uint8
             out["config"]["gathered_masks_shape"] = list(gathered.shape)
@@ -417,12 +475,26 @@ def main():
             out["roofline"]["context"] = ("split-fp16: 3 MFMAs issued per algorithmic product; under this kernel the board is "
                                           "power-limited (1300 W, shader clock 1.7-1.9 GHz of 2.4); hipBLASLt's fp16 8192^3 GEMM "
                                           "sustains 1275 TFLOP/s = 0.51 of `peak` on the same box (profiles/r03_s_power_probe.json)")
+        if out["roofline"] and kernels:
+            # the five largest kernel classes of the memory path by time per frame, each against the roofline that bounds it;
+            # `roofline` itself stays the largest one.  traffic = HBM-side bytes per launch from the committed PMC passes
+            for e in kernels[:5]:
+                pmc_kernel_traffic(e, (args.model, args.config, "one"))
+            out["roofline"]["kernels"] = kernels[:5]
+            out["roofline"]["kernels_how"] = (f"{lstt._kev_frames} sampled frames after the timed window (every 4th frame of 48, same "
+                                              "announcements): the LSTT's `rest` part issued eagerly with HIP events around every "
+                                              "launch, queued behind the previous frames' work; us_per_frame sums a class's launches")
+            out["roofline"]["memory_path_us_per_frame_sampled"] = sum(e["us_per_frame"] for e in kernels)
         if dropin is not None:
             out["dropin"] = dropin
-        if world == 1 and not args.no_cpu_baseline and args.model == "r50_deaotl":
+        if world == 1 and not args.no_cpu_baseline:
             cb, par = cpu_baseline_and_parity(cpu_model, model, cfg, args, dev)
             out["cpu_baseline"] = cb
             out.update(par)
+            if args.model == "r50_deaotl" and args.config == "480p_k4" and args.nsplit == 3:
+                ref_par = parity_vs_reference_fixture(model, cfg, args, dev)
+                if ref_par is not None:
+                    out["parity_vs_reference"] = ref_par
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -644,6 +716,7 @@ def clips64(args, world, rank, local_rank, dev, dist):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     if args.batched:       # this rank's clips in lockstep, one launch per kernel for all of them
         res = drv.run_clips([cache[c] for c in mine], num_frames=F_)
         t_issue = time.perf_counter() - t0             # host time to issue the clips (the GPU may still be running)
@@ -663,7 +736,12 @@ def clips64(args, world, rank, local_rank, dev, dist):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_cpu = time.process_time() - cpu0
     elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
+    PIN = getattr(args, "_pin", {})
+    rows = gather_rank_vectors(dist, [host_cpu, 1.0 if PIN.get("pinned") else 0.0,
+                                      float(PIN.get("numa_node") if PIN.get("numa_node") is not None else -1),
+                                      float(PIN.get("cpus", 0)), float(PIN.get("first_cpu", -1))], dev)
     hashes = D.hash_masks(host, n_clips, world)        # verification by-product, after the window (sha256 of 49 MB: 20-40 ms of host time)
     total_frames = n_clips * (F_ - 1)               # propagated frames (the reference frame is not a "frame/s" frame in evaluator.py:571-587)
     if rank == 0:
@@ -677,6 +755,10 @@ def clips64(args, world, rank, local_rank, dev, dist):
                        "clips": n_clips, "frames_per_clip": F_, "frames_per_sec_per_gpu": total_frames / elapsed / world,
                        "batched": bool(args.batched),
                        "per_rank_seconds": per_rank_s, "rank0_sections_s": sections,
+                       "per_rank_frames_per_sec": [args.clips_per_rank * (F_ - 1) / t_ for t_ in per_rank_s],
+                       "per_rank_host": [{"host_cpu_s": round(r[0], 3), "host_cpu_cores_busy": round(r[0] / t_, 2), "pinned": bool(r[1]),
+                                          "numa_node": int(r[2]), "cpus": int(r[3]), "first_cpu": int(r[4])}
+                                         for r, t_ in zip(rows, per_rank_s)],
                        "dist_backend": dist.get_backend() if dist is not None else None,
                        "parallelism": f"clips sharded {args.clips_per_rank}-per-GPU x{world}"
                                       + (" in lockstep (one launch per kernel for all clips of a rank)" if args.batched else "")
@@ -696,30 +778,40 @@ def db_eval_iou(annotation, segmentation):
     return 1.0 if union == 0 else inter / union
 
 
+def label_iou(a: np.ndarray, b: np.ndarray):
+    """Mean / min Jaccard index over EVERY id present in either label map (background and all live object ids: the
+    reference keeps all `max_obj_num` ids live, aot_engine.py:695-700), evaluation/source/metrics.py:db_eval_iou per id."""
+    ids = sorted(set(np.unique(a).tolist()) | set(np.unique(b).tolist()))
+    v = [db_eval_iou(a == o, b == o) for o in ids]
+    return float(np.mean(v)), float(np.min(v)), [int(o) for o in ids]
+
+
 def cpu_baseline_and_parity(cpu_model, gpu_model, cfg, args, dev):
     """(a) cpu_baseline: the oracle (CPU restatement of the reference path, fp32 PyTorch-CPU) timed
     on a bounded sample of the same workload: same clip generator, geometry and K; the bank is
-    pre-filled to T=K with gap=1, then `cpu_frames` steady-state frames are timed with the reference's
+    pre-filled (gap 1) to min(K, 4) slots, then `cpu_frames` frames are timed with the reference's
     timing window.  (b) parity, outside every timed region: a fresh HIP engine runs the same frames
     teacher-forced (both engines are fed the ORACLE's label, so the count is per frame, not the growth
-    of a chaotic closed loop): mismatching label pixels and mean object IoU against the oracle."""
-    import numpy as np
-    from oracle.engine_ref import OracleDeAOTEngine
+    of a chaotic closed loop): mismatching label pixels and the IoU over every id present against the oracle.
+    Serves every --model / --config of the one-clip mode (DeAOT and AOT oracle engines)."""
+    from oracle.engine_ref import OracleAOTEngine, OracleDeAOTEngine
     from rmem_amd.engine import build_engine
     from rmem_amd.synth import synth_clip
     # all cores is slower than a few dozen on many-core hosts for these op sizes (measured:
     # 256 threads -> 112 s/frame); use at most 32 and report the count actually used.
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    ora = OracleDeAOTEngine(cpu_model, long_term_mem_gap=1)
+    ora = (OracleDeAOTEngine if cfg.MODEL_VOS == "deaot" else OracleAOTEngine)(cpu_model, long_term_mem_gap=1)
     eng = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=gpu_model, gpu_id=dev.index or 0,
                        long_term_mem_gap=1, nsplit=args.nsplit)
     eng.eval()
-    n = args.cpu_frames
-    imgs, lab = synth_clip(0, 4 + n, H_IN, W_IN, 3)
+    big = H_IN > 600
+    n = min(args.cpu_frames, 2) if big else args.cpu_frames          # (720p: 8-11 s per frame on the CPU)
+    pre = min(cfg.mem_cap, 4)
+    imgs, lab = synth_clip(0, pre + n, H_IN, W_IN, 3)
     gimgs = [x.to(dev) for x in imgs]
     ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
     eng.add_reference_frame(gimgs[0], lab.to(dev), obj_nums=[3], frame_step=0)
-    mism, ious, lerr = [], [], []
+    mism, ious, iou_min, ids_seen, lerr = [], [], [], set(), []
 
     def step(t, timed):
         logit = ora.match_propogate_one_frame(imgs[t], output_size=(H_OUT, W_OUT))
@@ -733,33 +825,78 @@ def cpu_baseline_and_parity(cpu_model, gpu_model, cfg, args, dev):
         mine = torch.argmax(lg, dim=1, keepdim=True).cpu()
         a, b = pred.long().numpy()[0, 0], mine.numpy()[0, 0]
         mism.append(int((a != b).sum()))
-        ious.append(float(np.mean([db_eval_iou(a == o, b == o) for o in range(1, 4)])))
+        m, lo, ids = label_iou(a, b)
+        ious.append(m), iou_min.append(lo), ids_seen.update(ids)
         lerr.append(float((eng.aot_engines[0].pred_id_logits.cpu() - ologits).abs().max()))
         eng.update_memory(cur.to(dev))
 
     fed = []
-    for t in range(1, 4):
+    for t in range(1, pre):
         fed.append((t,) + step(t, False))
     ora.long_term_mem_gap = args.gap
     t0 = time.perf_counter()
-    for t in range(4, 4 + n):
+    for t in range(pre, pre + n):
         fed.append((t,) + step(t, True))
     el = time.perf_counter() - t0
     for t, pred, cur, ologits in fed:               # the HIP engine replays the same protocol
-        if t == 4:
+        if t == pre:
             eng.long_term_mem_gap = args.gap
             for e in eng.aot_engines:
                 e.long_term_mem_gap = args.gap
         hip_step(t, pred, cur, ologits)
     idx_ok = list(eng.aot_engines[0].long_memories_indexes) == list(ora.long_memories_indexes)
     cb = {"value": n / el, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-          "sample": f"{n} steady-state frames (T=4) of the same 480p K=4 workload, oracle/ on PyTorch-CPU fp32"}
+          "sample": f"{n} frames (bank of {pre} slots) of the same {H_OUT}p K={cfg.mem_cap} workload ({args.model}), oracle/ on PyTorch-CPU fp32"}
     par = {"mask_mismatch_px": mism, "mask_pixels_per_frame": int(H_OUT * W_OUT),
-           "iou_vs_oracle": float(np.mean(ious)), "iou_vs_oracle_min": float(np.min(ious)),
+           "iou_vs_oracle": float(np.mean(ious)), "iou_vs_oracle_min": float(np.min(iou_min)), "iou_ids": sorted(ids_seen),
            "logit_max_abs_err_vs_oracle": float(np.max(lerr)), "eviction_sequence_equal": bool(idx_ok),
            "parity_note": f"{len(mism)} teacher-forced frames (oracle labels fed to both), HIP engine vs CPU oracle, "
-                          "outside the timed regions; IoU = mean over 3 objects of evaluation/source/metrics.py:db_eval_iou"}
+                          "outside the timed regions; IoU = evaluation/source/metrics.py:db_eval_iou per id, mean (and min) over "
+                          "EVERY id present in either label map (iou_ids), background included"}
     return cb, par
+
+
+def parity_vs_reference_fixture(gpu_model, cfg, args, dev):
+    """'mask IoU vs ref' on the benchmarked schedule, against the REFERENCE itself: tests/golden/clip_480p_long.* holds
+    the reference's own closed-loop run of this workload (481x849, K = 4, the evaluator's gap 5, 46 frames: the bank is
+    full from frame 15, six evictions; make_golden.py:gen_clip_480p_long).  A fresh HIP engine runs the clip
+    teacher-forced with the reference's labels, next frames announced as in the timed loop; per frame: pixels off the
+    reference's label map, IoU over every id present; the kept-frame history must equal the reference's."""
+    gd = os.path.join(ROOT, "tests", "golden")
+    if not (os.path.exists(os.path.join(gd, "clip_480p_long.json")) and os.path.exists(os.path.join(gd, "clip_480p_long.npz"))):
+        return None
+    from rmem_amd.engine import build_engine
+    from rmem_amd.synth import synth_clip
+    meta = json.load(open(os.path.join(gd, "clip_480p_long.json")))
+    gold = np.load(os.path.join(gd, "clip_480p_long.npz"))
+    if (meta["H"], meta["W"], meta["former"] + meta["latter"]) != (H_IN, W_IN, cfg.mem_cap):
+        return None
+    eng = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=gpu_model, gpu_id=dev.index or 0,
+                       long_term_mem_gap=meta["gap"], nsplit=args.nsplit)
+    eng.eval()
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    imgs = [x.to(dev) for x in imgs]
+    out_hw = tuple(meta["out_hw"])
+    eng.add_reference_frame(imgs[0], lab.to(dev), obj_nums=[3], frame_step=0)
+    mism, ious, iou_min, ids_seen, idx_ok = [], [], [], set(), True
+    for t in range(1, meta["frames"]):
+        nxt = imgs[t + 1:t + 1 + eng.lookahead] or None
+        lg = eng.match_propogate_one_frame(imgs[t], output_size=out_hw, next_img=nxt)
+        mine = torch.argmax(torch.softmax(lg, dim=1), dim=1)[0].cpu().numpy().astype(np.uint8)
+        ref = gold["labels"][t - 1]
+        mism.append(int((mine != ref).sum()))
+        m, lo, ids = label_iou(ref, mine)
+        ious.append(m), iou_min.append(lo), ids_seen.update(ids)
+        fed = torch.from_numpy(ref).float()[None, None].to(dev)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        idx_ok = idx_ok and list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][t - 1]
+    return {"fixture": "tests/golden/clip_480p_long.npz (the reference's own fp32 CPU run; fp64 near-tie lists in clip_480p_long_fp64.npz)",
+            "frames": len(mism), "evictions": meta["evictions"], "gap": meta["gap"],
+            "mask_mismatch_px": mism, "mask_mismatch_px_total": int(sum(mism)), "mask_pixels_per_frame": int(out_hw[0] * out_hw[1]),
+            "iou_vs_reference": float(np.mean(ious)), "iou_vs_reference_min": float(np.min(iou_min)), "iou_ids": sorted(ids_seen),
+            "bank_index_history_equal": bool(idx_ok),
+            "note": "teacher-forced with the reference's labels; every differing pixel is an fp32 near-tie of the reference "
+                    "itself (tests/test_hip_engine.py::test_480p_long_clip_gap5_vs_reference checks each against the fp64 list)"}
 
 
 if __name__ == "__main__":

@@ -193,6 +193,10 @@ typedef struct {
                                               hold pf 64-key tiles each, the other ksplits - nfull share the rest evenly (0 = even).
                                               rmem_attn_read2 launches the short pieces last, behind the windowed units, so that
                                               they run on the CUs the windowed units leave early.  Direct launches only. */
+  float *dbg_logits; int64_t dbg_ld;       /* debug, rmem_attn_read_trace only (ignored by every other entry): when non-NULL every
+                                              pre-softmax logit scale*(Q.K + bias) (mode 0) / scale*Q.K + R (mode 1, keys inside the
+                                              window) is written to dbg_logits[q*dbg_ld + t*N + key] -- the tensor the reference
+                                              takes its softmax of (layers/attention.py:184, :344); other elements are left alone */
 } rmem_read_args;
 
 int rmem_attn_read(const rmem_read_args *a, void *stream);

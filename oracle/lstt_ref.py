@@ -113,10 +113,10 @@ def local_window_index(h: int, w: int, max_dis: int = 7):
 
 def local_gated_propagation(q: Tensor, k: Tensor, v: Tensor, u: Tensor, h: int, w: int,
                             rel_w: Tensor, rel_b: Tensor, dw_w: Tensor, proj_w: Tensor,
-                            proj_b: Tensor, max_dis: int = 7) -> Tuple[Tensor, Tensor]:
+                            proj_b: Tensor, max_dis: int = 7, logits_out: Optional[list] = None) -> Tuple[Tensor, Tensor]:
     """LocalGatedPropagation.forward, use_linear=False, enable_corr=False, heads=1
     (layers/attention.py:289-361).  q,k [N,128] (unscaled), v [N,1024], u [N,1024].
-    Returns (out [N,512], local_attn [N,225])."""
+    Returns (out [N,512], local_attn [N,225]); logits_out (a list) receives the pre-softmax logits [N,225]."""
     n, d = q.shape
     idx, inside = local_window_index(h, w, max_dis)
     rel = q @ rel_w.view(rel_w.shape[0], d).t() + rel_b          # :314 (unscaled q)
@@ -125,6 +125,8 @@ def local_gated_propagation(q: Tensor, k: Tensor, v: Tensor, u: Tensor, h: int, 
     kg = kg * inside.unsqueeze(-1)
     qk = torch.einsum("nc,noc->no", qs, kg) + rel                # :334-342
     qk = qk - (~inside).float() * 1e8                            # :344
+    if logits_out is not None:
+        logits_out.append(qk)
     attn = torch.softmax(qk, dim=1)                              # :346
     vg = v[idx.clamp(min=0)] * inside.unsqueeze(-1)              # local2global + matmul, :350-353
     agg = torch.einsum("no,noc->nc", attn, vg)
@@ -206,7 +208,7 @@ def gpm_layer(sd: SD, layer: int, tgt: Tensor, tgt_id: Optional[Tensor], mem: Me
         Q, sK, torch.cat([sV, sIDV], dim=1), Ucat, h, w,
         sd[sp + "relative_emb_k.weight"], sd[sp + "relative_emb_k.bias"],
         sd[sp + "dw_conv.conv.weight"], sd[sp + "projection.weight"],
-        sd[sp + "projection.bias"])
+        sd[sp + "projection.bias"], logits_out=(st_logits := []))
 
     tgt = tgt + o2[:, :d] + o3[:, :d]                                            # :1212-1220
     tgt_id = tgt_id_in + o2[:, d:] + o3[:, d:]
@@ -221,6 +223,7 @@ def gpm_layer(sd: SD, layer: int, tgt: Tensor, tgt_id: Optional[Tensor], mem: Me
         trace[f"l{layer}.V"] = V
         trace[f"l{layer}.Ucat"] = Ucat
         trace[f"l{layer}.lt_logits"] = logits
+        trace[f"l{layer}.st_logits"] = st_logits[0]
         trace[f"l{layer}.o2"] = o2
         trace[f"l{layer}.o3"] = o3
         trace[f"l{layer}.local_attn"] = local_attn

@@ -356,6 +356,18 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
       for (int e = 0; e < 16; ++e)
         y[e] = ((vm >> e) & 1u) ? fmaf(s[e >> 2][e & 3], sl2e, rbw[e] * 1.44269504088896341f) : RD_NEG;
     }
+    if constexpr (TRACE != 0) {
+      // debug (rmem_attn_read_trace with a.dbg_logits): every pre-softmax logit this lane computed, in the natural-log
+      // domain the reference's QK tensor is in (attention.py:184, :344) -- keys outside the image / window are left alone
+      if (a.dbg_logits && qvalid) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int tok = key0 + (e >> 2) * 16 + lb * 4 + (e & 3);
+          if (tok < a.N && y[e] > 0.5f * RD_NEG)
+            a.dbg_logits[(long)q * a.dbg_ld + (long)(MODE == 0 ? t : 0) * a.N + tok] = y[e] * 0.693147180559945f;
+        }
+      }
+    }
     return t;
   };
 

@@ -49,6 +49,11 @@ def gather_masks(local_masks: torch.Tensor, world: int, group=None) -> torch.Ten
         return local_masks
     # (a one-rank group that IS initialised goes through the collective: bench.py with RMEM_FORCE_DIST=1 runs the
     # whole RCCL path -- communicator, uint8 all-gather, device-side timing exchange -- on a single leased GPU)
+    gsize = dist.get_world_size(group)
+    if world == 1 and gsize > 1:           # a local run inside a multi-rank job: nothing to exchange
+        return local_masks
+    if world != gsize:
+        raise ValueError(f"gather_masks: world={world} but the process group has {gsize} ranks")
     if local_masks.dtype != torch.uint8:
         raise TypeError("masks are exchanged as uint8 label maps")
     src = local_masks.contiguous()
@@ -151,26 +156,33 @@ def run_sharded_dataset(driver, lengths: Sequence[int], world: int, rank: int, f
         results = driver.run_dataset(clips) if clips else []
     else:
         results = [driver.run_clip(frames_of(cid), num_frames=int(lengths[cid])) for cid in assign[rank]]
+    dev_of_driver = torch.device("cuda", int(driver.gpu_id)) if (getattr(driver, "gpu_id", None) is not None
+                                                                 and torch.cuda.is_available()) else torch.device("cpu")
     for cid, res in zip(assign[rank], results):
-        if int(res.masks.shape[0]) != int(lengths[cid]) - 1:
-            raise ValueError(f"clip {cid}: {int(res.masks.shape[0]) + 1} frames run, {int(lengths[cid])} announced")
+        n_run = 0 if res.masks is None else int(res.masks.shape[0])       # (a one-frame clip propagates nothing)
+        if n_run != int(lengths[cid]) - 1:
+            raise ValueError(f"clip {cid}: {n_run + 1} frames run, {int(lengths[cid])} announced")
         local.append(res.masks)
     shape = None
-    for m in local:
+    have = [m for m in local if m is not None]
+    for m in have:
         if shape is not None and tuple(m.shape[1:]) != shape:
             raise ValueError("clips of one run_sharded_dataset call must share the output size")
         shape = tuple(m.shape[1:])
+    # the device of the exchange is the DRIVER's (a rank without clips -- fewer clips than ranks -- has no mask to take it
+    # from, and an RCCL group cannot exchange host tensors); gloo groups exchange on the host
+    devs = have[0].device if have else dev_of_driver
     if world > 1:          # a rank without clips still contributes a (zero) block: agree on the size
         import torch.distributed as dist
         hw = torch.tensor(list(shape) if shape else [0, 0], dtype=torch.int64)
-        if local and local[0].is_cuda and dist.get_backend(group) != "gloo":
-            hw = hw.to(local[0].device)
+        if devs.type == "cuda" and dist.get_backend(group) != "gloo":
+            hw = hw.to(devs)
         dist.all_reduce(hw, op=dist.ReduceOp.MAX, group=group)
         shape = tuple(int(v) for v in hw.cpu())
-    devs = local[0].device if local else torch.device("cpu")
-    block = torch.zeros((per, max(fmax, 1)) + tuple(shape), dtype=torch.uint8, device=devs)
+    block = torch.zeros((per, max(fmax, 1)) + tuple(shape or (0, 0)), dtype=torch.uint8, device=devs)
     for j, m in enumerate(local):
-        block[j, :m.shape[0]] = m
+        if m is not None:
+            block[j, :m.shape[0]] = m
     gathered = gather_masks(block, world, group)
     if host_out is not None and tuple(host_out.shape) == tuple(gathered.shape):
         host_out.copy_(gathered, non_blocking=True)
@@ -284,6 +296,7 @@ class ClipResult:
         self.obj_idx = None
         self.gap = None
         self.batched: Optional[bool] = None            # BatchedClipDriver.run_dataset: shared a lockstep batch / ran alone
+        self.handed_over_at: Optional[int] = None      # batched test-time augmentation -> per-augmentation engines at this frame
 
     @property
     def fps(self) -> float:
@@ -398,7 +411,13 @@ class ClipDriver:
                 ahead.append(f)
         if ahead and self._aug_batched_ok(ahead[0]):
             return self._run_clip_batched_aug(ahead, it, gap, res, save_dir, on_frame)
-        frame_idx = -1
+        return self._serial_loop(ahead, it, gap, res, save_dir, on_frame, -1, labels_out, timers, writers)
+
+    def _serial_loop(self, ahead, it, gap, res, save_dir, on_frame, frame_idx, labels_out, timers, writers):
+        """The evaluator's per-frame loop (managers/evaluator.py:384-527) over the frames still in `ahead` / `it`, one
+        engine per augmentation.  frame_idx = index of the last frame already handled (-1: the clip starts here; the
+        batched-augmentation path hands a clip over mid-way when a new label brings more objects than one engine holds)."""
+        on_cuda = False
         while ahead:
             samples, ahead = ahead[0], ahead[1:]
             f = next(it, None)
@@ -549,8 +568,31 @@ def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
             label = torch.where(new == 0, label, new)
             n_new = int(label.max().item())
             if n_new > maxo:
-                raise NotImplementedError(f"{n_new} objects after a mid-clip label: RMEM_TTA=serial (one sub-engine per "
-                                          f"{maxo} objects per augmentation)")
+                # More objects than one engine holds (aot_engine.py:675-702 grows sub-engines): the batched engine's
+                # slots are the augmentations, so the clip is handed to the per-augmentation multi-object engines AT
+                # THIS FRAME -- a mid-clip add_reference_frame re-initialises the memory from the frame anyway
+                # (aot_engine.py:241-325), so nothing of the batched engine's state is needed -- and the evaluator's
+                # loop continues there (ClipDriver._serial_loop).
+                engines = [self._engine(i) for i in range(B)]
+                for e, s_, fl in zip(engines, samples, flips):
+                    e.restart_engine()
+                    e.long_term_mem_gap = gap
+                    e.add_reference_frame(s_["current_img"],       # (a fresh engine learns its input size from this call)
+                                          ClipDriver._resize_generic(label, tuple(s_["current_img"].shape[2:]), fl),
+                                          obj_nums=[n_new], frame_step=frame_idx)
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record()
+                timers.append((t0, t1))
+                labels_out.append(label)
+                if on_frame is not None:
+                    on_frame(frame_idx, label, engines)
+                name = meta0.get("current_name", f"{frame_idx:05d}")
+                name = name[0] if isinstance(name, (list, tuple)) else name
+                res.names.append(str(name))
+                if save_dir is not None:
+                    writers.append(save_mask(label, os.path.join(save_dir, str(name).split(".")[0] + ".png"), res.obj_idx))
+                res.handed_over_at = frame_idx
+                return self._serial_loop(ahead, it, gap, res, save_dir, on_frame, frame_idx, labels_out, timers, writers)
             cur = torch.cat([ClipDriver._resize_generic(label, eng.input_size_2d, fl) for fl in flips])
             eng.add_reference_frame(imgs, cur, obj_nums=[maxo] * B, frame_step=frame_idx)
         else:                                                  # evaluator.py:509-523
@@ -858,8 +900,8 @@ class BatchedClipDriver:
         mode "queue" (default): the clips of one frame size share the B slots through run_queue() -- a slot takes
         the next clip when its clip ends, whatever the lengths and gaps.  mode "lockstep": plan_ragged_batches()
         groups clips by (gap, size) into batches that run for their longest clip (run_clips).  Either way test-time
-        augmentation, mid-clip labels, > 10 objects and a lone clip of its group run through ClipDriver.run_clip --
-        the reference's one-clip loop.  ClipResult.batched tells which way a clip went."""
+        augmentation, mid-clip labels and > 10 objects run through ClipDriver.run_clip -- the reference's one-clip loop
+        (mode "lockstep": a lone clip of its group too).  ClipResult.batched tells which way a clip went."""
         if mode not in ("queue", "lockstep"):
             raise ValueError("mode: queue | lockstep")
         info = [self.clip_info(c) for c in clips]
@@ -885,9 +927,10 @@ class BatchedClipDriver:
                     groups.setdefault((tuple(c["size"]), tuple(c["ori_size"])), []).append(i)
             for key in sorted(groups):
                 ids = groups[key]
-                if len(ids) < 2:
-                    singles.extend(ids)
-                    continue
+                # (a LONE clip of its size also goes through the slot queue, the other slots idle: a clip's label maps
+                # must not depend on how many clips of its size the rank happens to hold -- the one-clip engine splits
+                # the projections' K range differently from the recorded launches, so a near-tie pixel could differ and
+                # with it the clip hash that run_sharded_dataset promises to be independent of the world size)
                 for i, r in zip(ids, self.run_queue([clips[i] for i in ids])):
                     results[i] = r
         if singles:

@@ -511,6 +511,18 @@ class DeAOTEngine(nn.Module):
                 ent[4].replay()
             l.launch_read2_layer0()
             tail.replay()
+        elif getattr(l, "_sample_kernels", False) and ent[4] is not None:
+            # bench.py's per-kernel roofline sample: the `rest` part of this frame issued EAGERLY with HIP events around
+            # every launch (lstt._ev).  In steady state the host runs frames ahead of the GPU (graph replays), so these
+            # launches queue behind the previous frame's work and start back to back like the replayed ones; the front
+            # part stays a graph (or ran hoisted).
+            l._sample_kernels = False
+            if not hoisted:
+                ent[4].replay()
+            l._kev = l._kev_store
+            l._forward_device(False, "rest")
+            l._kev = None
+            l._kev_frames += 1
         else:
             (ent[5] if hoisted else ent[0]).replay()      # the front part ran beside the previous decoder
         self._hoist_count = getattr(self, "_hoist_count", 0) + int(hoisted)

@@ -62,7 +62,7 @@ class ReadArgs(C.Structure):
         ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32), ("ncols", i32),
         ("scale", f32), ("bias", c_p), ("R", c_p), ("ldr", i32), ("h", i32), ("w", i32), ("rcs", i32),
         ("ksplits", i32), ("part", c_p), ("ml", c_p), ("lslot", c_p), ("sched", c_p),
-        ("nfull", i32), ("pf", i32),
+        ("nfull", i32), ("pf", i32), ("dbg_logits", c_p), ("dbg_ld", i64),
     ]
 
 

@@ -119,6 +119,10 @@ class DeAOTLSTT:
         self._events = []
         self._force_tiles = os.environ.get("RMEM_LINEAR", "") == "tiles"
         self._sample_read = False          # bench.py: time the next replayed frame's layer-0 read (DeAOTEngine._graphed_frame)
+        self._sample_kernels = False       # bench.py: issue the next frame's `rest` part eagerly with HIP events around every launch
+        self._kev = None                   # = _kev_store while a sampled frame is being issued, else None
+        self._kev_store: list = []         # [(kernel class, e0, e1, algorithmic flops, algorithmic bytes)] of the sampled frames
+        self._kev_frames = 0
         self._skip_read2 = False
         self.scale = 1.0 / math.sqrt(self.DATT)
         if weights_from is not None:
@@ -574,12 +578,64 @@ class DeAOTLSTT:
         np_ = self.KS if parts else 0
         pp0 = self.parts.data_ptr() if parts else None
         pp1 = self.parts.data_ptr() + 256 * 4 if parts else None
-        rc = hip.load().rmem_layernorm_red2(
+        with self._ev("layernorm_red2_kernel", nbytes=self.N * 512 * 4.0 * (np_ + 3)):
+            rc = self._ln2_launch(np_, pp0, pp1, gb0, out0, ldo0, off0, gb1, out1, ldo1, off1)
+        hip.check(rc, "rmem_layernorm_red2")
+
+    def _ln2_launch(self, np_, pp0, pp1, gb0, out0, ldo0, off0, gb1, out1, ldo1, off1):
+        return hip.load().rmem_layernorm_red2(
             self._tg.data_ptr(), self._tgi.data_ptr(), 256, pp0, pp1, np_, self.N * 512, 512,
             gb0[0].data_ptr(), gb0[1].data_ptr(), gb1[0].data_ptr(), gb1[1].data_ptr(), self.N, 256, 1e-5,
             out0.hi.data_ptr() + off0 * 2, out0.lo.data_ptr() + off0 * 2, ldo0,
             out1.hi.data_ptr() + off1 * 2, out1.lo.data_ptr() + off1 * 2, ldo1, hip.stream_ptr())
-        hip.check(rc, "rmem_layernorm_red2")
+
+    def _ev(self, name: str, flops: float = 0.0, nbytes: float = 0.0):
+        """Context manager: HIP events around one launch of the memory path while bench.py samples a frame
+        (self._kev is a list); a no-op otherwise.  flops / nbytes = the launch's ALGORITHMIC work (unpadded, one
+        product per multiply-add, every operand read once and every output written once in this layout)."""
+        import contextlib
+        if self._kev is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def cm():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            yield
+            e1.record()
+            self._kev.append((name, e0, e1, float(flops), float(nbytes)))
+        return cm()
+
+    def kernel_report(self, mfma_peak_tflops: float, hbm_peak_gbs: float = 8000.0):
+        """Per kernel class of the sampled frames: launches per frame, mean duration, time per frame, algorithmic work and
+        the fraction of the roofline that bounds the class (MFMA for the contractions, HBM for the element-wise ones)."""
+        if not self._kev_store or not self._kev_frames:
+            return []
+        torch.cuda.synchronize()
+        frames = self._kev_frames
+        acc: Dict[str, list] = {}
+        for name, e0, e1, fl, by in self._kev_store:
+            a = acc.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e3
+            a[2] += fl
+            a[3] += by
+        out = []
+        for name, (n, us, fl, by) in acc.items():
+            ent = {"kernel": name, "launches_per_frame": n / frames, "mean_us": us / n, "us_per_frame": us / frames}
+            if fl > 0:
+                ach = fl / (us * 1e-6) / 1e12
+                ent.update(bound="mfma", algorithmic_gflop_per_launch=fl / n / 1e9, achieved=ach, peak=mfma_peak_tflops,
+                           unit="TFLOP/s", frac=ach / mfma_peak_tflops)
+                if by > 0:
+                    ent["algorithmic_mb_per_launch"] = by / n / 1e6
+            else:
+                ach = by / (us * 1e-6) / 1e9
+                ent.update(bound="hbm", algorithmic_mb_per_launch=by / n / 1e6, achieved=ach, peak=hbm_peak_gbs,
+                           unit="GB/s", frac=ach / hbm_peak_gbs)
+            out.append(ent)
+        out.sort(key=lambda e: -e["us_per_frame"])
+        return out
 
     def _other_pair(self):
         """The residual-stream pair the next fused LayerNorm launch folds into (not the current one)."""
@@ -618,8 +674,12 @@ class DeAOTLSTT:
     def _read(self, A):
         """One fused read + its combine -> ws.G."""
         lib, st = hip.load(), hip.stream_ptr()
-        hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "rmem_attn_read")
-        hip.check(lib.rmem_attn_read_combine(C.byref(A[1]), st), "rmem_attn_read_combine")
+        N, ks = self.N, A[0].ksplits
+        with self._ev("read64_kernel (self read: T=1, Q=K)", flops=2.0 * N * A[0].T * N * (1024 + 128),
+                      nbytes=N * 4.0 * (A[0].T * 1152 + 128 + 1024)):
+            hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "rmem_attn_read")
+        with self._ev("read_combine_kernel", nbytes=(ks + 2) * N * 4096.0):
+            hip.check(lib.rmem_attn_read_combine(C.byref(A[1]), st), "rmem_attn_read_combine")
 
     def _read_pair(self, A, B):
         """The long-term (A) and windowed (B) reads of a layer: ONE read launch, ONE combine launch."""
@@ -630,15 +690,19 @@ class DeAOTLSTT:
         if self._skip_read2:               # part "tail": this launch is issued separately (launch_read2_layer0)
             self._skip_read2 = False
         else:
-            hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
+            with self._ev("read64x2_kernel (long-term + windowed read)", flops=self.read_flops(A[0].T),
+                          nbytes=self.N * 4.0 * ((A[0].T + 1) * 1152 + 2 * 128 + A[0].T + self.WIN + 2 * 1024)):
+                hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
         if self._timing:
             e1.record()
             self._events.append((e0, e1, A[0].T))
-        hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
+        with self._ev("read_combine2_kernel", nbytes=(A[0].ksplits + B[0].ksplits + 4) * self.N * 4096.0):
+            hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
 
     def _dwconv(self, ws: "_AttnWS", wt, out: Planes):
-        rc = hip.load().rmem_dwconv5x5_split(ws.G.data_ptr(), 1024, wt.data_ptr(), self.h, self.w, 1024,
-                                            out.hi.data_ptr(), out.lo.data_ptr(), 1024, hip.stream_ptr())
+        with self._ev("dwconv5x5_split_kernel", nbytes=self.N * 1024 * 8.0):
+            rc = hip.load().rmem_dwconv5x5_split(ws.G.data_ptr(), 1024, wt.data_ptr(), self.h, self.w, 1024,
+                                                out.hi.data_ptr(), out.lo.data_ptr(), 1024, hip.stream_ptr())
         hip.check(rc, "rmem_dwconv5x5_split")
 
     def _idv(self, l: int, slot: int, launch: bool = True):
@@ -765,10 +829,11 @@ class DeAOTLSTT:
             self._forward_layer(l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short)
         if do_rest:
             # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
-            hip.check(lib.rmem_groupnorm2(self._tg.data_ptr(), self._tgi.data_ptr(), N, 256,
-                                          self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
-                                          self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
-                      "rmem_groupnorm2")
+            with self._ev("gn2_stats_kernel + gn2_apply_kernel", nbytes=N * 512 * 4.0 * 3):
+                hip.check(lib.rmem_groupnorm2(self._tg.data_ptr(), self._tgi.data_ptr(), N, 256,
+                                              self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
+                                              self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
+                          "rmem_groupnorm2")
 
     def _forward_layer(self, l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short):
         N, Np, ns = self.N, self.Npad, self.nsplit
@@ -809,8 +874,12 @@ class DeAOTLSTT:
                 grp.append(hip.linear(self.z_pl[l], W.Widu, N, 512, 256, ldx=256, ldy=256, bias=W.bidu, act=1,
                                       d0=Ucat.data_ptr() + 512 * 4, ldd0=1024, nsplit=ns, tile=self._tile(64),
                                       launch=False))
+            cols = 128 + self.WIN + T + 512 + 512 + (512 if l > 0 else 0)
+            fl_front = 2.0 * N * 256 * cols
+            by_front = 4.0 * (N * 256 * (2 if l > 0 else 1) + cols * 256 + N * cols)
             if not fused:
-                hip.linear_grouped(grp)
+                with self._ev("linear_stream_kernel (projections)", flops=fl_front, nbytes=by_front):
+                    hip.linear_grouped(grp)
             else:
                 # ONE launch: (layers >= 1) norm1 / id_norm1 with the split-K fold, then every projection above from the
                 # row tile in LDS; layer 0: the planes rmem_layernorm_cn wrote are the tile (no fold, tgt_id = 0)
@@ -844,10 +913,11 @@ class DeAOTLSTT:
                             Ucat, False, self.ks_win)
         if self.branch_order == "serial":
             self._read_pair(A, B)
-            hip.check(lib.rmem_dwconv5x5_split2(
-                self.ws_main.G.data_ptr(), self.ws_side.G.data_ptr(), 1024, W.dw_lt.data_ptr(),
-                W.dw_st.data_ptr(), self.h, self.w, 1024, self.Ylt.hi.data_ptr(), self.Ylt.lo.data_ptr(),
-                self.Yst.hi.data_ptr(), self.Yst.lo.data_ptr(), 1024, hip.stream_ptr()), "rmem_dwconv5x5_split2")
+            with self._ev("dwconv5x5_split_kernel", nbytes=2 * N * 1024 * 8.0):
+                hip.check(lib.rmem_dwconv5x5_split2(
+                    self.ws_main.G.data_ptr(), self.ws_side.G.data_ptr(), 1024, W.dw_lt.data_ptr(),
+                    W.dw_st.data_ptr(), self.h, self.w, 1024, self.Ylt.hi.data_ptr(), self.Ylt.lo.data_ptr(),
+                    self.Yst.hi.data_ptr(), self.Yst.lo.data_ptr(), 1024, hip.stream_ptr()), "rmem_dwconv5x5_split2")
         else:
             self._read(B)
             self._dwconv(self.ws_side, W.dw_st, self.Yst)
@@ -855,9 +925,11 @@ class DeAOTLSTT:
             self._dwconv(self.ws_main, W.dw_lt, self.Ylt)
         # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
         #    adds happen in the norms that follow (rmem_layernorm_red)
-        hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
-                   kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=self._tile(192), ksplits=self.KS, parts=self.parts,
-                   part_stride=N * 512)       # 64 x 128 tiles: 27.5 -> 21.2 us (L2 -> LDS traffic -25 %)
+        with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * 2048 * 512,
+                      nbytes=4.0 * (N * 2048 + 512 * 2048 + self.KS * N * 512)):
+            hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
+                       kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=self._tile(192), ksplits=self.KS, parts=self.parts,
+                       part_stride=N * 512)       # 64 x 128 tiles: 27.5 -> 21.2 us (L2 -> LDS traffic -25 %)
         # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
         fused = self.rowres and not self._batched
         ln_inside = fused and self.rowres_fused
@@ -876,7 +948,9 @@ class DeAOTLSTT:
                        bsbias=512, bsd=512, nsplit=ns, tile=self._tile(64), launch=False)]
         sprobs = [(grp[0], W.Wqk_f, 0, 0), (grp[1], W.Wv12_f, 0, 256), (grp[2], W.Wu12_f, 0, 256)]
         if not fused:
-            hip.linear_grouped(grp)
+            with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * (512 * 128 + 4 * 256 * 512),
+                          nbytes=4.0 * (N * 512 + 128 * 512 + 4 * 512 * 256 + N * (128 + 2048))):
+                hip.linear_grouped(grp)
         elif not ln_inside:    # the planes of [norm2(tgt) | id_norm2(tgt_id)] exist: two 256-wide streams of s_pl
             hip.ln_linear_grouped([hip.rowres_stream(planes=self.s_pl, ldo=512),
                                    hip.rowres_stream(planes=self.s_pl, ldo=512, plane_off=256)], 1, N, 0, 0, 0, 1e-5, sprobs)
@@ -892,14 +966,18 @@ class DeAOTLSTT:
                                    False, self.ks_self))
         self._dwconv(self.ws_main, W.dw_self, self.Ylt)
         if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
-            hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
-                       tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
+            with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * 1024 * 512,
+                          nbytes=4.0 * (N * 1024 + 512 * 1024 + self.KS * N * 512)):
+                hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
+                           tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
         elif self.clips_per_launch == 1 and not self._force_tiles:
             # last layer: the same split-K launch; its partials are folded into tgt / tgt_id by the LayerNorm kernel
             # (planes into the free self-attention input buffer, unused) -- 12.9 + 6.3 us against 24.7 us for the
             # read-modify-write epilogue of a full-K launch -- and the GroupNorm reads tgt / tgt_id
-            hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
-                       tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
+            with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * 1024 * 512,
+                          nbytes=4.0 * (N * 1024 + 512 * 1024 + self.KS * N * 512)):
+                hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
+                           tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
             self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
         else:                  # (recorded launches) last layer: accumulate straight into tgt / tgt_id
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,

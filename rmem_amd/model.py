@@ -126,17 +126,24 @@ class DeAOT(nn.Module):
         Idempotent per (fold_bn, weights version, device): every engine calls it when it is built, and an engine
         built EARLIER holds hipGraphs that replay the folded tensors -- folding again would free the memory those
         graphs read (a second driver on the same model used to corrupt the first one's encoder that way).  It folds
-        again when the weights changed: rmem_amd.checkpoint.load_network() bumps `_weights_version`; after changing
-        weights by hand pass force=True, which bumps the version itself so that existing engines re-pack their LSTT
-        planes and re-capture their graphs (engine.py / batched.py: _stale_weights)."""
+        again when the weights changed: rmem_amd.checkpoint.load_network() bumps `_weights_version`; encoder weights
+        written in place by hand (load_state_dict, copy_) are noticed through the tensors' version counters; force=True
+        folds in any case.  The last two bump the version themselves so that existing engines re-pack their LSTT planes
+        and re-capture their graphs (engine.py / batched.py: _stale_weights)."""
         wv = self.__dict__.get("_weights_version", 0)
         dev = str(next(self.parameters()).device)
         have = self.__dict__.get("_enc_infer_state")
-        if not force and have == (bool(fold_bn), wv, dev):
+        # weights written in place since the last fold (load_state_dict / copy_ without load_network): every tensor carries
+        # a version counter that in-place writes bump -- a changed (storage, version) list means the folded copy is stale
+        import itertools
+        mark = hash(tuple((t.data_ptr(), t._version) for t in itertools.chain(self.encoder.parameters(), self.encoder.buffers())))
+        changed = have is not None and self.__dict__.get("_enc_infer_mark") != mark
+        if not force and not changed and have == (bool(fold_bn), wv, dev):
             return self
-        if force and have is not None:
+        if (force or changed) and have is not None and have[1] == wv:        # (load_network has bumped the version already)
             wv += 1
             object.__setattr__(self, "_weights_version", wv)
+        object.__setattr__(self, "_enc_infer_mark", mark)
         # kept out of nn.Module registration so that state_dict() keeps the reference's keys
         object.__setattr__(self, "_enc_infer", self.encoder.folded() if fold_bn else None)
         object.__setattr__(self, "_enc_infer_state", (bool(fold_bn), wv, dev))

@@ -68,3 +68,55 @@ def multiobj_label(H, W, n_obj=12):
         x0, x1 = int(W * (0.03 + 0.24 * c)), int(W * (0.03 + 0.24 * c + 0.19))
         lab[:, :, y0:y1, x0:x1] = o + 1
     return lab
+
+
+# ---- load_network cases (utils/checkpoint.py:75-101): a small module with the key shapes the rules look at (a 4-D
+# "id bank" whose input channels may be one short, 2-D / 1-D tensors, nested names) and the payload variants
+def ckpt_toy_net(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    net = torch.nn.Sequential()
+    net.add_module("patch_wise_id_bank", torch.nn.Conv2d(12, 8, 3, bias=True))
+    net.add_module("proj", torch.nn.Linear(6, 5))
+    net.add_module("norm", torch.nn.LayerNorm(5))
+    blk = torch.nn.Sequential()
+    blk.add_module("conv", torch.nn.Conv2d(4, 4, 1, bias=False))
+    blk.add_module("bn", torch.nn.BatchNorm2d(4))
+    net.add_module("block", blk)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g))
+        for b_ in net.buffers():
+            if b_.dtype.is_floating_point:
+                b_.copy_(torch.rand(b_.shape, generator=g) + 0.5)
+    return net
+
+
+def ckpt_cases():
+    """name -> checkpoint object as torch.save would hold it."""
+    src = ckpt_toy_net(1).state_dict()
+    r = lambda *s, seed=5: torch.randn(*s, generator=torch.Generator().manual_seed(seed))
+    pre = lambda d: {"module." + k: v.clone() for k, v in d.items()}
+    bank11 = {k: v.clone() for k, v in src.items()}
+    bank11["patch_wise_id_bank.weight"] = src["patch_wise_id_bank.weight"][:, :11].clone()
+    mism = {k: v.clone() for k, v in src.items()}
+    mism["proj.weight"] = r(5, 7)                         # 2-D, wrong inner size
+    mism["block.conv.weight"] = r(4, 5, 1, 1)             # 4-D, dim-1 one LONGER (rule 2 wants one shorter)
+    mism["block.bn.running_mean"] = r(3)
+    mism["not_in_model.weight"] = r(2, 2)
+    pmism = pre(mism)
+    pmism["module.patch_wise_id_bank.weight"] = src["patch_wise_id_bank.weight"][:, :11].clone()
+    mixed = {k: v.clone() for k, v in src.items() if k.startswith("proj")}
+    mixed.update(pre({k: v for k, v in src.items() if k.startswith("block")}))
+    mixed["module.module.norm.weight"] = src["norm.weight"].clone()      # doubly prefixed: stripped once, then unknown
+    return {
+        "plain": {k: v.clone() for k, v in src.items()},
+        "state_dict_key": {"state_dict": {k: v.clone() for k, v in src.items()}, "optimizer": {"state": {}}},
+        "model_key": {"model": {k: v.clone() for k, v in src.items()}},
+        "both_keys": {"state_dict": {k: v.clone() for k, v in src.items()}, "model": {"proj.weight": r(5, 6)}},
+        "module_prefixed": pre(src),
+        "bank11": bank11,
+        "bank11_prefixed": pre(bank11),
+        "mismatch": mism,
+        "mismatch_prefixed": pmism,
+        "mixed": mixed,
+    }

@@ -14,6 +14,7 @@ Fixtures are data only (inputs + the reference's outputs):
   multiengine_wrapper.*      AOTInferEngine.separate_mask / soft_logit_aggregation (> 10 objects)
   clip_480p_fp64.*           the same 481x849 clip through the reference in DOUBLE precision (near-tie arbitration)
   clip_480p_long*.json/.npz  the 481x849 clip at the evaluator's gap 5 over 46 frames (six evictions) + its fp64 tie lists
+  load_network_cases.*       the reference's load_network (utils/checkpoint.py:75-101) over ten payload variants
   *_amp.json/.npz            golden clips through the reference under fp16 autocast (its --amp mode), teacher-forced
 """
 from __future__ import annotations
@@ -64,16 +65,34 @@ def gen_blocks(model):
         i = block_inputs(layer, T, h, w, ref_frame)
         tgt, tgt_id = i["tgt"], i["tgt_id"]
         kw = dict(size_2d=(h, w), temporal_encoding=temporal, save_atten_weights=not ref_frame)
-        with torch.no_grad(), rh.quiet():
-            if ref_frame:
-                out = blk(tgt[:, None], None if tgt_id is None else tgt_id[:, None],
-                          None, None, curr_id_emb=i["id_emb"][:, None], **kw)
-            else:
-                out = blk(tgt[:, None], None if tgt_id is None else tgt_id[:, None],
-                          [i["bank_K"][:, :, None], i["bank_V"][:, :, None], None,
-                           i["bank_IDV"][:, :, None]],
-                          [to2d(i["short_K"], h, w), to2d(i["short_V"], h, w), None,
-                           to2d(i["short_IDV"], h, w)], **kw)
+        # the pre-softmax logits of the long-term GatedPropagation (attention.py:184-187: QK = (Q / T) @ K, then
+        # torch.softmax(QK, dim=-1)) and of the windowed read (attention.py:344-346: softmax over the 225 offsets): the
+        # inputs of the block's softmax calls are recorded (nothing is changed), told apart by their shapes
+        seen, orig_softmax = [], torch.softmax
+
+        def recording_softmax(x, dim, **kws):
+            seen.append((x.detach().clone(), dim))
+            return orig_softmax(x, dim, **kws)
+
+        torch.softmax = recording_softmax
+        try:
+            with torch.no_grad(), rh.quiet():
+                if ref_frame:
+                    out = blk(tgt[:, None], None if tgt_id is None else tgt_id[:, None],
+                              None, None, curr_id_emb=i["id_emb"][:, None], **kw)
+                else:
+                    out = blk(tgt[:, None], None if tgt_id is None else tgt_id[:, None],
+                              [i["bank_K"][:, :, None], i["bank_V"][:, :, None], None,
+                               i["bank_IDV"][:, :, None]],
+                              [to2d(i["short_K"], h, w), to2d(i["short_V"], h, w), None,
+                               to2d(i["short_IDV"], h, w)], **kw)
+        finally:
+            torch.softmax = orig_softmax
+        n = h * w
+        Tm = 1 if ref_frame else T
+        lt = [x for x, dim in seen if x.dim() == 4 and x.shape[-2] == n and x.shape[-1] == Tm * n and dim in (-1, 3)]
+        st = [x for x, dim in seen if x.dim() == 4 and x.shape[-2] == 225 and x.shape[-1] == n]
+        assert (len(lt) >= 1 or ref_frame) and len(st) == 1, [tuple(x.shape) for x, _ in seen]   # (reference frames take the SDPA branch: save_atten_weights is off)
         o_tgt, o_id, mems = out
         curr, glob, loc = mems
         d = dict(out_tgt=o_tgt[:, 0].numpy(), out_tgt_id=o_id[:, 0].numpy(),
@@ -83,6 +102,11 @@ def gen_blocks(model):
             d.update(glob_IDV=glob[3][0, :, 0].numpy())
         else:
             d.update(mass=blk.record_attn_weight.numpy())
+        # [N][T*N] long-term logits (the first softmax of that shape: with T = 1 a second one cannot occur -- the self
+        # attention goes through scaled_dot_product_attention), [225][N] windowed logits (-1e8 outside the image)
+        d.update(st_logits=st[0][0, 0].numpy())
+        if lt:
+            d.update(lt_logits=lt[0][0, 0].numpy())
         np.savez_compressed(os.path.join(HERE, block_case_name(layer, T, h, w, ref_frame) + ".npz"), **d)
 
 
@@ -569,6 +593,36 @@ def gen_clip_480p_long(frames=46, tie_margin=1e-4, resume=False):
     print("480p long fp64 arbitration:", info, flush=True)
 
 
+def gen_load_network_cases():
+    """The reference's OWN load_network (utils/checkpoint.py:75-101) run on CPU over the payload variants of
+    tests/golden/inputs.py:ckpt_cases -- torch.load's hard-coded CUDA map_location and net.cuda(gpu) are redirected from
+    outside the tree (the file still goes through torch.save / torch.load).  Stored per case: every tensor of the
+    resulting state_dict and the returned list of removed keys."""
+    import tempfile
+    from inputs import ckpt_cases, ckpt_toy_net
+    rh.import_reference()
+    from utils.checkpoint import load_network as ref_load_network
+    orig_load, orig_cuda = torch.load, torch.nn.Module.cuda
+    torch.load = lambda f, map_location=None, **kw: orig_load(f, map_location="cpu", **kw)
+    torch.nn.Module.cuda = lambda self, device=None: self
+    out, meta = {}, {}
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            for name, ckpt in ckpt_cases().items():
+                path = os.path.join(d, name + ".pth")
+                torch.save(ckpt, path)
+                net = ckpt_toy_net(0)
+                net, removed = ref_load_network(net, path, 0)
+                for k, v in net.state_dict().items():
+                    out[f"{name}/{k}"] = v.detach().numpy()
+                meta[name] = list(removed)
+    finally:
+        torch.load, torch.nn.Module.cuda = orig_load, orig_cuda
+    np.savez_compressed(os.path.join(HERE, "load_network_cases.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "load_network_cases.json"), "w"), indent=0, sort_keys=True)
+    print("load_network cases:", {k: v for k, v in meta.items()})
+
+
 def gen_amp_clips():
     """The reference's reduced-precision mode (`--amp`: tools/eval.py:45-47,90-92 wraps the whole evaluation in
     torch.cuda.amp.autocast) on the golden clips, TEACHER-FORCED with the labels of its fp32 run (so that every frame
@@ -629,6 +683,13 @@ def main():
     if "--fp64-only" in sys.argv:
         gen_clip_480p_fp64()
         return
+    if "--ckpt-only" in sys.argv:
+        gen_load_network_cases()
+        return
+    if "--blocks-only" in sys.argv:
+        cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
+        gen_blocks(model)
+        return
     if "--long-only" in sys.argv or "--long-fp64-only" in sys.argv:
         gen_clip_480p_long(resume="--long-fp64-only" in sys.argv)
         return
@@ -653,6 +714,7 @@ def main():
     gen_multiengine()
     gen_clip_480p_fp64()
     gen_clip_480p_long()
+    gen_load_network_cases()
     gen_amp_clips()
     os.system(f"du -sh {HERE}")
 

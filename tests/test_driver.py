@@ -178,6 +178,52 @@ def test_driver_hip_vs_reference_golden(fused, tta, golden_dir, monkeypatch):
     assert len(res.frame_ms) == meta["frames"] - 1
 
 
+@pytest.mark.gpu
+def test_tta_clip_that_grows_past_ten_objects_hands_over_to_serial_engines(monkeypatch):
+    """Flip test-time augmentation (the batched-augmentation path by default) with a mid-clip label that brings the clip
+    to 12 objects -- more than one engine holds (aot_engine.py:675-702 grows sub-engines).  The batched path must hand the
+    clip to the per-augmentation multi-object engines at that frame (it used to raise) and give what RMEM_TTA=serial gives
+    from the first frame: the same kept-frame histories, label maps equal on the frames before the hand-over (one engine
+    either way up to MIOpen's batch size) and within near-tie pixels of the serial run after it."""
+    from inputs import multiobj_label
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    H, W, frames, new_at, out_hw = 97, 129, 9, 4, (97, 129)
+    cfg = get_config("r50_deaotl", 1, 3)
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    load_synthetic_weights(model)
+    model = model.to(DEV)
+    imgs, lab = synth_clip(31, frames, H, W, 3)
+    big = multiobj_label(H, W, 12)
+
+    def clip():
+        out = []
+        for t in range(frames):
+            label = lab if t == 0 else (big if t == new_at else None)
+            out.append(D.make_samples(imgs[t].to(DEV), None if label is None else label.to(DEV), out_hw, 3, flip_aug=True,
+                                      name=f"{t:05d}.jpg"))
+        return out
+
+    runs = {}
+    for tta in ("batched", "serial"):
+        monkeypatch.setenv("RMEM_TTA", tta)
+        drv = D.ClipDriver(model, cfg, fixed_gap=2)
+        idx = []
+        res = drv.run_clip(clip(), num_frames=frames,
+                           on_frame=lambda t, lab_, engs: idx.append([[list(s.long_memories_indexes) for s in e.aot_engines] for e in engs]))
+        runs[tta] = (res, idx)
+    rb, rs = runs["batched"][0], runs["serial"][0]
+    assert rb.handed_over_at == new_at and rs.handed_over_at is None
+    assert tuple(rb.masks.shape) == tuple(rs.masks.shape) == (frames - 1, H, W)
+    mism = [int((rb.masks[i] != rs.masks[i]).sum()) for i in range(frames - 1)]
+    print("TTA + 12 objects: batched-then-handed-over vs serial, mismatching pixels per frame:", mism)
+    assert int(rb.masks[new_at - 1].max()) == 12 and int(rs.masks[new_at - 1].max()) == 12
+    assert runs["batched"][1][new_at - 1:] == runs["serial"][1][new_at - 1:]          # two sub-engines per augmentation from there on
+    assert all(len(e) == 2 for e in runs["batched"][1][-1])
+    assert max(mism[:new_at]) <= 2 and mism[new_at - 1] <= 2, mism                        # (closed loop afterwards: near-ties may grow)
+
+
 def _sharded_hip_worker(rank, world, port, q, n_clips, frames, H, W, product=False):
     import torch.distributed as dist
     from rmem_amd.config import get_config
@@ -283,6 +329,39 @@ def test_bench_gpus2_spawns_two_ranks_on_one_device():
     assert len(out["config"]["per_rank_frames_per_sec"]) == 2 and min(out["config"]["per_rank_frames_per_sec"]) > 0
     assert out["config"]["gathered_masks_shape"][0] == 2 and len(out["config"]["gathered_masks_sha256"]) == 64
     assert abs(out["value"] - 2 * 10 / (out["ms_per_step"] * 10 / 1e3)) < 1e-6 * out["value"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus8_on_one_device():
+    """8-rank readiness on the one leased GPU (the node itself is the driver's to run): `bench.py --gpus 8 --config clips64
+    --clips-per-rank 1 --clip-frames 4` with RMEM_DEVICE_OVERRIDE=0 RMEM_DIST_BACKEND=gloo -- eight processes rendezvous on
+    the loopback, every rank runs its clip through the driver, the masks are all-gathered in rank order, rank 0 prints ONE
+    line with eight per-rank entries (frames/s, host CPU, pinning), and every clip's sha256 equals the one-rank run of the
+    same eight clips (what rank a clip runs on changes nothing it computes)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for n, per in ((8, 1), (1, 8)):
+        env = dict(os.environ, RMEM_DEVICE_OVERRIDE="0", RMEM_DIST_BACKEND="gloo", RMEM_PIN="0" if n == 8 else "1")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--config", "clips64",
+                            "--clips-per-rank", str(per), "--clip-frames", "4"], env=env, capture_output=True, text=True,
+                           timeout=2400)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        outs[n] = json.loads(lines[0])
+    o8, o1 = outs[8], outs[1]
+    print({k: o8["config"][k] for k in ("per_rank_frames_per_sec", "per_rank_host")})
+    assert o8["n_gpus"] == 8 and o8["config"]["clips"] == 8 and o8["config"]["dist_backend"] == "gloo"
+    assert len(o8["config"]["per_rank_frames_per_sec"]) == 8 and min(o8["config"]["per_rank_frames_per_sec"]) > 0
+    assert len(o8["config"]["per_rank_host"]) == 8 and all(r["host_cpu_s"] > 0 for r in o8["config"]["per_rank_host"])
+    assert len(o8["clip_sha256"]) == 8 and len(set(o8["clip_sha256"])) == 8
+    assert o8["clip_sha256"] == o1["clip_sha256"] and o8["masks_sha256"] == o1["masks_sha256"]
+    assert o1["config"]["per_rank_host"][0]["pinned"] in (True, False)            # (reported either way)
 
 
 @pytest.mark.gpu
@@ -395,6 +474,23 @@ def test_bench_line_contract_single_gpu():
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert max(out["mask_mismatch_px"]) <= 4 and out["eviction_sequence_equal"] is True and out["iou_vs_oracle"] > 0.9999
+    # IoU over EVERY id present in either map (background + the ten live ids of the synthetic weights), not ids 1-3
+    assert 0 in out["iou_ids"] and len(out["iou_ids"]) >= 5 and out["iou_vs_oracle_min"] > 0.99
+    # the five largest kernel classes of the memory path, each against its own roofline; `roofline` is the largest
+    ks = r["kernels"]
+    assert 3 <= len(ks) <= 5 and ks[0]["kernel"].startswith("read64x2_kernel")
+    assert [k["us_per_frame"] for k in ks] == sorted((k["us_per_frame"] for k in ks), reverse=True)
+    for k in ks:
+        assert k["bound"] in ("mfma", "hbm") and 0 < k["frac"] < 1 and k["launches_per_frame"] >= 1
+        assert abs(k["us_per_frame"] - k["mean_us"] * k["launches_per_frame"]) < 1e-6 * k["us_per_frame"]
+        if k["bound"] == "mfma":
+            assert abs(k["achieved"] - k["algorithmic_gflop_per_launch"] * 1e9 / (k["mean_us"] * 1e-6) / 1e12) < 1e-6 * k["achieved"]
+    assert any(k["kernel"].startswith("linear_stream_kernel") for k in ks)
+    assert abs(ks[0]["mean_us"] - r["mean_us"]) < 0.25 * r["mean_us"]       # the two sampling methods see the same kernel
+    # 'mask IoU vs ref' on the benchmarked schedule: the reference's own 46-frame gap-5 run (tests/golden/clip_480p_long.*)
+    pr = out["parity_vs_reference"]
+    assert pr["frames"] == 45 and pr["evictions"] >= 5 and pr["bank_index_history_equal"] is True
+    assert pr["iou_vs_reference_min"] > 0.99 and max(pr["mask_mismatch_px"]) <= 6 and len(pr["iou_ids"]) >= 5
 
 
 @pytest.mark.gpu

@@ -451,10 +451,12 @@ def test_batched_engine_480p_vs_golden_and_unbatched(golden_dir):
     """BatchedDeAOTEngine at the BASELINE.json configs[3] geometry (481x849, K = 4), B = 4 clips in lockstep:
     slots 0 and 2 run the reference's golden clip, slots 1 and 3 two other synthetic clips, all
     teacher-forced (golden labels for 0 / 2, the unbatched engine's own labels for 1 / 3).
-    (a) slots 0 / 2 reproduce the reference's golden label maps like the unbatched engine does
-    (<= 4 pixels of 409,920 per frame) and its kept-frame history exactly;
-    (b) every slot against an UNBATCHED engine fed the same labels: equal eviction histories, label maps
-    within 4 pixels per frame, decoder logits within 2e-3.  What is bit-identical between the two is the
+    (a) slots 0 / 2 reproduce the reference's golden label maps up to fp64 near-ties -- every pixel that differs is in
+    the fixture's near-tie list (fp64 margin < 2e-5) and got one of the tie's two classes (tests/ties.py) -- and its
+    kept-frame history exactly;
+    (b) every slot against an UNBATCHED engine fed the same labels: equal eviction histories, decoder logits within 2e-3,
+    and every pixel whose label differs is a near-tie in the unbatched engine's own logits (margin below twice the logit
+    difference of that frame).  What is bit-identical between the two is the
     memory path (test_batched_lstt_equals_single_clips_bit_for_bit, incl. 31x54 tokens); MIOpen at
     batch 4 and at batch 1-2 picks different algorithms for the encoder / decoder convolutions, which
     moves near-tie pixels."""
@@ -463,8 +465,10 @@ def test_batched_engine_480p_vs_golden_and_unbatched(golden_dir):
     from rmem_amd.batched import BatchedDeAOTEngine
     from rmem_amd.engine import DeAOTEngine
     from rmem_amd.synth import synth_clip
+    from ties import Fp64Ties, oracle_margin_check
     meta = json.load(open(os.path.join(golden_dir, "clip_480p.json")))
     gold = np.load(os.path.join(golden_dir, "clip_480p.npz"))
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_480p_fp64.npz")))
     cfg, model = _model(meta["former"], meta["latter"])
     model.optimize_for_inference(True)
     B, frames, H, W = 4, meta["frames"], meta["H"], meta["W"]
@@ -488,11 +492,14 @@ def test_batched_engine_480p_vs_golden_and_unbatched(golden_dir):
         for i, e in enumerate(singles):
             lg = e.match_propogate_one_frame(clips[i][0][t].to(DEV), output_size=out_hw)
             lab = lg.argmax(1)
-            vs_single.append(int((lab[0] != lab_b[i]).sum()))
-            lerr = max(lerr, float((e.pred_id_logits[0] - bat.pred_id_logits[i]).abs().max()))
+            le = float((e.pred_id_logits[0] - bat.pred_id_logits[i]).abs().max())
+            lerr = max(lerr, le)
+            vs_single.append(oracle_margin_check(lab_b[i].cpu().numpy().astype(np.uint8), lg[0].cpu(), 2 * le + 1e-7,
+                                                 f"frame {t} slot {i} batched vs unbatched"))
             if seeds[i] == meta["seed"]:
                 g = torch.from_numpy(gold["labels"][t - 1]).to(DEV)
-                vs_gold.append(int((lab_b[i] != g).sum()))
+                n32, _, _ = ties.check(t, lab_b[i].cpu().numpy().astype(np.uint8), gold["labels"][t - 1], 2e-5)
+                vs_gold.append(n32)
                 cur = g[None, None].float()
             else:
                 cur = lab[None].float()
@@ -504,4 +511,4 @@ def test_batched_engine_480p_vs_golden_and_unbatched(golden_dir):
             assert bat.long_memories_indexes[i] == list(e.long_memories_indexes), (t, i)
         assert bat.long_memories_indexes[0] == meta["indexes"][t - 1] == bat.long_memories_indexes[2], t
     print("batched B=4 at 481x849: mismatching pixels vs golden", vs_gold, "vs unbatched", vs_single, "logit err", lerr)
-    assert max(vs_gold) <= 4 and max(vs_single) <= 4 and lerr < 2e-3, (vs_gold, vs_single, lerr)
+    assert lerr < 2e-3, (vs_gold, vs_single, lerr)

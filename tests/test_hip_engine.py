@@ -11,6 +11,12 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# Near-tie property of the product engine (tests/ties.py): a pixel may differ from the reference's fp32 label map only if
+# its two best class logits are closer than this in the reference's fp64 run.  The HIP memory path alone stays below 4e-6
+# (test_480p_lstt_isolated_from_miopen: 1e-5 asserted); MIOpen's encoder / decoder convolutions move the decoder logits by
+# up to 5e-6 against the CPU convolutions (profiles/r04a_parity_attribution.json), hence 2e-5 with them in the loop.
+PRODUCT_TIE_MARGIN = 2e-5
+PRODUCT_TIE_SLACK = 4      # label maps of a clip may be this many pixels further from fp64 than the fp32 reference is
 
 
 def _build(former=1, latter=3, gap=2, nsplit=3):
@@ -182,20 +188,26 @@ def test_480p_teacher_forced(nsplit, golden_dir):
     from rmem_amd.synth import synth_clip
     meta = json.load(open(os.path.join(golden_dir, "clip_480p.json")))
     gold = np.load(os.path.join(golden_dir, "clip_480p.npz"))
+    from ties import Fp64Ties
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_480p_fp64.npz")))
     cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"], nsplit)
     imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
     imgs = [x.to(DEV) for x in imgs]
     out_hw = tuple(meta["out_hw"])
     eng.restart_engine()
     eng.add_reference_frame(imgs[0], lab.to(DEV), obj_nums=[3], frame_step=0)
-    mism, idx_hist, lerrs = [], [], {}
+    mism, mism64, idx_hist, lerrs = [], [], [], {}
     for t in range(1, meta["frames"]):
         # the next frames are announced as the clip driver does: batched encoder prefetch and the
         # hoisted front part of the next frame's LSTT are part of what is checked against the golden maps
         nxt = imgs[t + 1:t + 1 + eng.lookahead] or None
         logit = eng.match_propogate_one_frame(imgs[t], output_size=out_hw, next_img=nxt)
         pred = torch.argmax(torch.softmax(logit, dim=1), dim=1, keepdim=True)
-        mism.append(int((pred[0, 0].cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        p8 = pred[0, 0].cpu().numpy().astype(np.uint8)
+        if nsplit == 3:      # every moved pixel is an fp64 near-tie and got one of the tie's two classes (tests/ties.py)
+            n32, n64, _ = ties.check(t, p8, gold["labels"][t - 1], PRODUCT_TIE_MARGIN)
+            mism64.append(n64)
+        mism.append(int((p8 != gold["labels"][t - 1]).sum()))
         if f"logits_{t}" in gold:
             ref = gold[f"logits_{t}"].astype(np.float32)
             lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - ref).max())
@@ -205,9 +217,12 @@ def test_480p_teacher_forced(nsplit, golden_dir):
     print(f"nsplit={nsplit} mismatching pixels per frame (of 409920):", mism, "logit err (fp16 gold):", lerrs)
     assert idx_hist == meta["indexes"]
     if nsplit == 3:
-        # measured 1-7 on every box so far; the encoder's MIOpen convolutions are not bit-reproducible
-        # between processes (tools/determinism_probe.py), each flip of a near-tie pixel counts one
-        assert max(mism) <= 4, mism           # measured 0-3 per frame of 409,920 on every box (round 2): measured max + 1
+        # not a pixel budget: the moved pixels were checked one by one above (fp64 near-ties); here the product engine
+        # (MIOpen encoder / decoder in the loop) must be no further from the fp64 maps than the fp32 CPU reference is
+        # ([0,0,0,1,0,0,1,1,3] = 6 over the clip) plus PRODUCT_TIE_SLACK
+        ref64 = sum(ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"]))
+        print("vs fp64 maps:", mism64, "fp32 reference vs fp64:", ref64)
+        assert sum(mism64) <= ref64 + PRODUCT_TIE_SLACK, (mism64, ref64)
     else:
         # plain fp16 operands (one plane each, fp32 accumulate) against the REFERENCE'S reduced-precision mode: the same
         # clip through the reference under fp16 autocast (its --amp switch, tools/eval.py:45-47), teacher-forced the same
@@ -219,6 +234,49 @@ def test_480p_teacher_forced(nsplit, golden_dir):
         assert max(mism) < min(amp), (mism, amp)       # ... and its worst frame (57-221 measured over the boxes of rounds 2-4)
         # stays below the reference's autocast run on ITS best frame (271)
     assert max(lerrs.values()) < (2e-2 if nsplit == 3 else 0.2)
+
+
+def test_480p_long_clip_gap5_vs_reference(golden_dir):
+    """BASELINE.json configs[1] at the schedule the benchmark runs: 481x849, K = 4, the evaluator's gap 5
+    (managers/evaluator.py:331-332), 46 frames -- the bank is full from frame 15 and frames 20 ... 45 evict six times --
+    against the REFERENCE's own closed-loop run (tests/golden/clip_480p_long.*, make_golden.py:gen_clip_480p_long),
+    teacher-forced with its labels, through the product engine with the next frames announced (encoder prefetch, hoisted
+    front part, hipGraph replay: the steady state bench.py times).  Asserted per frame: long_memories_indexes (every
+    eviction), and that every pixel off the reference's fp32 map is an fp64 near-tie that got one of the tie's two classes
+    (clip_480p_long_fp64.npz); per clip: not further from the fp64 maps than the fp32 reference itself + slack; decoder
+    logits of frames 1, 20, 45 against the fixture."""
+    from ties import Fp64Ties
+    from rmem_amd.synth import synth_clip
+    meta = json.load(open(os.path.join(golden_dir, "clip_480p_long.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_480p_long.npz"))
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_480p_long_fp64.npz")))
+    assert meta["gap"] == 5 and meta["evictions"] >= 5 and meta["frames"] >= 41
+    cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"], 3)
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    imgs = [x.to(DEV) for x in imgs]
+    out_hw = tuple(meta["out_hw"])
+    eng.restart_engine()
+    eng.add_reference_frame(imgs[0], lab.to(DEV), obj_nums=[3], frame_step=0)
+    mism, mism64, worst, lerrs = [], [], 0.0, {}
+    for t in range(1, meta["frames"]):
+        nxt = imgs[t + 1:t + 1 + eng.lookahead] or None
+        logit = eng.match_propogate_one_frame(imgs[t], output_size=out_hw, next_img=nxt)
+        p8 = torch.argmax(torch.softmax(logit, dim=1), dim=1)[0].cpu().numpy().astype(np.uint8)
+        n32, n64, w = ties.check(t, p8, gold["labels"][t - 1], PRODUCT_TIE_MARGIN)
+        mism.append(n32), mism64.append(n64)
+        worst = max(worst, w)
+        if f"logits_{t}" in gold:
+            ref = gold[f"logits_{t}"].astype(np.float32)
+            lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - ref).max())
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        assert list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][t - 1], (t, meta["indexes"][t - 1])
+    ref64 = [ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"])]
+    print("long 480p clip, gap 5: pixels off the reference's fp32 maps per frame:", mism)
+    print("  off the fp64 maps:", mism64, "= ", sum(mism64), "; the fp32 reference itself:", sum(ref64),
+          "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; logit err (fp16 fixture):", lerrs)
+    assert sum(mism64) <= sum(ref64) + 2 * PRODUCT_TIE_SLACK, (sum(mism64), sum(ref64))     # (five times the frames of the short clip)
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-2
 
 
 def test_480p_lstt_isolated_from_miopen(golden_dir):
@@ -459,6 +517,7 @@ def test_720p_k8_vs_oracle():
     grows past four slots (temporal positional embedding rows for T > 4) at the full size."""
     from oracle.engine_ref import OracleDeAOTEngine
     from rmem_amd.synth import synth_clip
+    from ties import oracle_margin_check
     H, W, frames = 721, 1281, 11      # bank 1 + 9 updates at gap 1: full at T = 8, one eviction at 46x81
     cfg, cpu_model, gpu_model, eng = _build(1, 7, 1)
     cpu_model.cfg = cfg
@@ -472,8 +531,12 @@ def test_720p_k8_vs_oracle():
         lo = ora.match_propogate_one_frame(imgs[t], output_size=(720, 1280))
         pg = torch.argmax(lg, dim=1, keepdim=True)
         po = torch.argmax(lo, dim=1, keepdim=True)
-        mism.append(int((pg.cpu() != po).sum()))
         lerr.append(float((eng.aot_engines[0].pred_id_logits.cpu() - ora.pred_id_logits).abs().max()))
+        # a label can only move where the oracle's own two best logits are closer than twice the logit error (the
+        # bilinear upsampling is a convex combination): every moved pixel is checked for exactly that, and for having
+        # received the runner-up class (tests/ties.py) -- the property, not a pixel budget
+        mism.append(oracle_margin_check(pg[0, 0].cpu().numpy().astype(np.uint8), lo[0], 2 * lerr[-1] + 1e-7, f"720p frame {t}"))
+        assert mism[-1] == int((pg.cpu() != po).sum())
         fed = F.interpolate(po.float(), size=ora.input_size_2d, mode="nearest")
         eng.update_memory(fed.to(DEV))
         ora.update_memory(fed)
@@ -481,8 +544,8 @@ def test_720p_k8_vs_oracle():
     print("720p K=8 mismatching pixels per frame (of 921600):", mism, "decoder-logit max abs err:", lerr)
     assert len(ora.long_memories_indexes) == 8 and ora.long_memories_indexes[0] == 0      # K = 8 steady state, evictions happened
     assert ora.long_memories_indexes != list(range(8))
-    # 1-3 measured (decoder logits within 2e-5); 2-18 when the planes were bf16
-    assert max(mism) <= 4 and max(lerr) < 2e-4, (mism, lerr)
+    # decoder logits within 2e-5 measured (1-3 near-tie pixels of 921,600 per frame; 2-18 when the planes were bf16)
+    assert max(lerr) < 5e-5, (mism, lerr)
 
 
 def test_paired_launches_bit_identical():
@@ -592,16 +655,18 @@ def test_graph_caches_are_bounded_per_geometry(monkeypatch):
     assert eng.long_memories_indexes == ref.long_memories_indexes
 
 
-def _closed_loop(e, dev, imgs, lab, H, W):
+def _closed_loop(e, dev, imgs, lab, H, W, keep_logits=False):
     e.restart_engine()
     e.add_reference_frame(imgs[0].to(dev), lab.to(dev), obj_nums=[3], frame_step=0)
-    labs = []
+    labs, logits = [], []
     for t in range(1, len(imgs)):
         logit = e.match_propogate_one_frame(imgs[t].to(dev), output_size=(H, W))
         pred = torch.argmax(logit, dim=1, keepdim=True).float()
         labs.append(pred[0, 0].cpu().numpy().astype(np.uint8))
+        if keep_logits:
+            logits.append(logit[0].detach().cpu().clone())
         e.update_memory(F.interpolate(pred, size=e.input_size_2d, mode="nearest"))
-    return labs
+    return (labs, logits) if keep_logits else labs
 
 
 CLOSED_LOOP_SEEDS = (1, 3, 4, 11)
@@ -636,31 +701,38 @@ def test_closed_loop_vs_oracle_small_clips():
 
 
 def test_closed_loop_product_engine_vs_oracle():
-    """The same closed loop on the PRODUCT engine (MIOpen encoder and decoder on the GPU).  MIOpen's
-    convolutions differ from the CPU's by ~1e-5 on the features, which can flip a near-tie pixel that
-    the loop then amplifies: a clip either matches pixel for pixel through the last frame or starts to
-    differ with a flip of <= 2 pixels.  The exact statement for the code this repository owns is
-    test_closed_loop_vs_oracle_small_clips above; this one bounds what MIOpen adds."""
+    """The same closed loop on the PRODUCT engine (MIOpen encoder and decoder on the GPU) under
+    rmem_amd.determinism.reproducible_convolutions() (tests/conftest.py applies it: MIOpen's implicit-GEMM family is not
+    reproducible call to call at this size).  Measured on every box of rounds 4-5: all four clips equal the CPU oracle's
+    label maps pixel for pixel through the last frame, and that is what is asserted.  MIOpen's solver choice may differ on
+    another box (its convolutions are within ~1e-5 of the CPU's, not equal); the escape is the property, not a count: a
+    clip that diverges must do so at pixels that are near-ties in the ORACLE's own logits (top-2 margin < 2e-5, the
+    runner-up class taken) -- printed with the margins -- and the kept-frame history must agree up to that frame."""
     from oracle.engine_ref import OracleDeAOTInferEngine
     from rmem_amd.synth import synth_clip
+    from ties import oracle_margin_check
+    assert os.environ.get("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM") == "0", "tests/conftest.py applies reproducible_convolutions()"
     cfg, cpu_model, gpu_model, eng = _build(gap=2)
     ora = OracleDeAOTInferEngine(cpu_model, long_term_mem_gap=2)
     H, W, frames = 97, 129, 11
     exact = 0
     for seed in CLOSED_LOOP_SEEDS:
         imgs, lab = synth_clip(seed, frames, H, W, 3)
-        a = _closed_loop(ora, "cpu", imgs, lab, H, W)
+        a, a_logits = _closed_loop(ora, "cpu", imgs, lab, H, W, keep_logits=True)
         b = _closed_loop(eng, DEV, imgs, lab, H, W)
         mism = [int((x != y).sum()) for x, y in zip(a, b)]
         print("closed loop (product engine) seed", seed, "mismatching pixels per frame:", mism)
-        first = next((m for m in mism if m), 0)
-        assert first <= 2, (seed, mism)
-        exact += int(not any(mism))
-        assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.engines[0].long_memories_indexes) or any(mism)
+        if any(mism):
+            f = next(i for i, m in enumerate(mism) if m)
+            n = oracle_margin_check(b[f], a_logits[f], 2e-5, f"seed {seed}, first diverging frame {f + 1}")
+            print(f"  seed {seed}: diverges at frame {f + 1} on {n} oracle near-tie pixel(s) (margin < 2e-5): MIOpen's "
+                  "convolutions differ from the CPU's by ~1e-5 on this box; the loop amplifies the flip afterwards")
+        else:
+            exact += 1
+            assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.engines[0].long_memories_indexes)
     print("closed loop (product engine): clips pixel-exact through the last frame:", exact, "of", len(CLOSED_LOOP_SEEDS))
-    # measured on the round-4 boxes: 4 of 4 (reproducible convolutions); MIOpen's solver choice differs between boxes
-    # (section 2 of DESIGN.md), so half of the clips is what is asserted
-    assert exact >= 2, exact
+    assert exact == len(CLOSED_LOOP_SEEDS) or os.environ.get("RMEM_TEST_ALLOW_MIOPEN_TIES") == "1", \
+        (exact, "a diverging clip passed the near-tie check above; set RMEM_TEST_ALLOW_MIOPEN_TIES=1 to accept it on this box")
 
 
 def test_long_clip_eviction_history_vs_oracle():
@@ -695,3 +767,69 @@ def test_long_clip_eviction_history_vs_oracle():
         prev = io
     print("long clip: evictions", evictions, "worst label mismatch", worst, "final indexes", prev)
     assert evictions >= 20
+
+
+def test_checkpoint_file_in_the_references_format_loads_into_engine_and_oracle(tmp_path):
+    """SURVEY 8f-3 end to end: a checkpoint FILE as the reference's save_network writes it
+    (utils/checkpoint.py:104-121: {'state_dict': ..., 'optimizer': ...} under <dir>/save_step_<step>.pth; here from a
+    DataParallel-wrapped model -- 'module.' keys -- with the 11-channel id bank of an earlier training stage) is picked by
+    select_checkpoint as the evaluator picks it (latest step, networks/managers/evaluator.py:59-110), loaded by
+    load_network into a freshly built GPU model and, from the same file, into the CPU model the oracle runs on.  The HIP
+    engine's first frames must then equal the oracle's label maps (97x129: exact) and decoder logits -- and differ from
+    what the weights before the load give."""
+    import types
+    from oracle.engine_ref import OracleDeAOTEngine
+    from ties import oracle_margin_check
+    from rmem_amd.checkpoint import load_for_evaluation
+    from rmem_amd.config import get_config
+    from rmem_amd.engine import build_engine
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+    cfg = get_config("r50_deaotl", 1, 3)
+    donor = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(donor, salt=3)
+    sd = {k: v.clone() for k, v in donor.state_dict().items()}
+    sd["patch_wise_id_bank.weight"] = sd["patch_wise_id_bank.weight"][:, :11].clone()          # rule 2 (un-prefixed key)
+    ck = {("module." + k if not k.startswith("patch_wise_id_bank") else k): v for k, v in sd.items()}
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    torch.save({"state_dict": {k: v * 0 for k, v in ck.items()}, "optimizer": {"state": {}}}, d / "save_step_100.pth")
+    torch.save({"state_dict": ck, "optimizer": {"state": {}}}, d / "save_step_2000.pth")
+    mk = lambda: types.SimpleNamespace(TEST_CKPT_PATH=None, TEST_CKPT_STEP=None, TEST_EMA=False, DIR_CKPT=str(d),
+                                       DIR_RESULT=str(tmp_path))
+    cpu_model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(cpu_model)                      # what the model holds BEFORE the load
+    gpu_model = build_vos_model("deaot", cfg).eval()
+    load_synthetic_weights(gpu_model)
+    imgs, lab = synth_clip(5, 4, 97, 129, 3)
+
+    def run_hip(model):
+        eng = build_engine("deaotengine", phase="eval", aot_model=model, gpu_id=0, long_term_mem_gap=2)
+        eng.eval()
+        eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+        outs = []
+        for t in range(1, 4):
+            lg = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(97, 129))
+            outs.append((lg.argmax(1)[0].cpu(), eng.aot_engines[0].pred_id_logits.cpu().clone()))
+            eng.update_memory(F.interpolate(lg.argmax(1, keepdim=True).float(), size=eng.input_size_2d, mode="nearest"))
+        return outs
+
+    before = run_hip(gpu_model.to(DEV))
+    cpu_model, label, removed = load_for_evaluation(cpu_model, mk())
+    gpu_model, label_g, removed_g = load_for_evaluation(gpu_model, mk(), device=DEV)
+    assert label == label_g == "2000" and removed == removed_g == []
+    w = cpu_model.state_dict()["patch_wise_id_bank.weight"]
+    assert torch.equal(w[:, :11], sd["patch_wise_id_bank.weight"]) and not torch.equal(w[:, 11], donor.state_dict()["patch_wise_id_bank.weight"][:, 11])
+    cpu_model.cfg = cfg
+    ora = OracleDeAOTEngine(cpu_model, long_term_mem_gap=2)
+    ora.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    after = run_hip(gpu_model)
+    for t in range(1, 4):
+        lo = ora.match_propogate_one_frame(imgs[t], output_size=(97, 129))
+        po = lo.argmax(1)[0]
+        err = float((after[t - 1][1] - ora.pred_id_logits).abs().max())
+        n = oracle_margin_check(after[t - 1][0].numpy().astype(np.uint8), lo[0], 2 * err + 1e-7, f"frame {t}")   # (MIOpen: near-ties only)
+        changed = float((after[t - 1][1] - before[t - 1][1]).abs().max())
+        print(f"frame {t}: pixels off the oracle (same file) {n}, logit err {err:.2e}; moved by the load {changed:.2e}")
+        assert n <= 2 and err < 2e-4 and changed > 1e-2
+        ora.update_memory(F.interpolate(po[None, None].float(), size=ora.input_size_2d, mode="nearest"))

@@ -481,6 +481,87 @@ def test_read_bank_logits_and_rescale(hip):
             assert err < 5e-5 and merr < 1e-5 and lerr < 1e-3, (spike, ksplits, err, merr, lerr)
 
 
+def _read_logits(hip, mode, T, N, Npad, K, Q, bias, h, w, R, ksplits, ldr=None, rcs=0):
+    """rmem_attn_read_trace with dbg_logits: every pre-softmax logit the fused read computed -> [N][T*N] (NaN = not
+    written: keys outside the image / window)."""
+    lib, st = hip.load(), hip.stream_ptr()
+    Vb = hip.Planes.empty((T, Npad // 16, 1024, 16), DEV)
+    part = torch.zeros(ksplits, Npad, 1024, device=DEV)
+    ml = torch.zeros(ksplits, Npad, 2, device=DEV)
+    out = torch.full((N, T * N), float("nan"), device=DEV)
+    nq = (N + 63) // 64
+    trace = torch.zeros(8 * ((nq * ksplits + 7) // 8) * 64, dtype=torch.int64, device=DEV)
+    ra = hip.ReadArgs()
+    ra.mode, ra.qh, ra.ql = mode, Q.hi.data_ptr(), Q.lo.data_ptr()
+    ra.kh, ra.kl, ra.k_slot_stride = K.hi.data_ptr(), K.lo.data_ptr(), Npad * 128
+    ra.vh, ra.vl, ra.v_slot_stride = Vb.hi.data_ptr(), Vb.lo.data_ptr(), 1024 * Npad
+    ra.T, ra.N, ra.Npad, ra.ncols, ra.scale = T, N, Npad, 1024, 1.0 / math.sqrt(128)
+    ra.bias = bias.data_ptr() if bias is not None else None
+    if R is not None:
+        ra.R, ra.ldr, ra.rcs = R.data_ptr(), (ldr if ldr is not None else R.shape[1]), rcs
+    ra.h, ra.w, ra.ksplits = h, w, ksplits
+    ra.part, ra.ml = part.data_ptr(), ml.data_ptr()
+    ra.dbg_logits, ra.dbg_ld = out.data_ptr(), T * N
+    hip.check(lib.rmem_attn_read_trace(C.byref(ra), trace.data_ptr(), st), "read_trace")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+LOGIT_CASES = [(0, 1, 5, 7), (1, 2, 5, 7), (1, 4, 8, 11), (2, 5, 8, 11), (1, 8, 5, 7), (1, 3, 9, 13)]
+
+
+@pytest.mark.parametrize("case", LOGIT_CASES, ids=lambda c: "l%d_T%d_%dx%d" % c)
+def test_read_logits_per_logit_vs_reference(hip, case, deaot_model, golden_dir):
+    """"Attention logits within 1e-3" (BASELINE.json north_star) checked PER LOGIT against the reference: the block fixtures
+    hold the inputs of the reference's two softmax calls -- GatedPropagation's QK = (Q / T) @ K with the temporal positional
+    embedding (attention.py:184-187, transformer.py:1140-1175) and LocalGatedPropagation's qk + relative bias over the
+    15 x 15 window (attention.py:334-344) -- recorded by make_golden.py:gen_blocks.  The fused read's debug entry
+    (rmem_attn_read_trace, rmem_read_args.dbg_logits) dumps every logit it computes from the same Q (the reference's
+    curr_K output), the same PE-free bank keys and the PE / relative-position biases formed as rmem_amd/lstt.py forms them."""
+    import os
+    from inputs import block_case_name, block_inputs
+    from rmem_amd.lstt import temporal_pe_rows
+    layer, T, h, w = case
+    gold = np.load(os.path.join(golden_dir, block_case_name(layer, T, h, w, False) + ".npz"))
+    i = block_inputs(layer, T, h, w, False)
+    sd = {k: v.detach() for k, v in deaot_model.state_dict().items()}
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    Q = torch.from_numpy(gold["curr_K"])                               # the block's Q projection = curr_K (transformer.py:1234)
+    cur_pe, mem_pe = sd["cur_pos_emb"][0], sd["mem_pos_emb"]
+    pad = lambda x: torch.cat([x, torch.zeros(Npad - N, x.shape[1])], 0)
+    # ---- long-term read: Q + cur_pe against the PE-free bank, the memory PE as a per-(query, slot) bias
+    Qpe = Q + cur_pe[None]
+    rows = temporal_pe_rows(T)
+    bias = (Qpe.double() @ mem_pe[rows].double().t()).float().to(DEV).contiguous()                      # [N][T]
+    Kb = torch.stack([pad(i["bank_K"][t]) for t in range(T)])
+    got = _read_logits(hip, 0, T, N, Npad, _planes(hip, Kb), _planes(hip, pad(Qpe)), bias, h, w, None, min(3, T))
+    ref = torch.from_numpy(gold["lt_logits"])
+    assert not torch.isnan(got).any(), "a long-term logit was not computed"
+    err = (got - ref).abs().max().item()
+    # ---- windowed read: unscaled Q for the relative bias (attention.py:314), scaled Q . K inside the 15 x 15 window
+    p = f"LSTT.layers.{layer}.short_term_attn.relative_emb_k."
+    R = (Q.double() @ sd[p + "weight"].reshape(225, 128).double().t() + sd[p + "bias"].double()).float().to(DEV).contiguous()
+    gotw = _read_logits(hip, 1, 1, N, Npad, _planes(hip, pad(i["short_K"])[None]), _planes(hip, pad(Q)), None, h, w, R, 1)
+    refw = torch.from_numpy(gold["st_logits"])                         # [225][N], -1e8 outside the image
+    errw, n_in = 0.0, 0
+    for q in range(N):
+        qy, qx = divmod(q, w)
+        for o in range(225):
+            ky, kx = qy + o // 15 - 7, qx + o % 15 - 7
+            inside = 0 <= ky < h and 0 <= kx < w
+            assert (refw[o, q].item() > -1e7) == inside
+            if inside:
+                g = gotw[q, ky * w + kx].item()
+                assert g == g, f"window logit (q={q}, o={o}) was not computed"
+                errw = max(errw, abs(g - refw[o, q].item()))
+                n_in += 1
+    assert int((~torch.isnan(gotw)).sum()) == n_in, "logits outside the window were computed"
+    print(f"l{layer} T={T} {h}x{w}: max |HIP logit - reference logit| long-term {err:.2e} (|logit| up to "
+          f"{ref.abs().max().item():.1f}), windowed {errw:.2e} over {n_in} in-window logits")
+    assert err < 1e-3 and errw < 1e-3, (err, errw)
+
+
 @pytest.mark.parametrize("ksplits", [1, 4])
 @pytest.mark.parametrize("h,w", [(5, 7), (9, 13), (20, 23), (31, 54)])
 def test_read_window(hip, ksplits, h, w):

@@ -338,6 +338,29 @@ def test_sharded_dataset_of_unequal_clips_world_invariant():
     assert out[2][1] == [8, 9] and out[3][1] == [6, 6, 5]       # propagated frames per rank (22 frames over 2 / 3 ranks)
 
 
+def test_sharded_dataset_with_fewer_clips_than_ranks_and_a_one_frame_clip():
+    """run_sharded_dataset when a rank gets NO clip (one clip, two ranks: that rank still takes part in the size
+    agreement and contributes a zero block) and when a clip has a single frame (nothing propagated: masks None) -- both
+    used to fail (device taken from a mask that does not exist; `None.shape`).  Same hashes as one rank; and
+    gather_masks refuses a world that is not the group's size instead of hanging in the collective."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for lengths in ([4], [1, 3]):
+        out = {}
+        for world in (1, 2):
+            q = ctx.Queue()
+            port = 35500 + os.getpid() % 2000 + world + 10 * len(lengths)
+            procs = [ctx.Process(target=_sharded_dataset_worker, args=(r, world, port, q, lengths, 49, 65)) for r in range(world)]
+            for p in procs:
+                p.start()
+            out[world] = q.get(timeout=600)
+            for p in procs:
+                p.join(timeout=600)
+                assert p.exitcode == 0
+        assert out[1][0] == out[2][0] and len(out[1][0]) == len(lengths)
+        assert sum(out[2][1]) == sum(n - 1 for n in lengths)
+
+
 def test_batched_clip_driver_validates_its_input_on_the_host():
     """BatchedClipDriver refuses what it cannot run in lockstep before anything is launched (no GPU
     needed): wrong clip count, clips whose lengths give different memory gaps, flip augmentation, mid-clip
@@ -574,3 +597,21 @@ def test_slot_queue_of_nothing_and_of_one_frame_clips():
     assert plan_slot_queue([], 4) == []
     # clips of one frame (a reference frame only): every step restarts slots, nothing is propagated
     assert plan_slot_queue([1, 1, 1], 2) == [[(0, 0), (1, 0)], [(2, 0), None]]
+
+
+def test_rank_pinning_plan_follows_the_numa_topology():
+    """rmem_amd/affinity.py: the ranks whose GPUs hang off one NUMA node split that node's physical cores (SMT siblings
+    together) into contiguous equal shares in rank order -- the 8-GPU node of profiles/r04_numa_topo.txt (two sockets of 64
+    cores, GPUs 0-2 and 7 on node 0, 3-6 on node 1); unknown topology or too few cores -> no pin."""
+    from rmem_amd.affinity import parse_cpulist, plan_node_shares
+    assert parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    node0 = [[c, c + 128] for c in range(0, 64)]
+    node1 = [[c, c + 128] for c in range(64, 128)]
+    shares = plan_node_shares([0, 0, 0, 1, 1, 1, 1, 0], {0: node0, 1: node1})
+    assert all(len(s) == 32 for s in shares)                                  # 16 cores x 2 threads each
+    assert shares[0][:3] == [0, 1, 2] and shares[0][16:19] == [128, 129, 130]
+    assert shares[7][0] == 48 and shares[3][0] == 64 and shares[6][0] == 112
+    flat = [c for s in shares for c in s]
+    assert len(flat) == len(set(flat)) == 256                                  # disjoint, everything used
+    assert plan_node_shares([None, 0], {0: node0}) == [None, sorted(c for g in node0 for c in g)]
+    assert plan_node_shares([0, 0, 0], {0: node0[:2]}) == [None, None, None]

@@ -48,9 +48,21 @@ def test_block_vs_golden(case, deaot_model, golden_dir):
     if not ref_frame:
         mem.K, mem.V, mem.IDV = list(i["bank_K"]), list(i["bank_V"]), list(i["bank_IDV"])
         mem.sK, mem.sV, mem.sIDV = i["short_K"], i["short_V"], i["short_IDV"]
+    trace = {}
     tgt, tgt_id, curr, mass, bank, short = R.gpm_layer(
         sd, layer, i["tgt"], i["tgt_id"], mem, h, w, sd["cur_pos_emb"][0], sd["mem_pos_emb"],
-        curr_id_emb=i["id_emb"] if ref_frame else None)
+        curr_id_emb=i["id_emb"] if ref_frame else None, trace=trace)
+    # pre-softmax logits of the two memory reads, element by element (attention.py:184, :344): what "attention logits
+    # within 1e-3" (BASELINE.json north_star) is measured on; the windowed ones are -1e8 outside the image on both sides
+    # (tolerance: fp32 re-association on values of magnitude up to ~100 -- a few ulp of the largest logit)
+    if "lt_logits" in gold.files:
+        lt_ref = gold["lt_logits"]
+        assert np.abs(trace[f"l{layer}.lt_logits"].numpy() - lt_ref).max() < max(TOL, 1e-6 * np.abs(lt_ref).max())
+    st_ref = gold["st_logits"].T                                     # reference layout [225][N]
+    st_o = trace[f"l{layer}.st_logits"].numpy()
+    inside = st_ref > -1e7
+    assert np.array_equal(inside, st_o > -1e7)
+    assert np.abs(st_o[inside] - st_ref[inside]).max() < max(TOL, 1e-6 * np.abs(st_ref[inside]).max())
     assert np.abs(tgt.numpy() - gold["out_tgt"]).max() < TOL
     assert np.abs(tgt_id.numpy() - gold["out_tgt_id"]).max() < TOL
     assert np.abs(curr[0].numpy() - gold["curr_K"]).max() < TOL
