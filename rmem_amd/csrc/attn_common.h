@@ -5,7 +5,7 @@
 // Logical -> physical slot map held in two 64-bit scalars (8 bits per slot, T <= 16).  A
 // per-k-tile `slot_map[t]` read is a dependent global load followed by s_waitcnt vmcnt(0): it
 // delays the issue of the tile's staging loads by a full memory latency and drains every load in
-// flight, which also defeats any deeper prefetch (measured with research/ubench/pv_trace).
+// flight, which also defeats any deeper prefetch (measured with a tracing copy of the round-2 kernel: git history, research/ubench/pv_trace.hip).
 struct SlotLut {
   unsigned long long w0, w1;
   __device__ __forceinline__ void load(const int* slot_map, int T) {

@@ -577,6 +577,8 @@ def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
                 for e, s_, fl in zip(engines, samples, flips):
                     e.restart_engine()
                     e.long_term_mem_gap = gap
+                    if hasattr(e, "adopt_frame_steps"):            # the one sub-engine per augmentation that ran so far keeps counting
+                        e.adopt_frame_steps([frame_idx])
                     e.add_reference_frame(s_["current_img"],       # (a fresh engine learns its input size from this call)
                                           ClipDriver._resize_generic(label, tuple(s_["current_img"].shape[2:]), fl),
                                           obj_nums=[n_new], frame_step=frame_idx)

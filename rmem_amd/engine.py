@@ -724,6 +724,7 @@ class DeAOTInferEngine(nn.Module):
         self._pool: List[DeAOTEngine] = []     # engines (and their HBM buffers) are reused across clips
         self._bat = None                       # the BatchedDeAOTEngine whose slots are the sub-engines (> 10 objects), or None
         self._bat_pool: dict = {}              # number of sub-engines -> BatchedDeAOTEngine, reused across clips
+        self._adopt_steps = None               # adopt_frame_steps(): frame counters of the sub-engines the next reference frame creates
         self.restart_engine()
 
     def restart_engine(self):                                   # aot_engine.py:598-602
@@ -746,7 +747,8 @@ class DeAOTInferEngine(nn.Module):
         from .batched import BatchedDeAOTEngine
         # every engine of the reference keeps its own frame counter: those that exist carry on, new ones start at 0
         counters = [int(e.frame_step) for e in self.aot_engines][:aot_num]
-        counters += [0] * (aot_num - len(counters))
+        adopt, self._adopt_steps = (self._adopt_steps or []), None
+        counters += [int(adopt[i]) if i < len(adopt) else 0 for i in range(len(counters), aot_num)]
         bat = self._bat
         if bat is None or bat.B != aot_num:
             singles = [e for e in self.aot_engines if isinstance(e, DeAOTEngine)]      # (a clip that grows past 10 objects)
@@ -766,6 +768,15 @@ class DeAOTInferEngine(nn.Module):
         masks = torch.cat([m.reshape(1, 1, *m.shape[-2:]) for m in self.separate_mask(mask)])
         bat.add_reference_frame(img, masks, obj_nums=[self.max_aot_obj_num] * aot_num, frame_step=frame_step)
         self.update_size()
+
+    def adopt_frame_steps(self, steps):
+        """The sub-engines the NEXT add_reference_frame creates take these frame counters instead of 0 (one entry per
+        sub-engine, in order).  A wrapper that takes over a clip mid-way (rmem_amd.driver: test-time augmentation handed
+        from the batched-augmentation engine to per-augmentation engines when a new label exceeds ten objects) stands in
+        for engines that ran since frame 0: in the reference those keep counting (long_memories_indexes and the gap
+        schedule follow the engine's own counter, aot_engine.py:322-323, 338-343), only sub-engines that appear with the
+        new label start at 0."""
+        self._adopt_steps = [int(v) for v in steps]
 
     def _new_engine(self) -> DeAOTEngine:
         """One sub-engine (<= max_aot_obj_num objects); tests substitute engines that run the encoder and
@@ -808,6 +819,7 @@ class DeAOTInferEngine(nn.Module):
         aot_num = max(aot_num, len(self.aot_engines))           # (engines are never dropped inside a clip: `while aot_num > len`)
         if self._batched_ok(aot_num):
             return self._add_reference_batched(img, mask, aot_num, frame_step)
+        adopt, self._adopt_steps = (self._adopt_steps or []), None
         while aot_num > len(self.aot_engines):
             if self._pool:
                 eng = self._pool.pop(0)
@@ -815,6 +827,8 @@ class DeAOTInferEngine(nn.Module):
             else:
                 eng = self._new_engine()
             eng.eval()
+            if len(self.aot_engines) < len(adopt):              # (adopt_frame_steps: this sub-engine stands in for one that ran the clip so far)
+                eng.frame_step = int(adopt[len(self.aot_engines)])
             self.aot_engines.append(eng)
         img_embs = self.AOT.encode_image(img) if len(self.aot_engines) > 1 else None    # shared encoder pass
         for eng, m in zip(self.aot_engines, self.separate_mask(mask)):
