@@ -23,13 +23,11 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, lo
     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
   }
   float s = v.x + v.y + v.z + v.w;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  s = wave_sum_xor_t(s);
   const float mean = s * (1.0f / 256.0f);
   const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
   float ss = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  ss = wave_sum_xor_t(ss);
   const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
   const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
   const float4 b = *reinterpret_cast<const float4*>(beta + lane * 4);
@@ -413,11 +411,8 @@ __device__ void gn2_stats_kernel(const Gn2Args& a, int) {
   }
 #pragma unroll
   for (int gidx = 0; gidx < 2; ++gidx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s[gidx] += __shfl_xor(s[gidx], o);
-      q[gidx] += __shfl_xor(q[gidx], o);
-    }
+    s[gidx] = wave_sum_xor_t(s[gidx]);
+    q[gidx] = wave_sum_xor_t(q[gidx]);
     if (lane == 0) {
       red[gidx][0][wave] = s[gidx];
       red[gidx][1][wave] = q[gidx];
@@ -448,8 +443,7 @@ __device__ void gn2_apply_kernel(const Gn2Args& a, int) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) p[j] += __shfl_xor(p[j], o);
+      p[j] = wave_sum_xor_t(p[j]);
     if (tid < 2) {
       const double cnt = (double)N * C;
       const double mean = p[tid * 2] / cnt;
@@ -570,8 +564,7 @@ __device__ void id_assign_kernel(const IdAssignArgs& a, int) {
 #pragma unroll
   for (int j = 0; j < TOK; ++j) {
     float s = acc[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum_xor_t(s);
     if (lane == 0) red[j][wave] = s;
   }
   __syncthreads();
@@ -581,8 +574,7 @@ __device__ void id_assign_kernel(const IdAssignArgs& a, int) {
     const float mean = (red[j][0] + red[j][1] + red[j][2] + red[j][3]) * (1.0f / 256.0f);
     d[j] = acc[j] - mean;
     float ss = d[j] * d[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    ss = wave_sum_xor_t(ss);
     if (lane == 0) red2[j][wave] = ss;
   }
   __syncthreads();
@@ -637,8 +629,7 @@ __device__ void mass_reduce_kernel(const MassReduceArgs& a, int) {
   for (int t = 0; t < T; ++t) {
     float s = 0.f;
     for (int q = tid; q < N; q += 1024) s += mass[(long)q * T + t] * fg[q];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum_xor_t(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
     if (tid == 0) {
@@ -870,11 +861,8 @@ __global__ __launch_bounds__(256) void gn_nchw_stats_kernel(const float* x, cons
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    q += __shfl_xor(q, o);
-  }
+  s = wave_sum_xor_t(s);
+  q = wave_sum_xor_t(q);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     red[0][wave] = s;
@@ -1039,11 +1027,8 @@ __global__ __launch_bounds__(256) void gn_tok_stats_kernel(const float* x, int N
     s += v;
     q += (double)v * v;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    q += __shfl_xor(q, o);
-  }
+  s = wave_sum_xor_t(s);
+  q = wave_sum_xor_t(q);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     red[0][wave] = s;
@@ -1117,8 +1102,7 @@ __global__ void pe_bias_heads_kernel(const float* Q, long ldq, const float* cur_
     for (int c0 = 0; c0 < d; c0 += 64) {      // lanes 0-31 -> head c0/32, lanes 32-63 -> head c0/32 + 1
       const int c = c0 + lane;
       float s = (Q[(long)q * ldq + c] + cur_pe[c]) * mem_pe[(long)rows.row[t] * d + c];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      s = wave_sum_xor_t<16>(s);
       if ((lane & 31) == 0) bias[((long)q * heads + (c >> 5)) * T + t] = s;
     }
   }

@@ -356,7 +356,7 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
       for (int e = 0; e < 16; ++e)
         y[e] = ((vm >> e) & 1u) ? fmaf(s[e >> 2][e & 3], sl2e, rbw[e] * 1.44269504088896341f) : RD_NEG;
     }
-    if constexpr (TRACE != 0) {
+    if constexpr (TRACE == 2) {
       // debug (rmem_attn_read_trace with a.dbg_logits): every pre-softmax logit this lane computed, in the natural-log
       // domain the reference's QK tensor is in (attention.py:184, :344) -- keys outside the image / window are left alone
       if (a.dbg_logits && qvalid) {
@@ -440,8 +440,13 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
     // the row's largest score of this tile (sentinels are far below): 4 lanes hold a query
     float rm = fmaxf(fmaxf(fmaxf(fmaxf(yc[0], yc[1]), fmaxf(yc[2], yc[3])), fmaxf(fmaxf(yc[4], yc[5]), fmaxf(yc[6], yc[7]))),
                      fmaxf(fmaxf(fmaxf(yc[8], yc[9]), fmaxf(yc[10], yc[11])), fmaxf(fmaxf(yc[12], yc[13]), fmaxf(yc[14], yc[15]))));
-    rm = fmaxf(rm, __shfl_xor(rm, 16));
-    rm = fmaxf(rm, __shfl_xor(rm, 32));
+    {                                                   // max over lanes ^ 16, ^ 32: lane swaps, no ds_bpermute round trips
+      float plo, phi;
+      xor16_pair(rm, plo, phi);
+      rm = fmaxf(plo, phi);
+      xor32_pair(rm, plo, phi);
+      rm = fmaxf(plo, phi);
+    }
     const bool bump = rm > mc + RD_BUMP;              // (mc = -3e38 before the first valid key: any valid score raises it)
     if (__any(bump)) {                                // (wave-uniform, rare) raise m of those rows to this tile's maximum
       const float mn = bump ? rm : mc;
@@ -460,8 +465,11 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
     const int t = ti.t;
     if (t != sum_t) {
       if (sum_t >= 0) {                               // (wave-uniform) slot finished: park its sum and what it refers to
-        float v = lcur + __shfl_xor(lcur, 16);
-        v += __shfl_xor(v, 32);
+        float plo, phi;                                 // lcur + lcur[^16], then + [^32] (the pair forms: a + b = b + a)
+        xor16_pair(lcur, plo, phi);
+        float v = plo + phi;
+        xor32_pair(v, plo, phi);
+        v = plo + phi;
         if (lb == 0) {
           sl_sum[(sum_t * 2 + grp) * 64 + row_s] = v;
           sl_m[(sum_t * 2 + grp) * 64 + row_s] = m_known;
@@ -726,10 +734,15 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
   {
     const float mfin = mrow[row_s];
     follow(mfin);
-    float v = lcur + __shfl_xor(lcur, 16);
-    v += __shfl_xor(v, 32);
-    float lt = l + __shfl_xor(l, 16);
-    lt += __shfl_xor(lt, 32);
+    float plo, phi;
+    xor16_pair(lcur, plo, phi);
+    float v = plo + phi;
+    xor32_pair(v, plo, phi);
+    v = plo + phi;
+    xor16_pair(l, plo, phi);
+    float lt = plo + phi;
+    xor32_pair(lt, plo, phi);
+    lt = plo + phi;
     if (lb == 0) {
       if (sum_t >= 0) {
         sl_sum[(sum_t * 2 + grp) * 64 + row_s] = v;
@@ -817,6 +830,12 @@ template <int VAR>
 __global__ __launch_bounds__(512) void read64_trace_kernel(rmem_read_args a, long long* trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   read64_body<1, VAR>(a, blockIdx.x, smem, trace);
+}
+// the tracing kernel + the dump of every pre-softmax logit (rmem_read_args.dbg_logits): an instantiation of its own so that
+// the stores do not sit in the kernel whose cycle stamps are read as timings
+__global__ __launch_bounds__(512) void read64_logits_kernel(rmem_read_args a, long long* trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  read64_body<2, 0>(a, blockIdx.x, smem, trace);
 }
 
 // The bank read (p[0], mode 0) and the windowed read (p[1], mode 1) of one layer in ONE launch.  Per
@@ -1072,7 +1091,8 @@ extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, vo
     hipLaunchKernelGGL(kern, dim3(8 * chunk), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), *ap,
                        reinterpret_cast<long long*>(trace));
   };
-  if (var == 4) go(&read64_trace_kernel<4>);
+  if (ap->dbg_logits) go(&read64_logits_kernel);
+  else if (var == 4) go(&read64_trace_kernel<4>);
   else if (var == 8) go(&read64_trace_kernel<8>);
   else if (var == 16) go(&read64_trace_kernel<16>);
   else go(&read64_trace_kernel<0>);
@@ -1096,12 +1116,10 @@ __device__ __forceinline__ void read_combine_body(const rmem_read_combine_args& 
       if (!(lz > 0.f)) mz = RD_NEG;
     }
     float mm = mz;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+    mm = wave_max_xor(mm);
     const float w = lz > 0.f ? expf(mz - mm) : 0.f;
     float L = w * lz;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o);
+    L = wave_sum_xor_t(L);
     if (tid < a.ksplits) wz[tid] = w;
     if (tid == 0) {
       stat[0] = mm;

@@ -90,6 +90,58 @@ __device__ __forceinline__ float dpp_lane(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
 }
 
+// The value of lane ^ O for O = 32, 16 (lane-swap + select), 8, 4, 2, 1 (DPP): drop-in for __shfl_xor(x, O) without the
+// ds_bpermute round trip; doubles go as two halves.
+template <int O>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t u) {
+  static_assert(O == 32 || O == 16 || O == 8 || O == 4 || O == 2 || O == 1, "power of two below 64");
+  if constexpr (O == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const uint32_t r0 = r[0], r1 = r[1];
+    return (__lane_id() & 32) ? r0 : r1;
+  } else if constexpr (O == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const uint32_t r0 = r[0], r1 = r[1];
+    return (__lane_id() & 16) ? r0 : r1;
+  } else {
+    const int v = (int)u;
+    if constexpr (O == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    else if constexpr (O == 4)
+      return (uint32_t)__builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false);
+    else if constexpr (O == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+  }
+}
+template <int O>
+__device__ __forceinline__ float xor_lane(float x) {
+  return __builtin_bit_cast(float, xor_lane_u32<O>(__builtin_bit_cast(uint32_t, x)));
+}
+template <int O>
+__device__ __forceinline__ double xor_lane(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned long long r = ((unsigned long long)xor_lane_u32<O>((uint32_t)(u >> 32)) << 32) | xor_lane_u32<O>((uint32_t)u);
+  return __builtin_bit_cast(double, r);
+}
+// s += s[lane ^ o] for o = FROM, FROM / 2, ..., 1 (the __shfl_xor butterfly, same partners in the same order)
+template <int FROM = 32, class T>
+__device__ __forceinline__ T wave_sum_xor_t(T s) {
+  if constexpr (FROM >= 32) s += xor_lane<32>(s);
+  if constexpr (FROM >= 16) s += xor_lane<16>(s);
+  if constexpr (FROM >= 8) s += xor_lane<8>(s);
+  if constexpr (FROM >= 4) s += xor_lane<4>(s);
+  if constexpr (FROM >= 2) s += xor_lane<2>(s);
+  s += xor_lane<1>(s);
+  return s;
+}
+__device__ __forceinline__ float wave_max_xor(float m) {
+  m = fmaxf(m, xor_lane<32>(m));
+  m = fmaxf(m, xor_lane<16>(m));
+  m = fmaxf(m, xor_lane<8>(m));
+  m = fmaxf(m, xor_lane<4>(m));
+  m = fmaxf(m, xor_lane<2>(m));
+  return fmaxf(m, xor_lane<1>(m));
+}
+
 // Sum over the 64 lanes, every lane gets it: the butterfly  s += s[lane ^ o]  for o = 32, 16, 8, 4, 2, 1 -- bit for bit
 // the chain of __shfl_xor steps it replaces (fp32 addition is commutative; the partner at every step is the same lane) --
 // on lane-swap and DPP instructions instead of twelve dependent ds_bpermute round trips per row (~1.5 k cycles per
