@@ -328,6 +328,13 @@ int rmem_dwconv5x5_split2(const float *g0, const float *g1, int64_t ldg, const f
 int rmem_groupnorm2(const float *tgt, const float *tgt_id, int32_t N, int32_t C,
                     const float *gamma, const float *beta, float eps, double *ws,
                     float *out, int64_t ldo, void *stream);
+/* The same with the split-K partials of the LAST projection folded in first (transformer.py:1231-1232: tgt += o[:, :256],
+ * tgt_id += o[:, 256:] of the self-attention projection): tgt[n][c] += sum_z parts[z*part_stride + n*ldpart + c],
+ * tgt_id[n][c] += sum_z parts[.. + C + c], splits in order (rmem_layernorm_red's arithmetic); the statistics pass writes the
+ * folded streams back, so tgt / tgt_id are inputs AND outputs.  Saves the launch that only folded. */
+int rmem_groupnorm2_fold(float *tgt, float *tgt_id, const float *parts, int32_t nparts, int64_t part_stride, int64_t ldpart,
+                         int32_t N, int32_t C, const float *gamma, const float *beta, float eps, double *ws, float *out,
+                         int64_t ldo, void *stream);
 
 /* ID assignment: label map -> one-hot(+ignore) -> Conv2d(k,stride,pad) -> LayerNorm_C
  * (utils/image.py:69-74, engines/aot_engine.py:208-232, models/aot.py:67-74,

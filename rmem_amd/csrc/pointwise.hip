@@ -376,12 +376,15 @@ extern "C" int rmem_dwconv5x5_split(const float* g, int64_t ldg, const float* wt
 struct Gn2Args {
   const float* tgt; const float* tgt_id; int N, C; const float* gamma; const float* beta; float eps; double* ws;
   int nblk; float* out; long ldo;
+  // rmem_groupnorm2_fold: split-K partials of the last projection (columns 0.. -> tgt, C.. -> tgt_id), summed into the two
+  // streams in split order by the statistics pass, which writes the folded streams back (tgt / tgt_id are then outputs too)
+  const float* parts; int nparts; long part_stride, ldpart;
 };
 // (Both passes are 27 workgroups at 480p -- a latency-bound launch each.  1024 threads per 64 tokens with every load of a
 // thread issued before its first use, and the per-block partial sums reduced by a wave instead of one thread walking them:
 // 12.5 + 12.3 us -> see DESIGN.md section 8.)
 __device__ void gn2_stats_kernel(const Gn2Args& a, int) {
-  const float* __restrict__ tgt = a.tgt; const float* __restrict__ tgt_id = a.tgt_id; const int N = a.N, C = a.C; double* ws = a.ws;
+  const float* tgt = a.tgt; const float* tgt_id = a.tgt_id; const int N = a.N, C = a.C; double* ws = a.ws;
   __shared__ double red[2][2][16];
   const int t0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,6 +401,32 @@ __device__ void gn2_stats_kernel(const Gn2Args& a, int) {
       const long off = ok[k] ? (long)tok * C + c : 0;
       va[k] = *reinterpret_cast<const float4*>(tgt + off);
       vb[k] = *reinterpret_cast<const float4*>(tgt_id + off);
+    }
+    if (a.nparts > 0) {                        // fold the partials (fixed order: rmem_layernorm_red's arithmetic), write back
+      for (int z = 0; z < a.nparts; ++z) {
+        float4 pa[4], pb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * 1024;
+          const int tok = t0 + i / per, c = (i % per) * 4;
+          const long off = ok[k] ? (long)z * a.part_stride + (long)tok * a.ldpart + c : 0;
+          pa[k] = *reinterpret_cast<const float4*>(a.parts + off);
+          pb[k] = *reinterpret_cast<const float4*>(a.parts + off + (ok[k] ? C : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          va[k].x += pa[k].x; va[k].y += pa[k].y; va[k].z += pa[k].z; va[k].w += pa[k].w;
+          vb[k].x += pb[k].x; vb[k].y += pb[k].y; vb[k].z += pb[k].z; vb[k].w += pb[k].w;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        const int i = i0 + k * 1024;
+        const long off = (long)(t0 + i / per) * C + (i % per) * 4;
+        *reinterpret_cast<float4*>(const_cast<float*>(tgt) + off) = va[k];
+        *reinterpret_cast<float4*>(const_cast<float*>(tgt_id) + off) = vb[k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -488,15 +517,24 @@ __device__ void gn2_apply_kernel(const Gn2Args& a, int) {
   }
 }
 
-extern "C" int rmem_groupnorm2(const float* tgt, const float* tgt_id, int32_t N, int32_t C, const float* gamma,
-                               const float* beta, float eps, double* ws, float* out, int64_t ldo, void* stream) {
-  if (!tgt || !tgt_id || !gamma || !beta || !ws || !out || N <= 0 || (C % 4) || (ldo % 4)) return RMEM_ERR_INVALID;
+extern "C" int rmem_groupnorm2_fold(float* tgt, float* tgt_id, const float* parts, int32_t nparts, int64_t part_stride,
+                                    int64_t ldpart, int32_t N, int32_t C, const float* gamma, const float* beta, float eps,
+                                    double* ws, float* out, int64_t ldo, void* stream) {
+  if (!tgt || !tgt_id || !gamma || !beta || !ws || !out || N <= 0 || (C % 4) || (ldo % 4) || nparts < 0 ||
+      (nparts > 0 && (!parts || (part_stride % 4) || (ldpart % 4) || ldpart < 2 * C)))
+    return RMEM_ERR_INVALID;
   const int nblk = (N + 63) / 64;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  Gn2Args a{tgt, tgt_id, N, C, gamma, beta, eps, ws, nblk, out, (long)ldo};
+  Gn2Args a{tgt, tgt_id, N, C, gamma, beta, eps, ws, nblk, out, (long)ldo, parts, nparts, (long)part_stride, (long)ldpart};
   const int rc = rmem::launch<Gn2Args, gn2_stats_kernel, 1024>(a, dim3(nblk), dim3(1024), 0, s);
   if (rc != RMEM_OK) return rc;
   return rmem::launch<Gn2Args, gn2_apply_kernel, 1024>(a, dim3(nblk), dim3(1024), 0, s);
+}
+
+extern "C" int rmem_groupnorm2(const float* tgt, const float* tgt_id, int32_t N, int32_t C, const float* gamma,
+                               const float* beta, float eps, double* ws, float* out, int64_t ldo, void* stream) {
+  return rmem_groupnorm2_fold(const_cast<float*>(tgt), const_cast<float*>(tgt_id), nullptr, 0, 0, 0, N, C, gamma, beta, eps, ws, out,
+                              ldo, stream);
 }
 
 // ------------------------------------------------------------------ ID assignment

@@ -935,6 +935,10 @@ __device__ __forceinline__ void sched_done(int* sched) {
   }
 }
 
+__global__ void zero_sched_kernel(int* sched) {
+  if (threadIdx.x < 2) sched[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(512) void read64x2_pull_kernel(Read2Args g, int* sched) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int total = 8 * (g.cha + g.chb + g.chs);
@@ -998,7 +1002,7 @@ static int read2_many(const rmem::RecOp& op, const char* d, long st, int B, hipS
   int* sched = static_cast<int*>(op.aux);              // (of the first clip's recording; one launch serves all clips)
   if (sched && (int)op.grid.x * B > ncu) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_many_pull_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
-    if (hipMemsetAsync(sched, 0, 2 * sizeof(int), s) != hipSuccess) return RMEM_ERR_LAUNCH;   // (see rmem_attn_read2)
+    hipLaunchKernelGGL(zero_sched_kernel, dim3(1), dim3(64), 0, s, sched);   // (a kernel, not a memset node: see rmem_attn_read2)
     hipLaunchKernelGGL(read64x2_many_pull_kernel, dim3(ncu), dim3(512), R6_LDS, s, d + op.off, st, B, sched);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
@@ -1049,10 +1053,13 @@ extern "C" int rmem_attn_read2(const rmem_read_args* ap, const rmem_read_args* b
   const int ncu = device_cus();
   if (ap->sched && 8 * (cha + chb + chs) > ncu) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&read64x2_pull_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
-    // The queue counters are zeroed on the launch stream in front of every pull launch (a memset node under capture):
-    // the last workgroup out also zeroes them, but a faulted or aborted launch would otherwise leave the next read
-    // skipping units silently.
-    if (hipMemsetAsync(ap->sched, 0, 2 * sizeof(int), static_cast<hipStream_t>(stream)) != hipSuccess) return RMEM_ERR_LAUNCH;
+    // The queue counters are zeroed on the launch stream in front of every pull launch: the last workgroup out also zeroes
+    // them, but a faulted or aborted launch would otherwise leave the next read skipping units silently.  By a KERNEL, not
+    // hipMemsetAsync: captured into a hipGraph the memset became a memset node, and graphs holding such nodes faulted
+    // ("Memory access fault by GPU") when they were replayed after eagerly issued frames had run in between -- the second
+    // 720p K=8 clip of a driver, whose first two frames are eager (tools/clip720_twice_probe.py; the plain kernels' graphs,
+    // which hold no memset node, never did: profiles/r05_720p_second_clip_fault.md).
+    hipLaunchKernelGGL(zero_sched_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), ap->sched);
     hipLaunchKernelGGL(read64x2_pull_kernel, dim3(ncu), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), g, ap->sched);
     RMEM_CHECK_LAUNCH();
     return RMEM_OK;

@@ -113,7 +113,7 @@ EXPORTS = [
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2", "rmem_layernorm_cn",
     "rmem_bias_act_nchw_batched", "rmem_dwconv5x5_split2",
     "rmem_attn_read", "rmem_attn_read_trace", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
-    "rmem_rec_end", "rmem_launch_recorded", "rmem_ln_linear_grouped", "rmem_ln_linear_grouped_trace",
+    "rmem_rec_end", "rmem_launch_recorded", "rmem_ln_linear_grouped", "rmem_ln_linear_grouped_trace", "rmem_groupnorm2_fold",
 ]
 # exports with a non-int return type
 EXPORTS_OTHER = ["rmem_rec_begin", "rmem_rec_free", "rmem_rec_count", "rmem_rec_size", "rmem_rec_data",
@@ -166,6 +166,7 @@ def load():
     lib.rmem_layernorm_split.argtypes = [c_p, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64, c_p, i64, c_p]
     lib.rmem_dwconv5x5_split.argtypes = [c_p, i64, c_p, i32, i32, i32, c_p, c_p, i64, c_p]
     lib.rmem_groupnorm2.argtypes = [c_p, c_p, i32, i32, c_p, c_p, f32, c_p, c_p, i64, c_p]
+    lib.rmem_groupnorm2_fold.argtypes = [c_p, c_p, c_p, i32, i64, i64, i32, i32, c_p, c_p, f32, c_p, c_p, i64, c_p]
     lib.rmem_id_assign.argtypes = [c_p, i32, i32, c_p, c_p, i32, i32, i32, i32, i32, i32, i32,
                                    c_p, c_p, f32, c_p, c_p, i64, c_p, i64, i32, c_p]
     lib.rmem_attn_mass_reduce.argtypes = [c_p, i32, i32, c_p, c_p, c_p]

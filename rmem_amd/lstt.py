@@ -808,6 +808,7 @@ class DeAOTLSTT:
             raise hip.RmemError("front/rest split needs a propagation frame and the paired schedule")
         cur, T = self.cur, self._T
         self._tg, self._tgi = self.tgt, self.tgt_id        # (the front part folds nothing: every part starts on the first pair)
+        self._gn_fold = False
         map_bank = self.maps.data_ptr()
         map_short = self.maps.data_ptr() + 16 * 4
         rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
@@ -829,11 +830,15 @@ class DeAOTLSTT:
             self._forward_layer(l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short)
         if do_rest:
             # -- final GroupNorm over [tgt | tgt_id] (transformer.py:806-808)
-            with self._ev("gn2_stats_kernel + gn2_apply_kernel", nbytes=N * 512 * 4.0 * 3):
-                hip.check(lib.rmem_groupnorm2(self._tg.data_ptr(), self._tgi.data_ptr(), N, 256,
-                                              self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
-                                              self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
-                          "rmem_groupnorm2")
+            # (one-clip engines: the last layer's projection left split-K partials -- folded here by the statistics pass
+            # instead of by a LayerNorm launch whose planes nobody read)
+            fold = self._gn_fold
+            with self._ev("gn2_stats_kernel + gn2_apply_kernel", nbytes=N * 512 * 4.0 * (3 + (self.KS if fold else 0))):
+                hip.check(lib.rmem_groupnorm2_fold(self._tg.data_ptr(), self._tgi.data_ptr(),
+                                                   self.parts.data_ptr() if fold else None, self.KS if fold else 0, N * 512, 512,
+                                                   N, 256, self.gn_gamma.data_ptr(), self.gn_beta.data_ptr(), 1e-5,
+                                                   self.gn_ws.data_ptr(), self.out.data_ptr(), 512, st),
+                          "rmem_groupnorm2_fold")
 
     def _forward_layer(self, l, W, Ucat, curK, curV, ref_frame, seg_a, seg_b, T, rows, map_bank, map_short):
         N, Np, ns = self.N, self.Npad, self.nsplit
@@ -978,7 +983,7 @@ class DeAOTLSTT:
                           nbytes=4.0 * (N * 1024 + 512 * 1024 + self.KS * N * 512)):
                 hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
                            tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
-            self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
+            self._gn_fold = True           # the GroupNorm's statistics pass folds these partials (rmem_groupnorm2_fold)
         else:                  # (recorded launches) last layer: accumulate straight into tgt / tgt_id
             hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self,
                        d0=self.tgt.data_ptr(), ldd0=256, d1=self.tgt_id.data_ptr(), ldd1=256,

@@ -373,6 +373,25 @@ def test_bench_gpus8_on_one_device():
 
 
 @pytest.mark.gpu
+def test_second_720p_clip_on_one_driver_replays_the_first_clips_graphs():
+    """Regression (round 5): at 721x1281, K = 8 the paired read has more units than CUs and takes the unit-queue kernel;
+    its queue counters used to be zeroed by hipMemsetAsync -- a memset NODE in the captured frame graphs -- and the second
+    clip of a driver (two eager frames, then replays of the first clip's graphs) died with "Memory access fault by GPU"
+    on ROCm 7.2.  The counters are zeroed by a kernel now.  Run in a child process (a GPU fault kills the process): three
+    clips on one driver must complete with identical label hashes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PROBE_FRAMES="14")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "clip720_twice_probe.py")], env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    lines = [l.split() for l in p.stdout.splitlines() if l.startswith("clip ")]
+    assert len(lines) == 3 and p.stdout.strip().endswith("ok")
+    assert len({l[-1] for l in lines}) == 1, lines           # the same clip three times: the same label maps
+
+
+@pytest.mark.gpu
 def test_bench_world1_over_rccl():
     """bench.py's N > 1 code path on the ONE leased GPU with the real backend: RMEM_FORCE_DIST=1 makes a one-rank
     RCCL group, so init_process_group("nccl"), the barriers, the uint8 all_gather_into_tensor of the masks and the

@@ -706,6 +706,43 @@ def test_linear_stream_equals_tile_kernels(hip, nsplit):
     assert torch.all(a["R"][-7:] == 3.0) and torch.all(b["R"][-7:] == 3.0)
 
 
+@pytest.mark.parametrize("N", [1674, 100])
+def test_groupnorm2_fold_equals_layernorm_fold_then_groupnorm(hip, N):
+    """rmem_groupnorm2_fold (the statistics pass of the final GroupNorm1D(2 groups), transformer.py:806-808, first sums the
+    split-K partials of the last self-attention projection into tgt / tgt_id, :1231-1232) against the two launches it
+    replaces -- rmem_layernorm_red2 as the fold (its planes unused) + rmem_groupnorm2: folded streams and output bit for
+    bit, and against an fp64 GroupNorm."""
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(N)
+    KS = 2
+    tgt, tgi = (_rand(rs, N, 256) * 2 + 0.3).to(DEV), (_rand(rs, N, 256) * 0.7).to(DEV)
+    parts = _rand(rs, KS, N, 512, scale=0.5).to(DEV)
+    gm, bt = (_rand(rs, 512) * 0.2 + 1).to(DEV), (_rand(rs, 512) * 0.1).to(DEV)
+    ws = torch.zeros(4 * ((N + 63) // 64), dtype=torch.float64, device=DEV)
+    # reference: LayerNorm launch as the fold, then the plain GroupNorm
+    a, b = tgt.clone(), tgi.clone()
+    dump = hip.Planes.empty((N, 512), DEV)
+    hip.check(lib.rmem_layernorm_red2(a.data_ptr(), b.data_ptr(), 256, parts.data_ptr(), parts.data_ptr() + 1024, KS, N * 512, 512,
+                                      gm.data_ptr(), bt.data_ptr(), gm.data_ptr(), bt.data_ptr(), N, 256, 1e-5,
+                                      dump.hi.data_ptr(), dump.lo.data_ptr(), 512, dump.hi.data_ptr() + 512, dump.lo.data_ptr() + 512, 512,
+                                      st), "ln_red2")
+    out_ref = torch.zeros(N, 512, device=DEV)
+    hip.check(lib.rmem_groupnorm2(a.data_ptr(), b.data_ptr(), N, 256, gm.data_ptr(), bt.data_ptr(), 1e-5, ws.data_ptr(),
+                                  out_ref.data_ptr(), 512, st), "gn2")
+    c, d = tgt.clone(), tgi.clone()
+    out = torch.zeros(N, 512, device=DEV)
+    hip.check(lib.rmem_groupnorm2_fold(c.data_ptr(), d.data_ptr(), parts.data_ptr(), KS, N * 512, 512, N, 256, gm.data_ptr(),
+                                       bt.data_ptr(), 1e-5, ws.data_ptr(), out.data_ptr(), 512, st), "gn2_fold")
+    torch.cuda.synchronize()
+    assert torch.equal(c, a) and torch.equal(d, b), "folded streams"
+    assert torch.equal(out, out_ref)
+    x = torch.cat([tgt.double().cpu() + parts[:, :, :256].double().sum(0).cpu(), tgi.double().cpu() + parts[:, :, 256:].double().sum(0).cpu()], 1)
+    g = x.view(N, 2, 256)
+    mean, var = g.mean(dim=(0, 2), keepdim=True), g.var(dim=(0, 2), unbiased=False, keepdim=True)
+    ref = ((g - mean) / torch.sqrt(var + 1e-5)).view(N, 512) * gm.double().cpu() + bt.double().cpu()
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-6
+
+
 def test_linear_single_stage_items_many_per_workgroup(hip):
     """Shapes whose work items hold ONE k-tile stage (K = 64; split-K down to one k-tile per split) with more than four
     items per workgroup of the streaming kernel: its four-entry item ring would be overwritten before the epilogue reads
