@@ -493,19 +493,26 @@ def test_bench_line_contract_single_gpu():
     assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None and out["data"] == "synthetic"
     assert abs(out["value"] - 12 / (out["ms_per_step"] * 12 / 1e3)) < 1e-6 * out["value"]
     assert "workload" in out["config"] and "model" not in out["config"]
-    r = out["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    top = out["roofline"]
+    # `roofline` = the kernel with the largest time per frame (kernels[0]); the fused attention read, timed by events inside
+    # the timed region, is `attention_read` when another kernel leads (the projection kernel does, since it is measured)
+    assert top["bound"] in ("mfma", "hbm") and top["peak"] in (2500.0, 8000.0) and 0.005 < top["frac"] < 0.6
+    assert abs(top["frac"] - top["achieved"] / top["peak"]) < 1e-9 and top["kernel"] == top["kernels"][0]["kernel"]
+    if top["bound"] == "mfma":
+        assert abs(top["achieved"] - top["algorithmic_flops_per_launch"] / (top["mean_us"] * 1e-6) / 1e12) < 1e-6 * top["achieved"]
+    r = top.get("attention_read", top)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["kernel"].startswith("read64x2")
     assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["mean_us"] * 1e-6) / 1e12) < 1e-6 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.03 < r["frac"] < 0.5
-    assert r["traffic"] is not None and r["traffic"] > 1e7
+    assert r["traffic"] is not None and r["traffic"] > 1e7 and top["traffic"] is not None
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert max(out["mask_mismatch_px"]) <= 4 and out["eviction_sequence_equal"] is True and out["iou_vs_oracle"] > 0.9999
     # IoU over EVERY id present in either map (background + the ten live ids of the synthetic weights), not ids 1-3
     assert 0 in out["iou_ids"] and len(out["iou_ids"]) >= 5 and out["iou_vs_oracle_min"] > 0.99
     # the five largest kernel classes of the memory path, each against its own roofline; `roofline` is the largest
-    ks = r["kernels"]
-    assert 3 <= len(ks) <= 5 and ks[0]["kernel"].startswith("read64x2_kernel")
+    ks = top["kernels"]
+    assert 3 <= len(ks) <= 5 and any(k["kernel"].startswith("read64x2_kernel") for k in ks[:2])
     assert [k["us_per_frame"] for k in ks] == sorted((k["us_per_frame"] for k in ks), reverse=True)
     for k in ks:
         assert k["bound"] in ("mfma", "hbm") and 0 < k["frac"] < 1 and k["launches_per_frame"] >= 1
@@ -513,7 +520,8 @@ def test_bench_line_contract_single_gpu():
         if k["bound"] == "mfma":
             assert abs(k["achieved"] - k["algorithmic_gflop_per_launch"] * 1e9 / (k["mean_us"] * 1e-6) / 1e12) < 1e-6 * k["achieved"]
     assert any(k["kernel"].startswith("linear_stream_kernel") for k in ks)
-    assert abs(ks[0]["mean_us"] - r["mean_us"]) < 0.25 * r["mean_us"]       # the two sampling methods see the same kernel
+    rk = next(k for k in ks if k["kernel"].startswith("read64x2_kernel"))
+    assert abs(rk["mean_us"] - r["mean_us"]) < 0.25 * r["mean_us"]          # the two sampling methods see the same kernel
     # 'mask IoU vs ref' on the benchmarked schedule: the reference's own 46-frame gap-5 run (tests/golden/clip_480p_long.*)
     pr = out["parity_vs_reference"]
     assert pr["frames"] == 45 and pr["evictions"] >= 5 and pr["bank_index_history_equal"] is True
