@@ -43,6 +43,7 @@ print(name, {k: {c: (round(v["mean"] / 1e6, 2) if isinstance(v, dict) else round
 PY
   find $O -name "*.csv" -size +1M -delete
 }
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 # (un-profiled benches FIRST: MIOpen picks slower solvers for the rest of a box's life once rocprofv3 has run on it)
 # 3. the benches of the round (un-profiled)
 timeout 600 python bench.py > $O/${TAG}_bench_x3.json 2> $O/bench_x3.err

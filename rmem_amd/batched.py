@@ -11,8 +11,13 @@ batch -- share the launches of the memory path:
     recorder (include/rmem_hip.h, csrc/launch.h) turns every entry point into "append the
     argument block" -- and the argument blobs are uploaded (one pinned-memory copy) and replayed
     by ``rmem_launch_recorded``: per kernel ONE launch whose grid covers the clips, each block
-    reading its clip's arguments from device memory.  Per clip the arithmetic is the single-clip
-    kernel's, bit for bit (tests/test_hip_batched.py);
+    reading its clip's arguments from device memory.  Per clip the arithmetic is, bit for bit, that of a
+    single-clip ``DeAOTLSTT`` built with ``clips_per_launch=B`` -- the same kernels' bodies with the same key splits
+    and the same four-way split-K of the projections (tests/test_hip_batched.py).  The ONE-clip engine
+    (``clips_per_launch=1``) runs the projections on the streaming kernel with a two-way split-K and folds the last
+    partials in the GroupNorm: fp32-equal, not bit-equal, so a near-tie pixel may differ between a clip run alone
+    and the same clip in a batch -- which is why ``BatchedClipDriver.run_dataset`` sends even a lone clip of its
+    frame size through the slot queue (clip hashes must not depend on how clips are grouped over ranks);
   * clips in the SAME state (same pass, same bank depth) share a launch; a clip in another state -- a
     slot that has just taken the next clip of a queue (reference frame, bank still filling), a clip on
     another gap schedule -- gets launches of its own group (``BatchedLSTT._run`` groups by recording

@@ -308,6 +308,68 @@ __device__ __forceinline__ void dwconv5x5_body(const float* g, long ldg, const f
   }
 }
 
+// The same arithmetic for RY consecutive output rows per thread: the (RY + 4) x (RX + 4) input window is loaded once, so an
+// input element is fetched (RX + 4) / RX * (RY + 4) / RY times (2.9 for 9 x 4) instead of 7.2 -- the one-row kernel's
+// re-reads only stay cheap while the neighbouring workgroups' lines survive in the XCD's L2, and in the frame the encoder
+// stream's convolutions evict them (27 us per two maps in the frame against 12 isolated, profiles/r05f_bench_x3.json).
+// Per output the taps are accumulated in the one-row kernel's order (row by row, left to right): bit-identical.
+template <int RX, int RY>
+__device__ __forceinline__ void dwconv5x5_rows_body(const float* g, long ldg, const float* wt, int h, int w, int C,
+                                                    h16_t* oh, h16_t* ol, long ldo, int bx, int by, int bz) {
+  const int x0 = bx * RX, y0 = by * RY;
+  const int c = bz * 256 + threadIdx.x;
+  if (c >= C) return;
+  float k[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) k[t] = wt[(long)t * C + c];
+  float v[RY + 4][RX + 4];
+#pragma unroll
+  for (int iy = 0; iy < RY + 4; ++iy) {
+    const int yy = y0 + iy - 2;
+    const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+#pragma unroll
+    for (int ix = 0; ix < RX + 4; ++ix) {
+      const int xx = x0 + ix - 2;
+      const int xc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      v[iy][ix] = g[(long)(yc * w + xc) * ldg + c];
+    }
+  }
+#pragma unroll
+  for (int ry = 0; ry < RY; ++ry) {
+    const int y = y0 + ry;
+    if (y >= h) break;
+    float acc[RX];
+#pragma unroll
+    for (int o = 0; o < RX; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int iy = 0; iy < 5; ++iy) {
+      const int yy = y + iy - 2;
+      const bool vy = yy >= 0 && yy < h;
+#pragma unroll
+      for (int ix = 0; ix < RX + 4; ++ix) {
+        const int xx = x0 + ix - 2;
+        const bool ok = vy && xx >= 0 && xx < w;
+#pragma unroll
+        for (int o = 0; o < RX; ++o) {
+          const int dx = ix - o;
+          if (dx < 0 || dx > 4) continue;
+          acc[o] += (ok ? v[ry + iy][ix] : 0.f) * k[iy * 5 + dx];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < RX; ++o) {
+      const int x = x0 + o;
+      if (x >= w) continue;
+      const long p = (long)y * w + x;
+      h16_t hi, lo;
+      split_f16(acc[o], hi, lo);
+      oh[p * ldo + c] = hi;
+      if (ol) ol[p * ldo + c] = lo;
+    }
+  }
+}
+
 // one map (p[0], nmaps = 1) or two maps of the same geometry (the gated long-term and short-term
 // aggregates of a layer) in one launch: z = map * nz + channel block
 // Block order.  The work items are (z = map x 256-channel block, row y, run of RX tokens); a thread's 5 x (RX + 4) input
@@ -335,9 +397,39 @@ __device__ void dwconv5x5_split_kernel(const DwArgs& a, int) {
   dwconv5x5_body<RX, V>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, bx, y, which ? bz - a.nz : bz);
 }
 
-// (RX, V) chosen by measurement; RMEM_DW="rx,v" overrides (tuning aid)
+template <int RX, int RY>
+__device__ void dwconv5x5_rows_kernel(const DwArgs& a, int) {
+  const int b = blockIdx.x;
+  const int wid = a.xcd ? (b & 7) * a.cap + (b >> 3) : b;
+  if (wid >= a.total) return;
+  const int gy = (a.h + RY - 1) / RY;
+  const int per_z = a.gx * gy;
+  const int bz = wid / per_z;
+  const int r = wid - bz * per_z;
+  const int by = r / a.gx, bx = r - by * a.gx;
+  const int which = bz < a.nz ? 0 : 1;
+  const DwOne& p = a.p[which];
+  dwconv5x5_rows_body<RX, RY>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, bx, by, which ? bz - a.nz : bz);
+}
+
+// (RX, V) chosen by measurement; RMEM_DW="rx,v" overrides (tuning aid); RMEM_DW_ROWS=RY (2, 3, 4): the RY-rows-per-thread
+// kernel with RX = 9 (0 = the one-row kernel)
 static int launch_dwconv(DwArgs& a, int nmaps, hipStream_t s) {
   static const char* env = getenv("RMEM_DW");
+  const char* rows_env = getenv("RMEM_DW_ROWS");      // (read per launch: the bit-identity test switches it inside one process)
+  const int ry = rows_env ? atoi(rows_env) : 0;
+  if (ry >= 2 && (a.C % 256) == 0) {
+    a.nz = a.C / 256;
+    a.gx = (a.w + 8) / 9;
+    a.total = a.gx * ((a.h + ry - 1) / ry) * nmaps * a.nz;
+    a.cap = (a.total + 7) / 8;
+    a.xcd = 1;
+    const dim3 grid(8 * a.cap);
+    if (ry == 2) return rmem::launch<DwArgs, dwconv5x5_rows_kernel<9, 2>, 256>(a, grid, dim3(256), 0, s);
+    if (ry == 3) return rmem::launch<DwArgs, dwconv5x5_rows_kernel<9, 3>, 256>(a, grid, dim3(256), 0, s);
+    if (ry == 4) return rmem::launch<DwArgs, dwconv5x5_rows_kernel<9, 4>, 256>(a, grid, dim3(256), 0, s);
+    return RMEM_ERR_INVALID;
+  }
   int rx = 9, v = 1;   // 480p one / two maps: 14.7 / 24.7 us with (6, 4), 9.6 / 16.7 with (9, 1); 720p 26.4 / 47.7 -> 18.9 / 30.6
   if (env) sscanf(env, "%d,%d", &rx, &v);
   if (a.C % (256 * v)) rx = 6, v = 4;

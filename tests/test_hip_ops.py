@@ -743,6 +743,36 @@ def test_groupnorm2_fold_equals_layernorm_fold_then_groupnorm(hip, N):
     assert (out.cpu().double() - ref).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("h,w", [(31, 54), (9, 13), (5, 7), (46, 81)])
+def test_dwconv_rows_per_thread_variants_bit_identical(hip, h, w, monkeypatch):
+    """The depth-wise 5 x 5 kernel with RY output rows per thread (RMEM_DW_ROWS = 2 / 3 / 4: the input window is loaded once
+    for RY rows, an input element is fetched 2.9-4.3 times instead of 7.2) against the one-row kernel: both maps of the
+    paired launch and the single-map launch, hi and lo planes bit for bit (the taps of an output are accumulated in the
+    same order), nothing written beyond the N rows."""
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(h * 100 + w)
+    N, C = h * w, 1024
+    g0, g1 = _rand(rs, N, C).to(DEV), _rand(rs, N, C).to(DEV)
+    w0, w1 = _rand(rs, 25, C, scale=0.2).to(DEV), _rand(rs, 25, C, scale=0.2).to(DEV)
+
+    def run():
+        o = [torch.full((N + 3, C), 7, dtype=torch.int16, device=DEV) for _ in range(6)]
+        hip.check(lib.rmem_dwconv5x5_split2(g0.data_ptr(), g1.data_ptr(), C, w0.data_ptr(), w1.data_ptr(), h, w, C,
+                                            o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), C, st), "dw2")
+        hip.check(lib.rmem_dwconv5x5_split(g1.data_ptr(), C, w0.data_ptr(), h, w, C, o[4].data_ptr(), o[5].data_ptr(), C, st), "dw")
+        torch.cuda.synchronize()
+        return o
+
+    monkeypatch.setenv("RMEM_DW_ROWS", "0")
+    ref = run()
+    for ry in ("2", "3", "4"):
+        monkeypatch.setenv("RMEM_DW_ROWS", ry)
+        got = run()
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (ry, i)
+        assert all(bool((t[N:] == 7).all()) for t in got)
+
+
 def test_linear_single_stage_items_many_per_workgroup(hip):
     """Shapes whose work items hold ONE k-tile stage (K = 64; split-K down to one k-tile per split) with more than four
     items per workgroup of the streaming kernel: its four-entry item ring would be overwritten before the epilogue reads

@@ -32,6 +32,13 @@ def main():
                                                       o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), C, st), "dw2")
     one(); torch.cuda.synchronize()
     chk = int(o[0].long().sum().item()) ^ int(o[1].long().sum().item())
-    print(json.dumps({"RMEM_DW": os.environ.get("RMEM_DW", "default"), "one_us": round(timeit(one), 2), "two_us": round(timeit(two), 2), "checksum": chk}))
+    print(json.dumps({"RMEM_DW": os.environ.get("RMEM_DW", "default"), "RMEM_DW_ROWS": os.environ.get("RMEM_DW_ROWS", "0"),
+                      "one_us": round(timeit(one), 2), "two_us": round(timeit(two), 2), "checksum": chk}))
+    if "--rows" in sys.argv:                   # the RY-rows-per-thread variants in the same process (the library reads the switch per launch)
+        for ry in ("0", "2", "3", "4"):
+            os.environ["RMEM_DW_ROWS"] = ry
+            one(); torch.cuda.synchronize()
+            c2 = int(o[0].long().sum().item()) ^ int(o[1].long().sum().item())
+            print(json.dumps({"RMEM_DW_ROWS": ry, "one_us": round(timeit(one), 2), "two_us": round(timeit(two), 2), "checksum": c2}))
 
 main()
