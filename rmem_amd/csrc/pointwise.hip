@@ -412,12 +412,14 @@ __device__ void dwconv5x5_rows_kernel(const DwArgs& a, int) {
   dwconv5x5_rows_body<RX, RY>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, bx, by, which ? bz - a.nz : bz);
 }
 
-// (RX, V) chosen by measurement; RMEM_DW="rx,v" overrides (tuning aid); RMEM_DW_ROWS=RY (2, 3, 4): the RY-rows-per-thread
-// kernel with RX = 9 (0 = the one-row kernel)
+// (RX, V) chosen by measurement; RMEM_DW="rx,v" overrides (tuning aid); RMEM_DW_ROWS=RY (2 = default, 3, 4): the
+// RY-rows-per-thread kernel with RX = 9; 0 = the one-row kernel
 static int launch_dwconv(DwArgs& a, int nmaps, hipStream_t s) {
   static const char* env = getenv("RMEM_DW");
   const char* rows_env = getenv("RMEM_DW_ROWS");      // (read per launch: the bit-identity test switches it inside one process)
-  const int ry = rows_env ? atoi(rows_env) : 0;
+  // default 2: two maps 14.7 -> 11.5 us isolated at 480p, 26.8 -> 19.6 at 720p, 160 -> 146 us per frame in the frame; 3 and 4
+  // rows are no faster isolated and slower in the frame (152 registers, one round of 384 workgroups): profiles/r05k_dwconv_rows.txt
+  const int ry = rows_env ? atoi(rows_env) : 2;
   if (ry >= 2 && (a.C % 256) == 0) {
     a.nz = a.C / 256;
     a.gx = (a.w + 8) / 9;
