@@ -585,6 +585,43 @@ def test_paired_launches_bit_identical():
             assert torch.equal(o0, o1) and torch.equal(m0, m1), order
 
 
+@pytest.mark.parametrize("h,w", [(12, 17), (31, 54)])
+def test_projection_paths_bit_identical_through_the_lstt(h, w, monkeypatch):
+    """RMEM_ROWRES = 0 (default: LayerNorm launch + streaming projection kernel), `planes` (LayerNorm launch + the
+    row-tile-resident kernel reading its planes) and `fused` (LayerNorm, split-K fold and projections in ONE launch, the
+    folded residual streams alternating between two buffer pairs) through whole LSTT passes -- reference frame, propagated
+    frames, memory updates, the last fold inside the GroupNorm: outputs, attention mass and every bank slot bit for bit."""
+    from rmem_amd.lstt import DeAOTLSTT
+    cfg, cpu_model, gpu_model, _ = _build()
+    N = h * w
+    H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
+    outs = {}
+    for mode in ("0", "planes", "fused"):
+        monkeypatch.setenv("RMEM_ROWRES", mode)
+        lstt = DeAOTLSTT(gpu_model, h, w, DEV, nsplit=3)
+        assert lstt.rowres == (mode != "0") and lstt.rowres_fused == (mode == "fused")
+        rs = np.random.RandomState(0)
+        rec = []
+        for t in range(5):
+            emb = torch.from_numpy(rs.standard_normal((N, 256)).astype(np.float32)).to(DEV)
+            label = torch.from_numpy(rs.randint(0, 4, (1, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
+            lab_u8 = F.interpolate(label, size=(H, W), mode="nearest")[0, 0].to(torch.uint8).to(DEV).contiguous()
+            if t == 0:
+                lstt.assign_identity(lab_u8)
+                out = lstt.forward(emb, ref_frame=True)
+            else:
+                out = lstt.forward(emb)
+                lstt.assign_identity(lab_u8)
+                lstt.update_short_memories(t % 2 == 0)
+            torch.cuda.synchronize()
+            rec.append((out.clone(), lstt.mass.clone()))
+        rec.append(tuple(torch.cat([b.hi.flatten(), b.lo.flatten()]).clone() for b in lstt.bankK + lstt.bankV))
+        outs[mode] = rec
+    for mode in ("planes", "fused"):
+        for a, b in zip(outs["0"], outs[mode]):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), mode
+
+
 def test_unit_queue_of_the_paired_read_bit_identical(monkeypatch):
     """More units than CUs (here 11 query tiles x (20 + 6) splits = 286): the paired read runs one workgroup per CU that
     pulls its further units from a counter (rmem_read_args.sched, read64x2_pull_kernel).  Which workgroup runs a unit
