@@ -326,21 +326,21 @@ class ClipDriver:
             else no_memory_gap
         self.fixed_gap = fixed_gap
         self.align_corners = bool(self.cfg.MODEL_ALIGN_CORNERS)
-        self._aug_bat: Dict[int, object] = {}          # number of augmentations -> BatchedDeAOTEngine (see _aug_batched_ok)
+        self._aug_bat: Dict[tuple, object] = {}        # (size group, augmentations in it) -> BatchedDeAOTEngine (see _aug_batched_ok)
 
     # -- engines
     def _aug_batched_ok(self, samples) -> bool:
-        """Test-time augmentation (managers/evaluator.py:337-353: one engine per augmentation, here the flipped copy)
-        as the slots of ONE BatchedDeAOTEngine: the augmented images of a frame are one encoder / decoder batch and
-        every launch of the memory path serves all of them -- the augmentations of a clip are in lockstep by
-        construction.  DeAOT block on the GPU, product engines, augmentations of one image size (flip, not
-        multi-scale), <= 10 objects; RMEM_TTA=serial keeps one engine after the other."""
+        """Test-time augmentation (managers/evaluator.py:337-353: one engine per augmentation -- the flipped copy, the
+        multi-scale copies) as the slots of one BatchedDeAOTEngine per image size: the augmented images of one size are
+        one encoder / decoder batch and every launch of the memory path serves all of them -- the augmentations of a
+        clip are in lockstep by construction.  DeAOT block on the GPU, product engines, at least two augmentations of
+        one size (flip, or flip x multi-scale: the flip pair of every scale), <= 10 objects; RMEM_TTA=serial keeps one
+        engine after the other."""
         if len(samples) < 2 or self._factory is not None or self.fused_post is False:
             return False
         if os.environ.get("RMEM_TTA", "batched") == "serial" or getattr(self.cfg, "MODEL_VOS", "") != "deaot":
             return False
-        img0 = samples[0]["current_img"]
-        if not img0.is_cuda or any(tuple(s["current_img"].shape) != tuple(img0.shape) for s in samples):
+        if not all(s["current_img"].is_cuda for s in samples) or len(_aug_groups(samples)) == len(samples):
             return False
         n = samples[0]["meta"]["obj_num"]
         n = int(n[0] if isinstance(n, (list, tuple)) else n)
@@ -513,25 +513,43 @@ class _AugEngineView:
     enc_size_2d = property(lambda self: self.bat.enc_size_2d)
 
 
+def _aug_groups(samples) -> List[List[int]]:
+    """The augmentations of a frame grouped by image size, in order of first appearance: [[aug indices], ...].  Flip
+    keeps the size, a multi-scale factor changes it (dataloaders/video_transforms.py MultiRestrictSize: for every scale
+    the restricted size, then the flipped copy), so the flip pair of every scale is one group."""
+    groups: Dict[tuple, List[int]] = {}
+    for i, s_ in enumerate(samples):
+        groups.setdefault(tuple(s_["current_img"].shape[1:]), []).append(i)
+    return list(groups.values())
+
+
 def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
-    """ClipDriver.run_clip for a clip with test-time augmentation through ONE BatchedDeAOTEngine whose slots are the
-    augmentations (ClipDriver._aug_batched_ok).  Same protocol per frame as the loop of run_clip: logits of every
-    augmentation -> un-flip, softmax, mean, argmax at the original size (rmem_labels_from_logits) -> per augmentation
-    flip + nearest resize -> update_memory; a mid-clip label re-references every slot (evaluator.py:484-508)."""
+    """ClipDriver.run_clip for a clip with test-time augmentation through ONE BatchedDeAOTEngine PER IMAGE SIZE whose
+    slots are the augmentations of that size (ClipDriver._aug_batched_ok; flip only: one engine, flip x multi-scale:
+    one engine per scale).  Same protocol per frame as the loop of run_clip: logits of every augmentation -> bilinear to
+    the original size, un-flip, softmax, mean, argmax (rmem_labels_from_logits takes sources of different sizes) -> per
+    augmentation flip + nearest resize -> update_memory; a mid-clip label re-references every slot
+    (evaluator.py:484-508)."""
     from . import hip
     from .batched import BatchedDeAOTEngine
-    B = len(ahead[0])
-    eng = self._aug_bat.get(B)
-    if eng is None:
-        eng = self._aug_bat[B] = BatchedDeAOTEngine(self.model, B, gpu_id=self.gpu_id,
-                                                    long_term_mem_gap=getattr(self.cfg, "TEST_LONG_TERM_MEM_GAP", 9999))
-    eng.restart_engine()
-    eng.long_term_mem_gap = gap
+    A = len(ahead[0])
+    groups = _aug_groups(ahead[0])
+    engs = []
+    for gi, idx in enumerate(groups):
+        key = (gi, len(idx))
+        e = self._aug_bat.get(key)
+        if e is None:
+            e = self._aug_bat[key] = BatchedDeAOTEngine(self.model, len(idx), gpu_id=self.gpu_id,
+                                                        long_term_mem_gap=getattr(self.cfg, "TEST_LONG_TERM_MEM_GAP", 9999))
+        e.restart_engine()
+        e.long_term_mem_gap = gap
+        engs.append(e)
     maxo = int(self.model.max_obj_num)
-    views = [_AugEngineView(eng, i) for i in range(B)]        # what on_frame callbacks read per augmentation
+    where = {a: (g, j) for g, idx in enumerate(groups) for j, a in enumerate(idx)}
+    views = [_AugEngineView(engs[where[a][0]], where[a][1]) for a in range(A)]   # what on_frame callbacks read per augmentation
     labels_out, timers, writers = [], [], []
-    cat = lambda samples: torch.cat([s_["current_img"] for s_ in samples])
-    pending = None                                            # (frame's sample list, its concatenated images): the prefetched batch
+    cat = lambda samples: [torch.cat([samples[a]["current_img"] for a in idx]) for idx in groups]
+    pending = None                                            # (frame's sample list, its per-group image batches): the prefetched batches
     frame_idx = -1
     while ahead:
         samples, ahead = ahead[0], ahead[1:]
@@ -539,8 +557,8 @@ def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
         if f is not None:
             ahead.append(f)
         frame_idx += 1
-        if len(samples) != B:
-            raise ValueError("the number of augmentations changed inside a clip")
+        if len(samples) != A or _aug_groups(samples) != groups:
+            raise ValueError("the augmentations changed inside a clip")
         flips = [bool(s_["meta"]["flip"]) for s_ in samples]
         meta0 = samples[0]["meta"]
         ori_hw = (int(meta0["height"]), int(meta0["width"]))
@@ -548,32 +566,36 @@ def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
         pending = None
         if frame_idx == 0:
             res.obj_idx = meta0.get("obj_idx")
-            labs = torch.cat([F.interpolate(s_["current_label"].float(), size=imgs.shape[2:], mode="nearest").int()
-                              for s_ in samples])
-            eng.add_reference_frame(imgs, labs, obj_nums=[maxo] * B, frame_step=0)
+            for e, idx, im in zip(engs, groups, imgs):
+                labs = torch.cat([F.interpolate(samples[a]["current_label"].float(), size=im.shape[2:], mode="nearest").int()
+                                  for a in idx])
+                e.add_reference_frame(im, labs, obj_nums=[maxo] * len(idx), frame_step=0)
             continue
         t0 = torch.cuda.Event(enable_timing=True)
         t0.record()
         nxt = None
-        if ahead and len(ahead[0]) == B:
+        if ahead and len(ahead[0]) == A and _aug_groups(ahead[0]) == groups:
             nxt = cat(ahead[0])
             pending = (ahead[0], nxt)
-        lg = eng.match_propogate_one_frame(imgs, output_size=None, next_imgs=nxt)
-        label = hip.labels_from_logits([lg[i:i + 1] for i in range(B)], flips, ori_hw, self.align_corners)
+        lgs = [None] * A
+        for g, (e, idx) in enumerate(zip(engs, groups)):
+            lg = e.match_propogate_one_frame(imgs[g], output_size=None, next_imgs=None if nxt is None else nxt[g])
+            for j, a in enumerate(idx):
+                lgs[a] = lg[j:j + 1]
+        label = hip.labels_from_logits(lgs, flips, ori_hw, self.align_corners)
         new_obj_label = next((s_["current_label"] for s_, fl in zip(samples, flips)
                               if (not fl) and s_.get("current_label") is not None), None)
-        lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
         if new_obj_label is not None:                          # evaluator.py:484-508
-            new = new_obj_label.to(lg.device).float()[0, 0].to(torch.uint8)
+            new = new_obj_label.to(label.device).float()[0, 0].to(torch.uint8)
             label = torch.where(new == 0, label, new)
             n_new = int(label.max().item())
             if n_new > maxo:
-                # More objects than one engine holds (aot_engine.py:675-702 grows sub-engines): the batched engine's
+                # More objects than one engine holds (aot_engine.py:675-702 grows sub-engines): the batched engines'
                 # slots are the augmentations, so the clip is handed to the per-augmentation multi-object engines AT
                 # THIS FRAME -- a mid-clip add_reference_frame re-initialises the memory from the frame anyway
-                # (aot_engine.py:241-325), so nothing of the batched engine's state is needed -- and the evaluator's
+                # (aot_engine.py:241-325), so nothing of the batched engines' state is needed -- and the evaluator's
                 # loop continues there (ClipDriver._serial_loop).
-                engines = [self._engine(i) for i in range(B)]
+                engines = [self._engine(i) for i in range(A)]
                 for e, s_, fl in zip(engines, samples, flips):
                     e.restart_engine()
                     e.long_term_mem_gap = gap
@@ -595,12 +617,15 @@ def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
                     writers.append(save_mask(label, os.path.join(save_dir, str(name).split(".")[0] + ".png"), res.obj_idx))
                 res.handed_over_at = frame_idx
                 return self._serial_loop(ahead, it, gap, res, save_dir, on_frame, frame_idx, labels_out, timers, writers)
-            cur = torch.cat([ClipDriver._resize_generic(label, eng.input_size_2d, fl) for fl in flips])
-            eng.add_reference_frame(imgs, cur, obj_nums=[maxo] * B, frame_step=frame_idx)
+            for e, idx, im in zip(engs, groups, imgs):
+                cur = torch.cat([ClipDriver._resize_generic(label, e.input_size_2d, flips[a]) for a in idx])
+                e.add_reference_frame(im, cur, obj_nums=[maxo] * len(idx), frame_step=frame_idx)
         else:                                                  # evaluator.py:509-523
-            for i, fl in enumerate(flips):
-                hip.label_resize_nearest(label, eng.input_size_2d, fl, out=lab_in[i])
-            eng.update_memory(lab_in)
+            for e, idx in zip(engs, groups):
+                lab_in = e.lstt.label_buffer(*e.input_size_2d)
+                for j, a in enumerate(idx):
+                    hip.label_resize_nearest(label, e.input_size_2d, flips[a], out=lab_in[j])
+                e.update_memory(lab_in)
         t1 = torch.cuda.Event(enable_timing=True)
         t1.record()
         timers.append((t0, t1))
@@ -619,6 +644,7 @@ def _run_clip_batched_aug(self, ahead, it, gap, res, save_dir, on_frame):
             th.join()
     res.masks = torch.stack(labels_out) if labels_out else None
     res.batched = True
+    res.aug_groups = [list(idx) for idx in groups]
     return res
 
 
@@ -947,16 +973,18 @@ class BatchedClipDriver:
 
 
 def make_samples(img: torch.Tensor, label: Optional[torch.Tensor], ori_hw, obj_num: int, flip_aug: bool = False,
-                 name: str = "", obj_idx=None) -> List[Dict]:
+                 name: str = "", obj_idx=None, scaled_imgs: Sequence[torch.Tensor] = ()) -> List[Dict]:
     """Sample list for one frame from a network-sized image [1,3,H,W] (and an original-sized
-    label [1,1,H0,W0] or None), with the flipped copy when `flip_aug`
-    (dataloaders/video_transforms.py:639-652)."""
+    label [1,1,H0,W0] or None), with the flipped copy when `flip_aug`; `scaled_imgs` = the same frame at the further
+    network sizes of multi-scale testing (restrict_size(..., scale=s)), each followed by its flipped copy -- the order
+    MultiRestrictSize emits (dataloaders/video_transforms.py:563-652: per scale, the copy, then its flip)."""
     out = []
-    for fl in ([False, True] if flip_aug else [False]):
-        s = {"current_img": img.flip(3) if fl else img,
-             "meta": {"flip": fl, "obj_num": [obj_num], "height": int(ori_hw[0]), "width": int(ori_hw[1]),
-                      "obj_idx": obj_idx, "current_name": name}}
-        if label is not None:
-            s["current_label"] = label.flip(3) if fl else label
-        out.append(s)
+    for im in [img] + list(scaled_imgs):
+        for fl in ([False, True] if flip_aug else [False]):
+            s = {"current_img": im.flip(3) if fl else im,
+                 "meta": {"flip": fl, "obj_num": [obj_num], "height": int(ori_hw[0]), "width": int(ori_hw[1]),
+                          "obj_idx": obj_idx, "current_name": name}}
+            if label is not None:
+                s["current_label"] = label.flip(3) if fl else label
+            out.append(s)
     return out

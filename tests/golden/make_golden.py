@@ -13,6 +13,7 @@ Fixtures are data only (inputs + the reference's outputs):
   clip_480p.json/.npz        481x849 clip: per-frame label hashes + a few logits (fp16)
   multiengine_wrapper.*      AOTInferEngine.separate_mask / soft_logit_aggregation (> 10 objects)
   clip_480p_fp64.*           the same 481x849 clip through the reference in DOUBLE precision (near-tie arbitration)
+  clip_tta_ms_gap2.*         multi-scale x flip test-time augmentation (four engines, two image sizes), new object mid-clip
   clip_480p_long*.json/.npz  the 481x849 clip at the evaluator's gap 5 over 46 frames (six evictions) + its fp64 tie lists
   load_network_cases.*       the reference's load_network (utils/checkpoint.py:75-101) over ten payload variants
   *_amp.json/.npz            golden clips through the reference under fp16 autocast (its --amp mode), teacher-forced
@@ -34,7 +35,7 @@ sys.path.insert(0, HERE)
 
 import refharness as rh  # noqa: E402
 from rmem_amd.synth import synth_clip  # noqa: E402
-from make_golden_inputs import ignore_region_label, tta_new_object_label  # noqa: E402
+from make_golden_inputs import ignore_region_label, tta_new_object_label, tta_scaled_images  # noqa: E402
 from inputs import (AOT_BLOCK_CASES, BLOCK_CASES, IDASSIGN_CASES, aot_block_case_name,  # noqa: E402
                     aot_block_inputs, block_case_name, block_inputs, idassign_label)
 
@@ -369,6 +370,76 @@ def gen_tta():
     print("tta clip indexes", indexes[-1], "labels max", int(torch.stack(labels).max()))
 
 
+def gen_tta_multiscale():
+    """Multi-scale x flip test-time augmentation (cfg.TEST_MULTISCALE = [1.0, 1.3] with TEST_FLIP: four engines, in the
+    order dataloaders/video_transforms.py:563-652 emits the samples -- per scale the plain copy, then the flipped one),
+    driven as managers/evaluator.py:337-527 drives them: logits of every engine resized to the original size, un-flipped,
+    softmaxed, averaged; the label flipped / nearest-resized back to every engine's own input size.  New object at
+    frame 6 of 8, gap 2 (no long-term update may follow a mid-clip re-reference in the reference, see gen_tta)."""
+    import copy
+    ref = rh.import_reference()
+    H, W, frames, gap, out_hw, new_at, scale = 97, 129, 8, 2, (90, 120), 6, 1.3
+    from rmem_amd.driver import restrict_size
+    H2, W2 = restrict_size(H, W, max_size=800, scale=scale, align_corners=True)
+    cfg, model, eng0 = rh.build_reference("r50_deaotl", 1, 3, gap)
+    engines = [eng0]
+    for _ in range(3):
+        e = ref["build_engine"](cfg.MODEL_ENGINE, phase="eval", aot_model=copy.deepcopy(model), gpu_id=0,
+                                long_term_mem_gap=gap)
+        e.eval()
+        engines.append(e)
+    flips = [False, True, False, True]
+    imgs, lab = synth_clip(29, frames, H, W, 3)
+    big = tta_scaled_images(imgs, (H2, W2))
+    src = [imgs, imgs, big, big]
+    lab0 = F.interpolate(lab.float(), size=out_hw, mode="nearest")
+    labels, indexes = [], []
+    with torch.no_grad(), rh.quiet():
+        for e in engines:
+            e.restart_engine()
+            e.long_term_mem_gap = gap
+        for t in range(frames):
+            all_preds, new_obj_label = [], None
+            cur_label = lab0 if t == 0 else (tta_new_object_label(out_hw) if t == new_at else None)
+            for e, fl, sr in zip(engines, flips, src):
+                img = sr[t].flip(3) if fl else sr[t]
+                cl = None if cur_label is None else (cur_label.flip(3) if fl else cur_label)
+                if t == 0:
+                    _l = F.interpolate(cl, size=img.shape[2:], mode="nearest").int()
+                    e.add_reference_frame(img, _l, frame_step=0, obj_nums=[3])
+                else:
+                    logit = e.match_propogate_one_frame(img, output_size=out_hw)
+                    if fl:
+                        logit = logit.flip(3)
+                    all_preds.append(torch.softmax(logit, dim=1))
+                    if not fl and cl is not None and new_obj_label is None:
+                        new_obj_label = cl
+            if t == 0:
+                continue
+            prob = torch.mean(torch.cat(all_preds, dim=0), dim=0, keepdim=True)
+            pred = torch.argmax(prob, dim=1, keepdim=True).float()
+            if new_obj_label is not None:
+                keep = (new_obj_label == 0).float()
+                pred = pred * keep + new_obj_label * (1 - keep)
+                new_nums = [int(pred.max().item())]
+                for e, fl, sr in zip(engines, flips, src):
+                    img = sr[t].flip(3) if fl else sr[t]
+                    cl = F.interpolate(pred.flip(3) if fl else pred, size=e.input_size_2d, mode="nearest")
+                    e.add_reference_frame(img, cl, obj_nums=new_nums, frame_step=t)
+            else:
+                for e, fl in zip(engines, flips):
+                    e.update_memory(F.interpolate(pred.flip(3) if fl else pred, size=e.input_size_2d, mode="nearest"))
+            labels.append(pred[0, 0].to(torch.uint8))
+            indexes.append([list(e.aot_engines[0].long_memories_indexes) for e in engines])
+    meta = dict(H=H, W=W, H2=H2, W2=W2, scale=scale, out_hw=list(out_hw), frames=frames, gap=gap, former=1, latter=3,
+                seed=29, flips=flips, new_at=new_at, indexes=indexes, label_sha=[sha(l) for l in labels],
+                input_sizes=[list(e.input_size_2d) for e in engines])
+    with open(os.path.join(HERE, "clip_tta_ms_gap2.json"), "w") as f:
+        json.dump(meta, f)
+    np.savez_compressed(os.path.join(HERE, "clip_tta_ms_gap2.npz"), labels=torch.stack(labels).numpy())
+    print("multi-scale tta clip: sizes", meta["input_sizes"], "indexes", indexes[-1], "labels max", int(torch.stack(labels).max()))
+
+
 def gen_multiengine():
     """the multi-engine wrapper's pure tensor functions, called on the imported reference
     itself (AOTInferEngine.separate_mask, aot_engine.py:604-618 label branch; soft_logit_aggregation,
@@ -674,6 +745,9 @@ def main():
     if "--tta-only" in sys.argv:
         gen_tta()
         return
+    if "--tta-ms-only" in sys.argv:
+        gen_tta_multiscale()
+        return
     if "--ignore-only" in sys.argv:
         gen_ignore_clip()
         return
@@ -710,6 +784,7 @@ def main():
         gen_aot_clips()
     gen_swin()
     gen_tta()
+    gen_tta_multiscale()
     gen_ignore_clip()
     gen_multiengine()
     gen_clip_480p_fp64()

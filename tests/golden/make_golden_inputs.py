@@ -17,3 +17,12 @@ def ignore_region_label(label0):
     H, W = lab.shape[-2:]
     lab[:, :, H // 8: H // 3, W // 5: W // 2] = 255
     return lab
+
+
+def tta_scaled_images(imgs, hw):
+    """The clip's frames at another network size (the multi-scale copies of test-time augmentation): bicubic, computed on
+    the CPU so that the generator and the tests feed identical bytes.  (The reference's dataloader resizes the decoded
+    image with cv2.INTER_CUBIC, dataloaders/video_transforms.py:625-641; which cubic kernel made the input is immaterial
+    to the path under test.)"""
+    import torch.nn.functional as F
+    return [F.interpolate(im.cpu().float(), size=tuple(hw), mode="bicubic", align_corners=False) for im in imgs]

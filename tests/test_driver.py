@@ -178,6 +178,74 @@ def test_driver_hip_vs_reference_golden(fused, tta, golden_dir, monkeypatch):
     assert len(res.frame_ms) == meta["frames"] - 1
 
 
+def _tta_ms_frames(meta, device="cpu"):
+    """The sample lists make_golden.py:gen_tta_multiscale fed the reference's four engines."""
+    from make_golden_inputs import tta_new_object_label, tta_scaled_images
+    out_hw = tuple(meta["out_hw"])
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    big = tta_scaled_images(imgs, (meta["H2"], meta["W2"]))
+    lab0 = F.interpolate(lab.float(), size=out_hw, mode="nearest")
+    frames = []
+    for t in range(meta["frames"]):
+        label = lab0 if t == 0 else (tta_new_object_label(out_hw) if t == meta["new_at"] else None)
+        frames.append(D.make_samples(imgs[t].to(device), None if label is None else label.to(device), out_hw, 3,
+                                     flip_aug=True, name=f"{t:05d}.jpg", scaled_imgs=[big[t].to(device)]))
+    return frames
+
+
+def test_multiscale_sample_order_and_sizes(golden_dir):
+    """make_samples emits what the reference's MultiRestrictSize emits for TEST_MULTISCALE=[1.0, 1.3] + flip: per scale
+    the copy and then its flip, the scaled size = restrict_size(scale=1.3) (the sizes the reference's engines saw)."""
+    meta = json.load(open(os.path.join(golden_dir, "clip_tta_ms_gap2.json")))
+    assert D.restrict_size(meta["H"], meta["W"], scale=meta["scale"]) == (meta["H2"], meta["W2"])
+    fr = _tta_ms_frames(meta)[0]
+    assert [bool(s["meta"]["flip"]) for s in fr] == meta["flips"]
+    assert [list(s["current_img"].shape[2:]) for s in fr] == meta["input_sizes"]
+    assert torch.equal(fr[3]["current_img"], fr[2]["current_img"].flip(3))
+    assert D._aug_groups(fr) == [[0, 1], [2, 3]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tta", ["batched", "serial"])
+def test_driver_multiscale_tta_vs_reference_golden(tta, golden_dir, monkeypatch):
+    """Multi-scale x flip test-time augmentation against the REFERENCE's label maps (clip_tta_ms_gap2, four reference
+    engines at two image sizes, new object at frame 6).  batched: one BatchedDeAOTEngine per image size whose slots are
+    that size's flip pair (the default); serial: four engines one after the other.  Same kept-frame histories as the
+    reference in every augmentation; label maps within a handful of near-tie pixels (closed loop, synthetic weights)."""
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    meta = json.load(open(os.path.join(golden_dir, "clip_tta_ms_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_tta_ms_gap2.npz"))["labels"]
+    cfg = get_config("r50_deaotl", meta["former"], meta["latter"])
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    load_synthetic_weights(model)
+    model = model.to(DEV)
+    monkeypatch.setenv("RMEM_TTA", tta)
+    drv = D.ClipDriver(model, cfg, fixed_gap=meta["gap"])
+    idx = []
+    res = drv.run_clip(_tta_ms_frames(meta, DEV), num_frames=meta["frames"],
+                       on_frame=lambda t, lab_, engs: idx.append([list(e.aot_engines[0].long_memories_indexes) for e in engs]))
+    assert bool(res.batched) == (tta == "batched")
+    if tta == "batched":
+        assert res.aug_groups == [[0, 1], [2, 3]] and res.handed_over_at is None
+        assert sorted(drv._aug_bat) == [(0, 2), (1, 2)]
+    # bank indexes: the reference's until the re-reference; from there the memory restarts from that frame (the reference
+    # keeps appending to a list that no longer describes its one-frame memory, aot_engine.py:320-322; engine.py)
+    new_at = meta["new_at"]
+    assert idx[:new_at - 1] == meta["indexes"][:new_at - 1]
+    assert idx[new_at - 1:] == [[[new_at]] * 4] * (meta["frames"] - new_at)
+    got = res.masks.cpu().numpy()
+    assert got.shape == gold.shape
+    mism = [int((got[i] != gold[i]).sum()) for i in range(len(gold))]
+    print("multi-scale TTA", tta, "mismatching pixels per frame (of %d):" % gold[0].size, mism)
+    assert int(got[meta["new_at"] - 1].max()) == int(gold[meta["new_at"] - 1].max())
+    assert max(mism) <= 2, mism
+    # a second clip on the same driver reuses both engines
+    res2 = drv.run_clip(_tta_ms_frames(meta, DEV), num_frames=meta["frames"])
+    assert torch.equal(res2.masks, res.masks)
+
+
 @pytest.mark.gpu
 def test_tta_clip_that_grows_past_ten_objects_hands_over_to_serial_engines(monkeypatch):
     """Flip test-time augmentation (the batched-augmentation path by default) with a mid-clip label that brings the clip
