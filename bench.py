@@ -357,13 +357,13 @@ def main():
         del_me = gather_masks(masks, world)
         torch.cuda.synchronize()
         del del_me
+    cpu0 = time.process_time()                # user + system time of every thread of this process (main + graph launcher)
+    thr0 = thread_cpu_seconds()               # (reads /proc for every thread, ~1 ms: taken BEFORE the bracket, not inside it)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    cpu0 = time.process_time()                # user + system time of every thread of this process (main + graph launcher)
-    thr0 = thread_cpu_seconds()
     # Steady-state frames replay hipGraphs.  The dominant kernel is timed by HIP events on its launch stream INSIDE
     # replayed frames: on every fifth frame the LSTT is replayed as front graph | the fused read of layer 0 launched on
     # its own between two events | tail graph (engine._graphed_frame) -- same kernels, same order, the prefetched
@@ -372,12 +372,20 @@ def main():
     # Models without the front / tail split (AOT block) keep the eagerly issued frame, one in fifty.
     n_eager = max(1, args.steps // 50)
     eager_at = {(i * args.steps) // n_eager for i in range(n_eager)}
+    step_ev = [] if os.environ.get("RMEM_BENCH_STEP_EVENTS") else None      # diagnosis: one event per step -> per-step ms on stderr
+    if step_ev is not None:
+        step_ev.append(torch.cuda.Event(enable_timing=True))
+        step_ev[-1].record(streams[0])
+        ev0_at = time.perf_counter() - t0
     for k in range(args.steps):
         if sampled:
             lstt._sample_read = (k % 5 == 2)
         else:
             lstt._timing = (k in eager_at) and not os.environ.get("RMEM_BENCH_NOSYNC")
         all_clips(t + k, masks)
+        if step_ev is not None:
+            step_ev.append(torch.cuda.Event(enable_timing=True))
+            step_ev[-1].record(streams[0])
     lstt._timing = False
     host_issue = time.perf_counter() - t0     # host-side launch time (GPU work still in flight)
     host_cpu = time.process_time() - cpu0     # CPU seconds this rank burned while issuing (all threads)
@@ -394,6 +402,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if step_ev is not None:
+        print("per-step ms (stream events):", [round(a.elapsed_time(b), 3) for a, b in zip(step_ev[:-1], step_ev[1:])],
+              "host issue ms %.2f, wall ms %.2f, first event at %.3f ms" % (host_issue * 1e3, elapsed * 1e3, ev0_at * 1e3), file=sys.stderr)
     elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
 
     fps = world * C * args.steps / elapsed
@@ -581,6 +592,9 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if step_ev is not None:
+        print("per-step ms (stream events):", [round(a.elapsed_time(b), 3) for a, b in zip(step_ev[:-1], step_ev[1:])],
+              "host issue ms %.2f, wall ms %.2f, first event at %.3f ms" % (host_issue * 1e3, elapsed * 1e3, ev0_at * 1e3), file=sys.stderr)
     elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
     fps = world * B * args.steps / elapsed
     c0 = eng.lstt.clips[0]
@@ -673,6 +687,9 @@ def clips_ragged(args, world, rank, dev, dist, drv, D):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if step_ev is not None:
+        print("per-step ms (stream events):", [round(a.elapsed_time(b), 3) for a, b in zip(step_ev[:-1], step_ev[1:])],
+              "host issue ms %.2f, wall ms %.2f, first event at %.3f ms" % (host_issue * 1e3, elapsed * 1e3, ev0_at * 1e3), file=sys.stderr)
     elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
     hashes = D.hash_dataset_masks(allm, lengths, world)       # (after the window, as in clips64)
     total = sum(lengths) - n_clips

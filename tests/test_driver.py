@@ -79,6 +79,22 @@ def test_driver_logic_vs_reference_golden(deaot_model, golden_dir):
     assert res.names[0] == "00001.jpg" and res.gap == meta["gap"]
 
 
+def test_driver_logic_multiscale_vs_reference_golden(deaot_model, golden_dir):
+    """The same with multi-scale x flip augmentation: four oracle engines at two image sizes, the evaluator's merge at
+    the original size (evaluator.py:424-441), labels bit-exact against the four reference engines."""
+    from oracle.engine_ref import OracleDeAOTEngine
+    meta = json.load(open(os.path.join(golden_dir, "clip_tta_ms_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_tta_ms_gap2.npz"))["labels"]
+    drv = D.ClipDriver(deaot_model, engine_factory=lambda m: OracleDeAOTEngine(m), fixed_gap=meta["gap"])
+    idx = []
+    res = drv.run_clip(_tta_ms_frames(meta), num_frames=meta["frames"],
+                       on_frame=lambda t, lab, engs: idx.append([list(e.long_memories_indexes) for e in engs]))
+    mism = [(res.masks[i].numpy() != gold[i]).sum() for i in range(len(gold))]
+    assert sum(mism) == 0, mism
+    assert idx == meta["indexes"]
+    assert [list(e.input_size_2d) for e in drv.engines] == meta["input_sizes"]
+
+
 # ------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("naug,align,geom", [(1, True, (31, 54, 121, 213, 480, 854)),
@@ -565,7 +581,8 @@ def test_bench_line_contract_single_gpu():
     # `roofline` = the kernel with the largest time per frame (kernels[0]); the fused attention read, timed by events inside
     # the timed region, is `attention_read` when another kernel leads (the projection kernel does, since it is measured)
     assert top["bound"] in ("mfma", "hbm") and top["peak"] in (2500.0, 8000.0) and 0.005 < top["frac"] < 0.6
-    assert abs(top["frac"] - top["achieved"] / top["peak"]) < 1e-9 and top["kernel"] == top["kernels"][0]["kernel"]
+    assert abs(top["frac"] - top["achieved"] / top["peak"]) < 1e-9
+    assert top["kernel"].split(" ")[0] == top["kernels"][0]["kernel"].split(" ")[0]      # (the read's own block words its name longer)
     if top["bound"] == "mfma":
         assert abs(top["achieved"] - top["algorithmic_flops_per_launch"] / (top["mean_us"] * 1e-6) / 1e12) < 1e-6 * top["achieved"]
     r = top.get("attention_read", top)
@@ -589,7 +606,9 @@ def test_bench_line_contract_single_gpu():
             assert abs(k["achieved"] - k["algorithmic_gflop_per_launch"] * 1e9 / (k["mean_us"] * 1e-6) / 1e12) < 1e-6 * k["achieved"]
     assert any(k["kernel"].startswith("linear_stream_kernel") for k in ks)
     rk = next(k for k in ks if k["kernel"].startswith("read64x2_kernel"))
-    assert abs(rk["mean_us"] - r["mean_us"]) < 0.25 * r["mean_us"]          # the two sampling methods see the same kernel
+    # the two sampling methods see the same kernel (two event samples in a 12-step run beside the encoder stream: launches of
+    # this kernel range 95-197 us inside a frame, profiles/r05_bench_x3_kernel_stats.md)
+    assert 0.5 < rk["mean_us"] / r["mean_us"] < 2.0
     # 'mask IoU vs ref' on the benchmarked schedule: the reference's own 46-frame gap-5 run (tests/golden/clip_480p_long.*)
     pr = out["parity_vs_reference"]
     assert pr["frames"] == 45 and pr["evictions"] >= 5 and pr["bank_index_history_equal"] is True
