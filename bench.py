@@ -592,9 +592,6 @@ def batched_steady(args, world, rank, dev, dist, cfg, model, mem_k):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if step_ev is not None:
-        print("per-step ms (stream events):", [round(a.elapsed_time(b), 3) for a, b in zip(step_ev[:-1], step_ev[1:])],
-              "host issue ms %.2f, wall ms %.2f, first event at %.3f ms" % (host_issue * 1e3, elapsed * 1e3, ev0_at * 1e3), file=sys.stderr)
     elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
     fps = world * B * args.steps / elapsed
     c0 = eng.lstt.clips[0]
@@ -687,9 +684,6 @@ def clips_ragged(args, world, rank, dev, dist, drv, D):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if step_ev is not None:
-        print("per-step ms (stream events):", [round(a.elapsed_time(b), 3) for a, b in zip(step_ev[:-1], step_ev[1:])],
-              "host issue ms %.2f, wall ms %.2f, first event at %.3f ms" % (host_issue * 1e3, elapsed * 1e3, ev0_at * 1e3), file=sys.stderr)
     elapsed, per_rank_s = max_over_ranks(dist, elapsed, dev)
     hashes = D.hash_dataset_masks(allm, lengths, world)       # (after the window, as in clips64)
     total = sum(lengths) - n_clips

@@ -615,3 +615,58 @@ def test_rank_pinning_plan_follows_the_numa_topology():
     assert len(flat) == len(set(flat)) == 256                                  # disjoint, everything used
     assert plan_node_shares([None, 0], {0: node0}) == [None, sorted(c for g in node0 for c in g)]
     assert plan_node_shares([0, 0, 0], {0: node0[:2]}) == [None, None, None]
+
+
+def _undefined_names(path):
+    """Names a function of the file loads that nothing in the function, the module or builtins binds (what pyflakes calls
+    an undefined name) -- legs of bench.py that only run with particular flags get no other check on the CPU."""
+    import ast
+    import builtins
+    tree = ast.parse(open(path).read())
+
+    def bound(node):
+        out = set()
+        for n in ast.walk(node):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                out.add(n.id)
+            elif isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                out.add(n.name)
+                if not isinstance(n, ast.ClassDef):
+                    a = n.args
+                    out.update(x.arg for x in a.args + a.kwonlyargs + a.posonlyargs)
+                    out.update(x.arg for x in (a.vararg, a.kwarg) if x is not None)
+            elif isinstance(n, ast.Lambda):
+                a = n.args
+                out.update(x.arg for x in a.args + a.kwonlyargs + a.posonlyargs)
+                out.update(x.arg for x in (a.vararg, a.kwarg) if x is not None)
+            elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                out.update((al.asname or al.name).split(".")[0] for al in n.names)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                out.add(n.name)
+            elif isinstance(n, (ast.Global, ast.Nonlocal)):
+                out.update(n.names)
+        return out
+
+    top = set()                                  # module scope: what top-level statements bind, not the functions' locals
+    for st in tree.body:
+        if isinstance(st, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+            top.add(st.name)
+        else:
+            top |= bound(st)
+    mod = top | set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+    bad = []
+    for fn in [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]:
+        have = mod | bound(fn)
+        for n in ast.walk(fn):
+            if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in have:
+                bad.append((fn.name, n.id, n.lineno))
+    return bad
+
+
+def test_no_undefined_names_in_bench_and_package():
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + \
+        sorted(glob.glob(os.path.join(root, "rmem_amd", "*.py"))) + sorted(glob.glob(os.path.join(root, "rmem_amd", "nets", "*.py")))
+    bad = {os.path.relpath(f, root): _undefined_names(f) for f in files}
+    assert not any(bad.values()), {k: v for k, v in bad.items() if v}
