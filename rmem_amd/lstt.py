@@ -124,6 +124,7 @@ class DeAOTLSTT:
         self._kev_store: list = []         # [(kernel class, e0, e1, algorithmic flops, algorithmic bytes)] of the sampled frames
         self._kev_frames = 0
         self._skip_read2 = False
+        self._split_parts = False
         self.scale = 1.0 / math.sqrt(self.DATT)
         if weights_from is not None:
             for k in ("cur_pe", "mem_pe", "id_ksize", "id_ncls", "id_stride", "id_pad", "id_wt", "id_bias", "id_gamma",
@@ -398,6 +399,11 @@ class DeAOTLSTT:
         self.ws_main = _AttnWS(self.Tmax, N, Np, max([self.ks_long, self.ks_self] + [u[0] for u in self.uneven.values()]), dev)
         self.ws_side = _AttnWS(1, N, Np, self.ks_win, dev)
         self.branch_order = os.environ.get("RMEM_BRANCH_ORDER", "serial")   # serial (paired launches) | serial_unpaired
+        # Layer 0's long-term read needs the current frame's Q and the bank only -- not the previous frame's label -- so on
+        # a front / rest split it can run with the front part (hoisted beside the previous frame's decoder,
+        # DeAOTEngine._try_hoist); the windowed read and the combine stay in `rest`.  Same kernels' arithmetic, separate
+        # launches for that layer (bit-identical: the split units are those of the paired launch).
+        self.early_long_read = os.environ.get("RMEM_EARLY_LONG_READ", "0") == "1"
         self.Ylt = Planes.empty((Np, 1024), dev)
         self.Yst = Planes.empty((Np, 1024), dev)
         # split-K of the projection GEMMs.  Under the streaming kernel two splits are one round of 216 items (19.1 / 12.9 us
@@ -681,9 +687,14 @@ class DeAOTLSTT:
         with self._ev("read_combine_kernel", nbytes=(ks + 2) * N * 4096.0):
             hip.check(lib.rmem_attn_read_combine(C.byref(A[1]), st), "rmem_attn_read_combine")
 
-    def _read_pair(self, A, B):
-        """The long-term (A) and windowed (B) reads of a layer: ONE read launch, ONE combine launch."""
+    def _read_pair(self, A, B, long_done: bool = False):
+        """The long-term (A) and windowed (B) reads of a layer: ONE read launch, ONE combine launch.  long_done: the
+        long-term read was launched with the front part (early_long_read) -- only the windowed read is left."""
         lib, st = hip.load(), hip.stream_ptr()
+        if long_done:
+            hip.check(lib.rmem_attn_read(C.byref(B[0]), st), "rmem_attn_read")
+            hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
+            return
         if self._timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -803,6 +814,7 @@ class DeAOTLSTT:
         # "tail" = "rest" without its first launch, the fused read of layer 0 (launch_read2_layer0 issues that one
         # between HIP events on sampled frames of bench.py)
         do_front, do_rest = part not in ("rest", "tail"), part != "front"
+        self._split_parts = part in ("front", "rest")
         self._skip_read2 = part == "tail"
         if part != "all" and (ref_frame or self.branch_order != "serial"):
             raise hip.RmemError("front/rest split needs a propagation frame and the paired schedule")
@@ -906,6 +918,12 @@ class DeAOTLSTT:
                     self._tg, self._tgi = to, tio
             if ref_frame:
                 self._idv(l, cur)
+        early = (l == 0 and self._split_parts and self.early_long_read and not ref_frame and self.branch_order == "serial"
+                 and not self._batched)
+        if early and seg_a:
+            A = self._read_args(self.ws_main, 0, T, self.bankK[l], self.bankV[l], map_bank, self.Qpe,
+                                self.bias_pe, Ucat, True, self.ks_long, uneven=True)
+            hip.check(lib.rmem_attn_read(C.byref(A[0]), hip.stream_ptr()), "rmem_attn_read")
         if not seg_b:
             return
         # -- long-term memory read (transformer.py:1140-1192, attention.py:174-209) and short-term
@@ -917,7 +935,7 @@ class DeAOTLSTT:
         B = self._read_args(self.ws_side, 1, 1, self.bankK[l], self.bankV[l], map_short, curK, None,
                             Ucat, False, self.ks_win)
         if self.branch_order == "serial":
-            self._read_pair(A, B)
+            self._read_pair(A, B, long_done=early)
             with self._ev("dwconv5x5_split_kernel", nbytes=2 * N * 1024 * 8.0):
                 hip.check(lib.rmem_dwconv5x5_split2(
                     self.ws_main.G.data_ptr(), self.ws_side.G.data_ptr(), 1024, W.dw_lt.data_ptr(),

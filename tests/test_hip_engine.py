@@ -488,10 +488,14 @@ def test_prefetch_lookahead_ring():
         ("repeated frame", lambda t: [imgs[t], imgs[t + 1]] if t + 1 < frames else None),
         ("hoisted front part of the next frame's LSTT",
          lambda t: [imgs[k] for k in range(t + 1, t + 1 + eng.lookahead) if k < frames] or None),
+        ("hoisted front + layer 0's long-term read launched with it (RMEM_EARLY_LONG_READ)",
+         lambda t: [imgs[k] for k in range(t + 1, t + 1 + eng.lookahead) if k < frames] or None),
     ]:
         hoist = name.startswith("hoisted")
+        early = "EARLY_LONG_READ" in name
         if hoist:                                   # graphs with the front / rest split are captured from now on
             sub0.hoist_enabled = True
+            sub0.lstt.early_long_read = early
             sub0._fg.clear()
             got, idx = run(ann)                     # first pass captures, second pass replays hoisted fronts
             sub0._hoist_count = 0
@@ -504,6 +508,10 @@ def test_prefetch_lookahead_ring():
             print("hoisted fronts replayed:", sub0._hoist_count)
             assert sub0._hoist_count >= 3
             sub0.hoist_enabled = False
+            sub0.lstt.early_long_read = False
+            if early:            # same schedule as the hoisted run, one launch split in two: the same bits
+                assert all(torch.equal(a, b) for a, b in zip(got, hoisted_got))
+            hoisted_got = got
     sub = eng.aot_engines[0]
     assert len(sub._pending) <= max(2, sub.lookahead)
     eng.restart_engine()                       # with passes still pending
