@@ -297,6 +297,7 @@ class ClipResult:
         self.gap = None
         self.batched: Optional[bool] = None            # BatchedClipDriver.run_dataset: shared a lockstep batch / ran alone
         self.handed_over_at: Optional[int] = None      # batched test-time augmentation -> per-augmentation engines at this frame
+        self.aug_groups: Optional[List[List[int]]] = None   # batched test-time augmentation: augmentation indexes per image size (one batched engine each)
 
     @property
     def fps(self) -> float:
