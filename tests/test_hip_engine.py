@@ -275,7 +275,14 @@ def test_480p_long_clip_gap5_vs_reference(golden_dir):
     print("long 480p clip, gap 5: pixels off the reference's fp32 maps per frame:", mism)
     print("  off the fp64 maps:", mism64, "= ", sum(mism64), "; the fp32 reference itself:", sum(ref64),
           "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; logit err (fp16 fixture):", lerrs)
-    assert sum(mism64) <= sum(ref64) + 2 * PRODUCT_TIE_SLACK, (sum(mism64), sum(ref64))     # (five times the frames of the short clip)
+    # Distance from the fp64 maps, as a statement about accuracy rather than a pixel budget: the fp32 reference itself is off
+    # fp64 on 20 pixels of this clip, all with fp64 margins below 2.1e-6 (172 pixels of the 45 frames are that close, 407
+    # closer than 5e-6).  Which of those a correct fp32-class path flips is a coin toss per pixel -- and a different one per
+    # PROCESS here, MIOpen's encoder features not being reproducible between processes: 22-30 over the round's boxes.
+    # Asserted: no moved pixel has a margin above four times the reference's own worst flip, and the clip is not more
+    # than twice as far from fp64 as the reference.
+    assert worst < 8.4e-6, worst
+    assert sum(mism64) <= 2 * sum(ref64), (sum(mism64), sum(ref64))
     assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-2
 
 
