@@ -528,8 +528,8 @@ def main():
             cb, par = cpu_baseline_and_parity(cpu_model, model, cfg, args, dev)
             out["cpu_baseline"] = cb
             out.update(par)
-            if args.model == "r50_deaotl" and args.config == "480p_k4" and args.nsplit == 3:
-                ref_par = parity_vs_reference_fixture(model, cfg, args, dev)
+            if args.model == "r50_deaotl" and args.config in ("480p_k4", "720p_k8") and args.nsplit == 3:
+                ref_par = parity_vs_reference_fixture(model, cfg, args, dev, "clip_480p_long" if args.config == "480p_k4" else "clip_720p_k8")
                 if ref_par is not None:
                     out["parity_vs_reference"] = ref_par
         print(json.dumps(out))
@@ -893,19 +893,20 @@ def cpu_baseline_and_parity(cpu_model, gpu_model, cfg, args, dev):
     return cb, par
 
 
-def parity_vs_reference_fixture(gpu_model, cfg, args, dev):
+def parity_vs_reference_fixture(gpu_model, cfg, args, dev, name="clip_480p_long"):
     """'mask IoU vs ref' on the benchmarked schedule, against the REFERENCE itself: tests/golden/clip_480p_long.* holds
     the reference's own closed-loop run of this workload (481x849, K = 4, the evaluator's gap 5, 46 frames: the bank is
-    full from frame 15, six evictions; make_golden.py:gen_clip_480p_long).  A fresh HIP engine runs the clip
+    full from frame 15, six evictions; make_golden.py:gen_clip_480p_long), clip_720p_k8.* that of configs[2] (721x1281,
+    K = 8, gap 1, 11 frames, three evictions).  A fresh HIP engine runs the clip
     teacher-forced with the reference's labels, next frames announced as in the timed loop; per frame: pixels off the
     reference's label map, IoU over every id present; the kept-frame history must equal the reference's."""
     gd = os.path.join(ROOT, "tests", "golden")
-    if not (os.path.exists(os.path.join(gd, "clip_480p_long.json")) and os.path.exists(os.path.join(gd, "clip_480p_long.npz"))):
+    if not (os.path.exists(os.path.join(gd, name + ".json")) and os.path.exists(os.path.join(gd, name + ".npz"))):
         return None
     from rmem_amd.engine import build_engine
     from rmem_amd.synth import synth_clip
-    meta = json.load(open(os.path.join(gd, "clip_480p_long.json")))
-    gold = np.load(os.path.join(gd, "clip_480p_long.npz"))
+    meta = json.load(open(os.path.join(gd, name + ".json")))
+    gold = np.load(os.path.join(gd, name + ".npz"))
     if (meta["H"], meta["W"], meta["former"] + meta["latter"]) != (H_IN, W_IN, cfg.mem_cap):
         return None
     eng = build_engine(cfg.MODEL_ENGINE, phase="eval", aot_model=gpu_model, gpu_id=dev.index or 0,
@@ -927,13 +928,14 @@ def parity_vs_reference_fixture(gpu_model, cfg, args, dev):
         fed = torch.from_numpy(ref).float()[None, None].to(dev)
         eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
         idx_ok = idx_ok and list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][t - 1]
-    return {"fixture": "tests/golden/clip_480p_long.npz (the reference's own fp32 CPU run; fp64 near-tie lists in clip_480p_long_fp64.npz)",
+    return {"fixture": f"tests/golden/{name}.npz (the reference's own fp32 CPU run; fp64 near-tie lists in {name}_fp64.npz)",
             "frames": len(mism), "evictions": meta["evictions"], "gap": meta["gap"],
             "mask_mismatch_px": mism, "mask_mismatch_px_total": int(sum(mism)), "mask_pixels_per_frame": int(out_hw[0] * out_hw[1]),
             "iou_vs_reference": float(np.mean(ious)), "iou_vs_reference_min": float(np.min(iou_min)), "iou_ids": sorted(ids_seen),
             "bank_index_history_equal": bool(idx_ok),
             "note": "teacher-forced with the reference's labels; every differing pixel is an fp32 near-tie of the reference "
-                    "itself (tests/test_hip_engine.py::test_480p_long_clip_gap5_vs_reference checks each against the fp64 list)"}
+                    "itself (tests/test_hip_engine.py::test_480p_long_clip_gap5_vs_reference / test_720p_k8_vs_reference check "
+                    "each against the fp64 list)"}
 
 
 if __name__ == "__main__":

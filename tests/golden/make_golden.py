@@ -15,6 +15,7 @@ Fixtures are data only (inputs + the reference's outputs):
   clip_480p_fp64.*           the same 481x849 clip through the reference in DOUBLE precision (near-tie arbitration)
   clip_tta_ms_gap2.*         multi-scale x flip test-time augmentation (four engines, two image sizes), new object mid-clip
   clip_480p_long*.json/.npz  the 481x849 clip at the evaluator's gap 5 over 46 frames (six evictions) + its fp64 tie lists
+  clip_720p_k8*.json/.npz    721x1281, K = 8, gap 1, 11 frames (bank full, eviction) + its fp64 tie lists
   load_network_cases.*       the reference's load_network (utils/checkpoint.py:75-101) over ten payload variants
   *_amp.json/.npz            golden clips through the reference under fp16 autocast (its --amp mode), teacher-forced
 """
@@ -581,27 +582,46 @@ def gen_clip_480p_long(frames=46, tie_margin=1e-4, resume=False):
                                  fp64 logits and the fp32 re-run's logits) and the pixels on which the fp32
                                  reference's own label differs from the fp64 one (always inside the tie list)
     """
+    _gen_long_clip("480p_long", 481, 849, (480, 854), 5, 1, 3, 0, frames, (1, 20, frames - 1), tie_margin, resume)
+
+
+def gen_clip_720p_k8(frames=11, tie_margin=1e-4, resume=False):
+    """BASELINE.json configs[2] through the reference itself: 721x1281 (46x81 = 3726 tokens), K = 8 (former 1 + latter 7),
+    3 objects, gap 1 so that the bank passes four slots (temporal-PE rows for T > 4), fills at T = 8 and evicts inside 11
+    frames -- the schedule tests/test_hip_engine.py::test_720p_k8_vs_oracle runs against the oracle.  Same files as the long
+    480p clip: clip_720p_k8.json/.npz (closed-loop fp32 run) and clip_720p_k8_fp64.* (double-precision near-tie lists)."""
+    _gen_long_clip("720p_k8", 721, 1281, (720, 1280), 1, 1, 7, 11, frames, (1, frames - 1), tie_margin, resume)
+
+
+def _gen_long_clip(tag, H, W, out_hw, gap, former, latter, seed, frames, cap, tie_margin=1e-4, resume=False):
+    """A closed-loop run of the reference at one of BASELINE.json's full sizes plus its double-precision arbitration:
+      clip_{tag}.json/.npz       the reference's closed-loop fp32 run: label maps, long_memories_indexes / EMA / visit
+                                 dictionaries / layer-0 attention mass after every frame, decoder logits (fp16) of the
+                                 frames in `cap`
+      clip_{tag}_fp64.npz        the same clip through the reference in DOUBLE precision, teacher-forced with those
+                                 labels: per frame the near-tie list (flat pixel index, the two best classes, their
+                                 fp64 logits and the fp32 re-run's logits) and the pixels on which the fp32
+                                 reference's own label differs from the fp64 one (always inside the tie list)
+    """
     ref = rh.import_reference()
-    H, W, out_hw, gap, former, latter, seed = 481, 849, (480, 854), 5, 1, 3, 0
     imgs32, lab = synth_clip(seed, frames, H, W, 3)
     if resume:             # (--long-fp64-only: the closed-loop run is on disk, redo the arbitration only)
-        meta = json.load(open(os.path.join(HERE, "clip_480p_long.json")))
-        gold_labels = np.load(os.path.join(HERE, "clip_480p_long.npz"))["labels"]
+        meta = json.load(open(os.path.join(HERE, f"clip_{tag}.json")))
+        gold_labels = np.load(os.path.join(HERE, f"clip_{tag}.npz"))["labels"]
         assert meta["frames"] == frames
     else:
         cfg, model, engine = rh.build_reference("r50_deaotl", former, latter, gap)
-        cap = (1, 20, frames - 1)
         rec = run_reference_clip(engine, imgs32, lab, out_hw, capture_logits=cap)
         n_evict = sum(1 for a, b in zip(rec["indexes"][:-1], rec["indexes"][1:]) if a != b and len(b) <= len(a))
         meta = dict(H=H, W=W, out_hw=list(out_hw), frames=frames, gap=gap, former=former, latter=latter, seed=seed,
                     indexes=rec["indexes"], ema=rec["ema"], visits=rec["visits"], hist=rec["hist"], mass0=rec["mass0"],
                     label_sha=[sha(l) for l in rec["labels"]], evictions=n_evict, logit_frames=list(cap))
-        json.dump(meta, open(os.path.join(HERE, "clip_480p_long.json"), "w"))
+        json.dump(meta, open(os.path.join(HERE, f"clip_{tag}.json"), "w"))
         gold_labels = torch.stack(rec["labels"]).numpy()
-        np.savez_compressed(os.path.join(HERE, "clip_480p_long.npz"),
+        np.savez_compressed(os.path.join(HERE, f"clip_{tag}.npz"),
                             **{f"logits_{t}": v.numpy().astype(np.float16) for t, v in rec["logits"].items()},
                             labels=gold_labels)
-        print("clip 480p long: evictions", n_evict, "indexes", rec["indexes"][-1], flush=True)
+        print(f"clip {tag}: evictions", n_evict, "indexes", rec["indexes"][-1], flush=True)
 
     AOTEngine = ref["aot_engine"].AOTEngine
     prev_assign = AOTEngine.assign_identity
@@ -659,9 +679,9 @@ def gen_clip_480p_long(frames=46, tie_margin=1e-4, resume=False):
         out[f"mism32_l64_{t}"] = l64.flatten()[mm].numpy()
         info["mism32_vs_64"].append(int(mm.numel()))
         info["n_tie"].append(int(tie.numel()))
-    np.savez_compressed(os.path.join(HERE, "clip_480p_long_fp64.npz"), **out)
-    json.dump(info, open(os.path.join(HERE, "clip_480p_long_fp64.json"), "w"))
-    print("480p long fp64 arbitration:", info, flush=True)
+    np.savez_compressed(os.path.join(HERE, f"clip_{tag}_fp64.npz"), **out)
+    json.dump(info, open(os.path.join(HERE, f"clip_{tag}_fp64.json"), "w"))
+    print(f"{tag} fp64 arbitration:", info, flush=True)
 
 
 def gen_load_network_cases():
@@ -767,6 +787,9 @@ def main():
     if "--long-only" in sys.argv or "--long-fp64-only" in sys.argv:
         gen_clip_480p_long(resume="--long-fp64-only" in sys.argv)
         return
+    if "--720p-only" in sys.argv or "--720p-fp64-only" in sys.argv:
+        gen_clip_720p_k8(resume="--720p-fp64-only" in sys.argv)
+        return
     if "--amp-only" in sys.argv:
         gen_amp_clips()
         return
@@ -789,6 +812,7 @@ def main():
     gen_multiengine()
     gen_clip_480p_fp64()
     gen_clip_480p_long()
+    gen_clip_720p_k8()
     gen_load_network_cases()
     gen_amp_clips()
     os.system(f"du -sh {HERE}")

@@ -563,6 +563,47 @@ def test_720p_k8_vs_oracle():
     assert max(lerr) < 5e-5, (mism, lerr)
 
 
+def test_720p_k8_vs_reference(golden_dir):
+    """BASELINE.json configs[2] against the REFERENCE's own run (tests/golden/clip_720p_k8.*, make_golden.py:
+    gen_clip_720p_k8: 721x1281, K = 8, gap 1, 11 frames -- the bank passes four slots, fills at eight and evicts),
+    teacher-forced with its labels through the product engine with the next frames announced.  Per frame:
+    long_memories_indexes equal; every pixel off the reference's fp32 map is an fp64 near-tie that received one of the
+    tie's two classes (clip_720p_k8_fp64.npz); per clip: at most twice as far from the fp64 maps as the fp32 reference
+    itself (+2: the clip is short); decoder logits of the first and last frame against the fixture."""
+    from ties import Fp64Ties
+    from rmem_amd.synth import synth_clip
+    meta = json.load(open(os.path.join(golden_dir, "clip_720p_k8.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_720p_k8.npz"))
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_720p_k8_fp64.npz")))
+    assert (meta["H"], meta["W"], meta["former"] + meta["latter"], meta["gap"]) == (721, 1281, 8, 1) and meta["evictions"] >= 1
+    cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"], 3)
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    imgs = [x.to(DEV) for x in imgs]
+    out_hw = tuple(meta["out_hw"])
+    eng.restart_engine()
+    eng.add_reference_frame(imgs[0], lab.to(DEV), obj_nums=[3], frame_step=0)
+    mism, mism64, worst, lerrs = [], [], 0.0, {}
+    for t in range(1, meta["frames"]):
+        nxt = imgs[t + 1:t + 1 + eng.lookahead] or None
+        logit = eng.match_propogate_one_frame(imgs[t], output_size=out_hw, next_img=nxt)
+        p8 = torch.argmax(torch.softmax(logit, dim=1), dim=1)[0].cpu().numpy().astype(np.uint8)
+        n32, n64, w = ties.check(t, p8, gold["labels"][t - 1], PRODUCT_TIE_MARGIN)
+        mism.append(n32), mism64.append(n64)
+        worst = max(worst, w)
+        if f"logits_{t}" in gold:
+            ref = gold[f"logits_{t}"].astype(np.float32)
+            lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - ref).max())
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        assert list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][t - 1], (t, meta["indexes"][t - 1])
+    ref64 = [ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"])]
+    print("720p K=8 vs the reference: pixels off its fp32 maps per frame (of 921600):", mism, "; off the fp64 maps:", mism64,
+          "; the fp32 reference itself:", ref64, "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; logit err (fp16 fixture):", lerrs)
+    assert len(meta["indexes"][-1]) == 8 and meta["indexes"][-1] != list(range(8))
+    assert sum(mism64) <= 2 * sum(ref64) + 2, (mism64, ref64)
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-2
+
+
 def test_paired_launches_bit_identical():
     """The long-term and windowed reads of a layer share their read / combine / depth-wise-conv
     launches (rmem_attn_read2, rmem_attn_read_combine2, rmem_dwconv5x5_split2): same kernels' bodies on

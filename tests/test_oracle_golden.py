@@ -185,3 +185,31 @@ def test_480p_clip(golden_dir):
     for t in (1, 8, 9):
         ref = gold[f"logits_{t}"].astype(np.float32)
         assert np.abs(rec["logits"][t].numpy() - ref).max() < 2e-2   # fp16 storage
+
+
+@pytest.mark.slow
+def test_720p_k8_clip_first_frames(golden_dir):
+    """BASELINE.json configs[2] (721x1281 = 3726 tokens, K = 8, gap 1): the oracle against the reference's own run
+    (clip_720p_k8.*), teacher-forced, over the first six propagated frames -- the bank grows 1 -> 7 slots, i.e. through the
+    temporal-PE rows for T > 4 at the full size (the whole clip with its evictions runs on the GPU box,
+    tests/test_hip_engine.py::test_720p_k8_vs_reference).  Kept-frame history equal; every pixel off the reference's map
+    is an fp64 near-tie (clip_720p_k8_fp64.npz, margin < 1e-5) that got one of the tie's two classes; decoder logits of
+    frame 1 against the fixture."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ties import Fp64Ties
+    meta = json.load(open(os.path.join(golden_dir, "clip_720p_k8.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_720p_k8.npz"))
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_720p_k8_fp64.npz")))
+    n = 7
+    torch.manual_seed(0)
+    model = build_vos_model("deaot", get_config("r50_deaotl", meta["former"], meta["latter"])).eval()
+    load_synthetic_weights(model)
+    rec = _run_oracle_clip(dict(meta, frames=n), model, teacher=gold["labels"])
+    assert rec["indexes"] == meta["indexes"][:n - 1] and len(rec["indexes"][-1]) == 7
+    mism = []
+    for t in range(1, n):
+        n32, n64, worst = ties.check(t, rec["labels"][t - 1].numpy(), gold["labels"][t - 1], 1e-5)
+        mism.append(n32)
+    print("720p K=8 oracle vs reference, pixels off per frame (of 921600):", mism)
+    assert np.abs(rec["logits"][1].numpy() - gold["logits_1"].astype(np.float32)).max() < 2e-2   # fp16 storage
