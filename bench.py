@@ -528,8 +528,10 @@ def main():
             cb, par = cpu_baseline_and_parity(cpu_model, model, cfg, args, dev)
             out["cpu_baseline"] = cb
             out.update(par)
-            if args.model == "r50_deaotl" and args.config in ("480p_k4", "720p_k8") and args.nsplit == 3:
-                ref_par = parity_vs_reference_fixture(model, cfg, args, dev, "clip_480p_long" if args.config == "480p_k4" else "clip_720p_k8")
+            fixture = {("r50_deaotl", "480p_k4"): "clip_480p_long", ("r50_deaotl", "720p_k8"): "clip_720p_k8",
+                       ("r50_aotl", "480p_k4"): "clip_aot_480p", ("swinb_aotl", "480p_k4"): "clip_swin_480p"}.get((args.model, args.config))
+            if fixture is not None and args.nsplit == 3:
+                ref_par = parity_vs_reference_fixture(model, cfg, args, dev, fixture)
                 if ref_par is not None:
                     out["parity_vs_reference"] = ref_par
         print(json.dumps(out))
@@ -897,7 +899,8 @@ def parity_vs_reference_fixture(gpu_model, cfg, args, dev, name="clip_480p_long"
     """'mask IoU vs ref' on the benchmarked schedule, against the REFERENCE itself: tests/golden/clip_480p_long.* holds
     the reference's own closed-loop run of this workload (481x849, K = 4, the evaluator's gap 5, 46 frames: the bank is
     full from frame 15, six evictions; make_golden.py:gen_clip_480p_long), clip_720p_k8.* that of configs[2] (721x1281,
-    K = 8, gap 1, 11 frames, three evictions).  A fresh HIP engine runs the clip
+    K = 8, gap 1, 11 frames, three evictions), clip_aot_480p.* / clip_swin_480p.* those of configs[0] / configs[4] (R50-AOTL
+    481x849 x 16 frames; SwinB-AOTL 480x848, gap 1, six evictions).  A fresh HIP engine runs the clip
     teacher-forced with the reference's labels, next frames announced as in the timed loop; per frame: pixels off the
     reference's label map, IoU over every id present; the kept-frame history must equal the reference's."""
     gd = os.path.join(ROOT, "tests", "golden")
@@ -929,7 +932,7 @@ def parity_vs_reference_fixture(gpu_model, cfg, args, dev, name="clip_480p_long"
         eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
         idx_ok = idx_ok and list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][t - 1]
     return {"fixture": f"tests/golden/{name}.npz (the reference's own fp32 CPU run; fp64 near-tie lists in {name}_fp64.npz)",
-            "frames": len(mism), "evictions": meta["evictions"], "gap": meta["gap"],
+            "frames": len(mism), "evictions": meta.get("evictions"), "gap": meta["gap"],
             "mask_mismatch_px": mism, "mask_mismatch_px_total": int(sum(mism)), "mask_pixels_per_frame": int(out_hw[0] * out_hw[1]),
             "iou_vs_reference": float(np.mean(ious)), "iou_vs_reference_min": float(np.min(iou_min)), "iou_ids": sorted(ids_seen),
             "bank_index_history_equal": bool(idx_ok),

@@ -16,6 +16,7 @@ Fixtures are data only (inputs + the reference's outputs):
   clip_tta_ms_gap2.*         multi-scale x flip test-time augmentation (four engines, two image sizes), new object mid-clip
   clip_480p_long*.json/.npz  the 481x849 clip at the evaluator's gap 5 over 46 frames (six evictions) + its fp64 tie lists
   clip_720p_k8*.json/.npz    721x1281, K = 8, gap 1, 11 frames (bank full, eviction) + its fp64 tie lists
+  clip_aot_480p_fp64.*, clip_swin_k4_gap2_fp64.*, clip_swin_480p*   fp64 tie lists of the AOT / Swin clips; SwinB-AOTL at 480x848
   load_network_cases.*       the reference's load_network (utils/checkpoint.py:75-101) over ten payload variants
   *_amp.json/.npz            golden clips through the reference under fp16 autocast (its --amp mode), teacher-forced
 """
@@ -593,7 +594,8 @@ def gen_clip_720p_k8(frames=11, tie_margin=1e-4, resume=False):
     _gen_long_clip("720p_k8", 721, 1281, (720, 1280), 1, 1, 7, 11, frames, (1, frames - 1), tie_margin, resume)
 
 
-def _gen_long_clip(tag, H, W, out_hw, gap, former, latter, seed, frames, cap, tie_margin=1e-4, resume=False):
+def _gen_long_clip(tag, H, W, out_hw, gap, former, latter, seed, frames, cap, tie_margin=1e-4, resume=False,
+                   model_name="r50_deaotl"):
     """A closed-loop run of the reference at one of BASELINE.json's full sizes plus its double-precision arbitration:
       clip_{tag}.json/.npz       the reference's closed-loop fp32 run: label maps, long_memories_indexes / EMA / visit
                                  dictionaries / layer-0 attention mass after every frame, decoder logits (fp16) of the
@@ -610,7 +612,7 @@ def _gen_long_clip(tag, H, W, out_hw, gap, former, latter, seed, frames, cap, ti
         gold_labels = np.load(os.path.join(HERE, f"clip_{tag}.npz"))["labels"]
         assert meta["frames"] == frames
     else:
-        cfg, model, engine = rh.build_reference("r50_deaotl", former, latter, gap)
+        cfg, model, engine = rh.build_reference(model_name, former, latter, gap)
         rec = run_reference_clip(engine, imgs32, lab, out_hw, capture_logits=cap)
         n_evict = sum(1 for a, b in zip(rec["indexes"][:-1], rec["indexes"][1:]) if a != b and len(b) <= len(a))
         meta = dict(H=H, W=W, out_hw=list(out_hw), frames=frames, gap=gap, former=former, latter=latter, seed=seed,
@@ -631,7 +633,7 @@ def _gen_long_clip(tag, H, W, out_hw, gap, former, latter, seed, frames, cap, ti
             self, oh.to(dtype), None if ign is None else ign.to(dtype))
         torch.set_default_dtype(dtype)
         try:
-            cfg, model, engine = rh.build_reference("r50_deaotl", former, latter, gap)
+            cfg, model, engine = rh.build_reference(model_name, former, latter, gap)
             ups, idx = [], []
             with torch.no_grad(), rh.quiet():
                 engine.restart_engine()
@@ -682,6 +684,25 @@ def _gen_long_clip(tag, H, W, out_hw, gap, former, latter, seed, frames, cap, ti
     np.savez_compressed(os.path.join(HERE, f"clip_{tag}_fp64.npz"), **out)
     json.dump(info, open(os.path.join(HERE, f"clip_{tag}_fp64.json"), "w"))
     print(f"{tag} fp64 arbitration:", info, flush=True)
+
+
+def gen_aot_fp64_lists():
+    """Double-precision near-tie lists for the AOT / Swin clips that already hold the reference's fp32 run (clip_aot_480p:
+    BASELINE.json configs[0], 481x849 x 16 frames; clip_swin_k4_gap2: the small Swin clip), so that their parity tests can
+    assert the near-tie property instead of pixel budgets -- and the reference's own run of configs[4] at its full size
+    (SwinB-AOTL + RMem, 480x848 -> 30x53 tokens, gap 1, 10 frames: the bank fills at frame 4, every later frame evicts)."""
+    part = os.environ.get("GOLDEN_PART", "all")      # the fp32 re-run of a stored clip must reproduce its labels bit for bit, which
+    # needs the thread count of the run that stored it (CPU GEMM reduction order): OMP_NUM_THREADS=7 for aot_480p,
+    # 8 for swin_k4_gap2, 7 for swin_480p (GOLDEN_RESUME=1 redoes only the fp64 part of swin_480p)
+    if part in ("all", "aot"):
+        _gen_long_clip("aot_480p", 481, 849, (480, 854), 5, 1, 3, 0, 16, (1, 15), resume=True, model_name="r50_aotl")
+    if part in ("all", "swin_small"):
+        _gen_long_clip("swin_k4_gap2", 128, 160, (128, 160), 2, 1, 3, 7, 12, (11,), resume=True, model_name="swinb_aotl")
+    if part in ("all", "swin_480p"):
+        # (tie list to 1e-3: on this backbone the fp32 reference itself leaves its fp64 run at margins up to 1.4e-4)
+        _gen_long_clip("swin_480p", 480, 848, (480, 854), 1, 1, 3, 5, 10, (1, 9), tie_margin=1e-3, model_name="swinb_aotl",
+                       resume=os.environ.get("GOLDEN_RESUME") == "1")
+
 
 
 def gen_load_network_cases():
@@ -787,6 +808,9 @@ def main():
     if "--long-only" in sys.argv or "--long-fp64-only" in sys.argv:
         gen_clip_480p_long(resume="--long-fp64-only" in sys.argv)
         return
+    if "--aot-fp64-only" in sys.argv:
+        gen_aot_fp64_lists()
+        return
     if "--720p-only" in sys.argv or "--720p-fp64-only" in sys.argv:
         gen_clip_720p_k8(resume="--720p-fp64-only" in sys.argv)
         return
@@ -813,6 +837,7 @@ def main():
     gen_clip_480p_fp64()
     gen_clip_480p_long()
     gen_clip_720p_k8()
+    gen_aot_fp64_lists()
     gen_load_network_cases()
     gen_amp_clips()
     os.system(f"du -sh {HERE}")

@@ -12,6 +12,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+TIE_MARGIN = 2e-5          # fp64 margin below which the product path (MIOpen encoder included) may decide a pixel differently (tests/ties.py)
+SWIN_TIE_MARGIN = 5e-4     # at 480x848 the fp32 REFERENCE itself leaves its fp64 run on 72 pixels with margins up to 1.4e-4 (24 Swin blocks in fp32)
 
 
 @pytest.fixture(scope="module")
@@ -228,20 +230,27 @@ def test_aot_480p_clip_teacher_forced(golden_dir):
     imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
     eng.restart_engine()
     eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
-    mism, idx_hist, lerrs = [], [], {}
+    from ties import Fp64Ties
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_aot_480p_fp64.npz")))
+    mism, mism64, idx_hist, lerrs = [], [], [], {}
     for t in range(1, meta["frames"]):
         logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=tuple(meta["out_hw"]))
-        pred = torch.argmax(logit, dim=1)[0]
-        mism.append(int((pred.cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        pred = torch.argmax(torch.softmax(logit, dim=1), dim=1)[0]
+        # every pixel off the reference's fp32 map must be an fp64 near-tie of the reference's own double-precision run
+        # (clip_aot_480p_fp64.npz) that received one of the tie's two classes -- the property, not a pixel budget
+        n32, n64, _ = ties.check(t, pred.cpu().numpy().astype(np.uint8), gold["labels"][t - 1], TIE_MARGIN)
+        mism.append(n32), mism64.append(n64)
         if f"logits_{t}" in gold:
             lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() -
                                     gold[f"logits_{t}"].astype(np.float32)).max())
         fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
         eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
         idx_hist.append(list(eng.aot_engines[0].long_memories_indexes))
-    print("AOT 480p mismatching pixels per frame (of 409920):", mism, "logit err:", lerrs)
+    ref64 = sum(ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"]))
+    print("AOT 480p pixels off the reference's fp32 maps per frame (of 409920):", mism, "; off the fp64 maps:", sum(mism64),
+          "; the fp32 reference itself:", ref64, "; logit err:", lerrs)
     assert idx_hist == meta["indexes"]
-    assert max(mism) <= 4, mism           # measured 0-3 per frame: measured max + 1
+    assert sum(mism64) <= 2 * ref64 + 2, (mism64, ref64)
     assert max(lerrs.values()) < 2e-2
 
 
@@ -261,18 +270,62 @@ def test_swin_aot_clip_teacher_forced(golden_dir):
                        long_term_mem_gap=meta["gap"])
     imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
     eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    from ties import Fp64Ties
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_swin_k4_gap2_fp64.npz")))
     mism, idx = [], []
     for t in range(1, meta["frames"]):
         logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(meta["H"], meta["W"]))
-        pred = torch.argmax(logit, dim=1)[0]
-        mism.append(int((pred.cpu().numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        pred = torch.argmax(torch.softmax(logit, dim=1), dim=1)[0]
+        mism.append(ties.check(t, pred.cpu().numpy().astype(np.uint8), gold["labels"][t - 1], SWIN_TIE_MARGIN)[0])
         fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
         eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
         idx.append(list(eng.aot_engines[0].long_memories_indexes))
-    print("swin mismatching pixels per frame (of %d):" % (meta["H"] * meta["W"]), mism)
+    print("swin pixels off the reference's maps per frame (of %d), each an fp64 near-tie:" % (meta["H"] * meta["W"]), mism)
     assert idx == meta["indexes"]
-    assert max(mism) <= 3, mism
     assert np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold["last_logits"]).max() < 3e-3
+
+
+def test_swin_aot_480x848_vs_reference(golden_dir):
+    """BASELINE.json configs[4] at its full geometry against the REFERENCE's own run (tests/golden/clip_swin_480p.*,
+    make_golden.py:gen_aot_fp64_lists: SwinB-AOTL + RMem, 480x848 -> 30x53 tokens, K = 4, gap 1, 10 frames -- the bank fills
+    at frame 4 and every later frame evicts), teacher-forced with its labels.  Kept-frame history equal on every frame;
+    every pixel off the reference's fp32 map is a near-tie of the reference's double-precision run (margin < 5e-4) that
+    received one of the tie's two classes (measured: no pixel off at all -- where the fp32 reference leaves its fp64 run, 72
+    pixels over the clip, this path leaves it on the same pixels); decoder logits
+    of the first and last frame against the fixture."""
+    import copy
+    from ties import Fp64Ties
+    from rmem_amd.config import get_config
+    from rmem_amd.engine import build_engine
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights, synth_clip
+    meta = json.load(open(os.path.join(golden_dir, "clip_swin_480p.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_swin_480p.npz"))
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_swin_480p_fp64.npz")))
+    assert (meta["H"], meta["W"], meta["gap"]) == (480, 848, 1) and meta["evictions"] >= 4
+    model = build_vos_model("aot", get_config("swinb_aotl", meta["former"], meta["latter"])).eval()
+    load_synthetic_weights(model)
+    eng = build_engine("aotengine", phase="eval", aot_model=copy.deepcopy(model).to(DEV), gpu_id=0, long_term_mem_gap=meta["gap"])
+    imgs, lab = synth_clip(meta["seed"], meta["frames"], meta["H"], meta["W"], 3)
+    out_hw = tuple(meta["out_hw"])
+    eng.add_reference_frame(imgs[0].to(DEV), lab.to(DEV), obj_nums=[3], frame_step=0)
+    assert eng.aot_engines[0].lstt.N == 30 * 53
+    mism, mism64, worst, lerrs = [], [], 0.0, {}
+    for t in range(1, meta["frames"]):
+        logit = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=out_hw)
+        p8 = torch.argmax(torch.softmax(logit, dim=1), dim=1)[0].cpu().numpy().astype(np.uint8)
+        n32, n64, w = ties.check(t, p8, gold["labels"][t - 1], SWIN_TIE_MARGIN)
+        mism.append(n32), mism64.append(n64)
+        worst = max(worst, w)
+        if f"logits_{t}" in gold:
+            lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - gold[f"logits_{t}"].astype(np.float32)).max())
+        fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
+        assert list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][t - 1], (t, meta["indexes"][t - 1])
+    ref64 = [ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"])]
+    print("SwinB-AOTL 480x848 vs the reference: pixels off its fp32 maps per frame (of 409920):", mism, "; off the fp64 maps:", mism64,
+          "; the fp32 reference itself:", ref64, "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; logit err (fp16 fixture):", lerrs)
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-2
 
 
 def test_swin_aot_480x848_vs_oracle():
@@ -282,6 +335,7 @@ def test_swin_aot_480x848_vs_oracle():
     frame 4 and every later frame reads a full bank (T = 4) and evicts one slot."""
     import copy
     from oracle.engine_ref import OracleAOTEngine
+    from ties import oracle_margin_check
     from rmem_amd.config import get_config
     from rmem_amd.engine import build_engine
     from rmem_amd.model import build_vos_model
@@ -302,8 +356,11 @@ def test_swin_aot_480x848_vs_oracle():
         lg = eng.match_propogate_one_frame(imgs[t].to(DEV), output_size=(480, 854))
         lo = ora.match_propogate_one_frame(imgs[t], output_size=(480, 854))
         po = torch.argmax(lo, dim=1, keepdim=True)
-        mism.append(int((torch.argmax(lg, dim=1, keepdim=True).cpu() != po).sum()))
         lerr.append(float((eng.aot_engines[0].pred_id_logits.cpu() - ora.pred_id_logits).abs().max()))
+        # a label may only move where the oracle's own two best logits are closer than twice the logit error, and to the
+        # runner-up class (tests/ties.py) -- the property, not a pixel budget
+        pg = torch.argmax(lg, dim=1)[0].cpu().numpy().astype(np.uint8)
+        mism.append(oracle_margin_check(pg, lo[0], 2 * lerr[-1] + 1e-7, f"swin 480x848 frame {t}"))
         fed = F.interpolate(po.float(), size=ora.input_size_2d, mode="nearest")
         eng.update_memory(fed.to(DEV))
         ora.update_memory(fed)
@@ -313,4 +370,4 @@ def test_swin_aot_480x848_vs_oracle():
           "kept frames:", hist[-1])
     evictions = sum(1 for a, b in zip(hist, hist[1:]) if len(b) == len(a) and a != b)
     assert len(hist[-1]) == 4 and evictions >= 4, hist          # the full-bank read and the eviction rule ran at 30x53
-    assert max(mism) <= 4 and max(lerr) < 2e-3, (mism, lerr)
+    assert max(lerr) < 2e-3, (mism, lerr)

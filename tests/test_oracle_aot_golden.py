@@ -94,9 +94,14 @@ def test_aot_480p_clip(aot_model, golden_dir):
     rec = _run(meta, aot_model, teacher=gold["labels"])
     assert rec["indexes"] == meta["indexes"]
     labels = torch.stack(rec["labels"]).numpy()
-    mism = (labels != gold["labels"]).reshape(labels.shape[0], -1).sum(axis=1)
-    print("AOT 480p mismatching pixels per frame:", mism.tolist())
-    assert mism.max() <= 4
+    # every pixel off the reference's map must be a near-tie of the reference's own double-precision run that received
+    # one of the tie's two classes (clip_aot_480p_fp64.npz, tests/ties.py) -- the property, not a pixel budget
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ties import Fp64Ties
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_aot_480p_fp64.npz")))
+    mism = [ties.check(t + 1, labels[t], gold["labels"][t], 1e-5)[0] for t in range(labels.shape[0])]
+    print("AOT 480p pixels off the reference's maps per frame, each an fp64 near-tie:", mism)
     for t in (1, 15):
         assert np.abs(rec["logits"][t].numpy() - gold[f"logits_{t}"].astype(np.float32)).max() < 2e-2
 
