@@ -382,9 +382,7 @@ class DeAOTLSTT:
         # 38.2 + 10.1 with 6) but not in the frame: the rate follows the CU-time a launch holds, not its isolated latency
         # (DESIGN.md section 9).  In-frame A/B on one box, three alternating repeats (profiles/r05n_split_sweep.txt):
         # 6 splits 521.6 / 523.1 / 523.2 frames/s, 4 splits 528.0 / 528.6 / 529.0, 3 splits 526.2 / 527.3 / 527.1, 1: 504.
-        # Kept at 6: with 4 the long 480p reference clip moves 30 pixels off the fp64 reference instead of 22-26 (all near-ties,
-        # but past the slack tests/test_hip_engine.py allows over the fp32 reference's own 20) -- 1 % is not worth that.
-        self.ks_self = max(1, min(budget // nq, tv, 6))
+        self.ks_self = max(1, min(budget // nq, tv, 4))
         # Uneven long-term splits of the paired read, per bank depth T: OFF by default (RMEM_UNEVEN=1 turns the chooser
         # on).  Measured at 480p K=4 (profiles/r04n_split_sweep.txt): (7 x 15 + 3) 110.5 us, (7 x 14 + 2 x 5) 123.0 us
         # against 101.6 us for the even (7, 2) -- with more units than CUs the launch goes through the unit queue, and the
