@@ -696,6 +696,12 @@ def gen_aot_fp64_lists():
     # 8 for swin_k4_gap2, 7 for swin_480p (GOLDEN_RESUME=1 redoes only the fp64 part of swin_480p)
     if part in ("all", "aot"):
         _gen_long_clip("aot_480p", 481, 849, (480, 854), 5, 1, 3, 0, 16, (1, 15), resume=True, model_name="r50_aotl")
+    if part in ("all", "small"):        # the small DeAOT / AOT clips: their fp32 runs are on disk (gen_clips, gen_aot_clips)
+        for name, H, W, frames, gap, former, latter in (("k4_gap2", 97, 129, 16, 2, 1, 3), ("k4_gap5", 97, 129, 24, 5, 1, 3),
+                                                        ("k8_gap2", 81, 113, 28, 2, 1, 7), ("k2_gap1", 81, 97, 10, 1, 1, 1)):
+            _gen_long_clip("small_" + name, H, W, (H, W), gap, former, latter, 11, frames, (frames - 1,), resume=True)
+        for name, H, W, frames, gap, former, latter in (("aot_k4_gap2", 97, 129, 16, 2, 1, 3), ("aot_k2_gap1", 81, 97, 10, 1, 1, 1)):
+            _gen_long_clip(name, H, W, (H, W), gap, former, latter, 11, frames, (frames - 1,), resume=True, model_name="r50_aotl")
     if part in ("all", "swin_small"):
         _gen_long_clip("swin_k4_gap2", 128, 160, (128, 160), 2, 1, 3, 7, 12, (11,), resume=True, model_name="swinb_aotl")
     if part in ("all", "swin_480p"):

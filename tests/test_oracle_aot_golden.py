@@ -74,6 +74,13 @@ def _run(meta, model, teacher=None):
     return rec
 
 
+def _ties(golden_dir, fname):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ties import Fp64Ties
+    return Fp64Ties(np.load(os.path.join(golden_dir, fname)))
+
+
 @pytest.mark.parametrize("name", ["aot_k4_gap2", "aot_k2_gap1"])
 def test_aot_small_clip(name, aot_model, golden_dir):
     meta = json.load(open(os.path.join(golden_dir, f"clip_{name}.json")))
@@ -81,8 +88,11 @@ def test_aot_small_clip(name, aot_model, golden_dir):
     rec = _run(meta, aot_model, teacher=gold["labels"])
     assert rec["indexes"] == meta["indexes"]
     labels = torch.stack(rec["labels"]).numpy()
-    mism = (labels != gold["labels"]).reshape(labels.shape[0], -1).sum(axis=1)
-    assert mism.max() <= 1, mism.tolist()
+    # every pixel off the reference's map: a near-tie of the reference's double-precision run that got one of the tie's two
+    # classes (clip_*_fp64.npz, tests/ties.py) -- the property, not a pixel budget
+    ties = _ties(golden_dir, f"clip_{name}_fp64.npz")
+    mism = [ties.check(t + 1, labels[t], gold["labels"][t], 1e-5)[0] for t in range(labels.shape[0])]
+    print(name, "pixels off the reference's maps per frame:", mism)
     assert np.abs(rec["logits"][meta["frames"] - 1].numpy() - gold["last_logits"]).max() < 1e-4
 
 
@@ -96,10 +106,7 @@ def test_aot_480p_clip(aot_model, golden_dir):
     labels = torch.stack(rec["labels"]).numpy()
     # every pixel off the reference's map must be a near-tie of the reference's own double-precision run that received
     # one of the tie's two classes (clip_aot_480p_fp64.npz, tests/ties.py) -- the property, not a pixel budget
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from ties import Fp64Ties
-    ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_aot_480p_fp64.npz")))
+    ties = _ties(golden_dir, "clip_aot_480p_fp64.npz")
     mism = [ties.check(t + 1, labels[t], gold["labels"][t], 1e-5)[0] for t in range(labels.shape[0])]
     print("AOT 480p pixels off the reference's maps per frame, each an fp64 near-tie:", mism)
     for t in (1, 15):
@@ -123,14 +130,14 @@ def test_swin_aot_clip(golden_dir):
     assert np.abs(feats[0].mean(dim=(2, 3)).numpy() - gold["enc4_mean"]).max() < 1e-5
     eng = OracleAOTEngine(model, long_term_mem_gap=meta["gap"])
     eng.add_reference_frame(imgs[0], lab, obj_nums=[3], frame_step=0)
+    ties = _ties(golden_dir, "clip_swin_k4_gap2_fp64.npz")
     mism, idx = [], []
     for t in range(1, meta["frames"]):
         logit = eng.match_propogate_one_frame(imgs[t], output_size=(meta["H"], meta["W"]))
-        pred = torch.argmax(logit, dim=1)[0]
-        mism.append(int((pred.numpy().astype(np.uint8) != gold["labels"][t - 1]).sum()))
+        pred = torch.argmax(torch.softmax(logit, dim=1), dim=1)[0]
+        mism.append(ties.check(t, pred.numpy().astype(np.uint8), gold["labels"][t - 1], 1e-5)[0])
         fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None]
         eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
         idx.append(list(eng.long_memories_indexes))
     assert idx == meta["indexes"]
-    assert max(mism) <= 1, mism
     assert np.abs(eng.pred_id_logits.numpy() - gold["last_logits"]).max() < 1e-4
