@@ -374,6 +374,7 @@ def test_multi_object_engines(mode, monkeypatch):
     labels: aggregated 21-channel logits, label maps and both engines' eviction sequences."""
     from inputs import multiobj_label
     from oracle.engine_ref import OracleDeAOTInferEngine
+    from ties import oracle_margin_check
     from rmem_amd.synth import synth_clip
     monkeypatch.setenv("RMEM_MULTI_ENGINE", mode)
     H, W, frames = 97, 129, 7
@@ -392,10 +393,13 @@ def test_multi_object_engines(mode, monkeypatch):
         lo = ora.match_propogate_one_frame(imgs[t], output_size=(H, W))
         assert logit.shape[1] == 21 and lo.shape[1] == 21
         po = torch.argmax(lo, dim=1, keepdim=True)
-        mism.append(int((torch.argmax(logit, dim=1, keepdim=True).cpu() != po).sum()))
         # torch.logit of probabilities clamped at 1e-5: compare where the clamp is not active
         act = (lo.abs() < 11.0)
         lerr.append(float((logit.cpu() - lo)[act].abs().max()))
+        # a label may only move where the oracle's own two best aggregated logits are closer than twice the logit error, and
+        # to the runner-up class (tests/ties.py) -- the property, not a pixel budget
+        mism.append(oracle_margin_check(torch.argmax(logit, dim=1)[0].cpu().numpy().astype(np.uint8), lo[0], 2 * lerr[-1] + 1e-7,
+                                        f"12 objects, frame {t}"))
         cur = F.interpolate(po.float(), size=ora.input_size_2d, mode="nearest")
         eng.update_memory(cur.to(DEV))
         ora.update_memory(cur)
@@ -403,7 +407,7 @@ def test_multi_object_engines(mode, monkeypatch):
             assert list(e.long_memories_indexes) == list(o.long_memories_indexes)
     print("12 objects / 2 engines: mismatching pixels per frame (of %d):" % (H * W), mism, "logit err:", lerr)
     assert int(torch.argmax(lo, dim=1).max()) > 10          # ids of the second engine do appear
-    assert max(mism) <= 2 and max(lerr) < 5e-3, (mism, lerr)
+    assert max(lerr) < 5e-3, (mism, lerr)
 
 
 def test_clip_that_grows_past_ten_objects_batched_equals_serial():
@@ -453,9 +457,12 @@ def test_clip_that_grows_past_ten_objects_batched_equals_serial():
         assert a[1] == b[1], (t, a[1], b[1])
         act = a[0].abs() < 11.0
         lerr.append(float((a[0] - b[0])[act].abs().max()))
-        mism.append(int((a[0].argmax(1) != b[0].argmax(1)).sum()))
+        # a label may only differ where the serial run's own two best logits are closer than twice the difference between
+        # the runs, and then by the runner-up class (tests/ties.py)
+        from ties import oracle_margin_check
+        mism.append(oracle_margin_check(b[0].argmax(1)[0].cpu().numpy().astype(np.uint8), a[0][0].cpu(), 2 * lerr[-1] + 1e-7, f"frame {t}"))
     print("grow 3 -> 12 -> 23 objects, batched vs serial: mismatching pixels", mism, "logit err", lerr)
-    assert max(mism) <= 2 and max(lerr) < 5e-3, (mism, lerr)
+    assert max(lerr) < 5e-3, (mism, lerr)
     assert int(ser[-1][0].argmax(1).max()) > 10
 
 
