@@ -199,6 +199,7 @@ __device__ void linear_grouped_many(const GroupedLinear& g, int) { linear_groupe
 
 static int validate_linear(rmem_linear_args& a);
 
+#include "linear_stream_v1.h"
 #include "linear_stream.h"
 #include "linear_rowres.h"
 
@@ -212,6 +213,20 @@ extern "C" int rmem_linear_trace(const rmem_linear_args* args, int32_t n, int64_
     if (validate_linear(v[i]) != RMEM_OK || v[i].nsplit != 3) return RMEM_ERR_INVALID;
   }
   if (!use_stream(v, n)) return RMEM_ERR_INVALID;
+  if (stream_form() == 2) {
+    StreamGroup2 g2;
+    const int total2 = stream2_group(v, n, g2);
+    if (stream2_covers(g2)) {
+      const char* ev = getenv("RMEM_STREAM_VAR");        // timing experiments (linear_stream2_kernel): 2 no requests, 3 no MFMAs, 4 no fragment reads
+      const int var = ev ? atoi(ev) : 1;
+      long long* tp = reinterpret_cast<long long*>(trace);
+      hipStream_t st = static_cast<hipStream_t>(stream);
+      if (var == 2) return launch_stream2<3, 2>(g2, total2, tp, st);
+      if (var == 3) return launch_stream2<3, 3>(g2, total2, tp, st);
+      if (var == 4) return launch_stream2<3, 4>(g2, total2, tp, st);
+      return launch_stream2<3, 1>(g2, total2, tp, st);
+    }
+  }
   StreamGroup g;
   const int total = stream_group(v, n, g);
   return launch_stream<3, 1>(g, total, reinterpret_cast<long long*>(trace), static_cast<hipStream_t>(stream));
@@ -254,6 +269,12 @@ extern "C" int rmem_linear_grouped(const rmem_linear_args* args, int32_t n, void
   g.tile_start[n] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (use_stream(g.p, n)) {
+    if (stream_form() == 2) {
+      StreamGroup2 g2;
+      const int tot2 = stream2_group(g.p, n, g2);
+      if (stream2_covers(g2))
+        return args[0].nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
+    }
     StreamGroup gs;
     const int tot = stream_group(g.p, n, gs);
     return args[0].nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
@@ -271,6 +292,11 @@ extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (validate_linear(a) != RMEM_OK) return RMEM_ERR_INVALID;
   if (use_stream(&a, 1)) {
+    if (stream_form() == 2) {
+      StreamGroup2 g2;
+      const int tot2 = stream2_group(&a, 1, g2);
+      if (stream2_covers(g2)) return a.nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
+    }
     StreamGroup gs;
     const int tot = stream_group(&a, 1, gs);
     return a.nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);

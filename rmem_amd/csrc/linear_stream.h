@@ -1,184 +1,266 @@
-// linear_stream.h -- the streaming projection kernel (included by linear.hip after linear_epilogue / GroupedLinear).
+// linear_stream.h -- the streaming projection kernel, second form (included by linear.hip after linear_stream_v1.h,
+// whose host-side checks -- use_stream, stream_cus -- and tail-tile epilogues it shares).
 //
-// The projections of the memory path are M = 1674 (480p) x N <= 512 x K <= 2048: a few hundred 64 x 64 tiles of 4-8
-// k-tiles each.  Under the tile-per-workgroup kernels of linear.hip a launch costs its fixed parts, not its MFMAs
-// (profiles/r04c_kbench_gemm.json, r04e_stream_trace.json): 9.4 us for the 27 tiles of a 4-column problem and 20.4 us for
-// the 837 tiles of a layer's grouped front launch, of which the matrix pipe needs 2.4 -- every tile pays a chain of
-// dependent scalar argument loads, one memory round trip per k-tile (operands through registers, ds_write_b128, two
-// barriers), a bias round trip and a 7 k-cycle generic epilogue.
+// What the first form (linear_stream_v1.h) measured, per workgroup, on the grouped front launch of a GPM layer
+// (rmem_linear_trace, profiles/r06a_stream_trace.json; 35.8 k cycles for two items of four stages = 6.1 k cycles of MFMA):
+//   3.9 k cycles from launch to the first request: ten DEPENDENT scalar-load round trips -- the per-problem descriptor was
+//         read field by field through dynamic indexes into the kernel argument, each field where it was first used;
+//   1.9 k in the first stage of every item: the same chain again for the next item's descriptor, inside the loop;
+//   3.2-7.9 k per item epilogue: argument fields loaded one at a time in the middle of the stores, sixteen 4-byte (or
+//         2-byte) stores per lane with 64-bit address arithmetic each, per-row and per-plane branches around every one.
+// The MFMA stream itself is untouched here: same stages, same ring, same order of operations per output element
+// (gemm_mainloop's: k ascending, per 16-deep step hi.lo, lo.hi, hi.hi) -- results equal the tile kernels' bit for bit.
 //
-// Here ONE persistent workgroup per CU (8 waves, two per SIMD) walks its share of the launch's work items
-// (problem, 64-row tile, 128-column tile, K range) as ONE continuous stream of k-tile stages:
-//   * operands by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of three 48 KB
-//     stages, requested two stages ahead ACROSS item boundaries -- the first stages of the next item are in flight while
-//     this item's last MFMAs and its epilogue run; one raw barrier per stage, counted vmcnt;
-//   * a stage = X tile [64 rows][64 k] + Y tile [128 rows][64 k], hi / lo planes, each row 128 B with its 16-byte chunks
-//     XOR-swizzled (lds_swz); the DMA lands lane-linear, so the swizzle is applied to the SOURCE address.  The bias of
-//     the item's columns rides along as a seventh request per wave and stage (256 B): no bias round trip in the epilogue;
-//   * wave (wr, wc) = (w >> 2, w & 3) owns the 32 x 32 accumulator tile at rows 32 wr, columns 32 wc: 16 registers; per
-//     stage 16 ds_read_b128 and 12 MFMAs (hi.lo, lo.hi, hi.hi per 16-deep k-step, gemm_mainloop's order: every output
-//     element sees the same operations in the same order as under the 4-wave kernels -- bit-identical results);
-//   * everything a stage needs from the argument blocks is resolved once per item into registers (packed per-problem
-//     descriptor StreamProb, float-reciprocal divisions); the compute side learns the item it is finishing from a
-//     four-entry ring in LDS instead of decoding it again;
-//   * the epilogue is specialised per destination kind (split-K partials, fp32 [+ SiLU, column stride], blocked-16 planes
-//     + SiLU) with the row checks hoisted for full tiles; other shapes take linear_epilogue.
+// What changed:
+//   * ONE round trip per descriptor.  Per problem a 256-byte StreamDesc, 64-byte aligned in the kernel argument, read with
+//     s_load_dwordx16 through the constant address space from the kernarg segment pointer: the load side takes three
+//     loads issued together, the epilogue two.  Everything the kernel needs of a problem is in it, precomputed by the host
+//     (reciprocals, tile counts, destination kind, vector-store eligibility).
+//   * Rolled epilogue through LDS.  The accumulators (+ bias, SiLU) leave in four rounds of eight rows: four ds_write_b32
+//     at (e * 64 + lane) * 4 -- linear, conflict-free -- and ONE ds_read_b128 at lane * 16 give every lane four
+//     consecutive columns of one row; fp32 destinations and split-K partials then take ONE 16-byte store per round and
+//     lane (4 per wave instead of 16 four-byte ones), row-major planes two 8-byte stores instead of eight 2-byte ones.  The
+//     loop is rolled (the accumulator vector is rotated by four registers per round): ~60 instructions fetched once
+//     instead of ~300 -- every launch starts with a cold instruction cache.  Blocked-16 planes (V operand layout) keep the
+//     accumulator's own layout -- four consecutive rows of a column ARE its 8-byte unit -- in the same rolled form.
+//     Tiles that cross M (one row tile in 27) and shapes the fast forms do not cover take the first form's epilogues.
+//   * 8 KB of LDS for the staging (1 KB per wave) behind the ring: 159 KB per workgroup.
 #pragma once
 
-template <int NS>
-struct StreamCfg {
-  static constexpr int BM = 64, BN = 128, BK = 64, NSPLIT = NS;
-  static constexpr int THREADS = 512;
-  static constexpr int WM = 32, WN = 32, TM = 1, TN = 1;
-  static constexpr int NPL = (NS == 1) ? 1 : 2;
-  static constexpr int X_BYTES = BM * 128, Y_BYTES = BN * 128;       // one plane of a stage
-  static constexpr int STAGE_BYTES = NPL * (X_BYTES + Y_BYTES);
-  static constexpr int NSTAGE = 3;
-  static constexpr int BIAS = NSTAGE * STAGE_BYTES;                   // [stage][wave][64 floats]: bias of the wave's columns
-  static constexpr int ITEMS = BIAS + NSTAGE * 8 * 256;               // [4] x int4: the items in flight (load side -> compute side)
-  static constexpr int DUMMY = ITEMS + 64;                            // 1 KiB nobody reads: target of requests past the last stage
-  static constexpr int LDS_BYTES = DUMMY + 1024;
-  static constexpr int DMA_PER_WAVE = 3 * NPL + 1;                    // X rows 8w.., Y rows 8w.. and 64 + 8w.. per plane, + bias
-};
+typedef int __attribute__((ext_vector_type(16))) i32x16_t;
+typedef int __attribute__((ext_vector_type(8))) i32x8_t;
+typedef float __attribute__((ext_vector_type(4))) f32x4s_t;
+typedef unsigned int __attribute__((ext_vector_type(2))) u32x2s_t;
+typedef const char __attribute__((address_space(4))) * kconst_ptr_t;
 
-enum { SK_GENERIC = 0, SK_PARTS = 1, SK_F32 = 2, SK_F32_SILU = 3, SK_BLOCKED = 4, SK_BLOCKED_SILU = 5, SK_PLANES = 6 };
+enum { S2_GENERIC = 0, S2_F32V = 1, S2_F32S = 2, S2_PLANES = 3, S2_BLOCKED = 4 };
+enum { S2F_SILU = 1, S2F_BIAS = 2, S2F_PARTS = 4 };
 
-// What the load side and the item decode need of a problem, packed so that one round of scalar loads fetches it
-struct StreamProb {
+// Per-problem descriptor.  Bytes 0-127: the load side; 128-159: shared; 128-255: the epilogue.
+struct alignas(64) StreamDesc {
   const h16_t* x[2][2];        // [K segment][plane]
   const h16_t* y[2][2];
   int ldx[2], ldy[2];          // leading dimensions per segment (elements)
-  int ktx_split, kty_split;    // k-tiles served by the first segment (1 << 30: one segment)
   long bsx, bsy;               // batch strides (elements)
-  int M, N, mt, nt;            // rows, columns, 64-row tiles, 128-column tiles
+  int ktx_split, kty_split;    // k-tiles served by the first segment (1 << 30: one segment)
+  int M, N;
+  int mt, nt;                  // 64-row tiles, 128-column tiles
   float inv_mt, inv_mtnt;
+  // ---- byte 128
   int kt_total, ksplits, per, kind;
+  const float* bias;           // per-column bias (nullptr: none)
+  long bsbias;
+  // ---- byte 160
+  void* dst[4];                // F32*: [0] = destination (split-K: parts); PLANES: pah, pal, pbh, pbl; BLOCKED: pah, pal
+  const float* addvec;         // PLANES with a second set
+  long bsd;                    // elements between batches (split-K: between splits) of the destination
+  int ld0, ld1;                // F32*: row stride, column stride; PLANES: ldpa, ldpb; BLOCKED: ldpa
+  int flags, pad0;
+  long pad1, pad2;
 };
+static_assert(sizeof(StreamDesc) == 256, "StreamDesc is four 64-byte scalar loads");
 
-struct StreamGroup {
+struct StreamGroup2 {
+  StreamDesc d[8];             // offset 0 of the kernarg segment
+  int tile_start[9];           // (64-byte aligned: one s_load_dwordx8 + one dword)
   int n;
-  int tile_start[9];
-  StreamProb q[8];
-  rmem_linear_args p[8];
 };
 
-// ---- specialised epilogues.  acc register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of the
-// wave's 32 x 32 tile; bc = bias of the lane's column (0 when the problem has none).
-template <bool FULL>
-__device__ __forceinline__ void stream_ep_parts(const rmem_linear_args& a, const f32x16_t& acc, int row0, int col, int bzz, float bc) {
-  if (col >= a.N) return;
-  float* out = a.parts + (long)bzz * a.part_stride + (long)row0 * a.N + col;
-  const float b = bzz == 0 ? bc : 0.f;
-  const long ld = a.N;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int dr = (r & 3) + 8 * (r >> 2);
-    if (FULL || row0 + dr < a.M) out[dr * ld] = acc[r] + b;
+// destinations are global memory: stores through address space 1 (the pointers are assembled from descriptor words, which
+// would otherwise make them generic -- flat_store, counted on both memory counters)
+#define RMEM_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T RMEM_GLOBAL* gptr(T* p) { return (T RMEM_GLOBAL*)p; }
+
+template <class T>
+__device__ __forceinline__ T kload(kconst_ptr_t p) {
+  return *reinterpret_cast<const T __attribute__((address_space(4)))*>(p);
+}
+
+// ---- epilogue rounds.  Before the call: acc[r] = value of row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of
+// the wave's 32 x 32 tile (bias and activation applied).  stg: this wave's KiB of staging.
+// Round g (0-3) covers rows 8 g .. 8 g + 7: after the exchange lane L holds row 8 g + 4 ((L >> 3) & 1) + (L >> 4), columns
+// 4 (L & 7) .. + 3.
+__device__ __forceinline__ f32x4s_t stage_round(const f32x16_t& acc, char* stg, int lane) {
+  float* w = reinterpret_cast<float*>(stg) + lane;
+  w[0] = acc[0];
+  w[64] = acc[1];
+  w[128] = acc[2];
+  w[192] = acc[3];
+  return *reinterpret_cast<const f32x4s_t*>(stg + lane * 16);       // (one wave: LDS operations complete in order)
+}
+__device__ __forceinline__ void rotate4(f32x16_t& acc) {
+  acc = __builtin_shufflevector(acc, acc, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
+}
+
+// fp32 destination with contiguous, 16-byte aligned columns (N % 4 == 0): one store per round and lane
+__device__ __forceinline__ void ep2_f32v(f32x16_t& acc, char* stg, int lane, float* dst, long ld, int row0, int col0, int M, int N) {
+  const int rr = 4 * ((lane >> 3) & 1) + (lane >> 4), col = col0 + 4 * (lane & 7);
+  float RMEM_GLOBAL* o = gptr(dst) + (long)(row0 + rr) * ld + col;
+  const bool cok = col < N;
+#pragma clang loop unroll(disable)
+  for (int g = 0; g < 4; ++g) {
+    const f32x4s_t t = stage_round(acc, stg, lane);
+    if (cok && row0 + 8 * g + rr < M) *reinterpret_cast<f32x4s_t RMEM_GLOBAL*>(o) = t;
+    o += 8 * ld;
+    rotate4(acc);
   }
 }
 
-template <bool FULL, bool SILU>
-__device__ __forceinline__ void stream_ep_f32(const rmem_linear_args& a, const f32x16_t& acc, int row0, int col, int bz, float bc) {
-  if (col >= a.N) return;
-  float* out = a.d0 + bz * a.bsd + (long)row0 * a.ldd0 + (long)col * (a.d0_cs > 0 ? a.d0_cs : 1);
-  const long ld = a.ldd0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int dr = (r & 3) + 8 * (r >> 2);
-    float v = acc[r] + bc;
-    if (SILU) v = silu_f(v);
-    if (FULL || row0 + dr < a.M) out[dr * ld] = v;
-  }
-}
-
-template <bool SILU>
-__device__ __forceinline__ void stream_ep_blocked(const rmem_linear_args& a, const f32x16_t& acc, int row0, int col, int bz, float bc) {
-  if (col >= a.N) return;
-  h16_t* pah = a.pah + bz * a.bspa;
-  h16_t* pal = a.pal ? a.pal + bz * a.bspa : nullptr;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {                // registers 4g .. 4g + 3: four consecutive rows of one 16-row block
-    const int r0 = row0 + 8 * g;
-    h16_t hh[4], ll[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = acc[4 * g + e] + bc;
-      if (SILU) v = silu_f(v);
-      split_f16(v, hh[e], ll[e]);
-    }
-    const long off = ((long)(r0 >> 4) * a.ldpa + col) * 16 + (r0 & 15);
-    if (r0 + 3 < a.M) {
-      uint2 wh, wl;
-      wh.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
-      wh.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
-      wl.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
-      wl.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
-      *reinterpret_cast<uint2*>(pah + off) = wh;
-      if (pal) *reinterpret_cast<uint2*>(pal + off) = wl;
-    } else {
+// fp32 destination, any column stride / alignment: four 4-byte stores per round and lane
+__device__ __forceinline__ void ep2_f32s(f32x16_t& acc, char* stg, int lane, float* dst, long ld, long cs, int row0, int col0, int M,
+                                         int N) {
+  const int rr = 4 * ((lane >> 3) & 1) + (lane >> 4), col = col0 + 4 * (lane & 7);
+  float RMEM_GLOBAL* o = gptr(dst) + (long)(row0 + rr) * ld + (long)col * cs;
+#pragma clang loop unroll(disable)
+  for (int g = 0; g < 4; ++g) {
+    const f32x4s_t t = stage_round(acc, stg, lane);
+    if (row0 + 8 * g + rr < M) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (r0 + e < a.M) {
-          pah[off + e] = hh[e];
-          if (pal) pal[off + e] = ll[e];
-        }
+        if (col + e < N) o[e * cs] = t[e];
     }
+    o += 8 * ld;
+    rotate4(acc);
   }
 }
 
-template <bool FULL>
-__device__ __forceinline__ void stream_ep_planes(const rmem_linear_args& a, const f32x16_t& acc, int row0, int col, int bz, float bc) {
-  if (col >= a.N) return;
-  h16_t* pah = a.pah + bz * a.bspa + (long)row0 * a.ldpa + col;
-  h16_t* pal = a.pal ? a.pal + bz * a.bspa + (long)row0 * a.ldpa + col : nullptr;
-  h16_t* pbh = a.pbh ? a.pbh + bz * a.bspa + (long)row0 * a.ldpb + col : nullptr;
-  h16_t* pbl = a.pbl ? a.pbl + bz * a.bspa + (long)row0 * a.ldpb + col : nullptr;
-  const float addv = (a.pbh && a.addvec) ? a.addvec[col] : 0.f;
+__device__ __forceinline__ void split4(const f32x4s_t t, u32x2s_t& wh, u32x2s_t& wl) {
+  h16_t hh[4], ll[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int dr = (r & 3) + 8 * (r >> 2);
-    if (FULL || row0 + dr < a.M) {
-      const float v = acc[r] + bc;
-      h16_t hi, lo;
-      split_f16(v, hi, lo);
-      pah[dr * a.ldpa] = hi;
-      if (pal) pal[dr * a.ldpa] = lo;
+  for (int e = 0; e < 4; ++e) split_f16(t[e], hh[e], ll[e]);
+  wh[0] = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+  wh[1] = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+  wl[0] = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16);
+  wl[1] = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+}
+
+// row-major hi / lo planes (+ a second pair holding value + addvec[col]); N % 4 == 0, leading dimensions % 4 == 0
+__device__ __forceinline__ void ep2_planes(f32x16_t& acc, char* stg, int lane, h16_t* pah, h16_t* pal, h16_t* pbh, h16_t* pbl,
+                                           const float* addvec, long lda, long ldb, int row0, int col0, int M, int N) {
+  const int rr = 4 * ((lane >> 3) & 1) + (lane >> 4), col = col0 + 4 * (lane & 7);
+  const bool cok = col < N;
+  long oa = (long)(row0 + rr) * lda + col, ob = (long)(row0 + rr) * ldb + col;
+  f32x4s_t av = {0.f, 0.f, 0.f, 0.f};
+  if (pbh && addvec && cok) av = *reinterpret_cast<const f32x4s_t RMEM_GLOBAL*>(gptr(addvec) + col);
+#pragma clang loop unroll(disable)
+  for (int g = 0; g < 4; ++g) {
+    const f32x4s_t t = stage_round(acc, stg, lane);
+    if (cok && row0 + 8 * g + rr < M) {
+      u32x2s_t wh, wl;
+      split4(t, wh, wl);
+      *reinterpret_cast<u32x2s_t RMEM_GLOBAL*>(gptr(pah) + oa) = wh;
+      if (pal) *reinterpret_cast<u32x2s_t RMEM_GLOBAL*>(gptr(pal) + oa) = wl;
       if (pbh) {
-        split_f16(v + addv, hi, lo);
-        pbh[dr * a.ldpb] = hi;
-        if (pbl) pbl[dr * a.ldpb] = lo;
+        f32x4s_t u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = t[e] + av[e];
+        split4(u, wh, wl);
+        *reinterpret_cast<u32x2s_t RMEM_GLOBAL*>(gptr(pbh) + ob) = wh;
+        if (pbl) *reinterpret_cast<u32x2s_t RMEM_GLOBAL*>(gptr(pbl) + ob) = wl;
       }
     }
+    oa += 8 * lda;
+    ob += 8 * ldb;
+    rotate4(acc);
   }
 }
 
-// Iteration `it` of the stream (it = -3, -2, ... : the first three only fill the pipeline; ONE loop body serves prologue
-// and steady state, so that the instructions a workgroup fetches once -- every launch starts with a cold instruction
-// cache, ~12 cycles per instruction of straight-line code -- are few):
-//   top      (it >= -1)  stage it + 1 has landed: counted wait (the requests of stage it + 2 may stay in flight), barrier --
-//                        which also says every wave has the fragments of stage it in registers, so its buffer is free;
-//   requests             of stage it + 3 into that buffer, spread behind the MFMA groups (a CU ingests a stage in ~770
-//                        cycles at 64 B/clk: issued in one block they hold every wave while the matrix pipe idles);
-//   MFMAs    (it >= 0)   of stage it from the fragment registers; behind each k-step's group its registers are refilled
-//                        with the fragments of stage it + 1 -- the LDS reads of a stage (128 KB per CU, ~510 cycles) run
-//                        under the MFMAs of the stage before instead of in front of their own;
-//   item end (it >= 0)   epilogue from the accumulators, the bias (read with the stage's fragments) and the item ring.
+// blocked-16 planes, tile fully inside M: registers 4 g .. 4 g + 3 of a lane are four consecutive rows of its column = one
+// 8-byte unit of the layout ((row / 16) * ldpa + col) * 16 + row % 16
+__device__ __forceinline__ void ep2_blocked(f32x16_t& acc, int lane, h16_t* pah, h16_t* pal, long ldpa, int row0, int col0, int N) {
+  const int col = col0 + (lane & 31);
+  if (col >= N) return;
+  const int r0 = row0 + 4 * (lane >> 5);                       // rows r0 + 8 g .. + 3: r0 % 4 == 0, inside one 16-row block
+  long off = ((long)(r0 >> 4) * ldpa + col) * 16 + (r0 & 15);
+#pragma clang loop unroll(disable)
+  for (int g = 0; g < 4; ++g) {
+    f32x4s_t t;
+    t[0] = acc[0];
+    t[1] = acc[1];
+    t[2] = acc[2];
+    t[3] = acc[3];
+    u32x2s_t wh, wl;
+    split4(t, wh, wl);
+    *reinterpret_cast<u32x2s_t RMEM_GLOBAL*>(gptr(pah) + off) = wh;
+    if (pal) *reinterpret_cast<u32x2s_t RMEM_GLOBAL*>(gptr(pal) + off) = wl;
+    off += (g & 1) ? (ldpa * 16 - 8) : 8;                       // rows + 8: the other half of the block, then the next block
+    rotate4(acc);
+  }
+}
+
+// the same for a tile that crosses M (one row tile of a problem at most): element stores under row checks
+__device__ __forceinline__ void ep2_blocked_tail(f32x16_t& acc, int lane, h16_t* pah, h16_t* pal, long ldpa, int row0, int col0, int M,
+                                                 int N) {
+  const int col = col0 + (lane & 31);
+  if (col >= N) return;
+  const int r0 = row0 + 4 * (lane >> 5);
+#pragma clang loop unroll(disable)
+  for (int g = 0; g < 4; ++g) {
+    const int r = r0 + 8 * g;
+    const long off = ((long)(r >> 4) * ldpa + col) * 16 + (r & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (r + e < M) {
+        h16_t hi, lo;
+        split_f16(acc[e], hi, lo);
+        gptr(pah)[off + e] = hi;
+        if (pal) gptr(pal)[off + e] = lo;
+      }
+    rotate4(acc);
+  }
+}
+
+template <int NS>
+struct Stream2Cfg : StreamCfg<NS> {
+  using B = StreamCfg<NS>;
+  static constexpr int STAGING = B::LDS_BYTES;                  // [wave][1 KiB]
+  static constexpr int LDS_BYTES = B::LDS_BYTES + 8 * 1024;
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+};
+
+// Iteration structure, ring, request order and MFMA order are the first form's (see linear_stream_v1.h); the comments here
+// are about what differs.
 template <int NS, int TRACE>
-__global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long long* trace) {
-  using Cfg = StreamCfg<NS>;
+__global__ __launch_bounds__(512) void linear_stream2_kernel(StreamGroup2 g, long long* trace) {
+  using Cfg = Stream2Cfg<NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // TRACE (rmem_linear_trace, tools/kbench_gemm.py): shader-clock stamps of wave 0 of every workgroup, trace[block][64]:
-  // [0] start, [1] entering the loop, then per stage s >= 0 [2 + 2 s] top of its iteration passed (stage s + 1 landed),
-  // [3 + 2 s] its MFMAs (and, on an item's last stage, the epilogue) issued; [62] stages run, [63] end
   long long* tr = (TRACE && trace) ? trace + (long)blockIdx.x * 64 : nullptr;
   if (TRACE && tr && threadIdx.x == 0) tr[0] = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  int ts[9];                                   // tile_start in registers: the item decode scans it without memory round trips
-#pragma unroll
-  for (int i = 0; i < 9; ++i) ts[i] = g.tile_start[i];
-  const int nprob = g.n;
+  // the descriptors are read from the kernarg segment itself (g is its first member: offset 0)
+  const kconst_ptr_t kbase = (kconst_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  int ts[9];
+  {
+    const i32x8_t t0 = kload<i32x8_t>(kbase + offsetof(StreamGroup2, tile_start));
+    ts[0] = t0[0]; ts[1] = t0[1]; ts[2] = t0[2]; ts[3] = t0[3]; ts[4] = t0[4]; ts[5] = t0[5]; ts[6] = t0[6]; ts[7] = t0[7];
+    ts[8] = kload<int>(kbase + offsetof(StreamGroup2, tile_start) + 32);
+  }
+  const int nprob = kload<int>(kbase + offsetof(StreamGroup2, n));
+  // Touch every 64-byte line of the eight descriptors now: a scalar-cache miss costs ~800 cycles (profiles/r06b: 2.3 k cycles
+  // to the loop with two dependent round trips), and without this the descriptor of every further item and the epilogue's
+  // half of each are first touched -- one miss each -- inside the stream.  The values are dropped.
+  // (one assembly block: thirty-two requests into one throw-away register and ONE wait, shared with the tile starts above;
+  // left to the compiler they come in four batches of eight with a wait behind each)
+  {
+    int sink;
+    asm volatile(
+        "s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\t"
+        "s_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\ts_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0\n\t"
+        "s_load_dword %0, %1, 0x200\n\ts_load_dword %0, %1, 0x240\n\ts_load_dword %0, %1, 0x280\n\ts_load_dword %0, %1, 0x2c0\n\t"
+        "s_load_dword %0, %1, 0x300\n\ts_load_dword %0, %1, 0x340\n\ts_load_dword %0, %1, 0x380\n\ts_load_dword %0, %1, 0x3c0\n\t"
+        "s_load_dword %0, %1, 0x400\n\ts_load_dword %0, %1, 0x440\n\ts_load_dword %0, %1, 0x480\n\ts_load_dword %0, %1, 0x4c0\n\t"
+        "s_load_dword %0, %1, 0x500\n\ts_load_dword %0, %1, 0x540\n\ts_load_dword %0, %1, 0x580\n\ts_load_dword %0, %1, 0x5c0\n\t"
+        "s_load_dword %0, %1, 0x600\n\ts_load_dword %0, %1, 0x640\n\ts_load_dword %0, %1, 0x680\n\ts_load_dword %0, %1, 0x6c0\n\t"
+        "s_load_dword %0, %1, 0x700\n\ts_load_dword %0, %1, 0x740\n\ts_load_dword %0, %1, 0x780\n\ts_load_dword %0, %1, 0x7c0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(sink)
+        : "s"(kbase)
+        : "memory");
+    (void)sink;
+  }
   int total = ts[0];
 #pragma unroll
   for (int i = 1; i < 9; ++i) total = i <= nprob ? ts[i] : total;
@@ -187,7 +269,6 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   int* items = reinterpret_cast<int*>(smem + Cfg::ITEMS);
 
-  // ---- fragment addresses: row = 32 wr / 32 wc + (lane & 31), 16-byte chunk 2 ks + (lane >> 5) at slot chunk ^ ((row >> 1) & 7)
   int a_off[4], b_off[4];
   {
     const int ar = wr * 32 + (lane & 31), br = wc * 32 + (lane & 31);
@@ -197,43 +278,65 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
       b_off[ks] = Cfg::NPL * Cfg::X_BYTES + lds_swz(br, ks * 2 + (lane >> 5));
     }
   }
-  // ---- DMA source: lane L of a piece (8 rows x 128 B) lands at row L >> 3, slot L & 7 and therefore fetches chunk
-  // (L & 7) ^ ((row >> 1) & 7) of its row; the pieces of wave w start at rows 8 w (X, Y) and 64 + 8 w (Y): same parity
   const int prow = wave * 8 + (lane >> 3);
   const int pchunk = (lane & 7) ^ ((prow >> 1) & 7);
 
-  // ---- load side (three stages ahead of the MFMAs).  Uniform: item index / sequence number, problem, k-tile range, the
-  // k-tile at which the operand pointers must be re-resolved (second K segment), the pointers at the current k-tile;
-  // per lane: byte offsets of the lane's rows (+ chunk) inside the current segment, the bias address.
+  // ---- load side.  The descriptor of the current item's problem (its first 160 bytes) lives in `q`: three scalar loads
+  // issued together, one wait.
+  // (unpacked into scalars through readfirstlane: left as vector elements, the selects between two of them -- first or
+  // second K segment -- become dynamically indexed extracts of a VGPR copy of the vector, with a waterfall loop)
+  int qa[32], qc[8];
+  auto q_fetch = [&](int i) __attribute__((always_inline)) {
+    const kconst_ptr_t dp = kbase + (long)i * (long)sizeof(StreamDesc);
+    i32x16_t a = kload<i32x16_t>(dp), b = kload<i32x16_t>(dp + 64);
+    i32x8_t c = kload<i32x8_t>(dp + 128);
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(c));                  // all three requested before the first is used
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      qa[w] = __builtin_amdgcn_readfirstlane(a[w]);
+      qa[16 + w] = __builtin_amdgcn_readfirstlane(b[w]);
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) qc[w] = __builtin_amdgcn_readfirstlane(c[w]);
+  };
+  // dword map of StreamDesc: x[s][p] at 4 s + 2 p, y[s][p] at 8 + 4 s + 2 p, ldx[s] 16 + s, ldy[s] 18 + s, bsx 20, bsy 22,
+  // ktx_split 24, kty_split 25, M 26, N 27, mt 28, nt 29, inv_mt 30, inv_mtnt 31 | qc: kt_total 0, ksplits 1, per 2, kind 3,
+  // bias 4, bsbias 6
+  auto q_i = [&](int w) __attribute__((always_inline)) { return qa[w]; };
+  auto q_l = [&](int w) __attribute__((always_inline)) {
+    return (long)(((unsigned long)(unsigned)qa[w + 1] << 32) | (unsigned)qa[w]);
+  };
+  auto q_ptr = [&](int w) __attribute__((always_inline)) { return reinterpret_cast<const char*>(q_l(w)); };
   int ld_idx = blockIdx.x, ld_seq = 0, ld_p = 0, ld_kt = 0, ld_kt1 = 0, ld_seg_end = 0, ld_bz = 0, ld_mx = 0, ld_ny = 0;
   bool ld_valid = true;
   const char* xs[2] = {nullptr, nullptr};
   const char* ys[2] = {nullptr, nullptr};
   long xo = 0, yo0 = 0, yo1 = 0;
   const char* bsrc = nullptr;
-  auto ld_segment = [&]() __attribute__((always_inline)) {      // pointers / offsets for k-tile ld_kt of the current item
-    const StreamProb& q = g.q[ld_p];
-    const int sx = ld_kt >= q.ktx_split ? 1 : 0, sy = ld_kt >= q.kty_split ? 1 : 0;
-    const int ktx = ld_kt - (sx ? q.ktx_split : 0), kty = ld_kt - (sy ? q.kty_split : 0);
-    const long bx = (long)ld_bz * q.bsx + ktx * 64, by = (long)ld_bz * q.bsy + kty * 64;
+  auto ld_segment = [&]() __attribute__((always_inline)) {
+    const int ktxs = q_i(24), ktys = q_i(25), M = q_i(26), N = q_i(27);
+    const int sx = ld_kt >= ktxs ? 1 : 0, sy = ld_kt >= ktys ? 1 : 0;
+    const int ktx = ld_kt - (sx ? ktxs : 0), kty = ld_kt - (sy ? ktys : 0);
+    const long bx = ((long)ld_bz * q_l(20) + ktx * 64) * 2, by = ((long)ld_bz * q_l(22) + kty * 64) * 2;
 #pragma unroll
     for (int pl = 0; pl < Cfg::NPL; ++pl) {
-      xs[pl] = reinterpret_cast<const char*>(q.x[sx][pl] + bx);
-      ys[pl] = reinterpret_cast<const char*>(q.y[sy][pl] + by);
+      xs[pl] = (sx ? q_ptr(4 + 2 * pl) : q_ptr(2 * pl)) + bx;
+      ys[pl] = (sy ? q_ptr(12 + 2 * pl) : q_ptr(8 + 2 * pl)) + by;
     }
+    const int ldxs = sx ? q_i(17) : q_i(16), ldys = sy ? q_i(19) : q_i(18);
     int rx = ld_mx * 64 + prow, ry0 = ld_ny * 128 + prow, ry1 = ry0 + 64;
-    rx = rx < q.M ? rx : q.M - 1;
-    ry0 = ry0 < q.N ? ry0 : q.N - 1;
-    ry1 = ry1 < q.N ? ry1 : q.N - 1;
-    xo = ((long)rx * q.ldx[sx] + pchunk * 8) * 2;
-    yo0 = ((long)ry0 * q.ldy[sy] + pchunk * 8) * 2;
-    yo1 = ((long)ry1 * q.ldy[sy] + pchunk * 8) * 2;
-    int e = ld_kt1;                            // next k-tile at which a segment starts, if inside the item
-    if (!sx && q.ktx_split < e) e = q.ktx_split;
-    if (!sy && q.kty_split < e) e = q.kty_split;
+    rx = rx < M ? rx : M - 1;
+    ry0 = ry0 < N ? ry0 : N - 1;
+    ry1 = ry1 < N ? ry1 : N - 1;
+    xo = ((long)rx * ldxs + pchunk * 8) * 2;
+    yo0 = ((long)ry0 * ldys + pchunk * 8) * 2;
+    yo1 = ((long)ry1 * ldys + pchunk * 8) * 2;
+    int e = ld_kt1;
+    if (!sx && ktxs < e) e = ktxs;
+    if (!sy && ktys < e) e = ktys;
     ld_seg_end = e;
   };
-  auto ld_item = [&]() __attribute__((always_inline)) {         // decode item ld_idx, publish it to the compute side
+  auto ld_item = [&]() __attribute__((always_inline)) {
     int i = 0, start = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
@@ -242,19 +345,21 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
       start = in ? ts[k] : start;
     }
     ld_p = i;
-    const StreamProb& q = g.q[i];
+    q_fetch(i);
+    const int mt = q_i(28), nt = q_i(29);
     int local = ld_idx - start;
-    ld_bz = __builtin_amdgcn_readfirstlane(fast_div(local, q.inv_mtnt));
-    local -= ld_bz * q.mt * q.nt;
-    ld_ny = __builtin_amdgcn_readfirstlane(fast_div(local, q.inv_mt));
-    ld_mx = local - ld_ny * q.mt;
+    ld_bz = __builtin_amdgcn_readfirstlane(fast_div(local, __builtin_bit_cast(float, q_i(31))));
+    local -= ld_bz * mt * nt;
+    ld_ny = __builtin_amdgcn_readfirstlane(fast_div(local, __builtin_bit_cast(float, q_i(30))));
+    ld_mx = local - ld_ny * mt;
+    const int kt_total = qc[0], ksplits = qc[1], per = qc[2];
     ld_kt = 0;
-    ld_kt1 = q.kt_total;
-    if (q.ksplits > 1) {
-      ld_kt = ld_bz * q.per;
-      ld_kt1 = ld_kt + q.per < q.kt_total ? ld_kt + q.per : q.kt_total;
+    ld_kt1 = kt_total;
+    if (ksplits > 1) {
+      ld_kt = ld_bz * per;
+      ld_kt1 = ld_kt + per < kt_total ? ld_kt + per : kt_total;
     }
-    if (tid == 0) {                            // (read by the compute side at least one barrier later)
+    if (tid == 0) {
       int4 d;
       d.x = ld_p;
       d.y = ld_mx | (ld_ny << 16);
@@ -263,26 +368,24 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
       *reinterpret_cast<int4*>(items + (ld_seq & 3) * 4) = d;
     }
     ++ld_seq;
-    const rmem_linear_args& a = g.p[i];
-    const int bzb = q.ksplits > 1 ? 0 : ld_bz;
+    const int bzb = ksplits > 1 ? 0 : ld_bz;
     int bcol = ld_ny * 128 + wc * 32 + (lane & 31);
-    bcol = bcol < q.N ? bcol : q.N - 1;
+    const int N = q_i(27);
+    bcol = bcol < N ? bcol : N - 1;
+    const char* bias = reinterpret_cast<const char*>(((unsigned long)(unsigned)qc[5] << 32) | (unsigned)qc[4]);
+    const long bsbias = (long)(((unsigned long)(unsigned)qc[7] << 32) | (unsigned)qc[6]);
     // (a problem without a per-column bias: any valid address, the value is not used)
-    bsrc = (a.bias && !a.bias_per_row) ? reinterpret_cast<const char*>(a.bias + bzb * a.bsbias + bcol)
-                                       : reinterpret_cast<const char*>(q.x[0][0]);
-    ld_bz = bzb;                               // (K splits share the operands)
+    bsrc = bias ? bias + ((long)bzb * bsbias + bcol) * 4 : q_ptr(0);
+    ld_bz = bzb;
     ld_segment();
   };
-  // Requests of one stage: DMA_PER_WAVE per wave (bias, then per plane X / Y rows 8w.. / Y rows 64 + 8w..), always issued
-  // (past the last stage: re-reads of the last valid addresses into the dummy KiB) so that every counted wait sees a
-  // constant number of requests.
   auto piece = [&](int buf, auto J) __attribute__((always_inline)) {
     constexpr int j = decltype(J)::value;
     if constexpr (j == 0) {
       const unsigned db = __builtin_amdgcn_readfirstlane(lds0 + (ld_valid ? Cfg::BIAS + (buf * 8 + wave) * 256 : Cfg::DUMMY));
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(db), "v"(bsrc) : "memory");
     } else {
-      constexpr int pl = (j - 1) / 3, w = (j - 1) % 3;       // plane; 0 = X, 1 = Y rows 8w.., 2 = Y rows 64 + 8w..
+      constexpr int pl = (j - 1) / 3, w = (j - 1) % 3;
       const int base = ld_valid ? buf * Cfg::STAGE_BYTES + wave * 1024 : Cfg::DUMMY;
       const int on = ld_valid ? 1 : 0;
       constexpr int off = w == 0 ? pl * Cfg::X_BYTES : Cfg::NPL * Cfg::X_BYTES + pl * Cfg::Y_BYTES + (w == 2 ? 8192 : 0);
@@ -291,7 +394,7 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(gp) : "memory");
     }
   };
-  auto advance = [&]() __attribute__((always_inline)) {      // after a stage's last request: next k-tile, segment or item
+  auto advance = [&]() __attribute__((always_inline)) {
     if (ld_valid) {
       ++ld_kt;
 #pragma unroll
@@ -305,7 +408,7 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
           ld_valid = ld_idx < total;
           if (ld_valid) {
             ld_item();
-          } else {                             // (the dummy requests re-read the last stage: never past an operand's end)
+          } else {
 #pragma unroll
             for (int pl = 0; pl < Cfg::NPL; ++pl) {
               xs[pl] -= 128;
@@ -322,7 +425,7 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  frag8_t fa[4][Cfg::NPL], fb[4][Cfg::NPL];   // fragments of the stage whose MFMAs run next
+  frag8_t fa[4][Cfg::NPL], fb[4][Cfg::NPL];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -332,7 +435,7 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
         fa[ks][pl][e] = 0;
         fb[ks][pl][e] = 0;
       }
-  float bc_cur = 0.f, bc_next = 0.f;          // bias of the lane's column: of the stage in the registers / being read
+  float bc_cur = 0.f, bc_next = 0.f;
 
   ld_item();
   if (TRACE && tr && threadIdx.x == 0) tr[1] = __builtin_readcyclecounter();
@@ -346,22 +449,22 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
     }
     if (TRACE && tr && threadIdx.x == 0 && it >= 0 && it < 30) tr[2 + 2 * it] = __builtin_readcyclecounter();
     const bool compute = it >= 0, refill = it >= -1;
-    if (compute && cp_left == 0)               // first stage of an item: how many stages it has
+    if (compute && cp_left == 0)
       cp_left = __builtin_amdgcn_readfirstlane(items[(cp_seq & 3) * 4 + 3]);
     bc_cur = bc_next;
-    const int nbuf = (it + 3) % Cfg::NSTAGE;   // buffer of stage it + 3 = the one stage it was read from
-    const int rbuf = (it + 4) % Cfg::NSTAGE;   // buffer of stage it + 1
+    const int nbuf = (it + 3) % Cfg::NSTAGE;
+    const int rbuf = (it + 4) % Cfg::NSTAGE;
     const char* st = smem + rbuf * Cfg::STAGE_BYTES;
     static_for<4>([&](auto KS) {
       constexpr int ks = decltype(KS)::value;
-      if (compute) {
-        if constexpr (NS == 3) {               // small terms first (gemm_mainloop's order)
+      if (compute && TRACE != 3) {             // (TRACE 2 / 3 / 4: timing experiments of the tracing kernel -- no requests /
+        if constexpr (NS == 3) {               //  no MFMAs / no fragment reads; results are wrong)  small terms first (gemm_mainloop's order)
           acc = RMEM_MFMA(fa[ks][0], fb[ks][1], acc);
           acc = RMEM_MFMA(fa[ks][1], fb[ks][0], acc);
         }
         acc = RMEM_MFMA(fa[ks][0], fb[ks][0], acc);
       }
-      if (refill) {
+      if (refill && TRACE != 4) {
 #pragma unroll
         for (int pl = 0; pl < Cfg::NPL; ++pl) {
           fa[ks][pl] = *reinterpret_cast<const frag8_t*>(st + a_off[ks] + pl * Cfg::X_BYTES);
@@ -370,45 +473,60 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
         if constexpr (ks == 0)
           bc_next = *reinterpret_cast<const float*>(smem + Cfg::BIAS + (rbuf * 8 + wave) * 256 + (lane & 31) * 4);
       }
-      // the requests of stage it + 3 (7 = 2 + 2 + 2 + 1, 4 = 1 + 1 + 1 + 1)
       constexpr int per = (Cfg::DMA_PER_WAVE + 3) / 4;
       static_for<per>([&](auto I) {
         constexpr int j = ks * per + decltype(I)::value;
-        if constexpr (j < Cfg::DMA_PER_WAVE) piece(nbuf, std::integral_constant<int, j>{});
+        if constexpr (j < Cfg::DMA_PER_WAVE && TRACE != 2) piece(nbuf, std::integral_constant<int, j>{});
       });
     });
     advance();
-    if (compute && --cp_left == 0) {           // item done: its epilogue, then the next item of this workgroup
+    if (compute && --cp_left == 0) {           // item done
       const int4 d = *reinterpret_cast<const int4*>(items + (cp_seq & 3) * 4);
       const int p = __builtin_amdgcn_readfirstlane(d.x), mn = __builtin_amdgcn_readfirstlane(d.y);
       const int bzz = __builtin_amdgcn_readfirstlane(d.z);
       const int m0 = (mn & 0xffff) * 64, n0 = (mn >> 16) * 128;
-      const rmem_linear_args& a = g.p[p];
-      const int kind = g.q[p].kind;
-      const float bc = (a.bias && !a.bias_per_row) ? bc_cur : 0.f;
-      const int row0 = m0 + wr * 32 + 4 * (lane >> 5), col = n0 + wc * 32 + (lane & 31);
-      const bool full = m0 + 64 <= a.M;        // (uniform)
-      const int bz = a.ksplits > 1 ? 0 : bzz;
-      if (kind == SK_PARTS) {
-        if (full) stream_ep_parts<true>(a, acc, row0, col, bzz, bc);
-        else stream_ep_parts<false>(a, acc, row0, col, bzz, bc);
-      } else if (kind == SK_F32) {
-        if (full) stream_ep_f32<true, false>(a, acc, row0, col, bz, bc);
-        else stream_ep_f32<false, false>(a, acc, row0, col, bz, bc);
-      } else if (kind == SK_F32_SILU) {
-        if (full) stream_ep_f32<true, true>(a, acc, row0, col, bz, bc);
-        else stream_ep_f32<false, true>(a, acc, row0, col, bz, bc);
-      } else if (kind == SK_BLOCKED) {
-        stream_ep_blocked<false>(a, acc, row0, col, bz, bc);
-      } else if (kind == SK_BLOCKED_SILU) {
-        stream_ep_blocked<true>(a, acc, row0, col, bz, bc);
-      } else if (kind == SK_PLANES) {
-        if (full) stream_ep_planes<true>(a, acc, row0, col, bz, bc);
-        else stream_ep_planes<false>(a, acc, row0, col, bz, bc);
-      } else {
-        f32x16_t t[1][1];
-        t[0][0] = acc;
-        linear_epilogue<Cfg>(a, t, m0, n0, bzz, wr, wc, lane);
+      // the epilogue's half of the descriptor + (M, N): three scalar loads, one wait
+      const kconst_ptr_t dp = kbase + (long)p * (long)sizeof(StreamDesc);
+      i32x16_t e0 = kload<i32x16_t>(dp + 128), e1 = kload<i32x16_t>(dp + 192);
+      int M = kload<int>(dp + 104), N = kload<int>(dp + 108);
+      asm volatile("" : "+s"(e0), "+s"(e1), "+s"(M), "+s"(N));
+      // dwords of e0: kt_total 0, ksplits 1, per 2, kind 3, bias 4-5, bsbias 6-7, dst[0] 8-9, dst[1] 10-11, dst[2] 12-13,
+      // dst[3] 14-15; e1: addvec 0-1, bsd 2-3, ld0 4, ld1 5, flags 6
+      auto e_ptr = [&](const i32x16_t& v, int w) __attribute__((always_inline)) {
+        return reinterpret_cast<char*>(((unsigned long)(unsigned)v[w + 1] << 32) | (unsigned)v[w]);
+      };
+      const int kind = e0[3], flags = e1[6];
+      const long bsd = (long)(((unsigned long)(unsigned)e1[3] << 32) | (unsigned)e1[2]);
+      const bool full = m0 + 64 <= M;          // (uniform)
+      if (n0 + wc * 32 < N) {                  // (wave-uniform: a 4-column problem keeps one wave in four)
+        const float bc = ((flags & S2F_BIAS) && (!(flags & S2F_PARTS) || bzz == 0)) ? bc_cur : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = acc[r] + bc;
+        if (flags & S2F_SILU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = silu_f(acc[r]);
+        }
+        const int row0 = m0 + wr * 32, col0 = n0 + wc * 32;
+        char* stg = smem + Cfg::STAGING + wave * 1024;
+        const long ld0 = e1[4], ld1 = e1[5];
+        if (kind == S2_F32V) {
+          ep2_f32v(acc, stg, lane, reinterpret_cast<float*>(e_ptr(e0, 8)) + bzz * bsd, ld0, row0, col0, M, N);
+        } else if (kind == S2_F32S) {
+          ep2_f32s(acc, stg, lane, reinterpret_cast<float*>(e_ptr(e0, 8)) + bzz * bsd, ld0, ld1, row0, col0, M, N);
+        } else if (kind == S2_PLANES) {
+          h16_t* pal = reinterpret_cast<h16_t*>(e_ptr(e0, 10));
+          h16_t* pbh = reinterpret_cast<h16_t*>(e_ptr(e0, 12));
+          h16_t* pbl = reinterpret_cast<h16_t*>(e_ptr(e0, 14));
+          ep2_planes(acc, stg, lane, reinterpret_cast<h16_t*>(e_ptr(e0, 8)) + bzz * bsd, pal ? pal + bzz * bsd : nullptr,
+                     pbh ? pbh + bzz * bsd : nullptr, pbl ? pbl + bzz * bsd : nullptr,
+                     reinterpret_cast<const float*>(e_ptr(e1, 0)), ld0, ld1, row0, col0, M, N);
+        } else {                               // S2_BLOCKED (the host keeps other shapes away from this kernel)
+          h16_t* pah = reinterpret_cast<h16_t*>(e_ptr(e0, 8)) + bzz * bsd;
+          h16_t* pal = reinterpret_cast<h16_t*>(e_ptr(e0, 10));
+          pal = pal ? pal + bzz * bsd : nullptr;
+          if (full) ep2_blocked(acc, lane, pah, pal, ld0, row0, col0, N);
+          else ep2_blocked_tail(acc, lane, pah, pal, ld0, row0, col0, M, N);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -420,7 +538,7 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
       tr[3 + 2 * it] = __builtin_readcyclecounter();
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dummy requests of the last stages)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (TRACE && tr && threadIdx.x == 0) {
     tr[62] = nst;
     tr[63] = __builtin_readcyclecounter();
@@ -428,89 +546,100 @@ __global__ __launch_bounds__(512) void linear_stream_kernel(StreamGroup g, long 
 }
 
 // ---- host side
-static int stream_kind(const rmem_linear_args& a) {
-  if (a.bias_per_row) return SK_GENERIC;
-  if (a.ksplits > 1) return SK_PARTS;
-  if (a.pa_blocked) return a.act == 1 ? SK_BLOCKED_SILU : (a.act == 0 ? SK_BLOCKED : SK_GENERIC);
-  if (a.d0 && !a.d1 && !a.pah && !a.pbh && !a.accumulate && a.csplit >= a.N && (a.act == 0 || a.act == 1))
-    return a.act == 1 ? SK_F32_SILU : SK_F32;
-  if (a.pah && !a.d0 && !a.d1 && a.act == 0) return SK_PLANES;
-  return SK_GENERIC;
+// (development switch, removed with the first form: RMEM_STREAM=1 keeps the first form for A/B runs)
+static int stream_form() {
+  static const char* e = getenv("RMEM_STREAM");
+  return (e && e[0] == '1') ? 1 : 2;
+}
+static bool aligned_to(const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+static void stream2_desc(const rmem_linear_args& a, StreamDesc& q) {
+  memset(&q, 0, sizeof(q));
+  q.x[0][0] = a.xh; q.x[0][1] = a.xl; q.x[1][0] = a.xh2; q.x[1][1] = a.xl2;
+  q.y[0][0] = a.yh; q.y[0][1] = a.yl; q.y[1][0] = a.yh2; q.y[1][1] = a.yl2;
+  q.ldx[0] = (int)a.ldx; q.ldx[1] = (int)a.ldx2; q.ldy[0] = (int)a.ldy; q.ldy[1] = (int)a.ldy2;
+  q.ktx_split = a.xh2 ? a.kx_split / 64 : (1 << 30);
+  q.kty_split = a.yh2 ? a.ky_split / 64 : (1 << 30);
+  q.bsx = a.bsx; q.bsy = a.bsy;
+  q.M = a.M; q.N = a.N;
+  q.mt = (a.M + 63) / 64; q.nt = (a.N + 127) / 128;
+  q.inv_mt = 1.0f / (float)q.mt;
+  q.inv_mtnt = 1.0f / (float)(q.mt * q.nt);
+  q.kt_total = a.K / 64;
+  q.ksplits = a.ksplits > 1 ? a.ksplits : 1;
+  q.per = (q.kt_total + q.ksplits - 1) / q.ksplits;
+  q.bias = (a.bias && !a.bias_per_row) ? a.bias : nullptr;
+  q.bsbias = a.bsbias;
+  q.flags = (a.act == 1 ? S2F_SILU : 0) | (q.bias ? S2F_BIAS : 0) | (a.ksplits > 1 ? S2F_PARTS : 0);
+  q.kind = S2_GENERIC;
+  const bool plain_act = a.act == 0 || a.act == 1;
+  if (a.bias_per_row || !plain_act) return;
+  if (a.ksplits > 1) {                          // raw partials [split][M][N] (validate_linear: no activation, no batches)
+    q.dst[0] = a.parts;
+    q.bsd = a.part_stride;
+    q.ld0 = a.N;
+    q.ld1 = 1;
+    q.kind = ((a.N % 4) == 0 && (a.part_stride % 4) == 0 && aligned_to(a.parts, 16)) ? S2_F32V : S2_F32S;
+    return;
+  }
+  if (a.pa_blocked) {                           // (validate_linear: the only output)
+    if (a.ldpa >= (1L << 27) || (a.bspa % 4) != 0 || !aligned_to(a.pah, 8) || (a.pal && !aligned_to(a.pal, 8))) return;
+    q.dst[0] = a.pah; q.dst[1] = a.pal;
+    q.bsd = a.bspa;
+    q.ld0 = (int)a.ldpa;
+    q.kind = S2_BLOCKED;
+    return;
+  }
+  if (a.d0 && !a.d1 && !a.pah && !a.pbh && !a.accumulate && a.csplit >= a.N && a.ldd0 < (1L << 31)) {
+    const long cs = a.d0_cs > 0 ? a.d0_cs : 1;
+    q.dst[0] = a.d0;
+    q.bsd = a.bsd;
+    q.ld0 = (int)a.ldd0;
+    q.ld1 = (int)cs;
+    q.kind = (cs == 1 && (a.N % 4) == 0 && (a.ldd0 % 4) == 0 && (a.bsd % 4) == 0 && aligned_to(a.d0, 16)) ? S2_F32V : S2_F32S;
+    return;
+  }
+  if (a.pah && !a.d0 && !a.d1 && a.act == 0 && (a.N % 4) == 0 && (a.ldpa % 4) == 0 && (a.bspa % 4) == 0 && a.ldpa < (1L << 31) &&
+      aligned_to(a.pah, 8) && (!a.pal || aligned_to(a.pal, 8))) {
+    if (a.pbh && ((a.ldpb % 4) != 0 || a.ldpb >= (1L << 31) || !aligned_to(a.pbh, 8) || (a.pbl && !aligned_to(a.pbl, 8)) ||
+                  (a.addvec && !aligned_to(a.addvec, 16))))
+      return;
+    q.dst[0] = a.pah; q.dst[1] = a.pal; q.dst[2] = a.pbh; q.dst[3] = a.pbl;
+    q.addvec = a.addvec;
+    q.bsd = a.bspa;
+    q.ld0 = (int)a.ldpa;
+    q.ld1 = (int)a.ldpb;
+    q.kind = S2_PLANES;
+  }
 }
 
-// items of a launch under the streaming kernel's 64 x 128 tiling (args already validated)
-static int stream_group(const rmem_linear_args* args, int n, StreamGroup& g) {
+static int stream2_group(const rmem_linear_args* args, int n, StreamGroup2& g) {
   g.n = n;
   int total = 0;
   for (int i = 0; i < n; ++i) {
-    g.p[i] = args[i];
-    const rmem_linear_args& a = g.p[i];
-    StreamProb& q = g.q[i];
-    q.x[0][0] = a.xh; q.x[0][1] = a.xl; q.x[1][0] = a.xh2; q.x[1][1] = a.xl2;
-    q.y[0][0] = a.yh; q.y[0][1] = a.yl; q.y[1][0] = a.yh2; q.y[1][1] = a.yl2;
-    q.ldx[0] = (int)a.ldx; q.ldx[1] = (int)a.ldx2; q.ldy[0] = (int)a.ldy; q.ldy[1] = (int)a.ldy2;
-    q.ktx_split = a.xh2 ? a.kx_split / 64 : (1 << 30);
-    q.kty_split = a.yh2 ? a.ky_split / 64 : (1 << 30);
-    q.bsx = a.bsx; q.bsy = a.bsy;
-    q.M = a.M; q.N = a.N;
-    q.mt = (a.M + 63) / 64; q.nt = (a.N + 127) / 128;
-    q.inv_mt = 1.0f / (float)q.mt;
-    q.inv_mtnt = 1.0f / (float)(q.mt * q.nt);
-    q.kt_total = a.K / 64;
-    q.ksplits = a.ksplits > 1 ? a.ksplits : 1;
-    q.per = (q.kt_total + q.ksplits - 1) / q.ksplits;
-    q.kind = stream_kind(a);
+    stream2_desc(args[i], g.d[i]);
     g.tile_start[i] = total;
-    total += q.mt * q.nt * (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
+    total += g.d[i].mt * g.d[i].nt * (args[i].ksplits > 1 ? args[i].ksplits : (args[i].nbatch > 0 ? args[i].nbatch : 1));
   }
-  g.tile_start[n] = total;
+  for (int i = n; i < 8; ++i) memset(&g.d[i], 0, sizeof(StreamDesc));
+  for (int i = n; i < 9; ++i) g.tile_start[i] = total;
   return total;
 }
-
-static int stream_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }
-  return n;
+// (shapes whose descriptor says S2_GENERIC -- per-row bias, accumulate, two fp32 destinations, planes beside fp32,
+// unaligned planes -- are not served by this kernel)
+static bool stream2_covers(const StreamGroup2& g) {
+  for (int i = 0; i < g.n; ++i)
+    if (g.d[i].kind == S2_GENERIC) return false;
+  return true;
 }
 
 template <int NS, int TRACE>
-static int launch_stream(const StreamGroup& g, int total, long long* trace, hipStream_t s) {
-  using Cfg = StreamCfg<NS>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_stream_kernel<NS, TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+static int launch_stream2(const StreamGroup2& g, int total, long long* trace, hipStream_t s) {
+  using Cfg = Stream2Cfg<NS>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_stream2_kernel<NS, TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             Cfg::LDS_BYTES);
   const int grid = total < stream_cus() ? total : stream_cus();
-  hipLaunchKernelGGL((linear_stream_kernel<NS, TRACE>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, g, trace);
+  hipLaunchKernelGGL((linear_stream2_kernel<NS, TRACE>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, g, trace);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
-}
-
-// The streaming kernel serves a launch issued directly whose problems ask for tile 0 (auto) or 256; tile 64 / 128 / 192
-// select the tile-per-workgroup kernels (kept for the recorded launches of several clips -- launch.h -- and as the
-// bit-identical cross-check), as does RMEM_LINEAR=tiles for every launch.  Stays with the tile kernels as well: items of a
-// single stage (see below), a split-K problem whose last split would be empty (ceil division; the stream counts one stage per k-tile of every item), leading
-// dimensions or item counts beyond what the packed descriptor holds.
-static bool use_stream(const rmem_linear_args* args, int n) {
-  static const char* e = getenv("RMEM_LINEAR");
-  if ((e && e[0] == 't') || rmem::current_recorder()) return false;
-  long items = 0;
-  for (int i = 0; i < n; ++i) {
-    const rmem_linear_args& a = args[i];
-    if (a.tile != 0 && a.tile != 256) return false;
-    if (a.ldx >= (1L << 30) || a.ldy >= (1L << 30) || a.ldx2 >= (1L << 30) || a.ldy2 >= (1L << 30)) return false;
-    if (a.M > 65535 * 64 || a.N > 32767 * 128) return false;
-    // an item of ONE stage: the load side runs up to four stages ahead and would publish the descriptor of item i + 4
-    // into the four-entry item ring before the epilogue of item i has read its slot (a workgroup with five or more
-    // items); such shapes (K = 64, or split-K down to one k-tile per split) stay with the tile kernels
-    if (a.K / 64 < 2) return false;
-    if (a.ksplits > 1) {
-      const int kt = a.K / 64, per = (kt + a.ksplits - 1) / a.ksplits;
-      if ((a.ksplits - 1) * per >= kt) return false;
-      if (per < 2 || kt - (a.ksplits - 1) * per < 2) return false;
-    }
-    items += (long)((a.M + 63) / 64) * ((a.N + 127) / 128) * (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
-  }
-  return items < (1L << 20);                   // (fast_div's exact range)
 }

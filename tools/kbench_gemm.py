@@ -63,14 +63,15 @@ def main():
     res["V+U"] = timeit(lambda: hip.linear_grouped([m["V"], m["U"]]), 20)
     res["V+U+IDU"] = timeit(lambda: hip.linear_grouped([m["V"], m["U"], m["IDU"]]), 20)
     res["all_but_R"] = timeit(lambda: hip.linear_grouped([m[k] for k in ("Q", "pe", "V", "U", "IDU")]), 20)
-    # the split-K projections, whole and at a quarter of the depth
+    # the split-K projections, whole and at a quarter of the depth (own partial buffer: L.parts holds L.KS = 2 splits)
+    parts4 = torch.zeros(4, N, 512, device=dev)
     for Kp in (2048, 512):
         res[f"proj_ls_K{Kp}_tile192_ks4"] = timeit(lambda: hip.linear(
             L.Ylt, W.Wp_ls, N, 512, Kp, ldx=1024, ldy=2048, x2=L.Yst, ldx2=1024, kx_split=min(1024, Kp // 2), bias=W.bp_ls,
-            nsplit=ns, tile=TILE2, ksplits=4, parts=L.parts, part_stride=N * 512), 20)
+            nsplit=ns, tile=TILE2, ksplits=4, parts=parts4, part_stride=N * 512), 20)
     res["proj_self_K1024_tile192_ks4"] = timeit(lambda: hip.linear(
         L.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns, tile=TILE2, ksplits=4,
-        parts=L.parts, part_stride=N * 512), 20)
+        parts=parts4, part_stride=N * 512), 20)
     res["proj_self_K1024_direct_tile64"] = timeit(lambda: hip.linear(
         L.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, d0=L.tgt.data_ptr(), ldd0=256,
         d1=L.tgt_id.data_ptr(), ldd1=256, csplit=256, accumulate=True, nsplit=ns), 20)
