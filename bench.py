@@ -135,8 +135,12 @@ def pmc_kernel_traffic(entry: dict, key) -> None:
         if isinstance(v, dict) and "hbm_bytes_per_launch" in v and (k.startswith(want + "_kernel") or k.startswith(alias.get(want, "\0"))):
             entry["traffic"] = v["hbm_bytes_per_launch"]
             entry["traffic_source"] = f"profiles/{name}"
+            # against the ALGORITHMIC bytes of SURVEY 8d (operands once + final outputs; no split partials): a class whose
+            # algorithmic bytes are zero (the combine) moves nothing but overhead -- its ratio is reported as null
             if entry.get("algorithmic_mb_per_launch"):
                 entry["traffic_over_algorithmic"] = v["hbm_bytes_per_launch"] / (entry["algorithmic_mb_per_launch"] * 1e6)
+            else:
+                entry["traffic_over_algorithmic"] = None
             return
 
 
@@ -521,7 +525,16 @@ def main():
                 out["roofline"] = rl
             out["roofline"]["kernels"] = kernels[:5]
             out["roofline"]["kernels_how"] = how
-            out["roofline"]["memory_path_us_per_frame_sampled"] = sum(e["us_per_frame"] for e in kernels)
+            mp_us = sum(e["us_per_frame"] for e in kernels)
+            out["roofline"]["memory_path_us_per_frame_sampled"] = mp_us
+            # ONE number for the whole memory path: algorithmic GFLOP of a frame (the sampled launches' own counts; SURVEY 8d
+            # gives 129.1 for 480p K=4 including the memory update's ID_V GEMMs, which run in the update graph and are not
+            # sampled) over the kernel time of the memory path in the frame, against the MFMA peak
+            mp_gf = sum(e.get("algorithmic_gflop_per_launch", 0.0) * e["launches_per_frame"] for e in kernels)
+            out["roofline"]["memory_path_gflop_per_frame"] = mp_gf
+            out["roofline"]["memory_path_frac"] = (mp_gf * 1e9 / (mp_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS) if mp_us > 0 else None
+            out["roofline"]["memory_path_overhead_mb_per_frame"] = sum(e.get("overhead_mb_per_launch", 0.0) * e["launches_per_frame"]
+                                                                        for e in kernels)
         if dropin is not None:
             out["dropin"] = dropin
         if world == 1 and not args.no_cpu_baseline:

@@ -226,7 +226,10 @@ __global__ __launch_bounds__(512) void linear_stream2_kernel(StreamGroup2 g, lon
   using Cfg = Stream2Cfg<NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   long long* tr = (TRACE && trace) ? trace + (long)blockIdx.x * 64 : nullptr;
-  if (TRACE && tr && threadIdx.x == 0) tr[0] = __builtin_readcyclecounter();
+  if (TRACE && tr && threadIdx.x == 0) {
+    tr[0] = __builtin_readcyclecounter();
+    tr[60] = __builtin_amdgcn_s_memrealtime();       // 100 MHz, one counter for the whole device: launch shape across workgroups
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -239,28 +242,6 @@ __global__ __launch_bounds__(512) void linear_stream2_kernel(StreamGroup2 g, lon
     ts[8] = kload<int>(kbase + offsetof(StreamGroup2, tile_start) + 32);
   }
   const int nprob = kload<int>(kbase + offsetof(StreamGroup2, n));
-  // Touch every 64-byte line of the eight descriptors now: a scalar-cache miss costs ~800 cycles (profiles/r06b: 2.3 k cycles
-  // to the loop with two dependent round trips), and without this the descriptor of every further item and the epilogue's
-  // half of each are first touched -- one miss each -- inside the stream.  The values are dropped.
-  // (one assembly block: thirty-two requests into one throw-away register and ONE wait, shared with the tile starts above;
-  // left to the compiler they come in four batches of eight with a wait behind each)
-  {
-    int sink;
-    asm volatile(
-        "s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\ts_load_dword %0, %1, 0xc0\n\t"
-        "s_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\ts_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0\n\t"
-        "s_load_dword %0, %1, 0x200\n\ts_load_dword %0, %1, 0x240\n\ts_load_dword %0, %1, 0x280\n\ts_load_dword %0, %1, 0x2c0\n\t"
-        "s_load_dword %0, %1, 0x300\n\ts_load_dword %0, %1, 0x340\n\ts_load_dword %0, %1, 0x380\n\ts_load_dword %0, %1, 0x3c0\n\t"
-        "s_load_dword %0, %1, 0x400\n\ts_load_dword %0, %1, 0x440\n\ts_load_dword %0, %1, 0x480\n\ts_load_dword %0, %1, 0x4c0\n\t"
-        "s_load_dword %0, %1, 0x500\n\ts_load_dword %0, %1, 0x540\n\ts_load_dword %0, %1, 0x580\n\ts_load_dword %0, %1, 0x5c0\n\t"
-        "s_load_dword %0, %1, 0x600\n\ts_load_dword %0, %1, 0x640\n\ts_load_dword %0, %1, 0x680\n\ts_load_dword %0, %1, 0x6c0\n\t"
-        "s_load_dword %0, %1, 0x700\n\ts_load_dword %0, %1, 0x740\n\ts_load_dword %0, %1, 0x780\n\ts_load_dword %0, %1, 0x7c0\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(sink)
-        : "s"(kbase)
-        : "memory");
-    (void)sink;
-  }
   int total = ts[0];
 #pragma unroll
   for (int i = 1; i < 9; ++i) total = i <= nprob ? ts[i] : total;
@@ -542,6 +523,7 @@ __global__ __launch_bounds__(512) void linear_stream2_kernel(StreamGroup2 g, lon
   if (TRACE && tr && threadIdx.x == 0) {
     tr[62] = nst;
     tr[63] = __builtin_readcyclecounter();
+    tr[61] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -597,10 +597,13 @@ class DeAOTLSTT:
             out0.hi.data_ptr() + off0 * 2, out0.lo.data_ptr() + off0 * 2, ldo0,
             out1.hi.data_ptr() + off1 * 2, out1.lo.data_ptr() + off1 * 2, ldo1, hip.stream_ptr())
 
-    def _ev(self, name: str, flops: float = 0.0, nbytes: float = 0.0):
+    def _ev(self, name: str, flops: float = 0.0, nbytes: float = 0.0, overhead: float = 0.0):
         """Context manager: HIP events around one launch of the memory path while bench.py samples a frame
-        (self._kev is a list); a no-op otherwise.  flops / nbytes = the launch's ALGORITHMIC work (unpadded, one
-        product per multiply-add, every operand read once and every output written once in this layout)."""
+        (self._kev is a list); a no-op otherwise.  flops / nbytes = the launch's ALGORITHMIC work as SURVEY section 8d counts
+        it (unpadded, one product per multiply-add, every operand read once and every final output written once; the bank
+        and Q at 2 bytes per element, fp32 outputs; projections with fp32-equivalent operands).  overhead = bytes the
+        design moves on top of that and no algorithm needs: the split partials of the key-split reads (written by the read,
+        re-read by the combine) and of the split-K projections."""
         import contextlib
         if self._kev is None:
             return contextlib.nullcontext()
@@ -611,7 +614,7 @@ class DeAOTLSTT:
             e0.record()
             yield
             e1.record()
-            self._kev.append((name, e0, e1, float(flops), float(nbytes)))
+            self._kev.append((name, e0, e1, float(flops), float(nbytes), float(overhead)))
         return cm()
 
     def kernel_report(self, mfma_peak_tflops: float, hbm_peak_gbs: float = 8000.0):
@@ -622,25 +625,27 @@ class DeAOTLSTT:
         torch.cuda.synchronize()
         frames = self._kev_frames
         acc: Dict[str, list] = {}
-        for name, e0, e1, fl, by in self._kev_store:
-            a = acc.setdefault(name, [0, 0.0, 0.0, 0.0])
+        for name, e0, e1, fl, by, ov in self._kev_store:
+            a = acc.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e3
             a[2] += fl
             a[3] += by
+            a[4] += ov
         out = []
-        for name, (n, us, fl, by) in acc.items():
-            ent = {"kernel": name, "launches_per_frame": n / frames, "mean_us": us / n, "us_per_frame": us / frames}
+        for name, (n, us, fl, by, ov) in acc.items():
+            ent = {"kernel": name, "launches_per_frame": n / frames, "mean_us": us / n, "us_per_frame": us / frames,
+                   "algorithmic_mb_per_launch": by / n / 1e6, "overhead_mb_per_launch": ov / n / 1e6}
             if fl > 0:
                 ach = fl / (us * 1e-6) / 1e12
                 ent.update(bound="mfma", algorithmic_gflop_per_launch=fl / n / 1e9, achieved=ach, peak=mfma_peak_tflops,
                            unit="TFLOP/s", frac=ach / mfma_peak_tflops)
-                if by > 0:
-                    ent["algorithmic_mb_per_launch"] = by / n / 1e6
             else:
+                # bandwidth-bound classes: `achieved` counts the ALGORITHMIC bytes only (a kernel that moves nothing but
+                # split partials -- the combine -- achieves 0); what it really moves per second is `moved_gbs`
                 ach = by / (us * 1e-6) / 1e9
-                ent.update(bound="hbm", algorithmic_mb_per_launch=by / n / 1e6, achieved=ach, peak=hbm_peak_gbs,
-                           unit="GB/s", frac=ach / hbm_peak_gbs)
+                ent.update(bound="hbm", achieved=ach, peak=hbm_peak_gbs, unit="GB/s", frac=ach / hbm_peak_gbs,
+                           moved_gbs=(by + ov) / (us * 1e-6) / 1e9)
             out.append(ent)
         out.sort(key=lambda e: -e["us_per_frame"])
         return out
@@ -684,9 +689,9 @@ class DeAOTLSTT:
         lib, st = hip.load(), hip.stream_ptr()
         N, ks = self.N, A[0].ksplits
         with self._ev("read64_kernel (self read: T=1, Q=K)", flops=2.0 * N * A[0].T * N * (1024 + 128),
-                      nbytes=N * 4.0 * (A[0].T * 1152 + 128 + 1024)):
+                      nbytes=N * (2.0 * (A[0].T * 1152 + 128) + 4.0 * 1024), overhead=ks * N * 4096.0):
             hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "rmem_attn_read")
-        with self._ev("read_combine_kernel", nbytes=(ks + 2) * N * 4096.0):
+        with self._ev("read_combine_kernel", nbytes=0.0, overhead=(ks + 2) * N * 4096.0):
             hip.check(lib.rmem_attn_read_combine(C.byref(A[1]), st), "rmem_attn_read_combine")
 
     def _read_pair(self, A, B, long_done: bool = False):
@@ -703,13 +708,16 @@ class DeAOTLSTT:
         if self._skip_read2:               # part "tail": this launch is issued separately (launch_read2_layer0)
             self._skip_read2 = False
         else:
+            # algorithmic bytes = SURVEY 8d's "long-term kernel I/O" (68.1 MB per frame / 3 at 480p K=4: bank and Q at 2
+            # bytes, fp32 output); the windowed read's operands (one more slot, the relative bias, its output) are NOT added
             with self._ev("read64x2_kernel (long-term + windowed read)", flops=self.read_flops(A[0].T),
-                          nbytes=self.N * 4.0 * ((A[0].T + 1) * 1152 + 2 * 128 + A[0].T + self.WIN + 2 * 1024)):
+                          nbytes=self.N * (2.0 * (A[0].T * 1152 + 128) + 4.0 * 1024),
+                          overhead=(A[0].ksplits + B[0].ksplits) * self.N * 4096.0):
                 hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
         if self._timing:
             e1.record()
             self._events.append((e0, e1, A[0].T))
-        with self._ev("read_combine2_kernel", nbytes=(A[0].ksplits + B[0].ksplits + 4) * self.N * 4096.0):
+        with self._ev("read_combine2_kernel", nbytes=0.0, overhead=(A[0].ksplits + B[0].ksplits + 4) * self.N * 4096.0):
             hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
 
     def _dwconv(self, ws: "_AttnWS", wt, out: Planes):
@@ -951,7 +959,7 @@ class DeAOTLSTT:
         # -- both projections (transformer.py:1212-1220) as ONE split-K GEMM; the residual
         #    adds happen in the norms that follow (rmem_layernorm_red)
         with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * 2048 * 512,
-                      nbytes=4.0 * (N * 2048 + 512 * 2048 + self.KS * N * 512)):
+                      nbytes=4.0 * (N * 2048 + 512 * 2048 + N * 512), overhead=4.0 * (self.KS - 1) * N * 512):
             hip.linear(self.Ylt, W.Wp_ls, N, 512, 2048, ldx=1024, ldy=2048, x2=self.Yst, ldx2=1024,
                        kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=self._tile(192), ksplits=self.KS, parts=self.parts,
                        part_stride=N * 512)       # 64 x 128 tiles: 27.5 -> 21.2 us (L2 -> LDS traffic -25 %)
@@ -992,7 +1000,7 @@ class DeAOTLSTT:
         self._dwconv(self.ws_main, W.dw_self, self.Ylt)
         if l + 1 < self.L:     # split-K, folded into the next layer's norm1 / id_norm1
             with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * 1024 * 512,
-                          nbytes=4.0 * (N * 1024 + 512 * 1024 + self.KS * N * 512)):
+                          nbytes=4.0 * (N * 1024 + 512 * 1024 + N * 512), overhead=4.0 * (self.KS - 1) * N * 512):
                 hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
                            tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
         elif self.clips_per_launch == 1 and not self._force_tiles:
@@ -1000,7 +1008,7 @@ class DeAOTLSTT:
             # (planes into the free self-attention input buffer, unused) -- 12.9 + 6.3 us against 24.7 us for the
             # read-modify-write epilogue of a full-K launch -- and the GroupNorm reads tgt / tgt_id
             with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * 1024 * 512,
-                          nbytes=4.0 * (N * 1024 + 512 * 1024 + self.KS * N * 512)):
+                          nbytes=4.0 * (N * 1024 + 512 * 1024 + N * 512), overhead=4.0 * (self.KS - 1) * N * 512):
                 hip.linear(self.Ylt, W.Wp_self, N, 512, 1024, ldx=1024, ldy=1024, bias=W.bp_self, nsplit=ns,
                            tile=self._tile(192), ksplits=self.KS, parts=self.parts, part_stride=N * 512)
             self._gn_fold = True           # the GroupNorm's statistics pass folds these partials (rmem_groupnorm2_fold)

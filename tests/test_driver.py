@@ -600,12 +600,25 @@ def test_bench_line_contract_single_gpu():
     assert 3 <= len(ks) <= 5 and any(k["kernel"].startswith("read64x2_kernel") for k in ks[:2])
     assert [k["us_per_frame"] for k in ks] == sorted((k["us_per_frame"] for k in ks), reverse=True)
     for k in ks:
-        assert k["bound"] in ("mfma", "hbm") and 0 < k["frac"] < 1 and k["launches_per_frame"] >= 1
+        assert k["bound"] in ("mfma", "hbm") and 0 <= k["frac"] < 1 and k["launches_per_frame"] >= 1
         assert abs(k["us_per_frame"] - k["mean_us"] * k["launches_per_frame"]) < 1e-6 * k["us_per_frame"]
+        # algorithmic bytes = SURVEY 8d's (operands once + final outputs); what the split design moves on top is `overhead`
+        assert k["algorithmic_mb_per_launch"] >= 0 and k["overhead_mb_per_launch"] >= 0
+        if k["kernel"].startswith("read_combine"):          # merges split partials: no algorithmic byte of its own
+            assert k["algorithmic_mb_per_launch"] == 0 and k["frac"] == 0 and k["overhead_mb_per_launch"] > 10 and k["moved_gbs"] > 0
+        else:
+            assert k["frac"] > 0
         if k["bound"] == "mfma":
             assert abs(k["achieved"] - k["algorithmic_gflop_per_launch"] * 1e9 / (k["mean_us"] * 1e-6) / 1e12) < 1e-6 * k["achieved"]
     assert any(k["kernel"].startswith("linear_stream_kernel") for k in ks)
     rk = next(k for k in ks if k["kernel"].startswith("read64x2_kernel"))
+    # 480p K=4: 22.7 MB per launch (68.1 MB per frame / 3) -- the split partials are overhead, not algorithmic
+    assert abs(rk["algorithmic_mb_per_launch"] - 22.72) < 0.05 and rk["overhead_mb_per_launch"] > 30
+    if rk.get("traffic"):
+        assert rk["traffic_over_algorithmic"] > 3.0
+    assert 0.005 < top["memory_path_frac"] < 0.5 and 100 < top["memory_path_gflop_per_frame"] < 135
+    assert abs(top["memory_path_frac"] - top["memory_path_gflop_per_frame"] * 1e9 / (top["memory_path_us_per_frame_sampled"] * 1e-6)
+               / 1e12 / 2500.0) < 1e-9
     # the two sampling methods see the same kernel (two event samples in a 12-step run beside the encoder stream: launches of
     # this kernel range 95-197 us inside a frame, profiles/r05_bench_x3_kernel_stats.md)
     assert 0.5 < rk["mean_us"] / r["mean_us"] < 2.0

@@ -117,6 +117,8 @@ def trace_main():
         t = tr.cpu()
         rows = []
         ends = []
+        rt0 = [int(t[b][60]) for b in range(256) if int(t[b][63]) != 0]
+        rt1 = [int(t[b][61]) for b in range(256) if int(t[b][63]) != 0]
         for b in range(256):
             r = t[b]
             if int(r[63]) == 0:
@@ -127,7 +129,13 @@ def trace_main():
                 stamps = [int(r[1] - r[0])] + [int(r[2 + i] - r[0]) for i in range(min(2 * n, 60))] + [int(r[63] - r[0])]
                 rows.append({"block": b, "stages": n, "cycles_since_start": stamps})
         ends.sort()
-        out[name] = {"workgroups": len(ends), "end_cycles_median": ends[len(ends) // 2], "end_cycles_max": ends[-1], "rows": rows}
+        # device-wide 100 MHz clock: first start -> last end of the launch, spread of the starts, and the shader clock implied
+        span = (max(rt1) - min(rt0)) / 100.0
+        durs = sorted((b - a) / 100.0 for a, b in zip(rt0, rt1))
+        out[name] = {"workgroups": len(ends), "end_cycles_median": ends[len(ends) // 2], "end_cycles_max": ends[-1],
+                     "span_us": round(span, 2), "start_spread_us": round((max(rt0) - min(rt0)) / 100.0, 2),
+                     "wg_us_median": round(durs[len(durs) // 2], 2), "wg_us_max": round(durs[-1], 2),
+                     "ghz": round(ends[len(ends) // 2] / max(durs[len(durs) // 2], 1e-9) / 1e3, 3), "rows": rows}
     print(json.dumps(out))
 
 
