@@ -200,6 +200,24 @@ def init_dist(world: int):
     return dist
 
 
+def first_convolutions_in_turn(dist, fn):
+    """Runs `fn` -- a warm-up that takes every convolution of the model through MIOpen for the first time -- on the rank
+    with LOCAL_RANK 0 first and on the node's other ranks after it.  Ranks that start together on a cold MIOpen cache
+    (kernel cache, user find-db) race for it, and a rank that loses a race can end up on another solver than the rank that
+    filled the entry -- label hashes then differ between an 8-rank and a 1-rank run of the same clips
+    (profiles/r05g_world_hash_probe.txt: 6 of 8 clips on the first run of a fresh box, none afterwards).  One barrier."""
+    if dist is None or dist.get_world_size() == 1:
+        return fn()
+    first = int(os.environ.get("LOCAL_RANK", "0")) == 0
+    if not first:
+        dist.barrier()
+    out = fn()
+    torch.cuda.synchronize()
+    if first:
+        dist.barrier()
+    return out
+
+
 def gather_rank_vectors(dist, vec, dev):
     """Every rank's list of floats -> [world][len] (one all-gather; the values themselves are host-side statistics)."""
     if dist is None:
@@ -746,11 +764,12 @@ def clips64(args, world, rank, local_rank, dev, dist):
         return [D.make_samples(imgs[t].to(dev), lab0 if t == 0 else None, (H_OUT, W_OUT), 3, name=f"{t:05d}.jpg")
                 for t in range(F_)]
 
-    # warm-up clip (MIOpen solver search, hipGraph captures of the first geometry): not timed
+    # warm-up clip (MIOpen solver search, hipGraph captures of the first geometry): not timed; the node's first rank before
+    # the others (first_convolutions_in_turn)
     if args.batched:
-        drv.run_clips([frames_of(10 ** 6 + i) for i in range(args.clips_per_rank)], num_frames=F_)
+        first_convolutions_in_turn(dist, lambda: drv.run_clips([frames_of(10 ** 6 + i) for i in range(args.clips_per_rank)], num_frames=F_))
     else:
-        drv.run_clip(frames_of(10 ** 6), num_frames=F_)
+        first_convolutions_in_turn(dist, lambda: drv.run_clip(frames_of(10 ** 6), num_frames=F_))
     # all clips of this rank are materialised first so that the timed window holds no host-side synthesis
     mine = D.shard_clips(n_clips, world, rank)
     cache = {c: frames_of(c) for c in mine}
