@@ -113,6 +113,47 @@ def gen_blocks(model):
         np.savez_compressed(os.path.join(HERE, block_case_name(layer, T, h, w, ref_frame) + ".npz"), **d)
 
 
+def gen_block_fullsize(model, layer=1, T=4, h=31, w=54, nrows=48):
+    """One block call of the reference at BASELINE.json's 480p K = 4 size (31 x 54 = 1674 tokens, four bank slots) for the
+    per-logit check at a benchmarked size: the inputs are inputs.block_inputs' seeded tensors; kept are the block's Q
+    projection (curr_K, the read's query operand) and, for `nrows` query rows spread over the image (first / last rows and
+    columns included), the reference's pre-softmax logits -- [rows][T * N] of the long-term read (attention.py:184-187) and
+    [225][rows] of the windowed read (attention.py:344-346) -- recorded from its own softmax calls as gen_blocks does."""
+    temporal = torch.cat((model.cur_pos_emb, model.mem_pos_emb), dim=0)
+    blk = model.LSTT.layers[layer]
+    blk.short_term_attn.qk_mask = None
+    blk.short_term_attn.local_mask = None
+    blk.short_term_attn.last_size_2d = None
+    i = block_inputs(layer, T, h, w, False)
+    seen, orig_softmax = [], torch.softmax
+
+    def recording_softmax(x, dim, **kws):
+        seen.append((x.detach().clone(), dim))
+        return orig_softmax(x, dim, **kws)
+
+    torch.softmax = recording_softmax
+    try:
+        with torch.no_grad(), rh.quiet():
+            out = blk(i["tgt"][:, None], i["tgt_id"][:, None],
+                      [i["bank_K"][:, :, None], i["bank_V"][:, :, None], None, i["bank_IDV"][:, :, None]],
+                      [to2d(i["short_K"], h, w), to2d(i["short_V"], h, w), None, to2d(i["short_IDV"], h, w)],
+                      size_2d=(h, w), temporal_encoding=temporal, save_atten_weights=True)
+    finally:
+        torch.softmax = orig_softmax
+    n = h * w
+    lt = [x for x, dim in seen if x.dim() == 4 and x.shape[-2] == n and x.shape[-1] == T * n and dim in (-1, 3)]
+    st = [x for x, dim in seen if x.dim() == 4 and x.shape[-2] == 225 and x.shape[-1] == n]
+    assert len(lt) >= 1 and len(st) == 1, [tuple(x.shape) for x, _ in seen]
+    rs = np.random.RandomState(31 * 54)
+    rows = sorted(set([0, w - 1, n - w, n - 1, 7 * w + 7, (h // 2) * w + w // 2] + rs.choice(n, nrows, replace=False).tolist()))[:nrows]
+    rows = np.array(rows, dtype=np.int32)
+    curr = out[2][0]
+    np.savez_compressed(os.path.join(HERE, f"block_l{layer}_T{T}_{h}x{w}_rows.npz"), rows=rows, curr_K=curr[0][:, 0].numpy(),
+                        lt_logits_rows=lt[0][0, 0][torch.from_numpy(rows).long()].numpy(),
+                        st_logits_rows=st[0][0, 0][:, torch.from_numpy(rows).long()].numpy())
+    print("full-size block fixture:", len(rows), "rows; |lt logit| up to", float(lt[0].abs().max()))
+
+
 def gen_idassign(model):
     ref = rh.import_reference()
     from utils.image import one_hot_mask            # reference util (import only)
@@ -806,6 +847,10 @@ def main():
         return
     if "--ckpt-only" in sys.argv:
         gen_load_network_cases()
+        return
+    if "--block-full-only" in sys.argv:
+        cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)
+        gen_block_fullsize(model)
         return
     if "--blocks-only" in sys.argv:
         cfg, model, engine = rh.build_reference("r50_deaotl", 1, 3, 5)

@@ -251,6 +251,7 @@ def test_480p_long_clip_gap5_vs_reference(golden_dir):
     from rmem_amd.synth import synth_clip
     meta = json.load(open(os.path.join(golden_dir, "clip_480p_long.json")))
     gold = np.load(os.path.join(golden_dir, "clip_480p_long.npz"))
+    gold32 = np.load(os.path.join(golden_dir, "clip_480p_long_logits32.npz"))       # the same frames' decoder logits in fp32 (make_logits32.py)
     ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_480p_long_fp64.npz")))
     assert meta["gap"] == 5 and meta["evictions"] >= 5 and meta["frames"] >= 41
     cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"], 3)
@@ -267,8 +268,8 @@ def test_480p_long_clip_gap5_vs_reference(golden_dir):
         n32, n64, w = ties.check(t, p8, gold["labels"][t - 1], PRODUCT_TIE_MARGIN)
         mism.append(n32), mism64.append(n64)
         worst = max(worst, w)
-        if f"logits_{t}" in gold:
-            ref = gold[f"logits_{t}"].astype(np.float32)
+        if f"logits_{t}" in gold32:
+            ref = gold32[f"logits_{t}"]
             lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - ref).max())
         fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
         eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
@@ -276,16 +277,18 @@ def test_480p_long_clip_gap5_vs_reference(golden_dir):
     ref64 = [ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"])]
     print("long 480p clip, gap 5: pixels off the reference's fp32 maps per frame:", mism)
     print("  off the fp64 maps:", mism64, "= ", sum(mism64), "; the fp32 reference itself:", sum(ref64),
-          "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; logit err (fp16 fixture):", lerrs)
+          "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; decoder-logit err (fp32 fixture):", lerrs)
     # Distance from the fp64 maps, as a statement about accuracy rather than a pixel budget: the fp32 reference itself is off
     # fp64 on 20 pixels of this clip, all with fp64 margins below 2.1e-6 (172 pixels of the 45 frames are that close, 407
     # closer than 5e-6).  Which of those a correct fp32-class path flips is a coin toss per pixel -- and a different one per
     # PROCESS here, MIOpen's encoder features not being reproducible between processes: 22-30 over the round's boxes.
-    # Asserted: no moved pixel has a margin above four times the reference's own worst flip, and the clip is not more
-    # than twice as far from fp64 as the reference.
-    assert worst < 8.4e-6, worst
-    assert sum(mism64) <= 2 * sum(ref64), (sum(mism64), sum(ref64))
-    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-2
+    # Asserted (round 6: at what was measured, not at twice it): no moved pixel has an fp64 margin above 5e-6 (3.2e-6
+    # measured; the reference's own worst flip is 2.1e-6), the clip is at most twelve pixels further from the fp64 maps
+    # than the fp32 reference (22-30 against 20 measured), and the decoder logits of frames 1, 20 and 45 are within 1e-4
+    # of the reference's fp32 logits (MIOpen's convolutions against oneDNN's: ~1e-5).
+    assert worst < 5e-6, worst
+    assert sum(mism64) <= sum(ref64) + 12, (sum(mism64), sum(ref64))
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 1e-4, lerrs
 
 
 def test_480p_lstt_isolated_from_miopen(golden_dir):
@@ -582,6 +585,8 @@ def test_720p_k8_vs_reference(golden_dir):
     from rmem_amd.synth import synth_clip
     meta = json.load(open(os.path.join(golden_dir, "clip_720p_k8.json")))
     gold = np.load(os.path.join(golden_dir, "clip_720p_k8.npz"))
+    gold32 = np.load(os.path.join(golden_dir, "clip_720p_k8_logits32.npz"))          # decoder logits of the same frames in fp32
+    gold32 = np.load(os.path.join(golden_dir, "clip_720p_k8_logits32.npz"))
     ties = Fp64Ties(np.load(os.path.join(golden_dir, "clip_720p_k8_fp64.npz")))
     assert (meta["H"], meta["W"], meta["former"] + meta["latter"], meta["gap"]) == (721, 1281, 8, 1) and meta["evictions"] >= 1
     cfg, cpu_model, gpu_model, eng = _build(meta["former"], meta["latter"], meta["gap"], 3)
@@ -598,18 +603,18 @@ def test_720p_k8_vs_reference(golden_dir):
         n32, n64, w = ties.check(t, p8, gold["labels"][t - 1], PRODUCT_TIE_MARGIN)
         mism.append(n32), mism64.append(n64)
         worst = max(worst, w)
-        if f"logits_{t}" in gold:
-            ref = gold[f"logits_{t}"].astype(np.float32)
+        if f"logits_{t}" in gold32:
+            ref = gold32[f"logits_{t}"]
             lerrs[t] = float(np.abs(eng.aot_engines[0].pred_id_logits.cpu().numpy() - ref).max())
         fed = torch.from_numpy(gold["labels"][t - 1]).float()[None, None].to(DEV)
         eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode="nearest"))
         assert list(eng.aot_engines[0].long_memories_indexes) == meta["indexes"][t - 1], (t, meta["indexes"][t - 1])
     ref64 = [ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"])]
     print("720p K=8 vs the reference: pixels off its fp32 maps per frame (of 921600):", mism, "; off the fp64 maps:", mism64,
-          "; the fp32 reference itself:", ref64, "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; logit err (fp16 fixture):", lerrs)
+          "; the fp32 reference itself:", ref64, "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; decoder-logit err (fp32 fixture):", lerrs)
     assert len(meta["indexes"][-1]) == 8 and meta["indexes"][-1] != list(range(8))
-    assert sum(mism64) <= 2 * sum(ref64) + 2, (mism64, ref64)
-    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-2
+    assert sum(mism64) <= sum(ref64) + 6, (mism64, ref64)         # (14 against the reference's own 13 measured)
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 1e-4, lerrs
 
 
 def test_paired_launches_bit_identical():
@@ -832,8 +837,7 @@ def test_closed_loop_product_engine_vs_oracle():
             exact += 1
             assert list(eng.aot_engines[0].long_memories_indexes) == list(ora.engines[0].long_memories_indexes)
     print("closed loop (product engine): clips pixel-exact through the last frame:", exact, "of", len(CLOSED_LOOP_SEEDS))
-    assert exact == len(CLOSED_LOOP_SEEDS) or os.environ.get("RMEM_TEST_ALLOW_MIOPEN_TIES") == "1", \
-        (exact, "a diverging clip passed the near-tie check above; set RMEM_TEST_ALLOW_MIOPEN_TIES=1 to accept it on this box")
+    assert exact == len(CLOSED_LOOP_SEEDS), (exact, "a clip diverged from the oracle (at oracle near-tie pixels: see above)")
 
 
 def test_long_clip_eviction_history_vs_oracle():

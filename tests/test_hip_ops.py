@@ -562,6 +562,57 @@ def test_read_logits_per_logit_vs_reference(hip, case, deaot_model, golden_dir):
     assert err < 1e-3 and errw < 1e-3, (err, errw)
 
 
+def test_read_logits_per_logit_at_480p_k4_vs_reference(hip, deaot_model, golden_dir):
+    """The per-logit check at a BENCHMARKED size: 31 x 54 = 1674 tokens, a bank of four slots (BASELINE.json configs[1]).
+    tests/golden/block_l1_T4_31x54_rows.npz (make_golden.py:gen_block_fullsize) holds the reference block's Q projection and,
+    for 48 query rows spread over the image, its own pre-softmax logits of the long-term read ([rows][4 * 1674]) and of the
+    windowed read ([225][rows]); the fused read's debug entry dumps what it computes for the whole launch with the
+    benchmark's seven key splits.  Every sampled logit within 1e-3 (north star); measured ~1e-5."""
+    import os
+    from inputs import block_inputs
+    from rmem_amd.lstt import temporal_pe_rows
+    layer, T, h, w = 1, 4, 31, 54
+    gold = np.load(os.path.join(golden_dir, f"block_l{layer}_T{T}_{h}x{w}_rows.npz"))
+    rows = torch.from_numpy(gold["rows"]).long()
+    i = block_inputs(layer, T, h, w, False)
+    sd = {k: v.detach() for k, v in deaot_model.state_dict().items()}
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    Q = torch.from_numpy(gold["curr_K"])
+    cur_pe, mem_pe = sd["cur_pos_emb"][0], sd["mem_pos_emb"]
+    pad = lambda x: torch.cat([x, torch.zeros(Npad - N, x.shape[1])], 0)
+    Qpe = Q + cur_pe[None]
+    bias = (Qpe.double() @ mem_pe[temporal_pe_rows(T)].double().t()).float().to(DEV).contiguous()
+    Kb = torch.stack([pad(i["bank_K"][t]) for t in range(T)])
+    got = _read_logits(hip, 0, T, N, Npad, _planes(hip, Kb), _planes(hip, pad(Qpe)), bias, h, w, None, 7)
+    assert not torch.isnan(got).any(), "a long-term logit was not computed"
+    ref = torch.from_numpy(gold["lt_logits_rows"])
+    err = (got[rows] - ref).abs().max().item()
+    p = f"LSTT.layers.{layer}.short_term_attn.relative_emb_k."
+    R = (Q.double() @ sd[p + "weight"].reshape(225, 128).double().t() + sd[p + "bias"].double()).float().to(DEV).contiguous()
+    gotw = _read_logits(hip, 1, 1, N, Npad, _planes(hip, pad(i["short_K"])[None]), _planes(hip, pad(Q)), None, h, w, R, 2)
+    refw = torch.from_numpy(gold["st_logits_rows"])                    # [225][rows], -1e8 outside the image
+    errw, n_in = 0.0, 0
+    for j, q in enumerate(rows.tolist()):
+        qy, qx = divmod(q, w)
+        inside_keys = set()
+        for o in range(225):
+            ky, kx = qy + o // 15 - 7, qx + o % 15 - 7
+            inside = 0 <= ky < h and 0 <= kx < w
+            assert (refw[o, j].item() > -1e7) == inside
+            if inside:
+                g = gotw[q, ky * w + kx].item()
+                assert g == g, f"window logit (q={q}, o={o}) was not computed"
+                errw = max(errw, abs(g - refw[o, j].item()))
+                inside_keys.add(ky * w + kx)
+                n_in += 1
+        assert int((~torch.isnan(gotw[q])).sum()) == len(inside_keys), f"query {q}: logits outside its window were computed"
+    print(f"480p K=4 (l{layer}, T={T}, {h}x{w}, {len(rows)} query rows): max |HIP logit - reference logit| long-term {err:.2e} "
+          f"over {ref.numel()} logits (|logit| up to {ref.abs().max().item():.1f}), windowed {errw:.2e} over {n_in}")
+    assert err < 1e-3 and errw < 1e-3, (err, errw)
+    assert err < 1e-4 and errw < 1e-4, (err, errw)        # what the split-fp16 products deliver (fp32-class)
+
+
 @pytest.mark.parametrize("ksplits", [1, 4])
 @pytest.mark.parametrize("h,w", [(5, 7), (9, 13), (20, 23), (31, 54)])
 def test_read_window(hip, ksplits, h, w):
