@@ -8,9 +8,11 @@
  *
  * Conventions
  *   - every pointer is a device (HBM) pointer unless marked "host";
- *   - no hidden allocation, no synchronisation, no global mutable state: the caller
- *     owns all buffers and workspaces; kernels are enqueued on `stream`
- *     (a hipStream_t passed as void*), so calls are hipGraph-capturable;
+ *   - no hidden allocation, no synchronisation: the caller owns all buffers and
+ *     workspaces; kernels are enqueued on `stream` (a hipStream_t passed as void*), so
+ *     calls are hipGraph-capturable.  The library reads no environment variable; its
+ *     only process-wide state is the set of tuning switches of rmem_configure() below
+ *     (and the per-thread launch recorder, rmem_rec_*);
  *   - return value: 0 = enqueued, <0 = error (RMEM_ERR_*); no exceptions cross the ABI;
  *   - "planes": an fp32 tensor carried as two fp16 tensors hi = fp16(x),
  *     lo = fp16(x - hi), values beyond +-65504 saturated (rmem_f16 = raw IEEE fp16 bits).
@@ -36,6 +38,18 @@ typedef uint16_t rmem_f16;
 
 /* ABI version (bumped on any signature change). */
 int rmem_abi_version(void);
+
+/* Process-wide tuning / debug switches (every one selects between kernels that compute the same results bit for bit, or
+ * serves a debug entry point).  Returns RMEM_ERR_INVALID for an unknown name or a value outside the range; takes effect for
+ * launches issued afterwards.  Names (range, default):
+ *   "linear_tiles"  (0-1, 0)   1: tile-per-workgroup projection kernels for every rmem_linear[_grouped] launch
+ *   "stream_form"   (1-2, 2)   streaming projection kernel: 2 = one-round-trip descriptors + rolled epilogue, 1 = first form
+ *   "stream_var"    (1-4, 1)   rmem_linear_trace only: 2 no operand requests, 3 no MFMAs, 4 no fragment reads (timings, wrong results)
+ *   "dw_rows"       (0-4, 2)   rmem_dwconv5x5_split[2]: output rows per thread (0 = the one-row kernel)
+ *   "dw_rx" (6-12, 9), "dw_v" (1-4, 1)   the one-row kernel's tokens / channels per thread; "dw_grid_order" (0-1, 0) plain block order
+ *   "ida_tokens" (1-2, 1), "ida_unroll" (8-32, 16)   rmem_id_assign
+ *   "read_var"      (0-31, 0)  rmem_attn_read_trace only: experiment mask of the tracing kernel */
+int rmem_configure(const char *name, int64_t value);
 
 /* How host threads of this process wait for `device` (hipSetDeviceFlags): blocking != 0 = sleep on the interrupt
  * (hipDeviceScheduleBlockingSync), 0 = the runtime's default, which spins on a core.  The engine's host thread runs up
@@ -101,43 +115,6 @@ int rmem_linear(const rmem_linear_args *a, void *stream);
  * of one LSTT stage share their input and individually cannot fill 256 CUs. */
 int rmem_linear_grouped(const rmem_linear_args *args, int32_t n, void *stream);
 
-/* LayerNorm fused with the grouped projections that read the normalised rows (one launch, row tile resident in LDS):
- * norm1 / id_norm1 + linear_QV / linear_U / linear_ID_U / relative_emb_k / temporal-PE bias, and norm2 / id_norm2 +
- * self_attn.linear_QK / V1 / V2 / U1 / U2 of GatedPropagationModule.forward (layers/transformer.py:1104-1123,1223-1232,
- * layers/attention.py:151-172,314).  Replaces rmem_layernorm_red[2] followed by rmem_linear_grouped; results are
- * bit-identical to that sequence.
- *
- * Up to two residual streams of 256 channels (tgt, tgt_id); the normalised row seen by the problems is the 512-wide
- * concatenation [LN(stream 0) | LN(stream 1)].  mode 0: stream s is LayerNorm(x + sum_z parts[z]) with the partials summed in
- * split order; when nparts > 0 the folded stream is written to xo, which must differ from x (the workgroups of a row tile
- * read x concurrently); oh/ol (optional) receive the normalised planes.  mode 1: the planes oh/ol already hold the
- * normalised rows (rmem_layernorm_cn wrote them) and are read.
- * Problem i computes D = act(Xn[:, xk0 + b*bxk : +K] . W_b^T + bias) for its batches b; lin gives M (= N rows), N, K
- * (128, 256, 384 or 512), bias, act, the destinations and batch strides exactly as for rmem_linear (xh/xl/yh/yl are ignored,
- * ksplits must be <= 1); wpk = the weight planes packed in MFMA fragment order:
- *   wpk[(((b * ceil(N/32) + u) * (K/16) + ks) * 2 + plane) * 512 + lane * 8 + e]
- *     = plane (0 hi, 1 lo) of W_b[u*32 + (lane & 31)][ks*16 + (lane >> 5)*8 + e]     (rows >= N: zero)
- * Not recordable (rmem_rec_begin): returns RMEM_ERR_INVALID while the thread records, and with RMEM_ROWRES=0. */
-typedef struct {
-  const float *x; float *xo; const float *parts;
-  const float *gamma, *beta;
-  rmem_f16 *oh, *ol; int64_t ldo;
-} rmem_rowres_stream;
-typedef struct {
-  rmem_linear_args lin;
-  const rmem_f16 *wpk;
-  int32_t xk0, bxk;
-} rmem_rowres_problem;
-int rmem_ln_linear_grouped(const rmem_rowres_stream *streams, int32_t nstreams, int32_t mode, int32_t N, int32_t nparts,
-                           int64_t part_stride, int64_t ldpart, float eps, const rmem_rowres_problem *probs, int32_t n,
-                           void *stream);
-/* Debug aid (tools/kbench_rowres.py): the same launch with shader-clock stamps per wave in trace[(workgroup * 8 + wave) * 8 + k]
- * ([0] start, [1] first weight fragments requested, [2] LayerNorm done, [3] barrier passed, [4] MFMAs issued, [5] end);
- * trace holds 64 int64 per workgroup (at most 8 * ceil(N / 512) * 16 workgroups), zeroed by the caller. */
-int rmem_ln_linear_grouped_trace(const rmem_rowres_stream *streams, int32_t nstreams, int32_t mode, int32_t N, int32_t nparts,
-                                 int64_t part_stride, int64_t ldpart, float eps, const rmem_rowres_problem *probs, int32_t n,
-                                 int64_t *trace, void *stream);
-
 /* Debug aid (tools/kbench_gemm.py): the streaming kernel for `n` problems with shader-clock stamps of every workgroup's
  * wave 0 written to trace[workgroup][64] ([0] start, [1] first requests out, [2 + 2 s] / [3 + 2 s] stage s landed / issued,
  * [62] stages, [63] end).  trace must hold 64 int64 per CU.  Split precision (nsplit = 3) only. */
@@ -193,6 +170,12 @@ typedef struct {
                                               hold pf 64-key tiles each, the other ksplits - nfull share the rest evenly (0 = even).
                                               rmem_attn_read2 launches the short pieces last, behind the windowed units, so that
                                               they run on the CUs the windowed units leave early.  Direct launches only. */
+  const float *gate; int64_t ldgate;       /* with ksplits == 1 and gout != NULL the read needs no combine: its units write the normalised, */
+  float *gout; int64_t ldgout;             /* gated aggregate gout[q][c] = gate[q][c] * O[q][c] / l[q] themselves (attention.py:206-209) -- what
+                                              rmem_attn_read_combine computes from one split, operation for operation (bit-identical) --
+                                              and no partial O (part is not written; ml still is).  The windowed read of a layer in one
+                                              split is as long as a long-term unit (the 15 x 15 band of a 64-query tile spans ~15 key tiles):
+                                              no partial round trip for it.  Ignored when ksplits > 1; lslot must be NULL (no mass). */
   float *dbg_logits; int64_t dbg_ld;       /* debug, rmem_attn_read_trace only (ignored by every other entry): when non-NULL every
                                               pre-softmax logit scale*(Q.K + bias) (mode 0) / scale*Q.K + R (mode 1, keys inside the
                                               window) is written to dbg_logits[q*dbg_ld + t*N + key] -- the tensor the reference

@@ -2,6 +2,7 @@
 // (SURVEY.md section 8f-2).  See launch.h for the mechanism and include/rmem_hip.h for the contract.
 #include "../../include/rmem_hip.h"
 #include "launch.h"
+#include <string.h>
 
 namespace rmem {
 static thread_local Recorder* tl_rec = nullptr;
@@ -9,6 +10,30 @@ Recorder* current_recorder() { return tl_rec; }
 }  // namespace rmem
 
 using rmem::Recorder;
+
+RmemConfig& rmem_config() {
+  static RmemConfig cfg;
+  return cfg;
+}
+
+// name -> field; unknown names and out-of-range values are refused (nothing changes)
+extern "C" int rmem_configure(const char* name, int64_t value) {
+  if (!name) return RMEM_ERR_INVALID;
+  RmemConfig& c = rmem_config();
+  const int v = (int)value;
+  struct Key { const char* name; int* field; int lo, hi; };
+  const Key keys[] = {{"linear_tiles", &c.linear_tiles, 0, 1}, {"stream_form", &c.stream_form, 1, 2}, {"stream_var", &c.stream_var, 1, 4},
+                      {"dw_rx", &c.dw_rx, 6, 12}, {"dw_v", &c.dw_v, 1, 4}, {"dw_rows", &c.dw_rows, 0, 4},
+                      {"dw_grid_order", &c.dw_grid_order, 0, 1}, {"ida_tokens", &c.ida_tokens, 1, 2}, {"ida_unroll", &c.ida_unroll, 8, 32},
+                      {"read_var", &c.read_var, 0, 31}};
+  for (const Key& k : keys)
+    if (strcmp(name, k.name) == 0) {
+      if (value < k.lo || value > k.hi) return RMEM_ERR_INVALID;
+      *k.field = v;
+      return RMEM_OK;
+    }
+  return RMEM_ERR_INVALID;
+}
 
 extern "C" void* rmem_rec_begin(void) {
   if (rmem::tl_rec) return nullptr;          // recordings do not nest

@@ -201,7 +201,6 @@ static int validate_linear(rmem_linear_args& a);
 
 #include "linear_stream_v1.h"
 #include "linear_stream.h"
-#include "linear_rowres.h"
 
 // Debug aid: the streaming kernel with cycle stamps (see linear_stream_kernel); trace must hold 64 int64 per workgroup
 // (at most one per CU).  nsplit = 3 only.
@@ -217,8 +216,7 @@ extern "C" int rmem_linear_trace(const rmem_linear_args* args, int32_t n, int64_
     StreamGroup2 g2;
     const int total2 = stream2_group(v, n, g2);
     if (stream2_covers(g2)) {
-      const char* ev = getenv("RMEM_STREAM_VAR");        // timing experiments (linear_stream2_kernel): 2 no requests, 3 no MFMAs, 4 no fragment reads
-      const int var = ev ? atoi(ev) : 1;
+      const int var = rmem_config().stream_var;          // timing experiments (linear_stream2_kernel): 2 no requests, 3 no MFMAs, 4 no fragment reads
       long long* tp = reinterpret_cast<long long*>(trace);
       hipStream_t st = static_cast<hipStream_t>(stream);
       if (var == 2) return launch_stream2<3, 2>(g2, total2, tp, st);

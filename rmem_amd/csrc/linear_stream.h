@@ -528,11 +528,8 @@ __global__ __launch_bounds__(512) void linear_stream2_kernel(StreamGroup2 g, lon
 }
 
 // ---- host side
-// (development switch, removed with the first form: RMEM_STREAM=1 keeps the first form for A/B runs)
-static int stream_form() {
-  static const char* e = getenv("RMEM_STREAM");
-  return (e && e[0] == '1') ? 1 : 2;
-}
+// (rmem_configure("stream_form", 1) keeps the first form for every launch: A/B runs)
+static int stream_form() { return rmem_config().stream_form; }
 static bool aligned_to(const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 static void stream2_desc(const rmem_linear_args& a, StreamDesc& q) {

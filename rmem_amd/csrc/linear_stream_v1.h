@@ -489,12 +489,11 @@ static int launch_stream(const StreamGroup& g, int total, long long* trace, hipS
 
 // The streaming kernel serves a launch issued directly whose problems ask for tile 0 (auto) or 256; tile 64 / 128 / 192
 // select the tile-per-workgroup kernels (kept for the recorded launches of several clips -- launch.h -- and as the
-// bit-identical cross-check), as does RMEM_LINEAR=tiles for every launch.  Stays with the tile kernels as well: items of a
+// bit-identical cross-check), as does rmem_configure("linear_tiles", 1) for every launch.  Stays with the tile kernels as well: items of a
 // single stage (see below), a split-K problem whose last split would be empty (ceil division; the stream counts one stage per k-tile of every item), leading
 // dimensions or item counts beyond what the packed descriptor holds.
 static bool use_stream(const rmem_linear_args* args, int n) {
-  static const char* e = getenv("RMEM_LINEAR");
-  if ((e && e[0] == 't') || rmem::current_recorder()) return false;
+  if (rmem_config().linear_tiles || rmem::current_recorder()) return false;
   long items = 0;
   for (int i = 0; i < n; ++i) {
     const rmem_linear_args& a = args[i];

@@ -412,14 +412,13 @@ __device__ void dwconv5x5_rows_kernel(const DwArgs& a, int) {
   dwconv5x5_rows_body<RX, RY>(p.g, a.ldg, p.wt, a.h, a.w, a.C, p.oh, p.ol, a.ldo, bx, by, which ? bz - a.nz : bz);
 }
 
-// (RX, V) chosen by measurement; RMEM_DW="rx,v" overrides (tuning aid); RMEM_DW_ROWS=RY (2 = default, 3, 4): the
-// RY-rows-per-thread kernel with RX = 9; 0 = the one-row kernel
+// (RX, V) chosen by measurement; rmem_configure("dw_rx" / "dw_v") overrides (tuning aid); "dw_rows" = RY (2 = default, 3, 4):
+// the RY-rows-per-thread kernel with RX = 9; 0 = the one-row kernel
 static int launch_dwconv(DwArgs& a, int nmaps, hipStream_t s) {
-  static const char* env = getenv("RMEM_DW");
-  const char* rows_env = getenv("RMEM_DW_ROWS");      // (read per launch: the bit-identity test switches it inside one process)
+  const RmemConfig& cfg = rmem_config();
   // default 2: two maps 14.7 -> 11.5 us isolated at 480p, 26.8 -> 19.6 at 720p, 160 -> 146 us per frame in the frame; 3 and 4
   // rows are no faster isolated and slower in the frame (152 registers, one round of 384 workgroups): profiles/r05k_dwconv_rows.txt
-  const int ry = rows_env ? atoi(rows_env) : 2;
+  const int ry = cfg.dw_rows;
   if (ry >= 2 && (a.C % 256) == 0) {
     a.nz = a.C / 256;
     a.gx = (a.w + 8) / 9;
@@ -432,15 +431,13 @@ static int launch_dwconv(DwArgs& a, int nmaps, hipStream_t s) {
     if (ry == 4) return rmem::launch<DwArgs, dwconv5x5_rows_kernel<9, 4>, 256>(a, grid, dim3(256), 0, s);
     return RMEM_ERR_INVALID;
   }
-  int rx = 9, v = 1;   // 480p one / two maps: 14.7 / 24.7 us with (6, 4), 9.6 / 16.7 with (9, 1); 720p 26.4 / 47.7 -> 18.9 / 30.6
-  if (env) sscanf(env, "%d,%d", &rx, &v);
+  int rx = cfg.dw_rx, v = cfg.dw_v;   // 480p one / two maps: 14.7 / 24.7 us with (6, 4), 9.6 / 16.7 with (9, 1); 720p 26.4 / 47.7 -> 18.9 / 30.6
   if (a.C % (256 * v)) rx = 6, v = 4;
   a.nz = (a.C + 256 * v - 1) / (256 * v);
   a.gx = (a.w + rx - 1) / rx;
   a.total = a.gx * a.h * nmaps * a.nz;
   a.cap = (a.total + 7) / 8;
-  static const char* ord = getenv("RMEM_DW_ORDER");
-  a.xcd = (ord && ord[0] == 'g') ? 0 : 1;
+  a.xcd = cfg.dw_grid_order ? 0 : 1;
   const dim3 grid(8 * a.cap);
 #define RMEM_DW_CASE(RX_, V_) \
   if (rx == RX_ && v == V_) return rmem::launch<DwArgs, dwconv5x5_split_kernel<RX_, V_>, 256>(a, grid, dim3(256), 0, s);
@@ -738,9 +735,7 @@ extern "C" int rmem_id_assign(const uint8_t* label, int32_t H, int32_t W, const 
     return RMEM_ERR_INVALID;
   IdAssignArgs a{label, H, W, wt, bias, ncls, ksize, stride, pad, ew, gamma, beta, eps, oh, ol, (long)ldo, of32,
                  (long)ldof, ignore_channel};
-  static const char* env = getenv("RMEM_IDA");       // "tokens per block, unroll" (tuning aid)
-  int tok = 1, unr = 16;   // 480p: 25.8 us (35 us before the offsets moved to SGPRs); 2 tokens per block 30.6
-  if (env) sscanf(env, "%d,%d", &tok, &unr);
+  const int tok = rmem_config().ida_tokens, unr = rmem_config().ida_unroll;   // (1, 16): 480p 25.8 us; 2 tokens per block 30.6
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define RMEM_IDA_CASE(T_, U_) \
   if (tok == T_ && unr == U_) \
@@ -1407,4 +1402,4 @@ extern "C" int rmem_set_host_wait(int32_t device, int32_t blocking) {
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 16; }   // 16: rmem_ln_linear_grouped (LayerNorm + grouped projections, row tile resident in LDS); 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_abi_version(void) { return 17; }   // 17: rmem_configure (no getenv in the library), rmem_read_args.gate / gout (single-split reads gate their own output), rmem_ln_linear_grouped removed; 16: rmem_ln_linear_grouped (LayerNorm + grouped projections, row tile resident in LDS); 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

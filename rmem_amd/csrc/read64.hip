@@ -771,8 +771,11 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
   __syncthreads();                                    // the images are dead, the statistics read: LDS is reused below
 
   // ---- flush O: transposed through LDS (the accumulator layout gives one column per lane, i.e. 4-byte
-  // stores; staged as [32 rows][128 columns] per wave the tile leaves as 16-byte stores of 512-byte rows)
+  // stores; staged as [32 rows][128 columns] per wave the tile leaves as 16-byte stores of 512-byte rows).
+  // One split and a gate given (a.gout): the rows leave normalised and gated -- rmem_attn_read_combine's arithmetic for
+  // one split, where the split weight is exp(0) = 1 and the sums collapse: g = (o * (1 / l)) * u -- and no partial is written.
   {
+    const bool fused = a.gout != nullptr && a.ksplits == 1;     // (uniform)
     char* stg = smem + wave * 16384;
     int lrow = hi, lcol = j;                        // opaque: keeps the row pointers out of the prologue
     R6_OPAQUE(lrow);
@@ -787,12 +790,33 @@ __device__ __forceinline__ void read64_mode(const rmem_read_args& a, const int b
           *reinterpret_cast<float*>(stg + row * 512 + (ci * 32 + lcol) * 4) = o[qi][ci][r];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS operations complete in order
-      float* orow = a.part + ((long)z * a.Npad + qtile * 64 + qi * 32) * a.ncols + wave * 128;
+      if (!fused) {
+        float* orow = a.part + ((long)z * a.Npad + qtile * 64 + qi * 32) * a.ncols + wave * 128;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 2 + lrow;
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + lcol * 16);
-        *reinterpret_cast<f32x4_t*>(orow + (long)row * a.ncols + lcol * 4) = v;
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 2 + lrow;
+          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + lcol * 16);
+          *reinterpret_cast<f32x4_t*>(orow + (long)row * a.ncols + lcol * 4) = v;
+        }
+      } else {
+        const int q0 = qtile * 64 + qi * 32;
+        const float* urow = a.gate + (long)q0 * a.ldgate + wave * 128 + lcol * 4;
+        float* grow = a.gout + (long)q0 * a.ldgout + wave * 128 + lcol * 4;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 2 + lrow;
+          if (q0 + row < a.N) {
+            const float inv_l = 1.0f / (l_ex[qi * 32 + row] + l_ex[64 + qi * 32 + row]);
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stg + row * 512 + lcol * 16);
+            const f32x4_t u = *reinterpret_cast<const f32x4_t*>(urow + (long)row * a.ldgate);
+            f32x4_t g;
+            g[0] = v[0] * inv_l * u[0];
+            g[1] = v[1] * inv_l * u[1];
+            g[2] = v[2] * inv_l * u[2];
+            g[3] = v[3] * inv_l * u[3];
+            *reinterpret_cast<f32x4_t*>(grow + (long)row * a.ldgout) = g;
+          }
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next round overwrites
     }
@@ -1014,7 +1038,10 @@ static int read2_many(const rmem::RecOp& op, const char* d, long st, int B, hipS
 
 static int read_args_ok(const rmem_read_args& a) {
   if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) != 0 || a.T <= 0 || a.T > 16 || a.ksplits <= 0 || a.ksplits > 32) return 0;
-  if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.part || !a.ml) return 0;
+  if (!a.qh || !a.ql || !a.kh || !a.kl || !a.vh || !a.vl || !a.ml) return 0;
+  const bool fused = a.gout != nullptr && a.ksplits == 1;      // (the gated aggregate leaves the read itself: no partial buffer needed)
+  if (!fused && !a.part) return 0;
+  if (fused && (!a.gate || a.lslot || (a.ldgate % 4) || (a.ldgout % 4) || a.ldgate < a.ncols || a.ldgout < a.ncols)) return 0;
   if (a.ncols != 1024) return 0;                      // eight waves x 128 columns of [V | ID_V]
   if (a.mode == 1 && (!a.R || a.h * a.w != a.N || a.T != 1 || a.w < 1 || a.ldr < 1)) return 0;
   if (a.mode != 0 && a.mode != 1) return 0;
@@ -1091,8 +1118,7 @@ extern "C" int rmem_attn_read(const rmem_read_args* ap, void* stream) {
 extern "C" int rmem_attn_read_trace(const rmem_read_args* ap, int64_t* trace, void* stream) {
   if (!ap || !trace || !read_args_ok(*ap) || rmem::current_recorder()) return RMEM_ERR_INVALID;
   const int chunk = read_chunk(*ap);
-  const char* ev = getenv("RMEM_READ_VAR");           // experiments (see read64_body)
-  const int var = ev ? atoi(ev) & 31 : 0;
+  const int var = rmem_config().read_var;             // experiments (see read64_body)
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
     hipLaunchKernelGGL(kern, dim3(8 * chunk), dim3(512), R6_LDS, static_cast<hipStream_t>(stream), *ap,

@@ -18,6 +18,20 @@
 #define RMEM_ERR_INVALID (-1)
 #define RMEM_ERR_LAUNCH (-2)
 
+// Process-wide tuning / debug switches of the library.  The library never reads the environment: a host sets these through
+// rmem_configure() (include/rmem_hip.h; rmem_amd/hip.py maps its RMEM_* variables onto it once, when it loads the library).
+struct RmemConfig {
+  int linear_tiles = 0;      // 1: tile-per-workgroup projection kernels for every launch (A/B and cross-check)
+  int stream_form = 2;       // 1: first form of the streaming projection kernel (kept for generic epilogue shapes), 2: second form
+  int stream_var = 1;        // rmem_linear_trace only: 2 no operand requests, 3 no MFMAs, 4 no fragment reads (timing experiments)
+  int dw_rx = 9, dw_v = 1;   // depth-wise conv, one-row kernel: tokens per thread, channels per thread
+  int dw_rows = 2;           // depth-wise conv: output rows per thread (0: the one-row kernel)
+  int dw_grid_order = 0;     // 1: plain grid order instead of the XCD-aware block order
+  int ida_tokens = 1, ida_unroll = 16;   // ID assignment: tokens per block, unroll
+  int read_var = 0;          // rmem_attn_read_trace only: experiment mask of the tracing kernel (4, 8, 16)
+};
+RmemConfig& rmem_config();   // batch.hip
+
 typedef unsigned short h16_t;  // raw 16 bits of a plane element (IEEE fp16)
 typedef __attribute__((ext_vector_type(8))) _Float16 frag8_t;   // MFMA operand fragment: 8 consecutive k of one row
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;

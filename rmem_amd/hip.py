@@ -44,15 +44,6 @@ class LinearArgs(C.Structure):
     ]
 
 
-class RowresStream(C.Structure):
-    _fields_ = [("x", c_p), ("xo", c_p), ("parts", c_p), ("gamma", c_p), ("beta", c_p),
-                ("oh", c_p), ("ol", c_p), ("ldo", i64)]
-
-
-class RowresProblem(C.Structure):
-    _fields_ = [("lin", LinearArgs), ("wpk", c_p), ("xk0", i32), ("bxk", i32)]
-
-
 class ReadArgs(C.Structure):
     _fields_ = [
         ("mode", i32),
@@ -62,7 +53,8 @@ class ReadArgs(C.Structure):
         ("slot_map", c_p), ("T", i32), ("N", i32), ("Npad", i32), ("ncols", i32),
         ("scale", f32), ("bias", c_p), ("R", c_p), ("ldr", i32), ("h", i32), ("w", i32), ("rcs", i32),
         ("ksplits", i32), ("part", c_p), ("ml", c_p), ("lslot", c_p), ("sched", c_p),
-        ("nfull", i32), ("pf", i32), ("dbg_logits", c_p), ("dbg_ld", i64),
+        ("nfull", i32), ("pf", i32), ("gate", c_p), ("ldgate", i64), ("gout", c_p), ("ldgout", i64),
+        ("dbg_logits", c_p), ("dbg_ld", i64),
     ]
 
 
@@ -103,7 +95,7 @@ class LabelSrc(C.Structure):
 
 
 EXPORTS = [
-    "rmem_abi_version", "rmem_set_host_wait", "rmem_linear", "rmem_linear_trace",
+    "rmem_abi_version", "rmem_configure", "rmem_set_host_wait", "rmem_linear", "rmem_linear_trace",
     "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_fg_weights", "rmem_bank_reset", "rmem_bank_append",
     "rmem_bank_policy_step", "rmem_split_planes", "rmem_groupnorm_nchw",
@@ -113,7 +105,7 @@ EXPORTS = [
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2", "rmem_layernorm_cn",
     "rmem_bias_act_nchw_batched", "rmem_dwconv5x5_split2",
     "rmem_attn_read", "rmem_attn_read_trace", "rmem_attn_read2", "rmem_attn_read_combine", "rmem_attn_read_combine2",
-    "rmem_rec_end", "rmem_launch_recorded", "rmem_ln_linear_grouped", "rmem_ln_linear_grouped_trace", "rmem_groupnorm2_fold",
+    "rmem_rec_end", "rmem_launch_recorded", "rmem_groupnorm2_fold",
 ]
 # exports with a non-int return type
 EXPORTS_OTHER = ["rmem_rec_begin", "rmem_rec_free", "rmem_rec_count", "rmem_rec_size", "rmem_rec_data",
@@ -124,7 +116,7 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 16          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
+ABI_VERSION = 17          # rmem_abi_version() of the library these ctypes structures describe (include/rmem_hip.h)
 
 
 def load():
@@ -142,13 +134,10 @@ def load():
                         "stale library -- rebuild with `python -m rmem_amd.build --force`")
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
+    lib.rmem_configure.argtypes = [C.c_char_p, i64]
     lib.rmem_linear.argtypes = [C.POINTER(LinearArgs), c_p]
     lib.rmem_linear_grouped.argtypes = [C.POINTER(LinearArgs), i32, c_p]
     lib.rmem_linear_trace.argtypes = [C.POINTER(LinearArgs), i32, c_p, c_p]
-    lib.rmem_ln_linear_grouped.argtypes = [C.POINTER(RowresStream), i32, i32, i32, i32, i64, i64, f32,
-                                           C.POINTER(RowresProblem), i32, c_p]
-    lib.rmem_ln_linear_grouped_trace.argtypes = [C.POINTER(RowresStream), i32, i32, i32, i32, i64, i64, f32,
-                                                 C.POINTER(RowresProblem), i32, c_p, c_p]
     lib.rmem_layernorm_red.argtypes = [c_p, i64, c_p, i32, i64, i64, c_p, c_p, i32, i32, f32, c_p, c_p, i64,
                                        c_p, i64, c_p]
     lib.rmem_bias_act_nchw.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p]
@@ -198,7 +187,34 @@ def load():
     lib.rmem_rec_signature.restype, lib.rmem_rec_signature.argtypes = C.c_uint64, [c_p]
     lib.rmem_launch_recorded.argtypes = [c_p, c_p, i64, i32, c_p]
     _LIB = lib
+    _configure_from_environment(lib)
     return lib
+
+
+# RMEM_* tuning variables -> rmem_configure() names.  The C library reads no environment variable; this host layer does, once,
+# when it loads the library (tests and tools switch kernels at run time with configure()).
+_ENV_SWITCHES = (
+    ("RMEM_LINEAR", lambda v: [("linear_tiles", 1 if v.startswith("t") else 0)]),
+    ("RMEM_STREAM", lambda v: [("stream_form", int(v))]),
+    ("RMEM_DW", lambda v: list(zip(("dw_rx", "dw_v"), (int(x) for x in v.split(","))))),
+    ("RMEM_DW_ROWS", lambda v: [("dw_rows", int(v))]),
+    ("RMEM_DW_ORDER", lambda v: [("dw_grid_order", 1 if v.startswith("g") else 0)]),
+    ("RMEM_IDA", lambda v: list(zip(("ida_tokens", "ida_unroll"), (int(x) for x in (v.split(",") + ["16"])[:2])))),
+)
+
+
+def _configure_from_environment(lib) -> None:
+    for var, parse in _ENV_SWITCHES:
+        val = os.environ.get(var)
+        if val:
+            for name, value in parse(val):
+                if lib.rmem_configure(name.encode(), int(value)) != 0:
+                    raise RmemError(f"{var}={val}: rmem_configure({name!r}, {value}) refused")
+
+
+def configure(name: str, value: int) -> None:
+    """rmem_configure: a process-wide tuning / debug switch of the library (names and ranges in include/rmem_hip.h)."""
+    check(load().rmem_configure(name.encode(), int(value)), f"rmem_configure({name!r}, {value})")
 
 
 def stream_ptr() -> int:
@@ -325,46 +341,6 @@ def linear_grouped(args):
     """One launch for up to 8 problems built with linear(..., launch=False)."""
     arr = (LinearArgs * len(args))(*args)
     check(load().rmem_linear_grouped(arr, len(args), stream_ptr()), "rmem_linear_grouped")
-
-
-def pack_frag(w: Planes) -> torch.Tensor:
-    """Weight planes [N][K] (or [batch][N][K]) -> the MFMA-fragment order rmem_ln_linear_grouped streams straight into
-    registers (include/rmem_hip.h): [batch][ceil(N/32)][K/16][plane][lane = (k / 8 % 2) * 32 + col % 32][8 halves]; rows
-    beyond N are zero."""
-    hi, lo = w.hi, w.lo
-    if hi.dim() == 2:
-        hi, lo = hi[None], lo[None]
-    nb, n, k = hi.shape
-    if k % 16:
-        raise RmemError("pack_frag: K must be a multiple of 16")
-    u = (n + 31) // 32
-    t = torch.zeros(2, nb, u * 32, k, dtype=torch.float16, device=hi.device)
-    t[0, :, :n], t[1, :, :n] = hi, lo
-    t = t.view(2, nb, u, 32, k // 16, 2, 8)              # plane, batch, unit, col, k-step, k-group, e
-    return t.permute(1, 2, 4, 0, 5, 3, 6).contiguous()   # batch, unit, k-step, plane, k-group, col, e
-
-
-def rowres_stream(x=None, xo=None, parts=None, gamma=None, beta=None, planes: Planes = None, ldo=256, plane_off=0):
-    st = RowresStream()
-    st.x, st.xo, st.parts, st.gamma, st.beta = ptr(x), ptr(xo), parts, ptr(gamma), ptr(beta)
-    if planes is not None:
-        st.oh, st.ol, st.ldo = planes.hi.data_ptr() + 2 * plane_off, planes.lo.data_ptr() + 2 * plane_off, ldo
-    return st
-
-
-def ln_linear_grouped(streams, mode, N, nparts, part_stride, ldpart, eps, probs, trace=None):
-    """rmem_ln_linear_grouped: `probs` = [(LinearArgs, packed weights tensor, xk0, bxk), ...]; trace = int64 device
-    tensor for the cycle-stamp variant (debug)."""
-    sa = (RowresStream * len(streams))(*streams)
-    pa = (RowresProblem * len(probs))()
-    for i, (lin, wpk, xk0, bxk) in enumerate(probs):
-        pa[i].lin, pa[i].wpk, pa[i].xk0, pa[i].bxk = lin, wpk.data_ptr(), xk0, bxk
-    if trace is not None:
-        check(load().rmem_ln_linear_grouped_trace(sa, len(streams), mode, N, nparts, part_stride, ldpart, eps, pa,
-                                                  len(probs), trace.data_ptr(), stream_ptr()), "rmem_ln_linear_grouped_trace")
-        return
-    check(load().rmem_ln_linear_grouped(sa, len(streams), mode, N, nparts, part_stride, ldpart, eps, pa, len(probs),
-                                        stream_ptr()), "rmem_ln_linear_grouped")
 
 
 def groupnorm_nchw(x: torch.Tensor, gn: torch.nn.GroupNorm, relu: bool, conv_bias=None) -> torch.Tensor:

@@ -120,6 +120,7 @@ class DeAOTLSTT:
         self._force_tiles = os.environ.get("RMEM_LINEAR", "") == "tiles"
         self._sample_read = False          # bench.py: time the next replayed frame's layer-0 read (DeAOTEngine._graphed_frame)
         self._sample_kernels = False       # bench.py: issue the next frame's `rest` part eagerly with HIP events around every launch
+        self.fuse_gate = os.environ.get("RMEM_FUSE_GATE", "1") != "0"      # single-split reads gate their own output (no combine)
         self._kev = None                   # = _kev_store while a sampled frame is being issued, else None
         self._kev_store: list = []         # [(kernel class, e0, e1, algorithmic flops, algorithmic bytes)] of the sampled frames
         self._kev_frames = 0
@@ -202,14 +203,6 @@ class DeAOTLSTT:
             W.Wp_self, W.bp_self = (self._pl(g("self_attn.projection.weight")),
                                     self._f(g("self_attn.projection.bias")))
             # the weights of the projections that read the normalised rows, in MFMA-fragment order for
-            # rmem_ln_linear_grouped (LayerNorm + grouped projections in one launch, csrc/linear_rowres.h)
-            W.Wq_f, W.Wrel_f, W.Wv_f, W.Wu_f = (hip.pack_frag(x) for x in (W.Wq, W.Wrel_x, W.Wv, W.Wu))
-            W.pe_f = {T: hip.pack_frag(v[0]) for T, v in W.pe_x.items()}
-            if l > 0:
-                W.Widu_f = hip.pack_frag(W.Widu)
-            W.Wqk_f = hip.pack_frag(W.Wqk)
-            W.Wv12_f = hip.pack_frag(Planes(W.Wv12.hi.view(2, 512, 256), W.Wv12.lo.view(2, 512, 256)))
-            W.Wu12_f = hip.pack_frag(Planes(W.Wu12.hi.view(2, 512, 256), W.Wu12.lo.view(2, 512, 256)))
             self.lw.append(W)
 
     # ------------------------------------------------------------------ key splits
@@ -340,20 +333,6 @@ class DeAOTLSTT:
         N, Np, dev = self.N, self.Npad, self.dev
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         self.tgt, self.tgt_id = z(N, 256), z(N, 256)
-        # LayerNorm + grouped projections as one launch (rmem_ln_linear_grouped): the workgroups of a row tile fold the
-        # split-K partials of the preceding projection while others still read the unfolded rows, so the folded residual
-        # streams go to a second pair of buffers and the two pairs alternate (self._tg / self._tgi = the current pair)
-        # RMEM_ROWRES: "fused" = the LayerNorm inside the launch (mode 0); "planes" = the LayerNorm launch stays and the
-        # row-tile-resident kernel reads its planes (mode 1); "0" (default) = LayerNorm launch + streaming kernel.
-        # All three are bit-identical (tests/test_hip_ops.py::test_ln_linear_grouped_equals_separate_launches) and, measured
-        # on one box in alternation (profiles/r05e_bench_ab_rowres.txt, r05c_lstt_modes.txt), equally fast: 523.6 / 521.2 /
-        # 521.0 frames/s, LSTT isolated 855.6 / 859.6 / 854.5 us -- the LayerNorm a workgroup repeats for its row tile is
-        # VALU-issue-bound (~9.6 k cycles per 64 rows: 150 instructions per row on two waves per SIMD) and eats what the
-        # single fetch of the activations saves; see DESIGN.md section 5.
-        rr = os.environ.get("RMEM_ROWRES", "0")
-        self.rowres = (self.clips_per_launch == 1 and os.environ.get("RMEM_LINEAR", "") != "tiles" and rr != "0")
-        self.rowres_fused = self.rowres and rr == "fused"
-        self.tgt_b, self.tgt_id_b = (z(N, 256), z(N, 256)) if self.rowres_fused else (None, None)
         self._tg, self._tgi = self.tgt, self.tgt_id
         self.sched = None if os.environ.get("RMEM_NO_PULL") == "1" else z(2, dt=torch.int32)   # rmem_read_args.sched
         self.x_pl = Planes.empty((Np, 256), dev)
@@ -650,13 +629,10 @@ class DeAOTLSTT:
         out.sort(key=lambda e: -e["us_per_frame"])
         return out
 
-    def _other_pair(self):
-        """The residual-stream pair the next fused LayerNorm launch folds into (not the current one)."""
-        return (self.tgt_b, self.tgt_id_b) if self._tg is self.tgt else (self.tgt, self.tgt_id)
-
     def _read_args(self, ws: "_AttnWS", mode: int, T: int, kpl: Planes, vpl: Planes, slot_map_ptr,
                    qpl: Planes, bias, U, want_mass: bool, ksplits: int, uneven: bool = False):
-        """Argument blocks (fused read, combine) of one read into workspace `ws`."""
+        """Argument blocks (fused read, combine) of one read into workspace `ws`.  A read in ONE split that records no
+        attention mass writes the gated aggregate itself (rmem_read_args.gate / gout): its combine block is unused."""
         Np = self.Npad
         ra = hip.ReadArgs()
         ra.mode, ra.qh, ra.ql = mode, qpl.hi.data_ptr(), qpl.lo.data_ptr()
@@ -677,6 +653,8 @@ class DeAOTLSTT:
         # unit queue of the paired read (used by the library only when a launch holds more units than the device has
         # CUs: 720p K=8, several clips per launch); RMEM_NO_PULL=1 leaves the surplus to the hardware's dispatch order
         ra.sched = self.sched.data_ptr() if (mode == 0 and self.sched is not None) else None
+        if ks == 1 and not want_mass and self.fuse_gate:
+            ra.gate, ra.ldgate, ra.gout, ra.ldgout = U.data_ptr(), 1024, ws.G.data_ptr(), 1024
         ca = hip.ReadCombineArgs()
         ca.T, ca.N, ca.Npad, ca.ncols, ca.ksplits = T, self.N, Np, 1024, ks
         ca.part, ca.ml, ca.lslot = ws.part.data_ptr(), ws.ml.data_ptr(), (ws.lslot.data_ptr() if want_mass else None)
@@ -691,6 +669,8 @@ class DeAOTLSTT:
         with self._ev("read64_kernel (self read: T=1, Q=K)", flops=2.0 * N * A[0].T * N * (1024 + 128),
                       nbytes=N * (2.0 * (A[0].T * 1152 + 128) + 4.0 * 1024), overhead=ks * N * 4096.0):
             hip.check(lib.rmem_attn_read(C.byref(A[0]), st), "rmem_attn_read")
+        if A[0].gout:            # (one split: the read gated its own output)
+            return
         with self._ev("read_combine_kernel", nbytes=0.0, overhead=(ks + 2) * N * 4096.0):
             hip.check(lib.rmem_attn_read_combine(C.byref(A[1]), st), "rmem_attn_read_combine")
 
@@ -698,9 +678,22 @@ class DeAOTLSTT:
         """The long-term (A) and windowed (B) reads of a layer: ONE read launch, ONE combine launch.  long_done: the
         long-term read was launched with the front part (early_long_read) -- only the windowed read is left."""
         lib, st = hip.load(), hip.stream_ptr()
+        def combine():
+            """Merges the key splits of the reads that have any (a read in one split gated its own output)."""
+            fa, fb = bool(A[0].gout), bool(B[0].gout)
+            if fa and fb:
+                return
+            if fa or fb:
+                X = B if fa else A
+                with self._ev("read_combine_kernel", nbytes=0.0, overhead=(X[0].ksplits + 2) * self.N * 4096.0):
+                    hip.check(lib.rmem_attn_read_combine(C.byref(X[1]), st), "rmem_attn_read_combine")
+                return
+            with self._ev("read_combine2_kernel", nbytes=0.0, overhead=(A[0].ksplits + B[0].ksplits + 4) * self.N * 4096.0):
+                hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
+
         if long_done:
             hip.check(lib.rmem_attn_read(C.byref(B[0]), st), "rmem_attn_read")
-            hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
+            combine()
             return
         if self._timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -712,13 +705,12 @@ class DeAOTLSTT:
             # bytes, fp32 output); the windowed read's operands (one more slot, the relative bias, its output) are NOT added
             with self._ev("read64x2_kernel (long-term + windowed read)", flops=self.read_flops(A[0].T),
                           nbytes=self.N * (2.0 * (A[0].T * 1152 + 128) + 4.0 * 1024),
-                          overhead=(A[0].ksplits + B[0].ksplits) * self.N * 4096.0):
+                          overhead=((0 if A[0].gout else A[0].ksplits) + (0 if B[0].gout else B[0].ksplits)) * self.N * 4096.0):
                 hip.check(lib.rmem_attn_read2(C.byref(A[0]), C.byref(B[0]), st), "rmem_attn_read2")
         if self._timing:
             e1.record()
             self._events.append((e0, e1, A[0].T))
-        with self._ev("read_combine2_kernel", nbytes=0.0, overhead=(A[0].ksplits + B[0].ksplits + 4) * self.N * 4096.0):
-            hip.check(lib.rmem_attn_read_combine2(C.byref(A[1]), C.byref(B[1]), st), "rmem_attn_read_combine2")
+        combine()
 
     def _dwconv(self, ws: "_AttnWS", wt, out: Planes):
         with self._ev("dwconv5x5_split_kernel", nbytes=self.N * 1024 * 8.0):
@@ -869,11 +861,8 @@ class DeAOTLSTT:
         if seg_a:
             # -- norms + projections (transformer.py:1104-1123); the norms first fold in the
             #    split-K partials of the previous layer's self-attention projection
-            fused = self.rowres and not self._batched
-            ln_inside = fused and self.rowres_fused
             if l > 0:
-                if not ln_inside:
-                    self._ln2(W.ln1, self.x_pl, 256, 0, W.lnid1, self.z_pl[l], 256, 0, parts=True)
+                self._ln2(W.ln1, self.x_pl, 256, 0, W.lnid1, self.z_pl[l], 256, 0, parts=True)
             elif getattr(self, "_src_cn", None) is not None:
                 src = self._src_cn
                 hip.check(lib.rmem_layernorm_cn(src.data_ptr(), src.stride(0), self.tgt.data_ptr(), self.tgt_id.data_ptr(),
@@ -904,28 +893,8 @@ class DeAOTLSTT:
             cols = 128 + self.WIN + T + 512 + 512 + (512 if l > 0 else 0)
             fl_front = 2.0 * N * 256 * cols
             by_front = 4.0 * (N * 256 * (2 if l > 0 else 1) + cols * 256 + N * cols)
-            if not fused:
-                with self._ev("linear_stream_kernel (projections)", flops=fl_front, nbytes=by_front):
-                    hip.linear_grouped(grp)
-            else:
-                # ONE launch: (layers >= 1) norm1 / id_norm1 with the split-K fold, then every projection above from the
-                # row tile in LDS; layer 0: the planes rmem_layernorm_cn wrote are the tile (no fold, tgt_id = 0)
-                fr = [W.Wq_f, W.Wrel_f, W.pe_f[T], W.Wv_f, W.Wu_f] + ([W.Widu_f] if l > 0 else [])
-                probs = [(a, f, 256 if i == 5 else 0, 0) for i, (a, f) in enumerate(zip(grp, fr))]
-                if l == 0:
-                    hip.ln_linear_grouped([hip.rowres_stream(planes=self.x_pl, ldo=256)], 1, N, 0, 0, 0, 1e-5, probs)
-                elif not ln_inside:
-                    hip.ln_linear_grouped([hip.rowres_stream(planes=self.x_pl, ldo=256),
-                                           hip.rowres_stream(planes=self.z_pl[l], ldo=256)], 1, N, 0, 0, 0, 1e-5, probs)
-                else:
-                    to, tio = self._other_pair()
-                    pp = self.parts.data_ptr()
-                    hip.ln_linear_grouped(
-                        [hip.rowres_stream(x=self._tg, xo=to, parts=pp, gamma=W.ln1[0], beta=W.ln1[1]),
-                         hip.rowres_stream(x=self._tgi, xo=tio, parts=pp + 256 * 4, gamma=W.lnid1[0], beta=W.lnid1[1],
-                                           planes=self.z_pl[l], ldo=256)],
-                        0, N, self.KS, N * 512, 512, 1e-5, probs)
-                    self._tg, self._tgi = to, tio
+            with self._ev("linear_stream_kernel (projections)", flops=fl_front, nbytes=by_front):
+                hip.linear_grouped(grp)
             if ref_frame:
                 self._idv(l, cur)
         early = (l == 0 and self._split_parts and self.early_long_read and not ref_frame and self.branch_order == "serial"
@@ -964,10 +933,7 @@ class DeAOTLSTT:
                        kx_split=1024, bias=W.bp_ls, nsplit=ns, tile=self._tile(192), ksplits=self.KS, parts=self.parts,
                        part_stride=N * 512)       # 64 x 128 tiles: 27.5 -> 21.2 us (L2 -> LDS traffic -25 %)
         # -- gated self attention (transformer.py:1223-1232, attention.py:151-209)
-        fused = self.rowres and not self._batched
-        ln_inside = fused and self.rowres_fused
-        if not ln_inside:
-            self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
+        self._ln2(W.ln2, self.s_pl, 512, 0, W.lnid2, self.s_pl, 512, 256, parts=True)
         sQK = Planes(self.selfQK.hi[0], self.selfQK.lo[0])
         grp = [
             hip.linear(self.s_pl, W.Wqk, N, 128, 512, ldx=512, ldy=512, bias=W.bqk, pa=sQK, ldpa=128,
@@ -979,22 +945,9 @@ class DeAOTLSTT:
             hip.linear(self.s_pl, W.Wu12, N, 512, 256, ldx=512, ldy=256, bias=W.bu12, act=1,
                        d0=self.Uself.data_ptr(), ldd0=1024, nbatch=2, bsx=256, bsy=512 * 256,
                        bsbias=512, bsd=512, nsplit=ns, tile=self._tile(64), launch=False)]
-        sprobs = [(grp[0], W.Wqk_f, 0, 0), (grp[1], W.Wv12_f, 0, 256), (grp[2], W.Wu12_f, 0, 256)]
-        if not fused:
-            with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * (512 * 128 + 4 * 256 * 512),
-                          nbytes=4.0 * (N * 512 + 128 * 512 + 4 * 512 * 256 + N * (128 + 2048))):
-                hip.linear_grouped(grp)
-        elif not ln_inside:    # the planes of [norm2(tgt) | id_norm2(tgt_id)] exist: two 256-wide streams of s_pl
-            hip.ln_linear_grouped([hip.rowres_stream(planes=self.s_pl, ldo=512),
-                                   hip.rowres_stream(planes=self.s_pl, ldo=512, plane_off=256)], 1, N, 0, 0, 0, 1e-5, sprobs)
-        else:              # norm2 / id_norm2 (+ the split-K fold of the projection above) and the three projections: one launch
-            to, tio = self._other_pair()
-            pp = self.parts.data_ptr()
-            hip.ln_linear_grouped(
-                [hip.rowres_stream(x=self._tg, xo=to, parts=pp, gamma=W.ln2[0], beta=W.ln2[1]),
-                 hip.rowres_stream(x=self._tgi, xo=tio, parts=pp + 256 * 4, gamma=W.lnid2[0], beta=W.lnid2[1])],
-                0, N, self.KS, N * 512, 512, 1e-5, sprobs)
-            self._tg, self._tgi = to, tio
+        with self._ev("linear_stream_kernel (projections)", flops=2.0 * N * (512 * 128 + 4 * 256 * 512),
+                      nbytes=4.0 * (N * 512 + 128 * 512 + 4 * 512 * 256 + N * (128 + 2048))):
+            hip.linear_grouped(grp)
         self._read(self._read_args(self.ws_main, 0, 1, self.selfQK, self.selfV, None, sQK, None, self.Uself,
                                    False, self.ks_self))
         self._dwconv(self.ws_main, W.dw_self, self.Ylt)

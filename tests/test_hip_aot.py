@@ -13,7 +13,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TIE_MARGIN = 2e-5          # fp64 margin below which the product path (MIOpen encoder included) may decide a pixel differently (tests/ties.py)
-SWIN_TIE_MARGIN = 5e-4     # at 480x848 the fp32 REFERENCE itself leaves its fp64 run on 72 pixels with margins up to 1.4e-4 (24 Swin blocks in fp32)
+SWIN_TIE_MARGIN = 2e-4     # at 480x848 the fp32 REFERENCE itself leaves its fp64 run on 72 pixels with margins up to 1.4e-4 (24 Swin blocks in fp32); the HIP path's worst moved pixel is that same 1.40e-4 one
 
 
 @pytest.fixture(scope="module")
@@ -253,7 +253,7 @@ def test_aot_480p_clip_teacher_forced(golden_dir):
           "; the fp32 reference itself:", ref64, "; logit err:", lerrs)
     assert idx_hist == meta["indexes"]
     assert sum(mism64) <= ref64 + 6, (mism64, ref64)              # (13 against the reference's own 14 measured)
-    assert sorted(lerrs) == [1, 15] and max(lerrs.values()) < 1e-4, lerrs
+    assert sorted(lerrs) == [1, 15] and max(lerrs.values()) < 2e-5, lerrs        # (2-5e-6 measured, profiles/r06_pytest_gpu_midround.log)
 
 
 def test_swin_aot_clip_teacher_forced(golden_dir):
@@ -328,7 +328,7 @@ def test_swin_aot_480x848_vs_reference(golden_dir):
     ref64 = [ties.n_ref32_vs_64(t, gold["labels"][t - 1]) for t in range(1, meta["frames"])]
     print("SwinB-AOTL 480x848 vs the reference: pixels off its fp32 maps per frame (of 409920):", mism, "; off the fp64 maps:", mism64,
           "; the fp32 reference itself:", ref64, "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; decoder-logit err (fp32 fixture):", lerrs)
-    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 1e-4, lerrs
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-5, lerrs        # (2-5e-6 measured, profiles/r06_pytest_gpu_midround.log)
 
 
 def test_swin_aot_480x848_vs_oracle():

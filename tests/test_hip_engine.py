@@ -288,7 +288,7 @@ def test_480p_long_clip_gap5_vs_reference(golden_dir):
     # of the reference's fp32 logits (MIOpen's convolutions against oneDNN's: ~1e-5).
     assert worst < 5e-6, worst
     assert sum(mism64) <= sum(ref64) + 12, (sum(mism64), sum(ref64))
-    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 1e-4, lerrs
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-5, lerrs        # (2-5e-6 measured, profiles/r06_pytest_gpu_midround.log)
 
 
 def test_480p_lstt_isolated_from_miopen(golden_dir):
@@ -614,7 +614,7 @@ def test_720p_k8_vs_reference(golden_dir):
           "; the fp32 reference itself:", ref64, "; largest fp64 margin of a moved pixel:", f"{worst:.2e}", "; decoder-logit err (fp32 fixture):", lerrs)
     assert len(meta["indexes"][-1]) == 8 and meta["indexes"][-1] != list(range(8))
     assert sum(mism64) <= sum(ref64) + 6, (mism64, ref64)         # (14 against the reference's own 13 measured)
-    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 1e-4, lerrs
+    assert sorted(lerrs) == sorted(meta["logit_frames"]) and max(lerrs.values()) < 2e-5, lerrs        # (2-5e-6 measured, profiles/r06_pytest_gpu_midround.log)
 
 
 def test_paired_launches_bit_identical():
@@ -652,43 +652,6 @@ def test_paired_launches_bit_identical():
     for order in ("serial_unpaired",):
         for (o0, m0), (o1, m1) in zip(outs["serial"], outs[order]):
             assert torch.equal(o0, o1) and torch.equal(m0, m1), order
-
-
-@pytest.mark.parametrize("h,w", [(12, 17), (31, 54)])
-def test_projection_paths_bit_identical_through_the_lstt(h, w, monkeypatch):
-    """RMEM_ROWRES = 0 (default: LayerNorm launch + streaming projection kernel), `planes` (LayerNorm launch + the
-    row-tile-resident kernel reading its planes) and `fused` (LayerNorm, split-K fold and projections in ONE launch, the
-    folded residual streams alternating between two buffer pairs) through whole LSTT passes -- reference frame, propagated
-    frames, memory updates, the last fold inside the GroupNorm: outputs, attention mass and every bank slot bit for bit."""
-    from rmem_amd.lstt import DeAOTLSTT
-    cfg, cpu_model, gpu_model, _ = _build()
-    N = h * w
-    H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
-    outs = {}
-    for mode in ("0", "planes", "fused"):
-        monkeypatch.setenv("RMEM_ROWRES", mode)
-        lstt = DeAOTLSTT(gpu_model, h, w, DEV, nsplit=3)
-        assert lstt.rowres == (mode != "0") and lstt.rowres_fused == (mode == "fused")
-        rs = np.random.RandomState(0)
-        rec = []
-        for t in range(5):
-            emb = torch.from_numpy(rs.standard_normal((N, 256)).astype(np.float32)).to(DEV)
-            label = torch.from_numpy(rs.randint(0, 4, (1, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
-            lab_u8 = F.interpolate(label, size=(H, W), mode="nearest")[0, 0].to(torch.uint8).to(DEV).contiguous()
-            if t == 0:
-                lstt.assign_identity(lab_u8)
-                out = lstt.forward(emb, ref_frame=True)
-            else:
-                out = lstt.forward(emb)
-                lstt.assign_identity(lab_u8)
-                lstt.update_short_memories(t % 2 == 0)
-            torch.cuda.synchronize()
-            rec.append((out.clone(), lstt.mass.clone()))
-        rec.append(tuple(torch.cat([b.hi.flatten(), b.lo.flatten()]).clone() for b in lstt.bankK + lstt.bankV))
-        outs[mode] = rec
-    for mode in ("planes", "fused"):
-        for a, b in zip(outs["0"], outs[mode]):
-            assert all(torch.equal(x, y) for x, y in zip(a, b)), mode
 
 
 def test_unit_queue_of_the_paired_read_bit_identical(monkeypatch):

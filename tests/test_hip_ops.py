@@ -286,7 +286,7 @@ def _block16(Vf):
 
 
 def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, ksplits, want_mass=True, ldr=None, rcs=0,
-              uneven=None):
+              uneven=None, fuse=False):
     """K: [S][Npad][128] planes, Vb: blocked-16 planes [S][Npad/16][1024][16], Q planes [Npad][128]."""
     lib, st = hip.load(), hip.stream_ptr()
     part = torch.full((ksplits, Npad, 1024), float("nan"), device=DEV)     # every valid row must be written
@@ -309,6 +309,13 @@ def _run_read(hip, mode, T, N, Npad, K, Vb, slot_map, Q, bias, U, h, w, R, kspli
         ra.nfull, ra.pf = uneven
     ra.part, ra.ml = part.data_ptr(), ml.data_ptr()
     ra.lslot = lslot.data_ptr() if want_mass else None
+    if fuse:                   # one split: the read writes the gated aggregate itself (rmem_read_args.gate / gout), no combine
+        assert ksplits == 1 and not want_mass
+        G.fill_(7.0)
+        ra.gate, ra.ldgate, ra.gout, ra.ldgout = U.data_ptr(), 1024, G.data_ptr(), 1024
+        hip.check(lib.rmem_attn_read(C.byref(ra), st), "read")
+        torch.cuda.synchronize()
+        return G, mass, part, ml
     hip.check(lib.rmem_attn_read(C.byref(ra), st), "read")
     ca = hip.ReadCombineArgs()
     ca.T, ca.N, ca.Npad, ca.ncols, ca.ksplits = T, N, Npad, 1024, ksplits
@@ -666,6 +673,31 @@ def _window_case(hip, ksplits, h, w, rising):
     assert torch.equal(G2, G)
 
 
+@pytest.mark.parametrize("h,w", [(5, 7), (9, 13), (20, 23), (31, 54)])
+def test_read_single_split_gates_its_own_output(hip, h, w):
+    """A read in ONE key split with rmem_read_args.gate / gout set writes G = U * O / l from its own epilogue -- no partial,
+    no combine launch: bit for bit what rmem_attn_read + rmem_attn_read_combine give for one split (windowed read and the
+    T = 1 bank read), every valid row written, nothing else touched, the partial buffer left alone."""
+    rs = np.random.RandomState(h * 31 + w)
+    N = h * w
+    Npad = (N + 127) // 128 * 128
+    Kf, Qf = torch.zeros(Npad, 128), torch.zeros(Npad, 128)
+    Kf[:N], Qf[:N] = _rand(rs, N, 128, scale=1.5), _rand(rs, N, 128, scale=1.5)
+    Kf[N:] = 37.0
+    Vf = torch.full((1, 1024, Npad), -53.0)
+    Vf[0, :, :N] = _rand(rs, 1024, N)
+    u = _rand(rs, N, 1024).to(DEV)
+    Rm = _rand(rs, N, 225, scale=0.3).to(DEV).contiguous()
+    for mode in (1, 0):
+        a = (hip, mode, 1, N, Npad, _planes(hip, Kf[None]), _planes(hip, _block16(Vf)), [0], _planes(hip, Qf), None, u, h, w,
+             Rm if mode == 1 else None, 1)
+        G0, _, _, ml0 = _run_read(*a, want_mass=False)
+        G1, _, part1, ml1 = _run_read(*a, want_mass=False, fuse=True)
+        assert torch.equal(G0.view(torch.int32), G1.view(torch.int32)), (mode, (G0 - G1).abs().max().item())
+        assert torch.equal(ml0[:, :N].view(torch.int32), ml1[:, :N].view(torch.int32))
+        assert bool(torch.isnan(part1).all()), "a fused read wrote a partial"
+
+
 def test_linear_blocked_output(hip):
     """rmem_linear with pa_blocked: silu(X.W^T + b) written as blocked-16 planes at a column window of
     a [Npad/16][1024][16] tensor (how V | ID_V of the bank are produced), nbatch = 2 included."""
@@ -796,7 +828,7 @@ def test_groupnorm2_fold_equals_layernorm_fold_then_groupnorm(hip, N):
 
 @pytest.mark.parametrize("h,w", [(31, 54), (9, 13), (5, 7), (46, 81)])
 def test_dwconv_rows_per_thread_variants_bit_identical(hip, h, w, monkeypatch):
-    """The depth-wise 5 x 5 kernel with RY output rows per thread (RMEM_DW_ROWS = 2 / 3 / 4: the input window is loaded once
+    """The depth-wise 5 x 5 kernel with RY output rows per thread (rmem_configure("dw_rows", 2 / 3 / 4): the input window is loaded once
     for RY rows, an input element is fetched 2.9-4.3 times instead of 7.2) against the one-row kernel: both maps of the
     paired launch and the single-map launch, hi and lo planes bit for bit (the taps of an output are accumulated in the
     same order), nothing written beyond the N rows."""
@@ -814,14 +846,17 @@ def test_dwconv_rows_per_thread_variants_bit_identical(hip, h, w, monkeypatch):
         torch.cuda.synchronize()
         return o
 
-    monkeypatch.setenv("RMEM_DW_ROWS", "0")
-    ref = run()
-    for ry in ("2", "3", "4"):
-        monkeypatch.setenv("RMEM_DW_ROWS", ry)
-        got = run()
-        for i, (a, b) in enumerate(zip(ref, got)):
-            assert torch.equal(a, b), (ry, i)
-        assert all(bool((t[N:] == 7).all()) for t in got)
+    try:
+        hip.configure("dw_rows", 0)
+        ref = run()
+        for ry in (2, 3, 4):
+            hip.configure("dw_rows", ry)
+            got = run()
+            for i, (a, b) in enumerate(zip(ref, got)):
+                assert torch.equal(a, b), (ry, i)
+            assert all(bool((t[N:] == 7).all()) for t in got)
+    finally:
+        hip.configure("dw_rows", 2)
 
 
 def test_linear_single_stage_items_many_per_workgroup(hip):
@@ -854,121 +889,6 @@ def test_linear_single_stage_items_many_per_workgroup(hip):
     assert torch.equal(parts[0], parts[1])
     ref2 = (x2.float().double() @ y2.float().double().t()).float()
     assert (parts[0].sum(0) - ref2).abs().max().item() < 3e-5 * ref2.abs().max().item()
-
-
-@pytest.mark.parametrize("nsplit", [3, 1])
-@pytest.mark.parametrize("N", [1674, 100, 64])
-def test_ln_linear_grouped_equals_separate_launches(hip, nsplit, N):
-    """rmem_ln_linear_grouped (csrc/linear_rowres.h: LayerNorm with the split-K fold + the grouped projections that read
-    the normalised rows, ONE launch, row tile resident in LDS, weights streamed in MFMA-fragment order) against the
-    sequence it replaces -- rmem_layernorm_red2 (folds in place, planes to HBM) + rmem_linear_grouped -- on the two launch
-    shapes of a GPM layer (transformer.py:1104-1123 and :1223-1232 / attention.py:151-172): every output, the folded
-    residual streams and the planes handed to later launches bit for bit; the unfolded streams untouched; mode 1 (planes
-    given) as well."""
-    lib, st = hip.load(), hip.stream_ptr()
-    rs = np.random.RandomState(1000 + N)
-    P = lambda x: _planes(hip, x)
-    KS, T = 2, 5
-    Np = (N + 127) // 128 * 128
-    tgt, tgi = (_rand(rs, N, 256) * 2 + 0.3).to(DEV), (_rand(rs, N, 256) * 0.7).to(DEV)
-    parts = _rand(rs, KS, N, 512, scale=0.5).to(DEV)
-    gb = [((_rand(rs, 256) * 0.2 + 1).to(DEV), (_rand(rs, 256) * 0.1).to(DEV)) for _ in range(2)]
-    Wq, Wr, Wpe, Wv, Wu, Wiu = (P(_rand(rs, n, 256, scale=0.1)) for n in (128, 225, T, 512, 512, 512))
-    bq, br, bpe, bv, bu, biu, addv = (_rand(rs, n).to(DEV) for n in (128, 225, T, 512, 512, 512, 128))
-    Wqk = P(_rand(rs, 128, 512, scale=0.1))
-    Wv12, Wu12 = P(_rand(rs, 1024, 256, scale=0.1)), P(_rand(rs, 1024, 256, scale=0.1))
-    bqk, bv12, bu12 = _rand(rs, 128).to(DEV), _rand(rs, 1024).to(DEV), _rand(rs, 1024).to(DEV)
-    pk = hip.pack_frag
-    two = lambda w: hip.Planes(w.hi.view(2, 512, 256), w.lo.view(2, 512, 256))
-    frags_front = [pk(w) for w in (Wq, Wr, Wpe, Wv, Wu, Wiu)]
-    frags_self = [pk(Wqk), pk(two(Wv12)), pk(two(Wu12))]
-
-    def outputs():
-        o = dict(pa=hip.Planes.empty((Np, 128), DEV), pb=hip.Planes.empty((Np, 128), DEV),
-                 R=torch.full((N * 225 + 225 * 226 + 7,), 3.0, device=DEV), pe=torch.full((N, T), 3.0, device=DEV),
-                 vb=hip.Planes.empty((Np // 16, 1024, 16), DEV), U=torch.full((N, 1024), 3.0, device=DEV),
-                 sqk=hip.Planes.empty((Np, 128), DEV), sv=hip.Planes.empty((Np // 16, 1024, 16), DEV),
-                 su=torch.full((N, 1024), 3.0, device=DEV))
-        return o
-
-    def front_args(o, x, z):
-        return [
-            hip.linear(x, Wq, N, 128, 256, ldx=256, ldy=256, bias=bq, pa=o["pa"], ldpa=128, pb=o["pb"], ldpb=128,
-                       addvec=addv, nsplit=nsplit, launch=False),
-            hip.linear(x, Wr, N, 225, 256, ldx=256, ldy=256, bias=br, d0=o["R"].data_ptr(), ldd0=225, d0_cs=226,
-                       nsplit=nsplit, launch=False),
-            hip.linear(x, Wpe, N, T, 256, ldx=256, ldy=256, bias=bpe, d0=o["pe"].data_ptr(), ldd0=T, nsplit=nsplit,
-                       launch=False),
-            hip.linear(x, Wv, N, 512, 256, ldx=256, ldy=256, bias=bv, act=1, pa=o["vb"], ldpa=1024, pa_blocked=True,
-                       nsplit=nsplit, launch=False),
-            hip.linear(x, Wu, N, 512, 256, ldx=256, ldy=256, bias=bu, act=1, d0=o["U"].data_ptr(), ldd0=1024,
-                       nsplit=nsplit, launch=False),
-            hip.linear(z, Wiu, N, 512, 256, ldx=256, ldy=256, bias=biu, act=1, d0=o["U"].data_ptr() + 512 * 4, ldd0=1024,
-                       nsplit=nsplit, launch=False)]
-
-    def self_args(o, s_):
-        return [
-            hip.linear(s_, Wqk, N, 128, 512, ldx=512, ldy=512, bias=bqk, pa=o["sqk"], ldpa=128, nsplit=nsplit, launch=False),
-            hip.linear(s_, Wv12, N, 512, 256, ldx=512, ldy=256, bias=bv12, act=1, pa=o["sv"], ldpa=1024, pa_blocked=True,
-                       nbatch=2, bsx=256, bsy=512 * 256, bsbias=512, bspa=512 * 16, nsplit=nsplit, launch=False),
-            hip.linear(s_, Wu12, N, 512, 256, ldx=512, ldy=256, bias=bu12, act=1, d0=o["su"].data_ptr(), ldd0=1024,
-                       nbatch=2, bsx=256, bsy=512 * 256, bsbias=512, bsd=512, nsplit=nsplit, launch=False)]
-
-    def ln2(x0, x1, o0, ld0, off0, o1, ld1, off1):
-        hip.check(lib.rmem_layernorm_red2(
-            x0.data_ptr(), x1.data_ptr(), 256, parts.data_ptr(), parts.data_ptr() + 256 * 4, KS, N * 512, 512,
-            gb[0][0].data_ptr(), gb[0][1].data_ptr(), gb[1][0].data_ptr(), gb[1][1].data_ptr(), N, 256, 1e-5,
-            o0.hi.data_ptr() + off0 * 2, o0.lo.data_ptr() + off0 * 2, ld0,
-            o1.hi.data_ptr() + off1 * 2, o1.lo.data_ptr() + off1 * 2, ld1, st), "ln_red2")
-
-    # ---- the separate launches
-    ref = outputs()
-    t_ref, ti_ref = tgt.clone(), tgi.clone()
-    x_pl, z_pl, s_pl = hip.Planes.empty((Np, 256), DEV), hip.Planes.empty((Np, 256), DEV), hip.Planes.empty((Np, 512), DEV)
-    ln2(t_ref, ti_ref, x_pl, 256, 0, z_pl, 256, 0)
-    hip.linear_grouped(front_args(ref, x_pl, z_pl))
-    t2, ti2 = tgt.clone(), tgi.clone()
-    ln2(t2, ti2, s_pl, 512, 0, s_pl, 512, 256)
-    hip.linear_grouped(self_args(ref, s_pl))
-    # ---- fused, mode 0
-    got = outputs()
-    t_in, ti_in = tgt.clone(), tgi.clone()
-    to, tio = torch.full_like(tgt, 7.0), torch.full_like(tgi, 7.0)
-    z_got = hip.Planes.empty((Np, 256), DEV)
-    streams = lambda zpl: [
-        hip.rowres_stream(x=t_in, xo=to, parts=parts.data_ptr(), gamma=gb[0][0], beta=gb[0][1]),
-        hip.rowres_stream(x=ti_in, xo=tio, parts=parts.data_ptr() + 256 * 4, gamma=gb[1][0], beta=gb[1][1], planes=zpl,
-                          ldo=256)]
-    hip.ln_linear_grouped(streams(z_got), 0, N, KS, N * 512, 512, 1e-5,
-                          [(a, f, 256 if i == 5 else 0, 0) for i, (a, f) in enumerate(zip(front_args(got, x_pl, z_pl), frags_front))])
-    torch.cuda.synchronize()
-    assert torch.equal(to, t_ref) and torch.equal(tio, ti_ref), "folded residual streams"
-    assert torch.equal(t_in, tgt) and torch.equal(ti_in, tgi), "the unfolded streams must stay untouched"
-    assert torch.equal(z_got.hi[:N], z_pl.hi[:N]) and torch.equal(z_got.lo[:N], z_pl.lo[:N])
-    to.fill_(7.0), tio.fill_(7.0)
-    sa = self_args(got, s_pl)
-    hip.ln_linear_grouped(streams(None), 0, N, KS, N * 512, 512, 1e-5,
-                          [(sa[0], frags_self[0], 0, 0), (sa[1], frags_self[1], 0, 256), (sa[2], frags_self[2], 0, 256)])
-    torch.cuda.synchronize()
-    assert torch.equal(to, t2) and torch.equal(tio, ti2)
-    for k in ref:
-        a, b = ref[k], got[k]
-        if isinstance(a, hip.Planes):
-            assert torch.equal(a.hi, b.hi), k
-            if nsplit == 3:
-                assert torch.equal(a.lo, b.lo), k
-        else:
-            assert torch.equal(a, b), k
-    assert torch.all(got["R"][-7:] == 3.0)
-    # ---- fused, mode 1: the planes are given (layer 0: rmem_layernorm_cn wrote them), one stream, no fold
-    got1 = outputs()
-    hip.ln_linear_grouped([hip.rowres_stream(planes=x_pl, ldo=256)], 1, N, 0, 0, 0, 1e-5,
-                          [(a, f, 0, 0) for a, f in zip(front_args(got1, x_pl, z_pl)[:5], frags_front[:5])])
-    torch.cuda.synchronize()
-    for k in ("pa", "pb", "vb"):
-        assert torch.equal(ref[k].hi, got1[k].hi), k
-    assert torch.equal(ref["R"], got1["R"]) and torch.equal(ref["pe"], got1["pe"])
-    assert torch.equal(ref["U"][:, :512], got1["U"][:, :512])
 
 
 @pytest.mark.parametrize("N", [35, 1674])

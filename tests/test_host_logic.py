@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/rmem_hip.h but not exported"
     assert declared == set(hip.EXPORTS)
     assert every - declared == set(hip.EXPORTS_OTHER)
-    assert lib.rmem_abi_version() == 16
+    assert lib.rmem_abi_version() == hip.ABI_VERSION == 17
 
 
 def test_launch_recorder_records_without_a_gpu():
@@ -63,9 +63,9 @@ def test_ctypes_struct_sizes_match_header_layout():
     src = r'''
     #include "rmem_hip.h"
     #include <stdio.h>
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_mha_args),
+    int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(rmem_linear_args), sizeof(rmem_mha_args),
                        sizeof(rmem_mha_combine_args), sizeof(rmem_read_args), sizeof(rmem_read_combine_args),
-                       sizeof(rmem_bank_state), sizeof(rmem_rowres_stream), sizeof(rmem_rowres_problem)); return 0; }'''
+                       sizeof(rmem_bank_state)); return 0; }'''
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
@@ -74,7 +74,25 @@ def test_ctypes_struct_sizes_match_header_layout():
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     assert sizes == [ctypes.sizeof(hip.LinearArgs), ctypes.sizeof(hip.MHAArgs),
                      ctypes.sizeof(hip.MHACombineArgs), ctypes.sizeof(hip.ReadArgs), ctypes.sizeof(hip.ReadCombineArgs),
-                     ctypes.sizeof(hip.BankState), ctypes.sizeof(hip.RowresStream), ctypes.sizeof(hip.RowresProblem)]
+                     ctypes.sizeof(hip.BankState)]
+
+
+def test_configure_switches_and_no_getenv_in_the_library():
+    """rmem_configure: known names inside their ranges are accepted, everything else is refused and changes nothing; and the
+    C library itself never reads the environment (the RMEM_* variables are mapped by rmem_amd/hip.py when it loads it)."""
+    from rmem_amd import hip
+    lib = hip.load()
+    assert lib.rmem_configure(b"dw_rows", 3) == 0 and lib.rmem_configure(b"dw_rows", 2) == 0
+    assert lib.rmem_configure(b"dw_rows", 9) == -1 and lib.rmem_configure(b"no_such_switch", 1) == -1
+    assert lib.rmem_configure(None, 1) == -1 and lib.rmem_configure(b"stream_form", 3) == -1
+    with pytest.raises(hip.RmemError):
+        hip.configure("linear_tiles", 2)
+    hip.configure("linear_tiles", 0)
+    csrc = os.path.join(ROOT, "rmem_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            code = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+            assert "getenv" not in code, f
 
 
 def test_product_path_never_imports_oracle():

@@ -36,7 +36,7 @@ def main():
                       "one_us": round(timeit(one), 2), "two_us": round(timeit(two), 2), "checksum": chk}))
     if "--rows" in sys.argv:                   # the RY-rows-per-thread variants in the same process (the library reads the switch per launch)
         for ry in ("0", "2", "3", "4"):
-            os.environ["RMEM_DW_ROWS"] = ry
+            hip.configure("dw_rows", int(ry))
             one(); torch.cuda.synchronize()
             c2 = int(o[0].long().sum().item()) ^ int(o[1].long().sum().item())
             print(json.dumps({"RMEM_DW_ROWS": ry, "one_us": round(timeit(one), 2), "two_us": round(timeit(two), 2), "checksum": c2}))

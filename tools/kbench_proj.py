@@ -106,6 +106,8 @@ def trace_main():
     hip, L, dev = build()
     P = problems(hip, L)
     lib = hip.load()
+    if os.environ.get("RMEM_STREAM_VAR"):      # timing experiments of the tracing kernel: 2 no requests, 3 no MFMAs, 4 no fragment reads
+        hip.configure("stream_var", int(os.environ["RMEM_STREAM_VAR"]))
     out = {}
     for name, grp in P.items():
         arr = (hip.LinearArgs * len(grp))(*grp)

@@ -118,7 +118,7 @@ def main():
             nblk = 8 * (((N + 63) // 64 * ks + 7) // 8)
             tr = torch.zeros(nblk, 64, dtype=torch.int64, device=dev)
             for var in ("4", "8", "0"):              # experiments of the tracing kernel (RMEM_READ_VAR); 0 = product, last
-                os.environ["RMEM_READ_VAR"] = var
+                hip.configure("read_var", int(var))
                 tr.zero_()
                 for _ in range(2):
                     hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace")
@@ -132,9 +132,9 @@ def main():
                     ent[f"var{var}_top_score_pv_barrier_w0_w4"] = [[round(float((tt[:, o + w] / ntv[:, 0]).mean())) for o in (40, 4, 12, 20)] for w in (0, 4)]
             ent["trace_kernel_us"] = round(timeit(lambda: hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace"), args.iters), 2)
             for var in [v for v in args.time_vars.split(",") if v]:      # whole-launch time of an experiment variant (16: one MFMA per product)
-                os.environ["RMEM_READ_VAR"] = var
+                hip.configure("read_var", int(var))
                 ent[f"trace_kernel_us_var{var}"] = round(timeit(lambda: hip.check(lib.rmem_attn_read_trace(C.byref(ra), tr.data_ptr(), st), "trace"), args.iters), 2)
-            os.environ["RMEM_READ_VAR"] = "0"
+            hip.configure("read_var", 0)
             t = tr.cpu().double()
             t = t[t[:, 3] > 0]
             if t.shape[0]:
