@@ -260,11 +260,12 @@ def main():
     # host placement: this rank's threads on its share of the NUMA node its GPU hangs off (rmem_amd/affinity.py), before
     # any thread pool exists; external launchers (torch.distributed.run sets OMP_NUM_THREADS=1 when it is unset) included
     from rmem_amd.affinity import pin_rank
+    from rmem_amd import hip as _hip
+    # (before anything initialises the HIP runtime -- pin_rank asks it for the GPU's PCI address)
+    _hip.set_host_wait(rank_device(local_rank))       # RMEM_BLOCKING_WAIT=1 only (opt-in): see rmem_amd.hip.set_host_wait
     PIN = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), rank_device)
     args._pin = PIN
     local_rank = rank_device(local_rank)
-    from rmem_amd import hip as _hip
-    _hip.set_host_wait(local_rank)       # RMEM_BLOCKING_WAIT=1 only (opt-in, before this process touches the device): see rmem_amd.hip.set_host_wait
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = init_dist(world)
@@ -357,7 +358,10 @@ def main():
         t += 1
         cur = n_graphs()
         stable, last = (stable + 1, last) if cur == last else (0, cur)
-    sampled = hasattr(sub.lstt, "launch_read2_layer0") and sub.hoist_enabled and os.environ.get("RMEM_BENCH_EAGER_SAMPLE") != "1"
+    # (with the opt-in early long-term read the front graph already holds layer 0's read: the sampled `tail` replay would
+    # issue it a second time and time a schedule that is not the one that runs -- no sampling then)
+    sampled = (hasattr(sub.lstt, "launch_read2_layer0") and sub.hoist_enabled and os.environ.get("RMEM_BENCH_EAGER_SAMPLE") != "1"
+               and not getattr(sub.lstt, "early_long_read", False))
     if sampled:                  # the `tail` graphs of the sampled frames (all slot variants) are captured here, not in the timed region
         sub.lstt._sample_read = True
         all_clips(t)

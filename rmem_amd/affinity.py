@@ -118,5 +118,18 @@ def pin_rank(local_rank: int, local_world: int, device_of_rank) -> Dict[str, obj
     except OSError as e:
         info["why"] = f"sched_setaffinity: {e}"
         return info
-    info.update(pinned=True, cpus=len(share), first_cpu=share[0], last_cpu=share[-1])
+    # sched_setaffinity(0, ...) moves the CALLING thread only; threads that already exist -- finding the GPU's PCI address
+    # above initialises the HIP runtime, whose helper threads (ROCr's event loop among them) are running by now -- keep
+    # the old mask, and only threads created from here on inherit the new one.  Move every existing thread too.
+    moved = 0
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), share)
+                moved += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    info.update(pinned=True, cpus=len(share), first_cpu=share[0], last_cpu=share[-1], threads_moved=moved)
     return info

@@ -75,7 +75,8 @@ def select_checkpoint(cfg) -> Tuple[str, Optional[str]]:
         ``<cfg.DIR_RESULT>/ema_ckpt`` (:84-85) -- the step was still chosen from the listing of the plain directory,
         as in the reference.  Path = ``<dir>/save_step_<step>.pth`` (:86-89);
       * otherwise the given path, label 'unknown' (:99-101).
-    Like the reference, the choice is also written back to ``cfg.DIR_CKPT`` / ``cfg.TEST_CKPT_PATH``."""
+    Like the reference, the choice is also written back to ``cfg.DIR_CKPT`` / ``cfg.TEST_CKPT_PATH`` -- so the function is
+    not idempotent: a second call finds TEST_CKPT_PATH set and returns ('unknown', that path) without listing anything."""
     if cfg.TEST_CKPT_PATH == "test":
         return "test", None
     if cfg.TEST_CKPT_PATH is None:
@@ -85,7 +86,17 @@ def select_checkpoint(cfg) -> Tuple[str, Optional[str]]:
             names = os.listdir(cfg.DIR_CKPT)
             if not names:
                 raise FileNotFoundError(f"No checkpoint in {cfg.DIR_CKPT}.")
-            ckpt = sorted(int(x.split("_")[-1].split(".")[0]) for x in names)[-1]
+            # the reference parses EVERY name (a stray .DS_Store or temporary file is a bare ValueError there); same rule
+            # -- the integer between the last '_' and the first '.' -- applied to the names it can apply to
+            steps = []
+            for x in names:
+                try:
+                    steps.append(int(x.split("_")[-1].split(".")[0]))
+                except ValueError:
+                    continue
+            if not steps:
+                raise FileNotFoundError(f"No checkpoint named *_<step>.* in {cfg.DIR_CKPT} (found: {sorted(names)[:5]}).")
+            ckpt = sorted(steps)[-1]
         if getattr(cfg, "TEST_EMA", False):
             cfg.DIR_CKPT = os.path.join(cfg.DIR_RESULT, "ema_ckpt")
         cfg.TEST_CKPT_PATH = os.path.join(cfg.DIR_CKPT, f"save_step_{ckpt}.pth")

@@ -272,10 +272,12 @@ extern "C" int rmem_linear_grouped(const rmem_linear_args* args, int32_t n, void
       const int tot2 = stream2_group(g.p, n, g2);
       if (stream2_covers(g2))
         return args[0].nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
+      // (a problem with a generic epilogue shape -- per-row bias, accumulate, two fp32 destinations: the tile kernels below)
+    } else {
+      StreamGroup gs;
+      const int tot = stream_group(g.p, n, gs);
+      return args[0].nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
     }
-    StreamGroup gs;
-    const int tot = stream_group(g.p, n, gs);
-    return args[0].nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
   }
   if (args[0].nsplit == 3)
     return rmem::launch<GroupedLinear, linear_grouped_kernel<3>, 256, linear_grouped_many<3>>(
@@ -294,10 +296,11 @@ extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
       StreamGroup2 g2;
       const int tot2 = stream2_group(&a, 1, g2);
       if (stream2_covers(g2)) return a.nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
+    } else {
+      StreamGroup gs;
+      const int tot = stream_group(&a, 1, gs);
+      return a.nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
     }
-    StreamGroup gs;
-    const int tot = stream_group(&a, 1, gs);
-    return a.nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
   }
   // tile-per-workgroup kernels: 64 x 64 unless 64 rows x 128 columns is asked for (the 128 x 128 instantiation -- 248
   // registers + 64 accumulator registers, 336 B of scratch, one wave per SIMD, never selected by the memory path -- is gone)

@@ -158,6 +158,15 @@ class DeAOTEngine(nn.Module):
             self._fg, self._ug, self._dg, self._tg = {}, {}, {}, {}
             self._geoms = []
         if self.lstt is not None:
+            # graph-pointer audit: the captured graphs hold raw addresses of the LSTT's buffers
+            sig = self.lstt.buffer_signature() if hasattr(self.lstt, "buffer_signature") else None
+            if getattr(self, "_graph_sig", sig) != sig:
+                import warnings
+                warnings.warn("rmem_amd: an LSTT buffer was reallocated since its hipGraphs were captured; dropping the graphs")
+                self._fg, self._ug, self._dg, self._tg = {}, {}, {}, {}
+                self._drop_pending()
+                self._drop_hoist()
+            self._graph_sig = sig
             self.lstt.clear_memory()
 
     def update_size(self, input_size, enc_size):                # aot_engine.py:565-568

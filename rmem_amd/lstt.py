@@ -227,6 +227,7 @@ class DeAOTLSTT:
         band = min(tv, ((min(h, 3 + 14) * w) + 63) // 64 + 1)       # key tiles visible to a 64-query tile (15x15 window)
         LONG, WIN, FIX = 9.5, 14.6, 14.0
         best = None
+        cands = []
         for kl in range(1, 33):
             for kw in range(1, 9):
                 if kl > long_tiles or kw > band:
@@ -248,6 +249,7 @@ class DeAOTLSTT:
                         heapq.heappush(free, t0 + c)
                         span = max(span, t0 + c)
                 key = (round(span, 1), kl + kw)
+                cands.append((span, kl, kw))
                 if best is None or key < best[0]:
                     best = (key, kl, kw)
         if best is None:
@@ -255,6 +257,18 @@ class DeAOTLSTT:
             # tile's keys stay in one unit
             return 1, 1
         kl, kw = best[1], best[2]
+        # One clip whose shortest launch fits the machine in one round: take the FEWEST units whose launch stays within 1.5 x
+        # that shortest one.  The frame is bound by the CU-time its kernels hold, not by the length of this launch (what the
+        # read leaves free the prefetched encoder pass uses): fewer, longer units carry fewer prologues, flushes and split
+        # partials, and a windowed read in ONE split needs no partial or combine at all (rmem_read_args.gout).  Measured at
+        # 480p K=4, same box, alternating (profiles/r06j_ks_sweep_fused.txt): (7, 2) 513.5 / 513.0 frames/s with a 110 us
+        # launch; (5, 1) 521.5 / 522.4 with a 140 us launch; (6, 1) 509 / 512, (7, 1) 514 / 511, (4, 1) 517 (the model's
+        # spans: 166 / 233 / 233 / 233 / 275 k cycles).  `RMEM_KS` overrides.
+        if clips == 1 and nq * (kl + kw) <= cus and os.environ.get("RMEM_SPLITS_SHORTEST") != "1":
+            lim = 1.5 * best[0][0]
+            ok = [(a + b, sp, a, b) for sp, a, b in cands if sp <= lim and nq * (a + b) <= cus]
+            if ok:
+                _, _, kl, kw = min(ok)
         # More units than CUs: the windowed units (last in dispatch order) queue on the few CUs per XCD the long-term
         # units leave free and end up as the makespan (720p K=8: 8 units of up to 22 tiles on 2 CUs per XCD, at the
         # throttled clock); halves of them pack better.  Measured (profiles/r03q_split_sweep_720p.txt): (4, 1) 743 us,
@@ -385,6 +399,10 @@ class DeAOTLSTT:
         # DeAOTEngine._try_hoist); the windowed read and the combine stay in `rest`.  Same kernels' arithmetic, separate
         # launches for that layer (bit-identical: the split units are those of the paired launch).
         self.early_long_read = os.environ.get("RMEM_EARLY_LONG_READ", "0") == "1"
+        if self.early_long_read and os.environ.get("RMEM_UNEVEN") == "1":
+            # (the early launch goes through rmem_attn_read, which honours even key splits only; the sampled-read timing of
+            # bench.py would also time a schedule that is not the one that runs)
+            raise hip.RmemError("RMEM_EARLY_LONG_READ=1 cannot be combined with RMEM_UNEVEN=1")
         self.Ylt = Planes.empty((Np, 1024), dev)
         self.Yst = Planes.empty((Np, 1024), dev)
         # split-K of the projection GEMMs.  Under the streaming kernel two splits are one round of 216 items (19.1 / 12.9 us
@@ -795,6 +813,26 @@ class DeAOTLSTT:
     def graph_key(self):
         """Everything a captured forward depends on besides device memory contents."""
         return (self._T, self.cur)
+
+    def buffer_signature(self):
+        """Addresses of every device buffer a captured graph of this LSTT bakes in (unit-queue counters, slot maps, residual
+        streams, planes, banks, read workspaces, ...).  The buffers are allocated once per LSTT, so the signature is constant
+        for its lifetime; the engine records it with its graphs and compares at every clip start (DeAOTEngine.restart_engine)
+        -- a graph must never be replayed against a pointer that has since been reallocated (advisor, round 5: the 720p
+        second-clip fault was bisected to a memset node, but a stale pointer would have shown the same symptoms)."""
+        ptrs = []
+        for name in sorted(self.__dict__):
+            if name.startswith("_"):           # (per-frame aliases and inputs: the encoder feature copy, the current stream pair)
+                continue
+            v = self.__dict__[name]
+            for t in (v if isinstance(v, (list, tuple)) else [v]):
+                if torch.is_tensor(t):
+                    ptrs.append(t.data_ptr())
+                elif isinstance(t, Planes):
+                    ptrs.extend((t.hi.data_ptr(), t.lo.data_ptr()))
+                elif isinstance(t, _AttnWS):
+                    ptrs.extend(x.data_ptr() for x in t.__dict__.values() if torch.is_tensor(x))
+        return hash(tuple(ptrs))
 
     def graph_variants(self):
         """Host states (attribute dicts) that differ only in graph_key() for the current T:

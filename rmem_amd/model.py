@@ -126,10 +126,13 @@ class DeAOT(nn.Module):
         Idempotent per (fold_bn, weights version, device): every engine calls it when it is built, and an engine
         built EARLIER holds hipGraphs that replay the folded tensors -- folding again would free the memory those
         graphs read (a second driver on the same model used to corrupt the first one's encoder that way).  It folds
-        again when the weights changed: rmem_amd.checkpoint.load_network() bumps `_weights_version`; encoder weights
-        written in place by hand (load_state_dict, copy_) are noticed through the tensors' version counters; force=True
-        folds in any case.  The last two bump the version themselves so that existing engines re-pack their LSTT planes
-        and re-capture their graphs (engine.py / batched.py: _stale_weights)."""
+        again when the weights changed: rmem_amd.checkpoint.load_network() bumps `_weights_version`; ENCODER weights
+        written in place by hand (load_state_dict, copy_) are noticed through the tensors' version counters -- but only
+        here, i.e. when the next engine is built; force=True folds in any case.  The last two bump the version themselves so
+        that existing engines re-pack their LSTT planes and re-capture their graphs at their next clip
+        (engine.py / batched.py: _stale_weights).  NOT covered: in-place edits of LSTT / decoder / ID-bank weights without
+        load_network(), and edits made while engines exist and no new one is built -- call
+        optimize_for_inference(force=True) (or load_network) after changing weights by hand."""
         wv = self.__dict__.get("_weights_version", 0)
         dev = str(next(self.parameters()).device)
         have = self.__dict__.get("_enc_infer_state")
