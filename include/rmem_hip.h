@@ -43,7 +43,6 @@ int rmem_abi_version(void);
  * serves a debug entry point).  Returns RMEM_ERR_INVALID for an unknown name or a value outside the range; takes effect for
  * launches issued afterwards.  Names (range, default):
  *   "linear_tiles"  (0-1, 0)   1: tile-per-workgroup projection kernels for every rmem_linear[_grouped] launch
- *   "stream_form"   (1-2, 2)   streaming projection kernel: 2 = one-round-trip descriptors + rolled epilogue, 1 = first form
  *   "stream_var"    (1-4, 1)   rmem_linear_trace only: 2 no operand requests, 3 no MFMAs, 4 no fragment reads (timings, wrong results)
  *   "dw_rows"       (0-4, 2)   rmem_dwconv5x5_split[2]: output rows per thread (0 = the one-row kernel)
  *   "dw_rx" (6-12, 9), "dw_v" (1-4, 1)   the one-row kernel's tokens / channels per thread; "dw_grid_order" (0-1, 0) plain block order

@@ -9,7 +9,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librmem_hip.so")
 SOURCES = ["linear.hip", "read64.hip", "mha.hip", "pointwise.hip", "postproc.hip", "batch.hip"]
-HEADERS = ["rmem_common.h", "gemm_core.h", "linear_stream.h", "linear_stream_v1.h", "attn_common.h", "launch.h", os.path.join("..", "..", "include", "rmem_hip.h")]
+HEADERS = ["rmem_common.h", "gemm_core.h", "linear_stream.h", "attn_common.h", "launch.h", os.path.join("..", "..", "include", "rmem_hip.h")]
 
 
 # mha.hip: VGPR form of every MFMA (no AGPRs: the 32x32 score and output tiles are read and written by

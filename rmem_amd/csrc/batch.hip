@@ -22,7 +22,7 @@ extern "C" int rmem_configure(const char* name, int64_t value) {
   RmemConfig& c = rmem_config();
   const int v = (int)value;
   struct Key { const char* name; int* field; int lo, hi; };
-  const Key keys[] = {{"linear_tiles", &c.linear_tiles, 0, 1}, {"stream_form", &c.stream_form, 1, 2}, {"stream_var", &c.stream_var, 1, 4},
+  const Key keys[] = {{"linear_tiles", &c.linear_tiles, 0, 1}, {"stream_var", &c.stream_var, 1, 4},
                       {"dw_rx", &c.dw_rx, 6, 12}, {"dw_v", &c.dw_v, 1, 4}, {"dw_rows", &c.dw_rows, 0, 4},
                       {"dw_grid_order", &c.dw_grid_order, 0, 1}, {"ida_tokens", &c.ida_tokens, 1, 2}, {"ida_unroll", &c.ida_unroll, 8, 32},
                       {"read_var", &c.read_var, 0, 31}};

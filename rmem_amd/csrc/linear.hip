@@ -199,7 +199,6 @@ __device__ void linear_grouped_many(const GroupedLinear& g, int) { linear_groupe
 
 static int validate_linear(rmem_linear_args& a);
 
-#include "linear_stream_v1.h"
 #include "linear_stream.h"
 
 // Debug aid: the streaming kernel with cycle stamps (see linear_stream_kernel); trace must hold 64 int64 per workgroup
@@ -212,22 +211,16 @@ extern "C" int rmem_linear_trace(const rmem_linear_args* args, int32_t n, int64_
     if (validate_linear(v[i]) != RMEM_OK || v[i].nsplit != 3) return RMEM_ERR_INVALID;
   }
   if (!use_stream(v, n)) return RMEM_ERR_INVALID;
-  if (stream_form() == 2) {
-    StreamGroup2 g2;
-    const int total2 = stream2_group(v, n, g2);
-    if (stream2_covers(g2)) {
-      const int var = rmem_config().stream_var;          // timing experiments (linear_stream2_kernel): 2 no requests, 3 no MFMAs, 4 no fragment reads
-      long long* tp = reinterpret_cast<long long*>(trace);
-      hipStream_t st = static_cast<hipStream_t>(stream);
-      if (var == 2) return launch_stream2<3, 2>(g2, total2, tp, st);
-      if (var == 3) return launch_stream2<3, 3>(g2, total2, tp, st);
-      if (var == 4) return launch_stream2<3, 4>(g2, total2, tp, st);
-      return launch_stream2<3, 1>(g2, total2, tp, st);
-    }
-  }
-  StreamGroup g;
-  const int total = stream_group(v, n, g);
-  return launch_stream<3, 1>(g, total, reinterpret_cast<long long*>(trace), static_cast<hipStream_t>(stream));
+  StreamGroup2 g2;
+  const int total2 = stream2_group(v, n, g2);
+  if (!stream2_covers(g2)) return RMEM_ERR_INVALID;
+  const int var = rmem_config().stream_var;          // timing experiments (linear_stream2_kernel): 2 no requests, 3 no MFMAs, 4 no fragment reads
+  long long* tp = reinterpret_cast<long long*>(trace);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (var == 2) return launch_stream2<3, 2>(g2, total2, tp, st);
+  if (var == 3) return launch_stream2<3, 3>(g2, total2, tp, st);
+  if (var == 4) return launch_stream2<3, 4>(g2, total2, tp, st);
+  return launch_stream2<3, 1>(g2, total2, tp, st);
 }
 
 template <int BM, int BN, int NS>
@@ -267,17 +260,11 @@ extern "C" int rmem_linear_grouped(const rmem_linear_args* args, int32_t n, void
   g.tile_start[n] = total;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (use_stream(g.p, n)) {
-    if (stream_form() == 2) {
-      StreamGroup2 g2;
-      const int tot2 = stream2_group(g.p, n, g2);
-      if (stream2_covers(g2))
-        return args[0].nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
-      // (a problem with a generic epilogue shape -- per-row bias, accumulate, two fp32 destinations: the tile kernels below)
-    } else {
-      StreamGroup gs;
-      const int tot = stream_group(g.p, n, gs);
-      return args[0].nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
-    }
+    StreamGroup2 g2;
+    const int tot2 = stream2_group(g.p, n, g2);
+    if (stream2_covers(g2))
+      return args[0].nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
+    // (a problem with a generic epilogue shape -- per-row bias, accumulate, two fp32 destinations: the tile kernels below)
   }
   if (args[0].nsplit == 3)
     return rmem::launch<GroupedLinear, linear_grouped_kernel<3>, 256, linear_grouped_many<3>>(
@@ -292,15 +279,9 @@ extern "C" int rmem_linear(const rmem_linear_args* ap, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (validate_linear(a) != RMEM_OK) return RMEM_ERR_INVALID;
   if (use_stream(&a, 1)) {
-    if (stream_form() == 2) {
-      StreamGroup2 g2;
-      const int tot2 = stream2_group(&a, 1, g2);
-      if (stream2_covers(g2)) return a.nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
-    } else {
-      StreamGroup gs;
-      const int tot = stream_group(&a, 1, gs);
-      return a.nsplit == 3 ? launch_stream<3, 0>(gs, tot, nullptr, s) : launch_stream<1, 0>(gs, tot, nullptr, s);
-    }
+    StreamGroup2 g2;
+    const int tot2 = stream2_group(&a, 1, g2);
+    if (stream2_covers(g2)) return a.nsplit == 3 ? launch_stream2<3, 0>(g2, tot2, nullptr, s) : launch_stream2<1, 0>(g2, tot2, nullptr, s);
   }
   // tile-per-workgroup kernels: 64 x 64 unless 64 rows x 128 columns is asked for (the 128 x 128 instantiation -- 248
   // registers + 64 accumulator registers, 336 B of scratch, one wave per SIMD, never selected by the memory path -- is gone)

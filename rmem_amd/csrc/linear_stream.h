@@ -1,7 +1,7 @@
-// linear_stream.h -- the streaming projection kernel, second form (included by linear.hip after linear_stream_v1.h,
-// whose host-side checks -- use_stream, stream_cus -- and tail-tile epilogues it shares).
+// linear_stream.h -- the streaming projection kernel (included by linear.hip after linear_epilogue / GroupedLinear).  This is
+// its second form (round 6); the first (round 4, `git log -- rmem_amd/csrc/linear_stream_v1.h`) measured as follows.
 //
-// What the first form (linear_stream_v1.h) measured, per workgroup, on the grouped front launch of a GPM layer
+// What the first form measured, per workgroup, on the grouped front launch of a GPM layer
 // (rmem_linear_trace, profiles/r06a_stream_trace.json; 35.8 k cycles for two items of four stages = 6.1 k cycles of MFMA):
 //   3.9 k cycles from launch to the first request: ten DEPENDENT scalar-load round trips -- the per-problem descriptor was
 //         read field by field through dynamic indexes into the kernel argument, each field where it was first used;
@@ -23,9 +23,31 @@
 //     loop is rolled (the accumulator vector is rotated by four registers per round): ~60 instructions fetched once
 //     instead of ~300 -- every launch starts with a cold instruction cache.  Blocked-16 planes (V operand layout) keep the
 //     accumulator's own layout -- four consecutive rows of a column ARE its 8-byte unit -- in the same rolled form.
-//     Tiles that cross M (one row tile in 27) and shapes the fast forms do not cover take the first form's epilogues.
+//     Blocked-16 tiles that cross M (one row tile in 27) take element stores under row checks; shapes the fast forms do not
+//     cover (per-row bias, accumulate, two fp32 destinations) are served by the tile-per-workgroup kernels.
 //   * 8 KB of LDS for the staging (1 KB per wave) behind the ring: 159 KB per workgroup.
 #pragma once
+
+// One persistent workgroup per CU (8 waves, two per SIMD) walks its share of the launch's items (problem, 64-row tile,
+// 128-column tile, K range) as ONE stream of k-tile stages: operands by LDS-DMA (global_load_lds_dwordx4: no staging
+// registers) into a ring of three 48 KB stages requested ACROSS item boundaries; a stage = X tile [64][64 k] + Y tile
+// [128][64 k], hi / lo planes, each row 128 B with its 16-byte chunks XOR-swizzled (the DMA lands lane-linear, so the swizzle
+// is applied to the SOURCE address); the bias of the item's columns rides along as a seventh request per wave and stage.
+template <int NS>
+struct StreamCfg {
+  static constexpr int BM = 64, BN = 128, BK = 64, NSPLIT = NS;
+  static constexpr int THREADS = 512;
+  static constexpr int WM = 32, WN = 32, TM = 1, TN = 1;
+  static constexpr int NPL = (NS == 1) ? 1 : 2;
+  static constexpr int X_BYTES = BM * 128, Y_BYTES = BN * 128;       // one plane of a stage
+  static constexpr int STAGE_BYTES = NPL * (X_BYTES + Y_BYTES);
+  static constexpr int NSTAGE = 3;
+  static constexpr int BIAS = NSTAGE * STAGE_BYTES;                   // [stage][wave][64 floats]: bias of the wave's columns
+  static constexpr int ITEMS = BIAS + NSTAGE * 8 * 256;               // [4] x int4: the items in flight (load side -> compute side)
+  static constexpr int DUMMY = ITEMS + 64;                            // 1 KiB nobody reads: target of requests past the last stage
+  static constexpr int LDS_BYTES = DUMMY + 1024;
+  static constexpr int DMA_PER_WAVE = 3 * NPL + 1;                    // X rows 8w.., Y rows 8w.. and 64 + 8w.. per plane, + bias
+};
 
 typedef int __attribute__((ext_vector_type(16))) i32x16_t;
 typedef int __attribute__((ext_vector_type(8))) i32x8_t;
@@ -528,8 +550,42 @@ __global__ __launch_bounds__(512) void linear_stream2_kernel(StreamGroup2 g, lon
 }
 
 // ---- host side
-// (rmem_configure("stream_form", 1) keeps the first form for every launch: A/B runs)
-static int stream_form() { return rmem_config().stream_form; }
+static int stream_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return n;
+}
+
+// The streaming kernel serves a launch issued directly whose problems ask for tile 0 (auto) or 256; tile 64 / 128 / 192
+// select the tile-per-workgroup kernels (kept for the recorded launches of several clips -- launch.h -- and as the
+// bit-identical cross-check), as does rmem_configure("linear_tiles", 1) for every launch.  Stays with the tile kernels as well: items of a
+// single stage (see below), a split-K problem whose last split would be empty (ceil division; the stream counts one stage per k-tile of every item), leading
+// dimensions or item counts beyond what the packed descriptor holds.
+static bool use_stream(const rmem_linear_args* args, int n) {
+  if (rmem_config().linear_tiles || rmem::current_recorder()) return false;
+  long items = 0;
+  for (int i = 0; i < n; ++i) {
+    const rmem_linear_args& a = args[i];
+    if (a.tile != 0 && a.tile != 256) return false;
+    if (a.ldx >= (1L << 30) || a.ldy >= (1L << 30) || a.ldx2 >= (1L << 30) || a.ldy2 >= (1L << 30)) return false;
+    if (a.M > 65535 * 64 || a.N > 32767 * 128) return false;
+    // an item of ONE stage: the load side runs up to four stages ahead and would publish the descriptor of item i + 4
+    // into the four-entry item ring before the epilogue of item i has read its slot (a workgroup with five or more
+    // items); such shapes (K = 64, or split-K down to one k-tile per split) stay with the tile kernels
+    if (a.K / 64 < 2) return false;
+    if (a.ksplits > 1) {
+      const int kt = a.K / 64, per = (kt + a.ksplits - 1) / a.ksplits;
+      if ((a.ksplits - 1) * per >= kt) return false;
+      if (per < 2 || kt - (a.ksplits - 1) * per < 2) return false;
+    }
+    items += (long)((a.M + 63) / 64) * ((a.N + 127) / 128) * (a.ksplits > 1 ? a.ksplits : (a.nbatch > 0 ? a.nbatch : 1));
+  }
+  return items < (1L << 20);                   // (fast_div's exact range)
+}
+
 static bool aligned_to(const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 static void stream2_desc(const rmem_linear_args& a, StreamDesc& q) {

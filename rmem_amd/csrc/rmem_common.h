@@ -22,7 +22,6 @@
 // rmem_configure() (include/rmem_hip.h; rmem_amd/hip.py maps its RMEM_* variables onto it once, when it loads the library).
 struct RmemConfig {
   int linear_tiles = 0;      // 1: tile-per-workgroup projection kernels for every launch (A/B and cross-check)
-  int stream_form = 2;       // 1: first form of the streaming projection kernel (kept for generic epilogue shapes), 2: second form
   int stream_var = 1;        // rmem_linear_trace only: 2 no operand requests, 3 no MFMAs, 4 no fragment reads (timing experiments)
   int dw_rx = 9, dw_v = 1;   // depth-wise conv, one-row kernel: tokens per thread, channels per thread
   int dw_rows = 2;           // depth-wise conv: output rows per thread (0: the one-row kernel)

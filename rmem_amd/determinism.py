@@ -48,6 +48,15 @@ def fix_random(seed: int = 1) -> None:
     # MIOpen: "fast" find mode (2) = find-db hit or the immediate-mode fallback, never a timed search
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     os.environ.setdefault("MIOPEN_FIND_ENFORCE", "1")          # NONE: never (re)search / update the find-db
+    # ... and an EMPTY user find-db of this process's own.  In MIOpen's default (hybrid) mode the first use of a convolution
+    # runs a timed search and records the winner in ~/.config/miopen; what a later process computes then depends on what
+    # earlier processes happened to time -- round 6 traced every clip-hash difference between runs of one command to that
+    # state (profiles/r06m_world_hash_matrix.txt: 1 or 8 ranks, cold or warm caches: one set of hashes; another find mode:
+    # another set; profiles/r05g: the first 8-rank run of a fresh box, searching under contention, differed from all later
+    # ones).  With no entries to find and no search allowed, the solver of every convolution is MIOpen's heuristic choice.
+    if "MIOPEN_USER_DB_PATH" not in os.environ:
+        import tempfile
+        os.environ["MIOPEN_USER_DB_PATH"] = tempfile.mkdtemp(prefix="rmem_miopen_userdb_")
     random.seed(seed + 1)
     np.random.seed(seed + 2)
     torch.manual_seed(seed + 3)

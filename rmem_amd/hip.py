@@ -195,7 +195,6 @@ def load():
 # when it loads the library (tests and tools switch kernels at run time with configure()).
 _ENV_SWITCHES = (
     ("RMEM_LINEAR", lambda v: [("linear_tiles", 1 if v.startswith("t") else 0)]),
-    ("RMEM_STREAM", lambda v: [("stream_form", int(v))]),
     ("RMEM_DW", lambda v: list(zip(("dw_rx", "dw_v"), (int(x) for x in v.split(","))))),
     ("RMEM_DW_ROWS", lambda v: [("dw_rows", int(v))]),
     ("RMEM_DW_ORDER", lambda v: [("dw_grid_order", 1 if v.startswith("g") else 0)]),

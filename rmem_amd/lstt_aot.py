@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -121,6 +122,12 @@ class AOTLSTT:
         # key splits: ~448 blocks (2 per CU x 224) of 4 independent waves each
         # key splits: ~5 waves per SIMD in flight (3 resident); 480p: 12 (T = 4: 78.8 us at 8, 64.5 at 12, 63.8 at 16)
         self.ks = max(1, min(16, int(round(1344.0 / ((Np // 128) * self.HEADS)))))
+        # key splits of the one-slot reads (short-term, self); RMEM_AOT_KS="long,short" overrides both (tuning)
+        self.ks_short = self.ks
+        if os.environ.get("RMEM_AOT_KS"):
+            v = [int(x) for x in os.environ["RMEM_AOT_KS"].split(",")]
+            self.ks = max(1, min(16, v[0]))
+            self.ks_short = max(1, min(self.ks, v[1] if len(v) > 1 else v[0]))
         self.opart = z(self.ks, Np, 256)
         self.ml = z(self.ks, Np, self.HEADS, 2)
         self.slot_ml = z(self.ks, Np, self.HEADS, self.Tmax, 2)
@@ -208,7 +215,8 @@ class AOTLSTT:
         a.kh, a.kl, a.k_slot_stride, a.ldk = k.hi.data_ptr() + k_off * 2, k.lo.data_ptr() + k_off * 2, k_slot_stride, ldk
         a.vh, a.vl, a.v_slot_stride, a.ldv = v.hi.data_ptr(), v.lo.data_ptr(), 256 * self.Npad, self.Npad
         a.slot_map, a.T, a.N, a.Npad, a.heads = slot_map_ptr, T, self.N, self.Npad, self.HEADS
-        a.scale, a.bias, a.ksplits = self.scale, hip.ptr(bias), self.ks
+        ks = self.ks if T > 1 else self.ks_short
+        a.scale, a.bias, a.ksplits = self.scale, hip.ptr(bias), ks
         a.opart, a.ml = self.opart.data_ptr(), self.ml.data_ptr()
         a.slot_ml = self.slot_ml.data_ptr() if want_mass else None
         a.nsplit = self.nsplit
@@ -222,7 +230,7 @@ class AOTLSTT:
             e1.record()
             self._events.append((e0, e1, T))
         c = hip.MHACombineArgs()
-        c.N, c.Npad, c.heads, c.T, c.ksplits = self.N, self.Npad, self.HEADS, T, self.ks
+        c.N, c.Npad, c.heads, c.T, c.ksplits = self.N, self.Npad, self.HEADS, T, ks
         c.opart, c.ml, c.slot_ml = self.opart.data_ptr(), self.ml.data_ptr(), a.slot_ml
         c.oh, c.ol, c.of32, c.ldo = self.ao_pl.hi.data_ptr(), self.ao_pl.lo.data_ptr(), None, 256
         c.mass = self.mass.data_ptr() if want_mass else None

@@ -84,7 +84,7 @@ def test_configure_switches_and_no_getenv_in_the_library():
     lib = hip.load()
     assert lib.rmem_configure(b"dw_rows", 3) == 0 and lib.rmem_configure(b"dw_rows", 2) == 0
     assert lib.rmem_configure(b"dw_rows", 9) == -1 and lib.rmem_configure(b"no_such_switch", 1) == -1
-    assert lib.rmem_configure(None, 1) == -1 and lib.rmem_configure(b"stream_form", 3) == -1
+    assert lib.rmem_configure(None, 1) == -1 and lib.rmem_configure(b"stream_var", 5) == -1
     with pytest.raises(hip.RmemError):
         hip.configure("linear_tiles", 2)
     hip.configure("linear_tiles", 0)

@@ -81,7 +81,7 @@ def padded(hip, pl, pad=64):
 def main():
     hip, L, dev = build()
     P = problems(hip, L)
-    res = {"form": os.environ.get("RMEM_STREAM", "2")}
+    res = {}
     for name, grp in P.items():
         res[name] = timeit(lambda: hip.linear_grouped(grp), 20)
     res["sum4"] = sum(res[k] for k in P)
