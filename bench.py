@@ -92,8 +92,8 @@ def parse():
 # HBM traffic of the dominant kernel: from separate rocprofv3 --pmc passes of the same bench command
 # (research/jobs/gpujob_profile_r03.sh: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, mean per
 # launch), committed under profiles/.  (model, config, clips) -> (file, kernel-name prefix in that file)
-PMC_FILES = {("r50_deaotl", "480p_k4", "one"): ("r05_pmc_x3.json", "read64x2_kernel"),
-             ("r50_deaotl", "720p_k8", "one"): ("r04m_pmc_720p_k8.json", "read64x2_pull_kernel"),
+PMC_FILES = {("r50_deaotl", "480p_k4", "one"): ("r06_pmc_x3.json", "read64x2_kernel"),
+             ("r50_deaotl", "720p_k8", "one"): ("r06_pmc_720p_k8.json", "read64x2_pull_kernel"),
              ("r50_deaotl", "480p_k4", "batched8"): ("r04m_pmc_batched8.json", "read64x2_many_pull_kernel"),
              ("r50_aotl", "480p_k4", "one"): ("r04m_pmc_aot.json", "mha_flash_kernel")}
 
@@ -102,7 +102,7 @@ def _pmc_path(name):
     """profiles/<name>, or the previous round's file of the same configuration while this round's is not collected yet."""
     if not name:
         return None, None
-    for n in (name, name.replace("r05_", "r04m_")):
+    for n in (name, name.replace("r06_", "r05_"), name.replace("r06_", "r04m_"), name.replace("r05_", "r04m_")):
         p = os.path.join(ROOT, "profiles", n)
         if os.path.exists(p):
             return p, n

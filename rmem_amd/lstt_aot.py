@@ -119,11 +119,16 @@ class AOTLSTT:
         self.x_pl, self.xq_pl = Planes.empty((Np, 256), dev), Planes.empty((Np, 256), dev)
         self.sQK = Planes.empty((Np, 512), dev)
         self.sVt = Planes.empty((1, 256, Np), dev)
-        # key splits: ~448 blocks (2 per CU x 224) of 4 independent waves each
-        # key splits: ~5 waves per SIMD in flight (3 resident); 480p: 12 (T = 4: 78.8 us at 8, 64.5 at 12, 63.8 at 16)
-        self.ks = max(1, min(16, int(round(1344.0 / ((Np // 128) * self.HEADS)))))
+        # Key splits, chosen for the frame (round 6; profiles/r06o_aot_ks_sweep.txt, same box, alternating, R50-AOTL 480p
+        # K=4 frames/s for (long, one-slot) splits): (12, 12) 455.7 / 456.6 -- the round-4 choice, tuned on the kernel's own
+        # length: 78.8 us at 8 splits, 64.5 at 12 --; (8, 8) 472; (12, 4) 476-482; (6, 4) 482.1 / 481.1; (5, 4) 482.8 / 484.0;
+        # (4, 2) 481.5 / 482.7; (3, 2) 477 / 473.  The frame follows the CU-time and the split-partial bytes a launch costs, not
+        # its length (the encoder stream uses what it leaves free): ~670 blocks for the bank read (6 splits at 480p: the
+        # kernel itself 63.9 us against 62.7), ~450 for the one-slot reads.
+        blocks = (Np // 128) * self.HEADS
+        self.ks = max(1, min(16, int(round(672.0 / blocks))))
         # key splits of the one-slot reads (short-term, self); RMEM_AOT_KS="long,short" overrides both (tuning)
-        self.ks_short = self.ks
+        self.ks_short = max(1, min(self.ks, int(round(448.0 / blocks))))
         if os.environ.get("RMEM_AOT_KS"):
             v = [int(x) for x in os.environ["RMEM_AOT_KS"].split(",")]
             self.ks = max(1, min(16, v[0]))
