@@ -325,6 +325,9 @@ class BatchedDeAOTEngine:
             self.lstt, self._eg, self._dg = None, {}, {}
         if self.lstt is not None:
             self.lstt.clear_memory()
+            for c in self.lstt.clips:
+                c.ref_frame_index = 0
+        self._cur_tokens = None               # encoder tokens of the frame the last call propagated (add_reference_slots)
 
     @property
     def long_memories_indexes(self) -> List[List[int]]:
@@ -363,6 +366,7 @@ class BatchedDeAOTEngine:
         self._lmi[i] = []
         self.active[i] = True
         self.lstt.clear_memory(i)
+        self.lstt.clips[i].ref_frame_index = 0
 
     def _stale_weights(self) -> bool:
         return self._lstt_wv != self.AOT.__dict__.get("_weights_version", 0)
@@ -503,6 +507,7 @@ class BatchedDeAOTEngine:
         self.active, self._ref_now = [True] * self.B, set()
         # no ignore channel on reference frames (aot_engine.py:304 -> :209-213)
         self.lstt.assign_identity(self._labels_u8(masks), ignore=False)
+        self._cur_tokens = None
         self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=True)
         # per slot, as every engine of the reference does for itself (aot_engine.py:241-325: last_mem_step := the
         # frame_step argument, or the engine's own counter; long_memories_indexes := [its own counter])
@@ -548,10 +553,44 @@ class BatchedDeAOTEngine:
         for i in range(self.B):
             if self.active[i] and i not in ref_slots:
                 self.frame_steps[i] += 1
-        self.lstt.forward(enc[-1].flatten(2).transpose(1, 2), ref_frame=[i in ref_slots for i in range(self.B)],
-                          active=self.active)
+        self._cur_tokens = enc[-1].flatten(2).transpose(1, 2)
+        self.lstt.forward(self._cur_tokens, ref_frame=[i in ref_slots for i in range(self.B)], active=self.active)
         self.pred_id_logits, up = self._decode(enc, output_size, imgs.is_cuda)
         return up
+
+    @torch.no_grad()
+    def add_reference_slots(self, refs: Dict[int, tuple]):
+        """A mid-clip reference frame for single slots -- the evaluator's answer to a frame that brings a label with NEW
+        objects (managers/evaluator.py:484-508: propagate, paste the new ids over the prediction, then
+        add_reference_frame(img, merged label) instead of update_memory).  refs: {slot: (merged label map at the network
+        size, object count)}; the frame is the one match_propogate_one_frame() has just propagated for that slot, so its
+        encoder features are at hand (the reference encodes the image a second time, aot_engine.py:262-270: same values).
+        Per slot what DeAOTEngine.add_reference_frame does mid-clip (aot_engine.py:241-325): ID assignment without the
+        ignore channel, a reference-mode pass of the LSTT -- the slot's bank restarts with this frame --, last_mem_step and
+        long_memories_indexes := the slot's frame counter.  The other slots take no part; update_memory() of this step
+        skips the slots named here.  (The reference-mode logits are not decoded: nothing reads them before the next
+        frame's.)"""
+        if not refs:
+            return
+        if self._cur_tokens is None:
+            raise RuntimeError("add_reference_slots follows match_propogate_one_frame of the same frame")
+        lab = self.lstt.label_buffer(*self.input_size_2d)
+        on = [i in refs for i in range(self.B)]
+        for i, (m, n) in refs.items():
+            if not self.active[i] or i in self._ref_now:
+                raise ValueError(f"slot {i} holds no propagated frame in this step")
+            if int(n) > self.AOT.max_obj_num:
+                raise NotImplementedError(f"more than {self.AOT.max_obj_num} objects per clip: use DeAOTInferEngine")
+            if m.data_ptr() != lab[i].data_ptr():
+                lab[i].copy_(m.reshape(lab.shape[1:]).to(torch.uint8))
+            self.obj_nums = self.obj_nums[:i] + [int(n)] + self.obj_nums[i + 1:]
+            self.lstt.clips[i].ref_frame_index = self.frame_steps[i]
+        self.lstt.assign_identity(lab, ignore=False, active=on)
+        self.lstt.forward(self._cur_tokens, ref_frame=on, active=on)
+        for i in refs:
+            self.last_mem_steps[i] = self.frame_steps[i]
+            self._lmi[i] = [self.frame_steps[i]]
+        self._ref_now |= set(refs)
 
     @torch.no_grad()
     def update_memory(self, masks):

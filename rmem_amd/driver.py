@@ -663,8 +663,9 @@ def plan_ragged_batches(clips_info: Sequence[Dict], B: int, no_memory_gap: bool 
     (gap, size, ori_size), longest first inside a group (a shorter clip idles -- its last frame is
     repeated and the output dropped -- until the longest of its batch ends), B per batch.  A group's
     remainder of >= 2 clips runs as a batch padded with repeats of its first clip (-1 marks a padding
-    slot); a single left-over clip, and every clip with test-time augmentation, mid-clip labels or more
-    than max_obj_num objects, goes to the one-clip driver.  `gap_of` (optional) replaces the gap rule (a
+    slot); a single left-over clip, and every clip with test-time augmentation or more than max_obj_num
+    objects, goes to the one-clip driver (a clip with mid-clip labels batches like any other: its slot turns the
+    frame into a reference frame, BatchedDeAOTEngine.add_reference_slots).  `gap_of` (optional) replaces the gap rule (a
     driver with a fixed gap).  Returns {"batches": [[clip ids (or -1)] * B], "singles": [clip ids]}; every
     clip id appears exactly once."""
     B = int(B)
@@ -676,7 +677,7 @@ def plan_ragged_batches(clips_info: Sequence[Dict], B: int, no_memory_gap: bool 
         n = int(c["num_frames"])
         if n < 1:
             raise ValueError(f"clip {i} is empty")
-        if int(c.get("n_aug", 1)) != 1 or bool(c.get("mid_labels", False)) or int(c.get("obj_num", 1)) > max_obj_num:
+        if int(c.get("n_aug", 1)) != 1 or int(c.get("obj_num", 1)) > max_obj_num:
             singles.append(i)
             continue
         gap = gap_of(n) if gap_of is not None else memory_gap(n, no_memory_gap)
@@ -735,13 +736,15 @@ class BatchedClipDriver:
     """B clips of one frame size and one memory-gap schedule in lockstep through
     rmem_amd.batched.BatchedDeAOTEngine: ONE launch per kernel of the memory path for all clips,
     encoder / decoder at batch B (BASELINE.json configs[3] runs 8 such clips per GPU).
-    Per clip the protocol is ClipDriver.run_clip's for one augmentation without mid-clip new objects
+    Per clip the protocol is ClipDriver.run_clip's for one augmentation
     (managers/evaluator.py:344-523): gap rule, reference frame, per frame decoder logits -> label map at
     the original size -> nearest resize to the network size -> update_memory.  run_clips(): B clips in
     lockstep (lengths may differ as long as the gap rule gives them the same gap); run_queue(): any number
     of clips of one frame size through the B slots, a slot taking the next clip when its clip ends, every
     clip on its own gap schedule; run_dataset(): any list of clips -- one queue per frame size, the rest
-    (augmentation, mid-clip labels, > 10 objects, a lone clip) through the one-clip driver."""
+    (augmentation, > 10 objects, a lone clip) through the one-clip driver.  A frame that brings a label with
+    new objects (managers/evaluator.py:484-508) is handled per slot in all three: the new ids go over the
+    prediction and the frame becomes that slot's reference frame while the other slots update as usual."""
 
     def __init__(self, model, B: int, cfg=None, gpu_id: int = 0, no_memory_gap: Optional[bool] = None,
                  fixed_gap: Optional[int] = None):
@@ -776,8 +779,6 @@ class BatchedClipDriver:
             raise ValueError("empty clip")
         if any(len(c[0]) != 1 for c in clips):
             raise ValueError("batched clips take one augmentation: use ClipDriver for test-time augmentation")
-        if any(s[0].get("current_label") is not None for c, n in zip(clips, lens) for s in c[1:n]):
-            raise NotImplementedError("mid-clip new objects: use ClipDriver")
         gaps = [self._gap_of(n) for n in lens]
         if any(g != gaps[0] for g in gaps):
             raise ValueError(f"batched clips must share the memory gap (lengths {lens} give gaps {gaps}): group them with "
@@ -815,10 +816,16 @@ class BatchedClipDriver:
         for t in range(1, nmax):
             cur, nxt = nxt, (stack(t + 1) if t + 1 < nmax else None)
             logit = eng.match_propogate_one_frame(cur, output_size=None, next_imgs=nxt)
+            refs = {}
             for i in range(B):
                 # (a finished clip's slot keeps running on its last frame; its rows of `out` past the clip's end are cut below)
                 lab = hip.labels_from_logits([logit[i:i + 1]], [False], ori_hw, self.align_corners, out=out[i, t - 1])
+                new = clips[i][t][0].get("current_label") if t < lens[i] else None
+                if new is not None:
+                    lab = self._paste_new_objects(lab, new, i)
+                    refs[i] = (lab_in[i], maxo)
                 hip.label_resize_nearest(lab, eng.input_size_2d, False, out=lab_in[i])
+            eng.add_reference_slots(refs)            # (evaluator.py:484-508: new objects -> the frame is a reference frame)
             eng.update_memory(lab_in)
         results = []
         for i, c in enumerate(clips):
@@ -827,6 +834,21 @@ class BatchedClipDriver:
             r.names = [str(s[0]["meta"].get("current_name", "")) for s in c[1:lens[i]]]
             results.append(r)
         return results
+
+    def _paste_new_objects(self, lab: torch.Tensor, new: torch.Tensor, i: int) -> torch.Tensor:
+        """managers/evaluator.py:484-496: the ids of a mid-clip label (a map at the original size, 0 where it says nothing)
+        go over the prediction, in place.  More ids than one engine holds need the one-clip driver's sub-engines."""
+        new = new.to(lab.device)[0, 0].to(torch.uint8)
+        if tuple(new.shape) != tuple(lab.shape):
+            raise ValueError(f"clip {i}: a mid-clip label must have the frames' original size {tuple(lab.shape)}")
+        lab.copy_(torch.where(new == 0, lab, new))
+        maxo = int(self.engine.AOT.max_obj_num)
+        ids = lab[lab != 255]
+        n = int(ids.max().item()) if ids.numel() else 0
+        if n > maxo:
+            raise NotImplementedError(f"clip {i} grows to {n} objects (> {maxo}) with a mid-clip label: use ClipDriver (one "
+                                      f"sub-engine per {maxo} objects, engines/aot_engine.py:675-702)")
+        return lab
 
     def _check_objects(self, clip, lab_net: torch.Tensor, i: int) -> None:
         """A clip with more than max_obj_num objects needs one sub-engine per 10 ids (engines/aot_engine.py:675-702):
@@ -858,8 +880,6 @@ class BatchedClipDriver:
             raise ValueError("empty clip")
         if any(len(c[0]) != 1 for c in clips):
             raise ValueError("batched clips take one augmentation: use ClipDriver for test-time augmentation")
-        if any(s[0].get("current_label") is not None for c in clips for s in c[1:]):
-            raise NotImplementedError("mid-clip new objects: use ClipDriver")
         meta = [c[0][0]["meta"] for c in clips]
         ori_hw = (int(meta[0]["height"]), int(meta[0]["width"]))
         size = tuple(clips[0][0][0]["current_img"].shape[2:])
@@ -896,11 +916,18 @@ class BatchedClipDriver:
             self.queue_stats["launch_groups"] += eng.lstt.groups_last
             if lab_in is None:
                 lab_in = eng.lstt.label_buffer(*eng.input_size_2d)
+            refs = {}
             for s_, e in enumerate(row):
                 if e is None or e[1] == 0:
                     continue
                 lab = hip.labels_from_logits([logit[s_:s_ + 1]], [False], ori_hw, self.align_corners, out=out[e[0]][e[1] - 1])
+                new = clips[e[0]][e[1]][0].get("current_label")
+                if new is not None:
+                    lab = self._paste_new_objects(lab, new, e[0])
+                    refs[s_] = (lab_in[s_], maxo)
                 hip.label_resize_nearest(lab, eng.input_size_2d, False, out=lab_in[s_])
+            # a frame that brought new objects becomes its slot's reference frame (evaluator.py:484-508), the others update
+            eng.add_reference_slots(refs)
             eng.update_memory(lab_in)
         results = []
         for i, c in enumerate(clips):
@@ -929,7 +956,7 @@ class BatchedClipDriver:
         mode "queue" (default): the clips of one frame size share the B slots through run_queue() -- a slot takes
         the next clip when its clip ends, whatever the lengths and gaps.  mode "lockstep": plan_ragged_batches()
         groups clips by (gap, size) into batches that run for their longest clip (run_clips).  Either way test-time
-        augmentation, mid-clip labels and > 10 objects run through ClipDriver.run_clip -- the reference's one-clip loop
+        augmentation and > 10 objects run through ClipDriver.run_clip -- the reference's one-clip loop
         (mode "lockstep": a lone clip of its group too).  ClipResult.batched tells which way a clip went."""
         if mode not in ("queue", "lockstep"):
             raise ValueError("mode: queue | lockstep")
@@ -950,7 +977,7 @@ class BatchedClipDriver:
             maxo = int(self.engine.AOT.max_obj_num)
             groups: Dict[tuple, List[int]] = {}
             for i, c in enumerate(info):
-                if int(c.get("n_aug", 1)) != 1 or bool(c.get("mid_labels", False)) or int(c.get("obj_num", 1)) > maxo:
+                if int(c.get("n_aug", 1)) != 1 or int(c.get("obj_num", 1)) > maxo:
                     singles.append(i)
                 else:
                     groups.setdefault((tuple(c["size"]), tuple(c["ori_size"])), []).append(i)

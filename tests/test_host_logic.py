@@ -381,8 +381,8 @@ def test_sharded_dataset_with_fewer_clips_than_ranks_and_a_one_frame_clip():
 
 def test_batched_clip_driver_validates_its_input_on_the_host():
     """BatchedClipDriver refuses what it cannot run in lockstep before anything is launched (no GPU
-    needed): wrong clip count, clips whose lengths give different memory gaps, flip augmentation, mid-clip
-    labels."""
+    needed): wrong clip count, clips whose lengths give different memory gaps, flip augmentation, more
+    objects than one engine holds."""
     from rmem_amd import driver as D
     from rmem_amd.config import get_config
     from rmem_amd.model import build_vos_model
@@ -399,8 +399,6 @@ def test_batched_clip_driver_validates_its_input_on_the_host():
         drv.run_clips([clip(4), clip(200)])
     with pytest.raises(ValueError):
         drv.run_clips([clip(4, aug=True), clip(4, aug=True)], num_frames=4)
-    with pytest.raises(NotImplementedError):
-        drv.run_clips([clip(4, mid=True), clip(4)], num_frames=4)
     # more objects than one engine holds (meta['obj_num'], or the label map when the meta has none): the
     # reference spawns a sub-engine per 10 ids (engines/aot_engine.py:675-702); the batched engine has none
     many = lambda n: [D.make_samples(img, lab if t == 0 else None, (33, 49), 12, name=f"{t:05d}.jpg") for t in range(n)]
@@ -419,8 +417,8 @@ def test_batched_clip_driver_validates_its_input_on_the_host():
 def test_plan_ragged_batches():
     """Which clips of a mixed dataset share a lockstep batch (driver.plan_ragged_batches): groups by (gap from the
     clip's own length -- managers/evaluator.py:327-331 --, network size, original size), longest first, B per batch,
-    a remainder of >= 2 padded with -1 slots, everything else (TTA, mid-clip labels, > 10 objects, a lone clip) to the
-    one-clip driver; every clip exactly once."""
+    a remainder of >= 2 padded with -1 slots, everything else (TTA, > 10 objects, a lone clip) to the one-clip driver;
+    a clip with mid-clip labels batches like any other (its slot re-references itself); every clip exactly once."""
     from rmem_amd import driver as D
     mk = lambda n, size=(465, 465), ori=(480, 480), **kw: dict(num_frames=n, size=size, ori_size=ori, **kw)
     info = [mk(40), mk(100), mk(165), mk(166),               # gaps 5, 5, 6 (round(5.5) = 6: Python rounds half to even, as the reference does), 6
@@ -438,10 +436,10 @@ def test_plan_ragged_batches():
         assert len({(gaps[i], info[i]["size"], info[i]["ori_size"]) for i in real}) == 1
         lens = [info[i]["num_frames"] for i in real]
         assert lens == sorted(lens, reverse=True)             # longest first: the batch runs for b[0]'s length
-    # gap 5 at 465x465: clips 1, 0, 8, 9 fill a batch, clip 12 is left alone; gap 6: clips 3, 2 padded; the two
-    # 481x849 clips (gap 5 both) padded; TTA / mid-clip labels / 12 objects / the lone gap-13 clip run alone
-    assert sorted(plan["batches"]) == sorted([[1, 0, 8, 9], [3, 2, -1, -1], [7, 10, -1, -1]])
-    assert plan["singles"] == [4, 5, 6, 11, 12]
+    # gap 5 at 465x465: clips 1, 5 (mid-clip labels), 0, 8 fill a batch, 9 and 12 a padded one; gap 6: clips 3, 2 padded;
+    # the two 481x849 clips (gap 5 both) padded; TTA / 12 objects / the lone gap-13 clip run alone
+    assert sorted(plan["batches"]) == sorted([[1, 5, 0, 8], [9, 12, -1, -1], [3, 2, -1, -1], [7, 10, -1, -1]])
+    assert plan["singles"] == [4, 6, 11]
     # a fixed gap removes the length from the key
     plan2 = D.plan_ragged_batches(info, 4, gap_of=lambda n: 3)
     assert any(11 in b for b in plan2["batches"])
