@@ -250,6 +250,19 @@ int rmem_layernorm_ex(const float *x, int64_t ldx, const float *x2, int64_t ldx2
                       int64_t ldpost, rmem_f16 *oh, rmem_f16 *ol, int64_t ldo, float *of32,
                       int64_t ldof, void *stream);
 
+/* Up to four rmem_layernorm_ex problems over the same N rows in ONE launch (per problem the same arithmetic, bit for bit).
+ * The AOT block normalises one input twice -- q = k = norm1(tgt) + pos beside v = norm1(tgt), transformer.py:558-561 -- and
+ * two inputs with one norm -- norm4(local_K + curr_K), norm4(local_V + curr_V), :656-662. */
+typedef struct {
+  const float *x; int64_t ldx;
+  const float *x2; int64_t ldx2;           /* optional second summand                  */
+  const float *gamma, *beta;
+  const float *post; int64_t ldpost;       /* optional: added after the affine          */
+  rmem_f16 *oh, *ol; int64_t ldo;          /* planes out (may be NULL)                  */
+  float *of32; int64_t ldof;               /* fp32 out (may be NULL)                    */
+} rmem_ln_args;
+int rmem_layernorm_multi(const rmem_ln_args *p, int32_t n, int32_t N, int32_t C, float eps, void *stream);
+
 /* Residual reduce + LayerNorm: x[row][:] += sum_z parts[z][row][:]  (z in split order, written
  * back to x), then y = LN(x)*gamma+beta -> planes (+ optional fp32).  Consumes the split-K
  * partials of the projection GEMM that precedes norm2/id_norm2/norm1/id_norm1

@@ -9,11 +9,11 @@
 // ------------------------------------------------------------------ LayerNorm -> planes
 // one wave per row, C = 256: 4 consecutive channels per lane (16-byte loads).
 // y = LN(x + x2) * gamma + beta + post  (x2, post optional)
-__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, long ldx, const float* x2, long ldx2,
-                                                              const float* gamma, const float* beta, int N,
-                                                              float eps, const float* post, long ldpost,
-                                                              h16_t* oh, h16_t* ol, long ldo, float* of32,
-                                                              long ldof) {
+__device__ __forceinline__ void layernorm_split_row(const float* x, long ldx, const float* x2, long ldx2,
+                                                    const float* gamma, const float* beta, int N,
+                                                    float eps, const float* post, long ldpost,
+                                                    h16_t* oh, h16_t* ol, long ldo, float* of32,
+                                                    long ldof) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
@@ -51,6 +51,27 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, lo
   }
 }
 
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* x, long ldx, const float* x2, long ldx2,
+                                                              const float* gamma, const float* beta, int N,
+                                                              float eps, const float* post, long ldpost,
+                                                              h16_t* oh, h16_t* ol, long ldo, float* of32,
+                                                              long ldof) {
+  layernorm_split_row(x, ldx, x2, ldx2, gamma, beta, N, eps, post, ldpost, oh, ol, ldo, of32, ldof);
+}
+
+// up to four such LayerNorms over the same N rows in ONE launch (blockIdx.y = problem): the AOT block normalises one
+// input twice (with and without the positional embedding) and two inputs with one norm -- each pair was two launches
+struct LnMultiArgs {
+  rmem_ln_args p[4];
+  int N;
+  float eps;
+};
+__global__ __launch_bounds__(256) void layernorm_multi_kernel(LnMultiArgs g) {
+  const rmem_ln_args& a = g.p[blockIdx.y];
+  layernorm_split_row(a.x, (long)a.ldx, a.x2, (long)a.ldx2, a.gamma, a.beta, g.N, g.eps, a.post, (long)a.ldpost,
+                      reinterpret_cast<h16_t*>(a.oh), reinterpret_cast<h16_t*>(a.ol), (long)a.ldo, a.of32, (long)a.ldof);
+}
+
 extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, int64_t ldx2, const float* gamma,
                                  const float* beta, int32_t N, int32_t C, float eps, const float* post,
                                  int64_t ldpost, rmem_f16* oh, rmem_f16* ol, int64_t ldo, float* of32,
@@ -61,6 +82,22 @@ extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, i
   hipLaunchKernelGGL(layernorm_split_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      (long)ldx, x2, (long)ldx2, gamma, beta, N, eps, post, (long)ldpost, oh, ol, (long)ldo, of32,
                      (long)ldof);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
+extern "C" int rmem_layernorm_multi(const rmem_ln_args* p, int32_t n, int32_t N, int32_t C, float eps, void* stream) {
+  if (!p || n <= 0 || n > 4 || N <= 0 || C != 256) return RMEM_ERR_INVALID;
+  LnMultiArgs g;
+  for (int i = 0; i < n; ++i) {
+    const rmem_ln_args& a = p[i];
+    if (!a.x || !a.gamma || !a.beta || (a.ldx % 4) || (a.ldo % 4) || (a.ldof % 4) || (a.ldx2 % 4) || (a.ldpost % 4))
+      return RMEM_ERR_INVALID;
+    g.p[i] = a;
+  }
+  g.N = N;
+  g.eps = eps;
+  hipLaunchKernelGGL(layernorm_multi_kernel, dim3((N + 3) / 4, n), dim3(256), 0, static_cast<hipStream_t>(stream), g);
   RMEM_CHECK_LAUNCH();
   return RMEM_OK;
 }
@@ -1402,4 +1439,4 @@ extern "C" int rmem_set_host_wait(int32_t device, int32_t blocking) {
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 17; }   // 17: rmem_configure (no getenv in the library), rmem_read_args.gate / gout (single-split reads gate their own output), rmem_ln_linear_grouped removed; 16: rmem_ln_linear_grouped (LayerNorm + grouped projections, row tile resident in LDS); 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_abi_version(void) { return 18; }   // 18: rmem_layernorm_multi (up to four LayerNorms in one launch); 17: rmem_configure (no getenv in the library), rmem_read_args.gate / gout (single-split reads gate their own output), rmem_ln_linear_grouped removed; 16: rmem_ln_linear_grouped (LayerNorm + grouped projections, row tile resident in LDS); 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

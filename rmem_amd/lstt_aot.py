@@ -137,6 +137,9 @@ class AOTLSTT:
         self.ml = z(self.ks, Np, self.HEADS, 2)
         self.slot_ml = z(self.ks, Np, self.HEADS, self.Tmax, 2)
         self.ao_pl = Planes.empty((Np, 256), dev)
+        self.ao2_pl = Planes.empty((Np, 256), dev)            # the short-term read's output (its projection shares a launch with the long-term one's)
+        # launches shared by independent members of a layer (RMEM_AOT_GROUP=0: one launch each, the round-5 schedule; bit-identical)
+        self.group_launches = os.environ.get("RMEM_AOT_GROUP", "1") != "0"
         self.y_f32 = [z(N, 256) for _ in range(L)]
         self.y_pl, self.yid_pl = Planes.empty((Np, 256), dev), Planes.empty((Np, 256), dev)
         self.Qc = z(N, 256)
@@ -205,6 +208,18 @@ class AOTLSTT:
             hip.ptr(of32), 256, hip.stream_ptr())
         hip.check(rc, "rmem_layernorm_ex")
 
+    def _ln_multi(self, problems):
+        """Several _ln() problems -- (x, gb, out, x2, post, of32) each -- in ONE launch (rmem_layernorm_multi: per problem
+        the arithmetic of rmem_layernorm_ex, bit for bit)."""
+        arr = (hip.LnArgs * len(problems))()
+        for a, (x, gb, out, x2, post, of32) in zip(arr, problems):
+            a.x, a.ldx, a.x2, a.ldx2 = x.data_ptr(), 256, hip.ptr(x2), 256
+            a.gamma, a.beta, a.post, a.ldpost = gb[0].data_ptr(), gb[1].data_ptr(), hip.ptr(post), 256
+            a.oh, a.ol, a.ldo = (out.hi.data_ptr() if out else None), (out.lo.data_ptr() if out else None), 256
+            a.of32, a.ldof = hip.ptr(of32), 256
+        hip.check(hip.load().rmem_layernorm_multi(arr, len(problems), self.N, 256, 1e-5, hip.stream_ptr()),
+                  "rmem_layernorm_multi")
+
     def _add_split(self, a, b, dst=None, out: Optional[Planes] = None):
         rc = hip.load().rmem_add_split(a.data_ptr(), hip.ptr(b), self.N * 256, hip.ptr(dst),
                                        out.hi.data_ptr() if out else None, out.lo.data_ptr() if out else None,
@@ -212,8 +227,9 @@ class AOTLSTT:
         hip.check(rc, "rmem_add_split")
 
     def _mha(self, q: Planes, ldq, q_off, k: Planes, k_off, ldk, k_slot_stride, v: Planes, slot_map_ptr, T, bias,
-             want_mass: bool, timed: bool = False):
-        """flash MHA + combine -> self.ao_pl (planes [Npad][256])."""
+             want_mass: bool, timed: bool = False, out: Optional[Planes] = None):
+        """flash MHA + combine -> `out` (default self.ao_pl; planes [Npad][256])."""
+        out = out if out is not None else self.ao_pl
         lib, st = hip.load(), hip.stream_ptr()
         a = hip.MHAArgs()
         a.qh, a.ql, a.ldq = q.hi.data_ptr() + q_off * 2, q.lo.data_ptr() + q_off * 2, ldq
@@ -237,7 +253,7 @@ class AOTLSTT:
         c = hip.MHACombineArgs()
         c.N, c.Npad, c.heads, c.T, c.ksplits = self.N, self.Npad, self.HEADS, T, ks
         c.opart, c.ml, c.slot_ml = self.opart.data_ptr(), self.ml.data_ptr(), a.slot_ml
-        c.oh, c.ol, c.of32, c.ldo = self.ao_pl.hi.data_ptr(), self.ao_pl.lo.data_ptr(), None, 256
+        c.oh, c.ol, c.of32, c.ldo = out.hi.data_ptr(), out.lo.data_ptr(), None, 256
         c.mass = self.mass.data_ptr() if want_mass else None
         hip.check(lib.rmem_mha_combine(C.byref(c), st), "rmem_mha_combine")
 
@@ -301,13 +317,21 @@ class AOTLSTT:
         for l in range(self.L):
             W = self.lw[l]
             curK, curV = self.bankK[l][cur], self.bankV[l][cur]
-            # -- self attention with sine PE on q, k (transformer.py:558-566)
-            self._ln(self.tgt, W.norm1, self.x_pl)
-            self._ln(self.tgt, W.norm1, self.xq_pl, post=self.pos)
-            hip.linear(self.xq_pl, W.Wqk_s, N, 512, 256, ldx=256, ldy=256, bias=W.bqk_s, pa=self.sQK, ldpa=512,
-                       nsplit=ns)
-            hip.linear(W.Wv_s, self.x_pl, 256, N, 256, ldx=256, ldy=256, bias=W.bv_s, bias_per_row=True,
-                       pa=Planes(self.sVt.hi[0], self.sVt.lo[0]), ldpa=Np, nsplit=ns)
+            grp = self.group_launches
+            # -- self attention with sine PE on q, k (transformer.py:558-566).  q = k = norm1(tgt) + pos and v = norm1(tgt):
+            #    one launch for the two norms, one for the two projections (independent problems of one stage)
+            if grp:
+                self._ln_multi([(self.tgt, W.norm1, self.x_pl, None, None, None),
+                                (self.tgt, W.norm1, self.xq_pl, None, self.pos, None)])
+            else:
+                self._ln(self.tgt, W.norm1, self.x_pl)
+                self._ln(self.tgt, W.norm1, self.xq_pl, post=self.pos)
+            qk = hip.linear(self.xq_pl, W.Wqk_s, N, 512, 256, ldx=256, ldy=256, bias=W.bqk_s, pa=self.sQK, ldpa=512,
+                            nsplit=ns, launch=not grp)
+            vs = hip.linear(W.Wv_s, self.x_pl, 256, N, 256, ldx=256, ldy=256, bias=W.bv_s, bias_per_row=True,
+                            pa=Planes(self.sVt.hi[0], self.sVt.lo[0]), ldpa=Np, nsplit=ns, launch=not grp)
+            if grp:
+                hip.linear_grouped([qk, vs])
             self._mha(self.sQK, 512, 0, self.sQK, 256, 512, 0, self.sVt, None, 1, None, False)
             hip.linear(self.ao_pl, W.Wp_s, N, 256, 256, ldx=256, ldy=256, bias=W.bp_s, d0=self.tgt.data_ptr(),
                        ldd0=256, accumulate=True, nsplit=ns)
@@ -329,28 +353,43 @@ class AOTLSTT:
                       "rmem_pe_bias_heads")
             self._mha(self.Qpe, 256, 0, self.bankK[l], 0, 256, kss, self.bankV[l], map_bank, T, self.bias_h,
                       want_mass=(l == 0), timed=self._timing)
-            hip.linear(self.ao_pl, W.Wp_lt, N, 256, 256, ldx=256, ldy=256, bias=W.bp_lt, d0=self.tgt.data_ptr(),
-                       ldd0=256, accumulate=True, nsplit=ns)
-            # -- short term on norm4(local + curr) (transformer.py:656-662)
-            self._ln(local_K, W.norm4, Planes(self.Ks_pl.hi[0], self.Ks_pl.lo[0]), x2=self.Qc)
-            self._ln(local_V, W.norm4, self.Vs_pl, x2=self.y_f32[l])
+            if not grp:
+                hip.linear(self.ao_pl, W.Wp_lt, N, 256, 256, ldx=256, ldy=256, bias=W.bp_lt, d0=self.tgt.data_ptr(),
+                           ldd0=256, accumulate=True, nsplit=ns)
+            # -- short term on norm4(local + curr) (transformer.py:656-662): the two norms in one launch
+            Ks0 = Planes(self.Ks_pl.hi[0], self.Ks_pl.lo[0])
+            if grp:
+                self._ln_multi([(local_K, W.norm4, Ks0, self.Qc, None, None),
+                                (local_V, W.norm4, self.Vs_pl, self.y_f32[l], None, None)])
+            else:
+                self._ln(local_K, W.norm4, Ks0, x2=self.Qc)
+                self._ln(local_V, W.norm4, self.Vs_pl, x2=self.y_f32[l])
             hip.check(lib.rmem_transpose_planes(self.Vs_pl.hi.data_ptr(), self.Vs_pl.lo.data_ptr(), 256, N, 256,
                                                 self.VsT.hi.data_ptr(), self.VsT.lo.data_ptr(), Np,
                                                 hip.stream_ptr()), "rmem_transpose_planes")
-            self._mha(curK, 256, 0, self.Ks_pl, 0, 256, 0, self.VsT, None, 1, None, False)
-            hip.linear(self.ao_pl, W.Wp_st, N, 256, 256, ldx=256, ldy=256, bias=W.bp_st,
-                       d0=self.tgt3[l].data_ptr(), ldd0=256, pa=self.t3_pl, ldpa=256, nsplit=ns)
+            ao_st = self.ao2_pl if grp else self.ao_pl
+            self._mha(curK, 256, 0, self.Ks_pl, 0, 256, 0, self.VsT, None, 1, None, False, out=ao_st)
+            # (grouped: the long-term read's projection -- it does not feed the short-term read -- shares the launch of the
+            # short-term one's; tgt receives the same two additions in the same order)
+            plt = hip.linear(self.ao_pl, W.Wp_lt, N, 256, 256, ldx=256, ldy=256, bias=W.bp_lt, d0=self.tgt.data_ptr(),
+                             ldd0=256, accumulate=True, nsplit=ns, launch=False) if grp else None
+            pst = hip.linear(ao_st, W.Wp_st, N, 256, 256, ldx=256, ldy=256, bias=W.bp_st,
+                             d0=self.tgt3[l].data_ptr(), ldd0=256, pa=self.t3_pl, ldpa=256, nsplit=ns, launch=not grp)
+            if grp:
+                hip.linear_grouped([plt, pst])
             self._add_split(self.tgt, self.tgt3[l], dst=self.tgt)                       # tgt += tgt3 (:680)
-            hip.linear(self.t3_pl, W.Wqm, N, 256, 256, ldx=256, ldy=256, bias=W.bqm, d0=nK[l].data_ptr(),
-                       ldd0=256, nsplit=ns)                                             # local_K (:675)
+            qm = hip.linear(self.t3_pl, W.Wqm, N, 256, 256, ldx=256, ldy=256, bias=W.bqm, d0=nK[l].data_ptr(),
+                            ldd0=256, nsplit=ns, launch=not grp)                        # local_K (:675)
             if ref_frame:
                 self._add_split(self.tgt3[l], self.idemb, out=self.t3id_pl)
                 hip.linear(self.t3id_pl, W.Wvm, N, 256, 256, ldx=256, ldy=256, bias=W.bvm,
                            d0=nV[l].data_ptr(), ldd0=256, nsplit=ns)
-            # -- feed forward (transformer.py:683-687, basic.py:15-35)
+            # -- feed forward (transformer.py:683-687, basic.py:15-35); its first projection shares the launch of local_K's
             self._ln(self.tgt, W.norm3, self.z_pl)
-            hip.linear(self.z_pl, W.W1, N, self.FF, 256, ldx=256, ldy=256, bias=W.b1, d0=self.a.data_ptr(),
-                       ldd0=self.FF, nsplit=ns)
+            ff1 = hip.linear(self.z_pl, W.W1, N, self.FF, 256, ldx=256, ldy=256, bias=W.b1, d0=self.a.data_ptr(),
+                             ldd0=self.FF, nsplit=ns, launch=not grp)
+            if grp:
+                hip.linear_grouped([ff1, qm])
             hip.check(lib.rmem_gn_gelu_tokens(self.a.data_ptr(), N, self.FF, 32, W.gn[0].data_ptr(),
                                               W.gn[1].data_ptr(), 1e-5, self.gn_ws.data_ptr(), self.g.data_ptr(),
                                               hip.stream_ptr()), "rmem_gn_gelu_tokens")

@@ -134,6 +134,95 @@ def test_aot_support_kernels(hip):
     assert (out.cpu().double() - ref).abs().max().item() < 1e-4
 
 
+def test_layernorm_multi_equals_single_launches(hip):
+    """rmem_layernorm_multi: up to four rmem_layernorm_ex problems over the same rows in one launch -- the AOT block's
+    norm1(tgt) / norm1(tgt) + pos pair and its norm4(local_K + K) / norm4(local_V + V) pair -- bit for bit the single
+    launches (planes and fp32), ragged row count, optional operands in every combination; bad arguments refused."""
+    lib, st = hip.load(), hip.stream_ptr()
+    rs = np.random.RandomState(3)
+    N = 203
+    g_ = lambda t: t.to(DEV).contiguous()
+    xs = [g_(_rand(rs, N, 256, scale=2) + 0.1 * i) for i in range(4)]
+    x2, post = g_(_rand(rs, N, 256)), g_(_rand(rs, N, 256))
+    gm, bt = g_(_rand(rs, 256) * 0.2 + 1), g_(_rand(rs, 256) * 0.1)
+    gm2, bt2 = g_(_rand(rs, 256) * 0.3 + 1), g_(_rand(rs, 256) * 0.2)
+    probs = [(xs[0], None, None, gm, bt, True, True), (xs[0], None, post, gm, bt, True, False),
+             (xs[1], x2, None, gm2, bt2, True, True), (xs[2], x2, post, gm2, bt2, False, True)]
+    single, multi = [], []
+    arr = (hip.LnArgs * 4)()
+    for i, (x, a2, po, g, b, planes, f32) in enumerate(probs):
+        pl = hip.Planes.empty((N, 256), DEV) if planes else None
+        of = torch.full((N, 256), 7.0, device=DEV) if f32 else None
+        hip.check(lib.rmem_layernorm_ex(x.data_ptr(), 256, hip.ptr(a2), 256, g.data_ptr(), b.data_ptr(), N, 256, 1e-5,
+                                        hip.ptr(po), 256, pl.hi.data_ptr() if pl else None, pl.lo.data_ptr() if pl else None,
+                                        256, hip.ptr(of), 256, st), "ln_ex")
+        single.append((pl, of))
+        pl2 = hip.Planes.empty((N, 256), DEV) if planes else None
+        of2 = torch.full((N, 256), 7.0, device=DEV) if f32 else None
+        a = arr[i]
+        a.x, a.ldx, a.x2, a.ldx2, a.gamma, a.beta = x.data_ptr(), 256, hip.ptr(a2), 256, g.data_ptr(), b.data_ptr()
+        a.post, a.ldpost = hip.ptr(po), 256
+        a.oh, a.ol, a.ldo = (pl2.hi.data_ptr() if pl2 else None), (pl2.lo.data_ptr() if pl2 else None), 256
+        a.of32, a.ldof = hip.ptr(of2), 256
+        multi.append((pl2, of2))
+    for n in (4, 2):
+        for pl2, of2 in multi:
+            if pl2 is not None:
+                pl2.hi.zero_(), pl2.lo.zero_()
+            if of2 is not None:
+                of2.fill_(7.0)
+        hip.check(lib.rmem_layernorm_multi(arr, n, N, 256, 1e-5, st), "ln_multi")
+        torch.cuda.synchronize()
+        for i, ((pl, of), (pl2, of2)) in enumerate(zip(single, multi)):
+            if i < n:
+                assert pl is None or (torch.equal(pl.hi, pl2.hi) and torch.equal(pl.lo, pl2.lo)), i
+                assert of is None or torch.equal(of, of2), i
+            else:
+                assert of2 is None or bool((of2 == 7.0).all())
+    assert lib.rmem_layernorm_multi(arr, 5, N, 256, 1e-5, st) != 0 and lib.rmem_layernorm_multi(arr, 0, N, 256, 1e-5, st) != 0
+    assert lib.rmem_layernorm_multi(arr, 2, N, 128, 1e-5, st) != 0
+
+
+def test_aot_block_shared_launches_bit_identical(monkeypatch):
+    """The AOT block's independent members share launches (two LayerNorm pairs, Wqk | Wv of the self attention, the
+    long- and short-term output projections, local_K | the feed-forward's first projection: five launches fewer per
+    layer).  Same problems, same kernels' arithmetic: outputs of every layer, attention mass, the banks and the short-term
+    memories equal the one-launch-each schedule (RMEM_AOT_GROUP=0) bit for bit, reference frame and updates included."""
+    from rmem_amd.lstt_aot import AOTLSTT
+    model, eng = _build_aot()
+    h, w = 12, 17
+    N = h * w
+    H, W = (h - 1) * 16 + 1, (w - 1) * 16 + 1
+    recs = {}
+    for g in ("1", "0"):
+        monkeypatch.setenv("RMEM_AOT_GROUP", g)
+        lstt = AOTLSTT(eng.AOT, h, w, DEV, nsplit=3)
+        assert lstt.group_launches == (g == "1")
+        rs = np.random.RandomState(0)
+        rec = []
+        for t in range(5):
+            emb = torch.from_numpy(rs.standard_normal((N, 256)).astype(np.float32)).to(DEV)
+            label = torch.from_numpy(rs.randint(0, 4, (1, 1, H // 8 + 1, W // 8 + 1)).astype(np.float32))
+            lab_u8 = F.interpolate(label, size=(H, W), mode="nearest")[0, 0].to(torch.uint8).to(DEV).contiguous()
+            if t == 0:
+                lstt.assign_identity(lab_u8)
+                outs = lstt.forward(emb, ref_frame=True)
+            else:
+                outs = lstt.forward(emb)
+                lstt.assign_identity(lab_u8)
+                lstt.update_short_memories(t % 2 == 0)
+            torch.cuda.synchronize()
+            rec.append([o.clone() for o in outs] + [lstt.mass.clone()] +
+                       [lstt.bankK[l].hi[lstt.cur].clone() for l in range(lstt.L)] +
+                       [lstt.bankV[l].lo[lstt.cur].clone() for l in range(lstt.L)] +
+                       [x.clone() for x in lstt.sK + lstt.sV + lstt.nsK + lstt.nsV])
+        recs[g] = rec
+    for t, (a, b) in enumerate(zip(recs["1"], recs["0"])):
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (t, i, (x.float() - y.float()).abs().max().item())
+    assert float(recs["1"][-1][0].abs().sum()) > 0
+
+
 def _build_aot(former=1, latter=3, gap=2, nsplit=3):
     import copy
     from rmem_amd.config import get_config

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/rmem_hip.h but not exported"
     assert declared == set(hip.EXPORTS)
     assert every - declared == set(hip.EXPORTS_OTHER)
-    assert lib.rmem_abi_version() == hip.ABI_VERSION == 17
+    assert lib.rmem_abi_version() == hip.ABI_VERSION == 18
 
 
 def test_launch_recorder_records_without_a_gpu():
