@@ -256,6 +256,8 @@ int rmem_layernorm_ex(const float *x, int64_t ldx, const float *x2, int64_t ldx2
 typedef struct {
   const float *x; int64_t ldx;
   const float *x2; int64_t ldx2;           /* optional second summand                  */
+  float *sum_out; int64_t ldsum;           /* optional: x + x2 written here (may be x itself: the residual add tgt += tgt3 in
+                                              front of norm3, transformer.py:680-683, without a launch of its own) */
   const float *gamma, *beta;
   const float *post; int64_t ldpost;       /* optional: added after the affine          */
   rmem_f16 *oh, *ol; int64_t ldo;          /* planes out (may be NULL)                  */
@@ -295,6 +297,15 @@ int rmem_transpose_planes(const rmem_f16 *ih, const rmem_f16 *il, int64_t ld, in
 /* dst (fp32, optional, may alias a) = a + b ; planes of the sum (optional).  n elements. */
 int rmem_add_split(const float *a, const float *b, int64_t n, float *dst, rmem_f16 *oh,
                    rmem_f16 *ol, void *stream);
+
+/* Up to eight such sums of `nelem` elements each in one launch (the AOT block's memory update: curr_V + id_emb and
+ * local_V + id_emb of every layer, transformer.py:277-287). */
+typedef struct {
+  const float *a, *b;                      /* b may be NULL                             */
+  float *dst;                              /* fp32 sum (optional, may alias a)          */
+  rmem_f16 *oh, *ol;                       /* planes of the sum (optional)              */
+} rmem_add_args;
+int rmem_add_split_multi(const rmem_add_args *p, int32_t n, int64_t nelem, void *stream);
 
 /* GNActDWConv2d front half (layers/basic.py:27-32): GroupNorm(groups) over token-major
  * [N][C] (statistics over C/groups channels x N tokens) followed by exact GELU -> fp32.

@@ -13,7 +13,7 @@ __device__ __forceinline__ void layernorm_split_row(const float* x, long ldx, co
                                                     const float* gamma, const float* beta, int N,
                                                     float eps, const float* post, long ldpost,
                                                     h16_t* oh, h16_t* ol, long ldo, float* of32,
-                                                    long ldof) {
+                                                    long ldof, float* sum_out = nullptr, long ldsum = 0) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N) return;
@@ -21,6 +21,7 @@ __device__ __forceinline__ void layernorm_split_row(const float* x, long ldx, co
   if (x2) {
     const float4 w = *reinterpret_cast<const float4*>(x2 + (long)row * ldx2 + lane * 4);
     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    if (sum_out) *reinterpret_cast<float4*>(sum_out + (long)row * ldsum + lane * 4) = v;   // (a row is read and written by one wave)
   }
   float s = v.x + v.y + v.z + v.w;
   s = wave_sum_xor_t(s);
@@ -69,7 +70,8 @@ struct LnMultiArgs {
 __global__ __launch_bounds__(256) void layernorm_multi_kernel(LnMultiArgs g) {
   const rmem_ln_args& a = g.p[blockIdx.y];
   layernorm_split_row(a.x, (long)a.ldx, a.x2, (long)a.ldx2, a.gamma, a.beta, g.N, g.eps, a.post, (long)a.ldpost,
-                      reinterpret_cast<h16_t*>(a.oh), reinterpret_cast<h16_t*>(a.ol), (long)a.ldo, a.of32, (long)a.ldof);
+                      reinterpret_cast<h16_t*>(a.oh), reinterpret_cast<h16_t*>(a.ol), (long)a.ldo, a.of32, (long)a.ldof,
+                      a.sum_out, (long)a.ldsum);
 }
 
 extern "C" int rmem_layernorm_ex(const float* x, int64_t ldx, const float* x2, int64_t ldx2, const float* gamma,
@@ -91,7 +93,8 @@ extern "C" int rmem_layernorm_multi(const rmem_ln_args* p, int32_t n, int32_t N,
   LnMultiArgs g;
   for (int i = 0; i < n; ++i) {
     const rmem_ln_args& a = p[i];
-    if (!a.x || !a.gamma || !a.beta || (a.ldx % 4) || (a.ldo % 4) || (a.ldof % 4) || (a.ldx2 % 4) || (a.ldpost % 4))
+    if (!a.x || !a.gamma || !a.beta || (a.ldx % 4) || (a.ldo % 4) || (a.ldof % 4) || (a.ldx2 % 4) || (a.ldpost % 4) ||
+        (a.ldsum % 4) || (a.sum_out && !a.x2))
       return RMEM_ERR_INVALID;
     g.p[i] = a;
   }
@@ -1162,6 +1165,45 @@ __global__ void add_split_kernel(const float* a, const float* b, long n, float* 
   }
 }
 
+// up to eight such sums of n elements each in ONE launch (blockIdx.y = problem)
+struct AddMultiArgs {
+  rmem_add_args p[8];
+  long n;
+};
+__global__ void add_split_multi_kernel(AddMultiArgs g) {
+  const rmem_add_args& q = g.p[blockIdx.y];
+  const float* a = q.a;
+  const float* b = q.b;
+  float* dst = q.dst;
+  h16_t* oh = reinterpret_cast<h16_t*>(q.oh);
+  h16_t* ol = reinterpret_cast<h16_t*>(q.ol);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += (long)gridDim.x * blockDim.x) {
+    const float v = a[i] + (b ? b[i] : 0.f);
+    if (dst) dst[i] = v;
+    if (oh) {
+      h16_t h, l;
+      split_f16(v, h, l);
+      oh[i] = h;
+      if (ol) ol[i] = l;
+    }
+  }
+}
+
+extern "C" int rmem_add_split_multi(const rmem_add_args* p, int32_t n, int64_t nelem, void* stream) {
+  if (!p || n <= 0 || n > 8 || nelem <= 0) return RMEM_ERR_INVALID;
+  AddMultiArgs g;
+  for (int i = 0; i < n; ++i) {
+    if (!p[i].a || (!p[i].dst && !p[i].oh)) return RMEM_ERR_INVALID;
+    g.p[i] = p[i];
+  }
+  g.n = (long)nelem;
+  long blocks = (nelem + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(add_split_multi_kernel, dim3((unsigned)blocks, n), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_add_split(const float* a, const float* b, int64_t n, float* dst, rmem_f16* oh, rmem_f16* ol,
                               void* stream) {
   if (!a || n <= 0 || (!dst && !oh)) return RMEM_ERR_INVALID;
@@ -1439,4 +1481,4 @@ extern "C" int rmem_set_host_wait(int32_t device, int32_t blocking) {
   return RMEM_OK;
 }
 
-extern "C" int rmem_abi_version(void) { return 18; }   // 18: rmem_layernorm_multi (up to four LayerNorms in one launch); 17: rmem_configure (no getenv in the library), rmem_read_args.gate / gout (single-split reads gate their own output), rmem_ln_linear_grouped removed; 16: rmem_ln_linear_grouped (LayerNorm + grouped projections, row tile resident in LDS); 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read
+extern "C" int rmem_abi_version(void) { return 18; }   // 18: rmem_layernorm_multi, rmem_add_split_multi (several LayerNorms / sums in one launch); 17: rmem_configure (no getenv in the library), rmem_read_args.gate / gout (single-split reads gate their own output), rmem_ln_linear_grouped removed; 16: rmem_ln_linear_grouped (LayerNorm + grouped projections, row tile resident in LDS); 15: rmem_set_host_wait; 14: rmem_read_args.nfull / pf (uneven key splits), rmem_layernorm_cn; 13: streaming projection kernel (rmem_linear_args.tile 0 / 256), rmem_linear_trace; 12: rmem_read_args.sched (unit queue of the paired read); 11: read64 kernel (ncols = 1024), rmem_attn_read_trace, device-side eviction (rmem_fg_weights, rmem_bank_*); 10: the three-launch materialised-P attention (rmem_attn_scores[2] / pv / combine[2]) removed; 9: launch recorder (rmem_rec_*, rmem_launch_recorded); 8: rmem_f16 naming, rmem_id_assign(ignore_channel), fused memory read

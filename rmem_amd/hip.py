@@ -60,9 +60,13 @@ class ReadArgs(C.Structure):
 
 class LnArgs(C.Structure):
     _fields_ = [
-        ("x", c_p), ("ldx", i64), ("x2", c_p), ("ldx2", i64), ("gamma", c_p), ("beta", c_p),
+        ("x", c_p), ("ldx", i64), ("x2", c_p), ("ldx2", i64), ("sum_out", c_p), ("ldsum", i64), ("gamma", c_p), ("beta", c_p),
         ("post", c_p), ("ldpost", i64), ("oh", c_p), ("ol", c_p), ("ldo", i64), ("of32", c_p), ("ldof", i64),
     ]
+
+
+class AddArgs(C.Structure):
+    _fields_ = [("a", c_p), ("b", c_p), ("dst", c_p), ("oh", c_p), ("ol", c_p)]
 
 
 class ReadCombineArgs(C.Structure):
@@ -106,7 +110,7 @@ EXPORTS = [
     "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_fg_weights", "rmem_bank_reset", "rmem_bank_append",
     "rmem_bank_policy_step", "rmem_split_planes", "rmem_groupnorm_nchw",
-    "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_layernorm_multi", "rmem_transpose_planes", "rmem_add_split",
+    "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_layernorm_multi", "rmem_transpose_planes", "rmem_add_split", "rmem_add_split_multi",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2", "rmem_layernorm_cn",
@@ -179,6 +183,7 @@ def load():
                                       c_p, i64, c_p]
     lib.rmem_layernorm_multi.argtypes = [C.POINTER(LnArgs), i32, i32, i32, f32, c_p]
     lib.rmem_transpose_planes.argtypes = [c_p, c_p, i64, i32, i32, c_p, c_p, i64, c_p]
+    lib.rmem_add_split_multi.argtypes = [C.POINTER(AddArgs), i32, i64, c_p]
     lib.rmem_add_split.argtypes = [c_p, c_p, i64, c_p, c_p, c_p, c_p]
     lib.rmem_gn_gelu_tokens.argtypes = [c_p, i32, i32, i32, c_p, c_p, f32, c_p, c_p, c_p]
     lib.rmem_pe_bias_heads.argtypes = [c_p, i64, c_p, c_p, C.POINTER(i32), i32, i32, i32, c_p, c_p]

@@ -98,6 +98,20 @@ class AOTLSTT:
             W.Wp_s, W.bp_s = self._pl(g("self_attn.projection.weight")), self._f(g("self_attn.projection.bias"))
             W.Wq, W.bq = self._pl(g("linear_Q.weight")), self._f(g("linear_Q.bias"))
             W.Wv, W.bv = self._pl(g("linear_V.weight")), self._f(g("linear_V.bias"))
+            # The per-head temporal-PE bias of the long-term read, bias[q][h][t] = (Q[q] + cur_pe)_h . mem_pe[row(t)]_h
+            # (transformer.py:600-631), is linear in the layer input y = norm2(tgt): with Wq folded in once in fp64 it is a
+            # projection of y onto heads x T columns -- a member of Q's launch instead of a dependent launch after it.
+            wq64, bq64 = g("linear_Q.weight").double(), g("linear_Q.bias").double()
+            mem64, cur64 = sd["mem_pos_emb"].double(), sd["cur_pos_emb"][0].double()      # [4][256], [256]
+            hd = self.D // self.HEADS
+            W.pe_h = {}                                                                    # T -> (planes [heads*T][256], bias [heads*T])
+            for T in range(1, self.cap + 2):
+                r = temporal_pe_rows(T)
+                m = mem64[r].view(T, self.HEADS, hd).permute(1, 0, 2)                      # [heads][T][hd]
+                wq_h = wq64.view(self.HEADS, hd, -1)                                       # [heads][hd][256]
+                w_ht = torch.einsum("htc,hck->htk", m, wq_h).reshape(self.HEADS * T, -1)
+                b_ht = torch.einsum("htc,hc->ht", m, (bq64 + cur64).view(self.HEADS, hd)).reshape(self.HEADS * T)
+                W.pe_h[T] = (self._pl(w_ht.float()), self._f(b_ht.float()))
             W.Wqm, W.bqm = self._pl(g("linear_QMem.weight")), self._f(g("linear_QMem.bias"))
             W.Wvm, W.bvm = self._pl(g("linear_VMem.weight")), self._f(g("linear_VMem.bias"))
             W.Wp_lt, W.bp_lt = (self._pl(g("long_term_attn.projection.weight")),
@@ -142,6 +156,9 @@ class AOTLSTT:
         self.group_launches = os.environ.get("RMEM_AOT_GROUP", "1") != "0"
         self.y_f32 = [z(N, 256) for _ in range(L)]
         self.y_pl, self.yid_pl = Planes.empty((Np, 256), dev), Planes.empty((Np, 256), dev)
+        # per layer: the update's sums (curr_V + id_emb, local_V + id_emb) of all layers are formed in one launch
+        self.yid_l = [Planes.empty((Np, 256), dev) for _ in range(L)]
+        self.t3id_l = [Planes.empty((Np, 256), dev) for _ in range(L)]
         self.Qc = z(N, 256)
         self.Qpe = Planes.empty((Np, 256), dev)
         self.bankK = [Planes.empty((self.S, Np, 256), dev) for _ in range(L)]
@@ -209,11 +226,13 @@ class AOTLSTT:
         hip.check(rc, "rmem_layernorm_ex")
 
     def _ln_multi(self, problems):
-        """Several _ln() problems -- (x, gb, out, x2, post, of32) each -- in ONE launch (rmem_layernorm_multi: per problem
+        """Several _ln() problems -- (x, gb, out, x2, post, of32[, sum_out]) each -- in ONE launch (rmem_layernorm_multi: per problem
         the arithmetic of rmem_layernorm_ex, bit for bit)."""
         arr = (hip.LnArgs * len(problems))()
-        for a, (x, gb, out, x2, post, of32) in zip(arr, problems):
+        for a, pr in zip(arr, problems):
+            x, gb, out, x2, post, of32 = pr[:6]
             a.x, a.ldx, a.x2, a.ldx2 = x.data_ptr(), 256, hip.ptr(x2), 256
+            a.sum_out, a.ldsum = (hip.ptr(pr[6]) if len(pr) > 6 else None), 256       # (x + x2 written back: a residual add)
             a.gamma, a.beta, a.post, a.ldpost = gb[0].data_ptr(), gb[1].data_ptr(), hip.ptr(post), 256
             a.oh, a.ol, a.ldo = (out.hi.data_ptr() if out else None), (out.lo.data_ptr() if out else None), 256
             a.of32, a.ldof = hip.ptr(of32), 256
@@ -310,7 +329,6 @@ class AOTLSTT:
         lib = hip.load()
         cur, T = self.cur, self._T
         map_bank = self.maps.data_ptr()
-        rows = (C.c_int32 * 16)(*(temporal_pe_rows(T) + [0] * (16 - T)))
         kss = Np * 256
         sK, sV = (self.sK, self.sV) if self._flip == 0 else (self.nsK, self.nsV)        # current short memory
         nK, nV = (self.nsK, self.nsV) if self._flip == 0 else (self.sK, self.sV)        # written this frame
@@ -321,8 +339,9 @@ class AOTLSTT:
             # -- self attention with sine PE on q, k (transformer.py:558-566).  q = k = norm1(tgt) + pos and v = norm1(tgt):
             #    one launch for the two norms, one for the two projections (independent problems of one stage)
             if grp:
-                self._ln_multi([(self.tgt, W.norm1, self.x_pl, None, None, None),
-                                (self.tgt, W.norm1, self.xq_pl, None, self.pos, None)])
+                if l == 0:              # (layers 1..: issued with the previous layer's output norm, same input)
+                    self._ln_multi([(self.tgt, W.norm1, self.x_pl, None, None, None),
+                                    (self.tgt, W.norm1, self.xq_pl, None, self.pos, None)])
             else:
                 self._ln(self.tgt, W.norm1, self.x_pl)
                 self._ln(self.tgt, W.norm1, self.xq_pl, post=self.pos)
@@ -337,8 +356,13 @@ class AOTLSTT:
                        ldd0=256, accumulate=True, nsplit=ns)
             # -- long / short term (transformer.py:569-592)
             self._ln(self.tgt, W.norm2, self.y_pl, of32=self.y_f32[l])
-            hip.linear(self.y_pl, W.Wq, N, 256, 256, ldx=256, ldy=256, bias=W.bq, d0=self.Qc.data_ptr(), ldd0=256,
-                       pa=curK, ldpa=256, pb=self.Qpe, ldpb=256, addvec=self.cur_pe, nsplit=ns)
+            pq = hip.linear(self.y_pl, W.Wq, N, 256, 256, ldx=256, ldy=256, bias=W.bq, d0=self.Qc.data_ptr(), ldd0=256,
+                            pa=curK, ldpa=256, pb=self.Qpe, ldpb=256, addvec=self.cur_pe, nsplit=ns, launch=not grp)
+            pe = W.pe_h[T]
+            pb = hip.linear(self.y_pl, pe[0], N, self.HEADS * T, 256, ldx=256, ldy=256, bias=pe[1],
+                            d0=self.bias_h.data_ptr(), ldd0=self.HEADS * T, nsplit=ns, launch=not grp)
+            if grp:
+                hip.linear_grouped([pq, pb])
             if ref_frame:
                 self._add_split(self.y_f32[l], self.idemb, out=self.yid_pl)
                 hip.linear(W.Wv, self.yid_pl, 256, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True,
@@ -348,9 +372,6 @@ class AOTLSTT:
                 local_K, local_V = self.Qc, self.refV
             else:
                 local_K, local_V = sK[l], sV[l]
-            hip.check(lib.rmem_pe_bias_heads(self.Qc.data_ptr(), 256, self.cur_pe.data_ptr(), self.mem_pe.data_ptr(),
-                                             rows, T, N, self.HEADS, self.bias_h.data_ptr(), hip.stream_ptr()),
-                      "rmem_pe_bias_heads")
             self._mha(self.Qpe, 256, 0, self.bankK[l], 0, 256, kss, self.bankV[l], map_bank, T, self.bias_h,
                       want_mass=(l == 0), timed=self._timing)
             if not grp:
@@ -377,7 +398,8 @@ class AOTLSTT:
                              d0=self.tgt3[l].data_ptr(), ldd0=256, pa=self.t3_pl, ldpa=256, nsplit=ns, launch=not grp)
             if grp:
                 hip.linear_grouped([plt, pst])
-            self._add_split(self.tgt, self.tgt3[l], dst=self.tgt)                       # tgt += tgt3 (:680)
+            if not grp:
+                self._add_split(self.tgt, self.tgt3[l], dst=self.tgt)                   # tgt += tgt3 (:680)
             qm = hip.linear(self.t3_pl, W.Wqm, N, 256, 256, ldx=256, ldy=256, bias=W.bqm, d0=nK[l].data_ptr(),
                             ldd0=256, nsplit=ns, launch=not grp)                        # local_K (:675)
             if ref_frame:
@@ -385,7 +407,10 @@ class AOTLSTT:
                 hip.linear(self.t3id_pl, W.Wvm, N, 256, 256, ldx=256, ldy=256, bias=W.bvm,
                            d0=nV[l].data_ptr(), ldd0=256, nsplit=ns)
             # -- feed forward (transformer.py:683-687, basic.py:15-35); its first projection shares the launch of local_K's
-            self._ln(self.tgt, W.norm3, self.z_pl)
+            if grp:                     # tgt += tgt3 (:680) inside the norm's launch: the same single addition per element
+                self._ln_multi([(self.tgt, W.norm3, self.z_pl, self.tgt3[l], None, None, self.tgt)])
+            else:
+                self._ln(self.tgt, W.norm3, self.z_pl)
             ff1 = hip.linear(self.z_pl, W.W1, N, self.FF, 256, ldx=256, ldy=256, bias=W.b1, d0=self.a.data_ptr(),
                              ldd0=self.FF, nsplit=ns, launch=not grp)
             if grp:
@@ -398,7 +423,13 @@ class AOTLSTT:
                                                hip.stream_ptr()), "rmem_dwconv5x5_split")
             hip.linear(self.gdw_pl, W.W2, N, 256, self.FF, ldx=self.FF, ldy=self.FF, bias=W.b2,
                        d0=self.tgt.data_ptr(), ldd0=256, accumulate=True, nsplit=ns)
-            self._ln(self.tgt, W.dnorm, None, of32=self.outs[l])                        # :248-259
+            if grp and l + 1 < self.L:  # the layer's output norm (:248-259) and the next layer's norm1 pair read the same tgt
+                Wn = self.lw[l + 1]
+                self._ln_multi([(self.tgt, W.dnorm, None, None, None, self.outs[l]),
+                                (self.tgt, Wn.norm1, self.x_pl, None, None, None),
+                                (self.tgt, Wn.norm1, self.xq_pl, None, self.pos, None)])
+            else:
+                self._ln(self.tgt, W.dnorm, None, of32=self.outs[l])                    # :248-259
 
     # ------------------------------------------------------------------ memory update
     def update_short_memories(self, update_long: bool):
@@ -412,6 +443,26 @@ class AOTLSTT:
     def _update_device(self, update_long: bool):
         N, Np, ns = self.N, self.Npad, self.nsplit
         nV = self.nsV if self._flip == 0 else self.sV
+        if self.group_launches:
+            # every layer's sums in ONE launch, every layer's projections in ONE (independent problems: two launches per
+            # update instead of two or four per layer; per problem the same arithmetic)
+            sums, lins = [], []
+            for l in range(self.L):
+                W = self.lw[l]
+                if update_long:      # curr_V <- linear_V(curr_V + id_emb) (only consumed by the long bank)
+                    sums.append((self.y_f32[l], self.idemb, None, self.yid_l[l]))
+                    lins.append(hip.linear(W.Wv, self.yid_l[l], 256, N, 256, ldx=256, ldy=256, bias=W.bv, bias_per_row=True,
+                                           pa=self.bankV[l][self.cur], ldpa=Np, nsplit=ns, launch=False))
+                sums.append((self.tgt3[l], self.idemb, None, self.t3id_l[l]))
+                lins.append(hip.linear(self.t3id_l[l], W.Wvm, N, 256, 256, ldx=256, ldy=256, bias=W.bvm,
+                                       d0=nV[l].data_ptr(), ldd0=256, nsplit=ns, launch=False))
+            arr = (hip.AddArgs * len(sums))()
+            for q, (a, b, dst, out) in zip(arr, sums):
+                q.a, q.b, q.dst, q.oh, q.ol = a.data_ptr(), b.data_ptr(), hip.ptr(dst), out.hi.data_ptr(), out.lo.data_ptr()
+            hip.check(hip.load().rmem_add_split_multi(arr, len(sums), N * 256, hip.stream_ptr()), "rmem_add_split_multi")
+            for k in range(0, len(lins), 8):
+                hip.linear_grouped(lins[k:k + 8])
+            return
         for l in range(self.L):
             W = self.lw[l]
             if update_long:      # curr_V <- linear_V(curr_V + id_emb) (only consumed by the long bank)
