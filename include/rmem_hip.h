@@ -225,6 +225,9 @@ typedef struct {
 } rmem_mha_args;
 
 int rmem_mha_flash(const rmem_mha_args *a, void *stream);
+/* two independent reads in one launch (the AOT block's long-term and short-term reads of a layer, transformer.py:632-635 and
+ * :656-662: same Npad, heads, nsplit; workspaces of their own) */
+int rmem_mha_flash2(const rmem_mha_args *a, const rmem_mha_args *b, void *stream);
 
 typedef struct {
   int32_t N, Npad, heads, T, ksplits;
@@ -234,6 +237,7 @@ typedef struct {
 } rmem_mha_combine_args;
 
 int rmem_mha_combine(const rmem_mha_combine_args *a, void *stream);
+int rmem_mha_combine2(const rmem_mha_combine_args *a, const rmem_mha_combine_args *b, void *stream);
 
 /* ------------------------------------------------------------------ pointwise / norms */
 /* LayerNorm over C=256 channels -> planes (+ optional fp32); nn.LayerNorm of

@@ -34,14 +34,14 @@ constexpr int MHA_KPL = 64 * 64, MHA_VROW = 136, MHA_VPL = 32 * MHA_VROW;
 // is only touched when a maximum moves) on a VALU-bound loop: 180 registers and ~145 VALU per tile against 146
 // registers (3 waves per SIMD) and ~95.
 template <int NS>
-__global__ __launch_bounds__(256, 2) void mha_flash_kernel(rmem_mha_args a) {
+__device__ __forceinline__ void mha_flash_body(const rmem_mha_args& a, const int z) {
   constexpr int NPL = NS == 1 ? 1 : 2;
   constexpr int STAGE_BYTES = NPL * (MHA_KPL + MHA_VPL);
   __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, j = lane & 31;
-  const int h = blockIdx.y, z = blockIdx.z;
+  const int h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + j;   // this lane's query (column of S^T / O^T)
   const int sps = a.Npad / 64;                       // 64-key stages per slot
   const int nstages = a.T * sps;
@@ -262,6 +262,47 @@ __global__ __launch_bounds__(256, 2) void mha_flash_kernel(rmem_mha_args a) {
   }
 }
 
+template <int NS>
+__global__ __launch_bounds__(256, 2) void mha_flash_kernel(rmem_mha_args a) {
+  mha_flash_body<NS>(a, blockIdx.z);
+}
+
+// Two independent reads of one layer in ONE launch (the AOT block's long-term read and its short-term read both start from
+// Q / K of the layer and feed different projections): blockIdx.z < p[0].ksplits serves p[0], the rest p[1].
+struct Mha2Args {
+  rmem_mha_args p[2];
+};
+template <int NS>
+__global__ __launch_bounds__(256, 2) void mha_flash2_kernel(Mha2Args g) {
+  const int za = g.p[0].ksplits;
+  const bool first = (int)blockIdx.z < za;            // (ONE inlined body: its LDS image must not be allocated twice)
+  const rmem_mha_args& a = first ? g.p[0] : g.p[1];
+  mha_flash_body<NS>(a, first ? (int)blockIdx.z : (int)blockIdx.z - za);
+}
+
+static int mha_args_ok(const rmem_mha_args& a) {
+  if (a.N <= 0 || a.Npad < a.N || (a.Npad % 128) || a.T <= 0 || a.heads <= 0 || a.ksplits <= 0) return 0;
+  if (!a.qh || !a.kh || !a.vh || !a.opart || !a.ml) return 0;
+  if ((a.ldq % 8) || (a.ldk % 8) || (a.ldv % 8) || (a.k_slot_stride % 8) || (a.v_slot_stride % 8)) return 0;
+  if (a.nsplit != 1 && a.nsplit != 3) return 0;
+  if (a.nsplit == 3 && (!a.ql || !a.kl || !a.vl)) return 0;
+  return 1;
+}
+
+extern "C" int rmem_mha_flash2(const rmem_mha_args* ap, const rmem_mha_args* bp, void* stream) {
+  if (!ap || !bp || !mha_args_ok(*ap) || !mha_args_ok(*bp)) return RMEM_ERR_INVALID;
+  if (ap->Npad != bp->Npad || ap->heads != bp->heads || ap->nsplit != bp->nsplit) return RMEM_ERR_INVALID;
+  Mha2Args g;
+  g.p[0] = *ap;
+  g.p[1] = *bp;
+  dim3 grid(ap->Npad / 128, ap->heads, ap->ksplits + bp->ksplits);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ap->nsplit == 3) hipLaunchKernelGGL(mha_flash2_kernel<3>, grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(mha_flash2_kernel<1>, grid, dim3(256), 0, s, g);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
+}
+
 extern "C" int rmem_mha_flash(const rmem_mha_args* ap, void* stream) {
   if (!ap) return RMEM_ERR_INVALID;
   const rmem_mha_args& a = *ap;
@@ -283,9 +324,8 @@ extern "C" int rmem_mha_flash(const rmem_mha_args* ap, void* stream) {
 }
 
 // ------------------------------------------------------------------ merge key splits
-__global__ __launch_bounds__(256) void mha_combine_kernel(rmem_mha_combine_args a) {
+__device__ __forceinline__ void mha_combine_body(const rmem_mha_combine_args& a, const int q) {
   __shared__ float mh[8], Lh[8];
-  const int q = blockIdx.x;
   const int c = threadIdx.x;           // channel (heads * 32 = 256)
   const int h = c >> 5;
   float m = -3.0e38f;
@@ -322,6 +362,33 @@ __global__ __launch_bounds__(256) void mha_combine_kernel(rmem_mha_combine_args 
       a.mass[(long)q * a.T + c] = acc / (float)a.heads;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void mha_combine_kernel(rmem_mha_combine_args a) {
+  mha_combine_body(a, blockIdx.x);
+}
+struct MhaCombine2Args {
+  rmem_mha_combine_args p[2];
+};
+__global__ __launch_bounds__(256) void mha_combine2_kernel(MhaCombine2Args g) {
+  const int na = g.p[0].N;
+  const bool first = (int)blockIdx.x < na;
+  const rmem_mha_combine_args& a = first ? g.p[0] : g.p[1];
+  mha_combine_body(a, first ? (int)blockIdx.x : (int)blockIdx.x - na);
+}
+static int mha_combine_ok(const rmem_mha_combine_args& a) {
+  if (a.N <= 0 || a.heads != 8 || a.ksplits <= 0 || !a.opart || !a.ml || !a.oh || a.T > 64) return 0;
+  if (a.mass && !a.slot_ml) return 0;
+  return 1;
+}
+extern "C" int rmem_mha_combine2(const rmem_mha_combine_args* ap, const rmem_mha_combine_args* bp, void* stream) {
+  if (!ap || !bp || !mha_combine_ok(*ap) || !mha_combine_ok(*bp)) return RMEM_ERR_INVALID;
+  MhaCombine2Args g;
+  g.p[0] = *ap;
+  g.p[1] = *bp;
+  hipLaunchKernelGGL(mha_combine2_kernel, dim3(ap->N + bp->N), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  RMEM_CHECK_LAUNCH();
+  return RMEM_OK;
 }
 
 extern "C" int rmem_mha_combine(const rmem_mha_combine_args* ap, void* stream) {

@@ -110,7 +110,7 @@ EXPORTS = [
     "rmem_layernorm_split", "rmem_dwconv5x5_split", "rmem_groupnorm2",
     "rmem_id_assign", "rmem_attn_mass_reduce", "rmem_fg_weights", "rmem_bank_reset", "rmem_bank_append",
     "rmem_bank_policy_step", "rmem_split_planes", "rmem_groupnorm_nchw",
-    "rmem_mha_flash", "rmem_mha_combine", "rmem_layernorm_ex", "rmem_layernorm_multi", "rmem_transpose_planes", "rmem_add_split", "rmem_add_split_multi",
+    "rmem_mha_flash", "rmem_mha_flash2", "rmem_mha_combine", "rmem_mha_combine2", "rmem_layernorm_ex", "rmem_layernorm_multi", "rmem_transpose_planes", "rmem_add_split", "rmem_add_split_multi",
     "rmem_gn_gelu_tokens", "rmem_pe_bias_heads", "rmem_linear_grouped", "rmem_layernorm_red", "rmem_bias_act_nchw", "rmem_set_ints",
     "rmem_labels_from_logits", "rmem_label_resize_nearest", "rmem_upsample_add_nchw", "rmem_groupnorm_nchw_bias",
     "rmem_upsample_add_nchw_out", "rmem_layernorm_red2", "rmem_layernorm_cn",
@@ -179,6 +179,8 @@ def load():
     lib.rmem_groupnorm_nchw_bias.argtypes = [c_p, c_p, c_p, i32, i64, i32, c_p, c_p, f32, i32, c_p, c_p]
     lib.rmem_mha_flash.argtypes = [C.POINTER(MHAArgs), c_p]
     lib.rmem_mha_combine.argtypes = [C.POINTER(MHACombineArgs), c_p]
+    lib.rmem_mha_flash2.argtypes = [C.POINTER(MHAArgs), C.POINTER(MHAArgs), c_p]
+    lib.rmem_mha_combine2.argtypes = [C.POINTER(MHACombineArgs), C.POINTER(MHACombineArgs), c_p]
     lib.rmem_layernorm_ex.argtypes = [c_p, i64, c_p, i64, c_p, c_p, i32, i32, f32, c_p, i64, c_p, c_p, i64,
                                       c_p, i64, c_p]
     lib.rmem_layernorm_multi.argtypes = [C.POINTER(LnArgs), i32, i32, i32, f32, c_p]
