@@ -23,7 +23,6 @@ independent, so the shard is static (clip i -> rank i mod world) and the masks a
 with one all-gather (RCCL on GPUs, gloo in the CPU tests)."""
 from __future__ import annotations
 
-import contextlib
 import os
 import threading
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
@@ -329,7 +328,6 @@ class ClipDriver:
         self.fixed_gap = fixed_gap
         self.align_corners = bool(self.cfg.MODEL_ALIGN_CORNERS)
         self._aug_bat: Dict[tuple, object] = {}        # (size group, augmentations in it) -> BatchedDeAOTEngine (see _aug_batched_ok)
-        self._aug_streams: list = []                   # one HIP stream per augmentation engine of the one-engine-each loop
 
     # -- engines
     def _aug_batched_ok(self, samples) -> bool:
@@ -361,25 +359,6 @@ class ClipDriver:
             eng.eval()
             self.engines.append(eng)
         return self.engines[aug_idx]
-
-    def _streams_for(self, n: int, device) -> Optional[list]:
-        """One HIP stream per augmentation engine when several engines run one after the other on the host (the AOT block,
-        RMEM_TTA=serial, more than ten objects): an engine's frame is a chain of small launches that leaves most of the
-        machine idle, and the engines of a frame are independent until their logits meet -- on streams of their own the
-        chains overlap (two R50-AOTL clips in flight: 628 against 525 frames/s, profiles/r06ab_aot_clips_in_flight.txt).
-        Engine i issues ALL its work on stream i (its hipGraphs, its prefetch stream and its memory belong to it); the
-        frame's label kernels run on the caller's stream, ordered by events.  RMEM_TTA_STREAMS=0: everything on the
-        caller's stream."""
-        if n < 2 or os.environ.get("RMEM_TTA_STREAMS", "1") == "0":
-            return None
-        from .streams import concurrent_stream
-        main = torch.cuda.current_stream(device)
-        if not self._aug_streams:
-            self._aug_streams = [main]
-        while len(self._aug_streams) < n:
-            self._aug_streams.append(concurrent_stream(device))
-        self._aug_streams[0] = main
-        return self._aug_streams[:n]
 
     def _can_fuse(self, engines, sample0) -> bool:
         """Fused device post-processing needs the un-aggregated decoder logits of every
@@ -453,31 +432,13 @@ class ClipDriver:
             obj_nums = [int(v) for v in meta0["obj_num"]] if isinstance(meta0["obj_num"], (list, tuple)) \
                 else [int(meta0["obj_num"])]
             on_cuda = samples[0]["current_img"].is_cuda
-            streams = self._streams_for(len(engines), samples[0]["current_img"].device) if on_cuda else None
-            main = torch.cuda.current_stream(samples[0]["current_img"].device) if streams else None
-
-            def on_stream(i):
-                """Context in which engine i issues its work: its own stream, behind everything the caller's has queued."""
-                if streams is None or i == 0:
-                    return contextlib.nullcontext()
-                streams[i].wait_stream(main)
-                return torch.cuda.stream(streams[i])
-
-            def join():
-                """The caller's stream waits for every engine's stream (logits / memory updates of this frame)."""
-                if streams is not None:
-                    for st in streams[1:]:
-                        main.wait_stream(st)
-
             if frame_idx == 0:
                 res.obj_idx = meta0.get("obj_idx")
-                for i, (e, s) in enumerate(zip(engines, samples)):
+                for e, s in zip(engines, samples):
                     e.long_term_mem_gap = gap
                     img = s["current_img"]
                     lab = F.interpolate(s["current_label"].float(), size=img.shape[2:], mode="nearest").int()
-                    with on_stream(i):
-                        e.add_reference_frame(img, lab, frame_step=0, obj_nums=obj_nums)
-                join()
+                    e.add_reference_frame(img, lab, frame_step=0, obj_nums=obj_nums)
                 continue
             if on_cuda:
                 t0 = torch.cuda.Event(enable_timing=True)
@@ -488,15 +449,10 @@ class ClipDriver:
                 kw = {}
                 if getattr(e, "supports_prefetch", False) and ahead and all(len(a) > i for a in ahead):
                     kw["next_img"] = [a[i]["current_img"] for a in ahead]
-                with on_stream(i):
-                    lg = e.match_propogate_one_frame(s["current_img"], output_size=None if fuse else ori_hw, **kw)
+                lg = e.match_propogate_one_frame(s["current_img"], output_size=None if fuse else ori_hw, **kw)
                 logits.append(lg)
                 if (not fl) and s.get("current_label") is not None and new_obj_label is None:
                     new_obj_label = s["current_label"].to(lg.device).float()
-            join()
-            if streams is not None:
-                for lg in logits[1:]:
-                    lg.record_stream(main)                     # (allocated on its engine's stream, read on the caller's)
             if fuse:
                 from . import hip
                 label = hip.labels_from_logits([lg.contiguous() for lg in logits], flips, ori_hw,
@@ -507,14 +463,11 @@ class ClipDriver:
                 new = new_obj_label[0, 0].to(torch.uint8)
                 label = torch.where(new == 0, label, new)
                 new_nums = [int(label.max().item())]
-                for i, (e, s, fl) in enumerate(zip(engines, samples, flips)):
+                for e, s, fl in zip(engines, samples, flips):
                     cur = self._resize_generic(label, e.input_size_2d, fl)
-                    with on_stream(i):
-                        if i > 0 and streams is not None:
-                            cur.record_stream(streams[i])
-                        e.add_reference_frame(s["current_img"], cur, obj_nums=new_nums, frame_step=frame_idx)
+                    e.add_reference_frame(s["current_img"], cur, obj_nums=new_nums, frame_step=frame_idx)
             else:                                                # evaluator.py:509-523
-                for i, (e, fl) in enumerate(zip(engines, flips)):
+                for e, fl in zip(engines, flips):
                     if fuse:
                         from . import hip
                         subs = getattr(e, "aot_engines", [])
@@ -523,11 +476,7 @@ class ClipDriver:
                         cur = hip.label_resize_nearest(label, e.input_size_2d, fl, out=buf)[None, None]
                     else:
                         cur = self._resize_generic(label, e.input_size_2d, fl)
-                    with on_stream(i):
-                        if i > 0 and streams is not None:
-                            cur.record_stream(streams[i])
-                        e.update_memory(cur)
-            join()
+                    e.update_memory(cur)
             if on_cuda:
                 t1 = torch.cuda.Event(enable_timing=True)
                 t1.record()
