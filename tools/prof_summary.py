@@ -41,11 +41,13 @@ def trace_rows_from_db(path):
 
 def from_trace(path, frames):
     """Steady-state summary from a rocprofv3 kernel trace (CSV or rocpd .db): only the dispatches of the last
-    `frames` frames (delimited by the once-per-frame gn2_apply_kernel) are counted, which
+    `frames` frames (delimited by the once-per-frame gn2_apply_kernel; AOT block: id_assign_kernel) are counted, which
     excludes MIOpen find-mode / first-call kernels of the warm-up."""
     rows = trace_rows_from_db(path) if path.endswith(".db") else list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     marks = [i for i, r in enumerate(rows) if "gn2_apply_kernel" in r["Kernel_Name"]]
+    if not marks:          # the AOT block has no final GroupNorm: its frames are delimited by the once-per-frame ID assignment
+        marks = [i for i, r in enumerate(rows) if "id_assign_kernel" in r["Kernel_Name"]]
     start = marks[-frames - 1] + 1 if len(marks) > frames else 0
     end = marks[-1] + 1
     agg = {}
