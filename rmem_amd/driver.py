@@ -23,6 +23,7 @@ independent, so the shard is static (clip i -> rank i mod world) and the masks a
 with one all-gather (RCCL on GPUs, gloo in the CPU tests)."""
 from __future__ import annotations
 
+import contextlib
 import os
 import threading
 from typing import Callable, Dict, Iterable, List, Optional, Sequence
@@ -391,6 +392,18 @@ class ClipDriver:
         """One clip.  `frames` yields the per-frame sample lists; `num_frames` (len of the clip)
         sets the memory gap (evaluator.py:327-331) -- required unless `frames` has a len().
         `on_frame(frame_idx, label_u8, engines)` is called after each propagated frame."""
+        gen = self.clip_steps(frames, num_frames, save_dir, on_frame)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+
+    def clip_steps(self, frames: Iterable[List[Dict]], num_frames: Optional[int] = None,
+                   save_dir: Optional[str] = None, on_frame: Optional[Callable] = None):
+        """run_clip() as a generator: yields after every frame it has ISSUED (nothing is waited for) and returns the
+        ClipResult -- what lets one host thread keep several clips in flight, each on a HIP stream of its own
+        (InFlightClipDriver).  Every step of one clip must run under the same current stream."""
         if num_frames is None:
             num_frames = len(frames)        # type: ignore[arg-type]
         gap = self.fixed_gap if self.fixed_gap is not None else memory_gap(num_frames, self.no_memory_gap)
@@ -401,7 +414,6 @@ class ClipDriver:
         labels_out: List[torch.Tensor] = []
         timers = []
         writers = []
-        on_cuda = False
         it = iter(frames)
         from .engine import default_lookahead
         depth = default_lookahead()                       # look-ahead (encoder prefetch)
@@ -412,12 +424,22 @@ class ClipDriver:
                 ahead.append(f)
         if ahead and self._aug_batched_ok(ahead[0]):
             return self._run_clip_batched_aug(ahead, it, gap, res, save_dir, on_frame)
-        return self._serial_loop(ahead, it, gap, res, save_dir, on_frame, -1, labels_out, timers, writers)
+        return (yield from self._serial_frames(ahead, it, gap, res, save_dir, on_frame, -1, labels_out, timers, writers))
 
-    def _serial_loop(self, ahead, it, gap, res, save_dir, on_frame, frame_idx, labels_out, timers, writers):
+    def _serial_loop(self, *args):
+        """_serial_frames() run to its end (the batched-augmentation path hands a clip over mid-way)."""
+        gen = self._serial_frames(*args)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+
+    def _serial_frames(self, ahead, it, gap, res, save_dir, on_frame, frame_idx, labels_out, timers, writers):
         """The evaluator's per-frame loop (managers/evaluator.py:384-527) over the frames still in `ahead` / `it`, one
-        engine per augmentation.  frame_idx = index of the last frame already handled (-1: the clip starts here; the
-        batched-augmentation path hands a clip over mid-way when a new label brings more objects than one engine holds)."""
+        engine per augmentation; a generator that yields after every frame.  frame_idx = index of the last frame already
+        handled (-1: the clip starts here; the batched-augmentation path hands a clip over mid-way when a new label brings
+        more objects than one engine holds)."""
         on_cuda = False
         while ahead:
             samples, ahead = ahead[0], ahead[1:]
@@ -439,6 +461,7 @@ class ClipDriver:
                     img = s["current_img"]
                     lab = F.interpolate(s["current_label"].float(), size=img.shape[2:], mode="nearest").int()
                     e.add_reference_frame(img, lab, frame_step=0, obj_nums=obj_nums)
+                yield frame_idx
                 continue
             if on_cuda:
                 t0 = torch.cuda.Event(enable_timing=True)
@@ -490,14 +513,87 @@ class ClipDriver:
             if save_dir is not None:
                 writers.append(save_mask(label, os.path.join(save_dir, str(name).split(".")[0] + ".png"),
                                          res.obj_idx))
+            yield frame_idx
         if on_cuda:
-            torch.cuda.synchronize()
+            # (the clip's own stream -- its engines' side streams have been joined by their last frame --, not the device:
+            # other clips may be in flight on streams of their own)
+            torch.cuda.current_stream(labels_out[0].device if labels_out else None).synchronize()
             res.frame_ms = [a.elapsed_time(b) for a, b in timers]
         for th in writers:
             if th is not None:
                 th.join()
         res.masks = torch.stack(labels_out) if labels_out else None
         return res
+
+
+class InFlightClipDriver:
+    """`lanes` clips in flight on one GPU: one ClipDriver (its engines, their graphs) and one HIP stream per lane, ONE host
+    thread that issues the lanes' frames in turn (hipGraph capture is process-global: host threads would collide), a lane
+    taking the next clip of the list when its clip ends -- the reference's worker processes sharing a GPU
+    (managers/evaluator.py:276-295) without the processes.  A single clip leaves the machine idle between the launches
+    of its chain; a second clip fills the gaps: two R50-AOTL clips run at 628 frames/s against 525 for one, R50-DeAOTL
+    555-569 against 538, a third lane adds nothing (profiles/r06ab_aot_clips_in_flight.txt).  Works for every model and
+    everything ClipDriver.run_clip takes (augmentation, mid-clip objects, more than ten objects); per clip the label
+    maps are those of ClipDriver.run_clip."""
+
+    def __init__(self, model, lanes: int = 2, cfg=None, gpu_id: int = 0, **kw):
+        self.lanes = [ClipDriver(model, cfg, gpu_id=gpu_id, **kw) for _ in range(max(1, int(lanes)))]
+        self._streams: list = []
+
+    def _lane_streams(self, device):
+        from .streams import concurrent_stream
+        main = torch.cuda.current_stream(device)
+        if not self._streams:
+            self._streams = [main] + [concurrent_stream(device) for _ in self.lanes[1:]]
+        self._streams[0] = main
+        return self._streams
+
+    @torch.no_grad()
+    def run_clips(self, clips: Sequence[Sequence[List[Dict]]], save_dirs: Optional[Sequence[Optional[str]]] = None,
+                  on_frame: Optional[Callable] = None) -> List[ClipResult]:
+        """clips[i][t] = the sample list of frame t of clip i (any lengths, sizes, augmentations) -> one ClipResult per
+        clip, in order."""
+        results: List[Optional[ClipResult]] = [None] * len(clips)
+        if not clips:
+            return []
+        dev = clips[0][0][0]["current_img"].device
+        on_cuda = dev.type == "cuda"
+        streams = self._lane_streams(dev) if on_cuda else [None] * len(self.lanes)
+        main = streams[0]
+        nxt = 0
+        running: List[Optional[tuple]] = [None] * len(self.lanes)         # (clip id, generator)
+
+        def on(i):
+            if not on_cuda or i == 0:
+                return contextlib.nullcontext()
+            return torch.cuda.stream(streams[i])
+
+        if on_cuda:
+            for st in streams[1:]:
+                st.wait_stream(main)                      # the clips' tensors were made on the caller's stream
+        while True:
+            busy = False
+            for i, lane in enumerate(self.lanes):
+                if running[i] is None and nxt < len(clips):
+                    cid, nxt = nxt, nxt + 1
+                    sd = save_dirs[cid] if save_dirs is not None else None
+                    running[i] = (cid, lane.clip_steps(clips[cid], len(clips[cid]), sd, on_frame))
+                if running[i] is None:
+                    continue
+                busy = True
+                cid, gen = running[i]
+                with on(i):
+                    try:
+                        next(gen)
+                    except StopIteration as stop:
+                        results[cid] = stop.value
+                        running[i] = None
+            if not busy:
+                break
+        if on_cuda:
+            for st in streams[1:]:
+                main.wait_stream(st)
+        return results
 
 
 class _AugEngineView:

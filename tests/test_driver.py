@@ -772,3 +772,43 @@ def test_bench_ragged_dataset_through_the_slot_queue():
     assert cfg["frames_per_rank"] == [sum(cfg["lengths"]) - n]
     assert cfg["queue_stats_rank0"]["busy_slot_steps"] == sum(cfg["lengths"])
     assert len(out["clip_sha256"]) == n and len(set(out["clip_sha256"])) == n and out["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["r50_aotl", "r50_deaotl"])
+def test_clips_in_flight_equal_one_clip_at_a_time(name):
+    """InFlightClipDriver: five clips of different lengths (one with flip augmentation, one with a mid-clip new object)
+    through two lanes -- one ClipDriver and one HIP stream each, a single host thread issuing their frames in turn, a lane
+    taking the next clip when its clip ends.  Per clip the label maps, names and gaps EQUAL ClipDriver.run_clip's run one
+    clip at a time (the same engines' arithmetic; a stream changes no value), whichever lane served it, and a second pass
+    over the same driver reproduces them."""
+    from rmem_amd.config import get_config
+    from rmem_amd.model import build_vos_model
+    from rmem_amd.synth import load_synthetic_weights
+    H, W = 97, 129
+    cfg = get_config(name, 1, 3)
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    load_synthetic_weights(model)
+    model = model.to(DEV)
+    lens = [6, 4, 7, 3, 5]
+
+    def clip(cid, n):
+        imgs, lab = synth_clip(1200 + cid, n, H, W, 3)
+        new = torch.zeros(1, 1, H, W)
+        new[:, :, 10:30, 60:100] = 4
+        lab_of = lambda t: lab if t == 0 else (new if (cid == 2 and t == 3) else None)
+        return [D.make_samples(imgs[t].to(DEV), None if lab_of(t) is None else lab_of(t).to(DEV), (H, W), 3,
+                               flip_aug=(cid == 1), name=f"{t:05d}.jpg") for t in range(n)]
+    clips = [clip(i, n) for i, n in enumerate(lens)]
+    one = D.ClipDriver(model, cfg, fixed_gap=2)
+    want = [one.run_clip(c, num_frames=len(c)) for c in clips]
+    fly = D.InFlightClipDriver(model, 2, cfg, fixed_gap=2)
+    for rep in range(2):
+        got = fly.run_clips(clips)
+        torch.cuda.synchronize()
+        assert len(got) == len(clips)
+        for i, (g, w_) in enumerate(zip(got, want)):
+            assert g.gap == w_.gap and g.names == w_.names and tuple(g.masks.shape) == (lens[i] - 1, H, W)
+            assert torch.equal(g.masks, w_.masks), (rep, i, [int((g.masks[t] != w_.masks[t]).sum()) for t in range(lens[i] - 1)])
+    assert int((got[2].masks[2:] == 4).sum()) > 0 and bool((got[2].masks[2][10:30, 60:100] == 4).all())
+    assert D.InFlightClipDriver(model, 3, cfg).run_clips([]) == []
