@@ -95,6 +95,36 @@ def test_driver_logic_multiscale_vs_reference_golden(deaot_model, golden_dir):
     assert [list(e.input_size_2d) for e in drv.engines] == meta["input_sizes"]
 
 
+def test_clips_in_flight_host_logic_with_oracle_engines(deaot_model, golden_dir):
+    """InFlightClipDriver's lane logic on the CPU (oracle engines injected, no streams): three clips -- the reference's
+    flip-augmented golden clip with its mid-clip object among them -- through two lanes, a lane taking the next clip when
+    its clip ends; results in clip order, each equal to ClipDriver.run_clip one clip at a time (the golden clip: bit-exact
+    against the reference's label maps), a second pass over the same lanes equal again, on_frame called once per
+    propagated frame."""
+    from oracle.engine_ref import OracleDeAOTEngine
+    meta = json.load(open(os.path.join(golden_dir, "clip_tta_k4_gap2.json")))
+    gold = np.load(os.path.join(golden_dir, "clip_tta_k4_gap2.npz"))["labels"]
+    fac = lambda m: OracleDeAOTEngine(m)
+    out_hw = tuple(meta["out_hw"])
+
+    def short(seed, n):
+        imgs, lab = synth_clip(seed, n, meta["H"], meta["W"], 3)
+        lab0 = F.interpolate(lab.float(), size=out_hw, mode="nearest")
+        return [D.make_samples(imgs[t], lab0 if t == 0 else None, out_hw, 3, name=f"{t:05d}.jpg") for t in range(n)]
+    clips = [short(77, 3), _tta_frames(meta), short(78, 4)]
+    one = D.ClipDriver(deaot_model, engine_factory=fac, fixed_gap=meta["gap"])
+    want = [one.run_clip(c, num_frames=len(c)) for c in clips]
+    fly = D.InFlightClipDriver(deaot_model, 2, engine_factory=fac, fixed_gap=meta["gap"])
+    for rep in range(2):
+        calls = []
+        got = fly.run_clips(clips, on_frame=lambda t, lab, engs: calls.append(t))
+        assert len(calls) == sum(len(c) - 1 for c in clips)
+        for g, w_ in zip(got, want):
+            assert g.names == w_.names and g.gap == w_.gap and torch.equal(g.masks, w_.masks)
+        assert sum(int((got[1].masks[i].numpy() != gold[i]).sum()) for i in range(len(gold))) == 0
+    assert D.InFlightClipDriver(deaot_model, 2, engine_factory=fac).run_clips([]) == []
+
+
 # ------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("naug,align,geom", [(1, True, (31, 54, 121, 213, 480, 854)),
