@@ -155,6 +155,10 @@ def run_sharded_dataset(driver, lengths: Sequence[int], world: int, rank: int, f
         # slot takes the next clip when its clip ends) -- the reference's worker queue twice over, ranks x slots
         clips = [frames_of(cid)[:int(lengths[cid])] for cid in assign[rank]]
         results = driver.run_dataset(clips) if clips else []
+    elif isinstance(driver, InFlightClipDriver):
+        # this rank's clips in flight on its lanes (any model: the AOT block, Swin, augmentation)
+        clips = [frames_of(cid)[:int(lengths[cid])] for cid in assign[rank]]
+        results = driver.run_clips(clips) if clips else []
     else:
         results = [driver.run_clip(frames_of(cid), num_frames=int(lengths[cid])) for cid in assign[rank]]
     dev_of_driver = torch.device("cuda", int(driver.gpu_id)) if (getattr(driver, "gpu_id", None) is not None
@@ -538,6 +542,7 @@ class InFlightClipDriver:
 
     def __init__(self, model, lanes: int = 2, cfg=None, gpu_id: int = 0, **kw):
         self.lanes = [ClipDriver(model, cfg, gpu_id=gpu_id, **kw) for _ in range(max(1, int(lanes)))]
+        self.gpu_id = gpu_id
         self._streams: list = []
 
     def _lane_streams(self, device):

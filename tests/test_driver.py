@@ -123,6 +123,12 @@ def test_clips_in_flight_host_logic_with_oracle_engines(deaot_model, golden_dir)
             assert g.names == w_.names and g.gap == w_.gap and torch.equal(g.masks, w_.masks)
         assert sum(int((got[1].masks[i].numpy() != gold[i]).sum()) for i in range(len(gold))) == 0
     assert D.InFlightClipDriver(deaot_model, 2, engine_factory=fac).run_clips([]) == []
+    # ... and as the per-rank driver of run_sharded_dataset: the same clip hashes as one clip at a time
+    plain = [short(77, 3), short(79, 5), short(78, 4)]
+    lens = [len(c) for c in plain]
+    h_one, n_one = D.run_sharded_dataset(one, lens, 1, 0, lambda cid: plain[cid])
+    h_fly, n_fly = D.run_sharded_dataset(fly, lens, 1, 0, lambda cid: plain[cid])
+    assert h_one == h_fly and n_one == n_fly == [sum(n - 1 for n in lens)]
 
 
 # ------------------------------------------------------------------------------- GPU
